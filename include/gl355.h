@@ -1,0 +1,180 @@
+/*
+ * gl355.h -- C ABI of libgl355, the MI355X (gfx950) prover hot path behind the reference's
+ * plonky2 call sites.
+ *
+ * The reference (DoHoonKim8/stark-verifier) has no FFI of its own: the seam is the Cargo edge into
+ * plonky2 @ 72229c47 (Cargo.lock:1573-1612).  Each entry point below names the plonky2 item it
+ * replaces and the reference call site that reaches it; INTEGRATION.md shows the Rust `extern "C"`
+ * shim a maintainer would patch into plonky2 to bind them.
+ *
+ * Conventions
+ *   - Field elements are uint64_t, little-endian; ANY u64 is accepted on input (reduced mod
+ *     p = 2^64 - 2^32 + 1), outputs are canonical (< p).  Extension elements (F_p[X]/(X^2-7)) are
+ *     two consecutive u64 (c0, c1).
+ *   - Every data pointer may be a HOST pointer or a DEVICE pointer (hipMalloc / gl355_malloc / a
+ *     torch tensor's data_ptr).  Host buffers are staged through HBM by the library (the call
+ *     returns after the result is back in the host buffer); device buffers are used in place and
+ *     the call returns after enqueueing on the context's stream (use gl355_ctx_sync).
+ *   - The caller owns every buffer; the library never frees caller memory.
+ *   - Every function returns int32_t: 0 = OK, < 0 = GL355_E_*.  No exception or abort crosses
+ *     the boundary.  gl355_last_error(ctx) gives the text of the last failure on that context.
+ *   - A gl355_ctx is bound to one device and one stream; contexts are independent, so the API is
+ *     re-entrant from many host threads (the reference calls prove() from rayon workers,
+ *     src/plonky2_semaphore/recursion.rs:214-227,300-308) as long as each thread uses its own ctx.
+ */
+#ifndef GL355_H
+#define GL355_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GL355_OK 0
+#define GL355_E_INVALID_ARG (-1)
+#define GL355_E_NO_DEVICE (-2)
+#define GL355_E_OOM (-3)
+#define GL355_E_HIP (-4)
+#define GL355_E_UNSUPPORTED (-5)
+
+#define GL355_P UINT64_C(0xFFFFFFFF00000001) /* chip/native_chip/arithmetic_chip.rs:19 */
+#define GL355_COSET_SHIFT UINT64_C(7)        /* chip/plonk/plonk_verifier_chip.rs:225-227 */
+#define GL355_SALT_SIZE 4                    /* types/assigned.rs:67-71 */
+
+typedef struct gl355_ctx gl355_ctx;
+typedef struct gl355_oracle gl355_oracle; /* a committed polynomial batch resident in HBM */
+
+/* ---- context ------------------------------------------------------------------------------ */
+int32_t gl355_ctx_create(int32_t device, gl355_ctx** out);
+/* use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
+int32_t gl355_ctx_create_on_stream(int32_t device, void* hip_stream, gl355_ctx** out);
+int32_t gl355_ctx_destroy(gl355_ctx* ctx);
+int32_t gl355_ctx_sync(gl355_ctx* ctx);
+const char* gl355_last_error(gl355_ctx* ctx);
+const char* gl355_version(void);
+int32_t gl355_device_count(int32_t* out);
+
+/* device memory helpers so a non-torch host (the Rust shim) can keep operands resident */
+int32_t gl355_malloc(gl355_ctx* ctx, size_t bytes, void** dptr);
+int32_t gl355_free(gl355_ctx* ctx, void* dptr);
+int32_t gl355_memcpy_h2d(gl355_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int32_t gl355_memcpy_d2h(gl355_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* HIP-event timer on the context's stream (what bench.py times kernels with) */
+int32_t gl355_timer_start(gl355_ctx* ctx);
+int32_t gl355_timer_stop(gl355_ctx* ctx, float* ms);
+
+/* ---- a1: GoldilocksField / QuadraticExtension (plonky2_field; signal.rs:1,5) ---------------- */
+enum { GL355_OP_ADD = 0, GL355_OP_SUB = 1, GL355_OP_MUL = 2, GL355_OP_INV = 3,
+       GL355_OP_EXT_MUL = 4, GL355_OP_EXT_INV = 5 };
+/* out[i] = a[i] (op) b[i]; for EXT ops n counts extension elements; b ignored for *_INV */
+int32_t gl355_field_batch(gl355_ctx* ctx, int32_t op, const uint64_t* a, const uint64_t* b,
+                          uint64_t* out, uint64_t n);
+
+/* ---- a2: fft_with_options / ifft_with_options (plonky2_field::fft) --------------------------
+ * In place, natural order in and out.  batch columns, column c at data + c*stride, n = 2^log_n.
+ * forward: out[j] = sum_i in[i] * omega_n^(i j), omega_n = 7^((p-1)/n)  (fri_chip.rs:162-163). */
+int32_t gl355_ntt(gl355_ctx* ctx, uint64_t* data, uint32_t log_n, uint32_t batch, uint64_t stride,
+                  int32_t inverse);
+/* coset_fft / coset_ifft: forward evaluates on shift*<omega>; inverse interpolates from it. */
+int32_t gl355_coset_ntt(gl355_ctx* ctx, uint64_t* data, uint32_t log_n, uint32_t batch,
+                        uint64_t stride, uint64_t shift, int32_t inverse);
+
+/* ---- a3: PolynomialCoeffs::lde + coset_fft_with_options --------------------------------------
+ * coeffs: batch columns of n; out: batch columns of N = n << rate_bits;
+ * natural order: out[c][j] = P_c(shift * omega_N^j). */
+int32_t gl355_lde(gl355_ctx* ctx, const uint64_t* coeffs, uint32_t log_n, uint32_t rate_bits,
+                  uint64_t shift, uint32_t batch, uint64_t* out);
+/* same values in the commitment's bit-reversed order: out[c][i] = P_c(shift*omega_N^bitrev(i))
+ * (fri_chip.rs:245-264).  This is the single-write fast path the commit pipeline uses. */
+int32_t gl355_lde_bitrev(gl355_ctx* ctx, const uint64_t* coeffs, uint32_t log_n, uint32_t rate_bits,
+                         uint64_t shift, uint32_t batch, uint64_t* out);
+
+/* ---- a5: plonky2_util::transpose / reverse_index_bits_in_place (fri_chip.rs:6,189) ---------- */
+/* out[c][r] = in[r][c]; in is rows x cols row-major */
+int32_t gl355_transpose(gl355_ctx* ctx, const uint64_t* in, uint64_t rows, uint64_t cols, uint64_t* out);
+/* rows of row_len u64: row i <-> row bitrev(i), in place */
+int32_t gl355_reverse_index_bits(gl355_ctx* ctx, uint64_t* data, uint64_t n_rows, uint32_t row_len);
+
+/* ---- a6: PoseidonPermutation::permute (access_set.rs:67; gates/poseidon.rs:26-322) ----------- */
+int32_t gl355_poseidon_permute(gl355_ctx* ctx, uint64_t* states /* count x 12 */, uint64_t count);
+
+/* ---- a7: hash_n_to_m_no_pad / hash_or_noop / two_to_one (hasher_chip.rs:122-148) ------------- */
+/* n inputs of len elements each (row-major) -> n digests of 4; always runs the sponge */
+int32_t gl355_hash_no_pad(gl355_ctx* ctx, const uint64_t* inputs, uint64_t n, uint32_t len, uint64_t* digests);
+/* Merkle leaf digests: len <= 4 copies (zero padded), else sponge (merkle_proof_chip.rs:52-57) */
+int32_t gl355_hash_leaves(gl355_ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len,
+                          uint64_t* digests);
+int32_t gl355_two_to_one(gl355_ctx* ctx, const uint64_t* left, const uint64_t* right, uint64_t n, uint64_t* out);
+
+/* ---- a8: MerkleTree::new / prove (signal.rs:40, access_set.rs:205, recursion.rs:360, circuit.rs:91)
+ * leaves: n_leaves x leaf_len row-major.  digests: 2*(n_leaves - 2^cap_height) x 4 u64 in
+ * plonky2's layout (per cap subtree: left-subtree || left-child || right-child || right-subtree,
+ * recursively) so MerkleTree::prove keeps working on it.  cap: 2^cap_height x 4. */
+int32_t gl355_merkle_build(gl355_ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len,
+                           uint32_t cap_height, uint64_t* digests, uint64_t* cap);
+/* siblings leaf -> cap: (log2(n_leaves) - cap_height) x 4 u64 (host buffer) */
+int32_t gl355_merkle_prove(gl355_ctx* ctx, const uint64_t* digests, uint64_t n_leaves, uint32_t cap_height,
+                           uint64_t leaf_index, uint64_t* siblings);
+
+/* ---- a4 (+a14): PolynomialBatch::from_values / from_coeffs (4x per proof) ---------------------
+ * values: batch columns of n (column-major), evaluations on <omega_n> (is_coeffs = 0) or
+ * coefficients (is_coeffs = 1).  salt: NULL, or GL355_SALT_SIZE columns of N = n << rate_bits
+ * random elements appended to every leaf when the oracle is blinded (natural order, i.e. exactly
+ * what plonky2 appends to the LDE before its transpose).  The oracle keeps coefficients, the LDE
+ * (column-major, bit-reversed row order), digests and cap resident on the device. */
+int32_t gl355_commit(gl355_ctx* ctx, const uint64_t* values, uint32_t log_n, uint32_t batch,
+                     uint32_t rate_bits, int32_t is_coeffs, const uint64_t* salt, uint32_t cap_height,
+                     gl355_oracle** out);
+int32_t gl355_oracle_destroy(gl355_oracle* o);
+int32_t gl355_oracle_info(const gl355_oracle* o, uint32_t* log_n, uint32_t* rate_bits, uint32_t* batch,
+                          uint32_t* leaf_len, uint32_t* cap_height);
+int32_t gl355_oracle_cap(const gl355_oracle* o, uint64_t* cap /* 2^cap_height x 4 */);
+int32_t gl355_oracle_coeffs(const gl355_oracle* o, uint64_t* coeffs /* batch x n */);
+/* plonky2-layout exports (row-major leaves [N][leaf_len], digests) for MerkleTree { leaves, digests, cap } */
+int32_t gl355_oracle_leaves(const gl355_oracle* o, uint64_t* leaves);
+int32_t gl355_oracle_digests(const gl355_oracle* o, uint64_t* digests);
+/* device pointers for resident pipelines: LDE column c at lde + c*N (bit-reversed rows) */
+const uint64_t* gl355_oracle_lde_ptr(const gl355_oracle* o);
+const uint64_t* gl355_oracle_coeffs_ptr(const gl355_oracle* o);
+/* MerkleTree::get + prove for one query index (fri_prover_query_round): leaf [leaf_len] and
+ * siblings [(log2 N - cap_height) x 4] to host buffers */
+int32_t gl355_oracle_open(const gl355_oracle* o, uint64_t index, uint64_t* leaf, uint64_t* siblings);
+
+/* ---- a11: PolynomialBatch::prove_openings (fri_chip.rs:112-149) ------------------------------
+ * One opening batch over polynomials taken from resident oracles:
+ *   C(X) = sum_i alpha^i p_i(X);  Q = (C - C(z)) / (X - z), padded to n;  acc = acc*alpha^k + Q
+ * polys[i] = (oracle, column) in batch order; acc: n extension coefficients (in/out). */
+typedef struct { const gl355_oracle* oracle; uint32_t column; } gl355_poly_ref;
+int32_t gl355_deep_batch(gl355_ctx* ctx, const gl355_poly_ref* polys, uint32_t n_polys,
+                         const uint64_t alpha[2], const uint64_t z[2], uint64_t* acc);
+/* openings: out[i] = p_i(z) in the extension field (OpeningSet::new) */
+int32_t gl355_eval_polys(gl355_ctx* ctx, const gl355_poly_ref* polys, uint32_t n_polys,
+                         const uint64_t z[2], uint64_t* out);
+/* extension-field LDE of the final DEEP polynomial: coeffs n ext -> out N ext, natural order */
+int32_t gl355_lde_ext(gl355_ctx* ctx, const uint64_t* coeffs, uint32_t log_n, uint32_t rate_bits,
+                      uint64_t shift, uint64_t* out);
+
+/* ---- a12: fri_committed_trees (fri_chip.rs:168-226,275-316) ---------------------------------- */
+/* arity-2 fold of n extension coefficients: out[k] = c[2k] + beta*c[2k+1] */
+int32_t gl355_fri_fold(gl355_ctx* ctx, const uint64_t* coeffs, uint64_t n, const uint64_t beta[2], uint64_t* out);
+/* commit-phase layer tree from natural-order extension values (n ext): leaves = pairs in
+ * bit-reversed order, flattened to 4 u64 (no leaf hash); outputs as gl355_merkle_build */
+int32_t gl355_fri_layer_commit(gl355_ctx* ctx, const uint64_t* values, uint64_t n, uint32_t cap_height,
+                               uint64_t* leaves, uint64_t* digests, uint64_t* cap);
+
+/* ---- a13: fri_proof_of_work (fri_chip.rs:364-376, plonk_verifier_chip.rs:136-137) ------------- */
+/* smallest w >= start such that permute(state with state[pos] = w)[7] has >= bits leading zeros */
+int32_t gl355_pow_grind(gl355_ctx* ctx, const uint64_t state[12], uint32_t pos, uint32_t bits,
+                        uint64_t start, uint64_t* witness);
+
+/* ---- a9: wires_permutation_partial_products_and_zs (vanishing_poly.rs:54-108,183-218) --------- */
+int32_t gl355_zs_partial_products(gl355_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas,
+                                  const uint64_t* k_is, uint32_t log_n, uint32_t n_routed,
+                                  uint32_t max_degree, uint64_t beta, uint64_t gamma,
+                                  uint64_t* z_out, uint64_t* pp_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GL355_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of libgl355.so (include/gl355.h).  Fails loudly when the HIP library is missing:
+there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgl355.so")
+
+u64p = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+
+
+class Gl355Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("gl355 error %d: %s" % (code, msg))
+        self.code = code
+
+
+class PolyRef(C.Structure):
+    _fields_ = [("oracle", vp), ("column", C.c_uint32)]
+
+
+# name -> (restype, argtypes).  Data pointers are void* so numpy arrays, torch data_ptr() ints and
+# raw device pointers all pass through the same signature.
+SIGNATURES = {
+    "gl355_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(vp)]),
+    "gl355_ctx_create_on_stream": (C.c_int32, [C.c_int32, vp, C.POINTER(vp)]),
+    "gl355_ctx_destroy": (C.c_int32, [vp]),
+    "gl355_ctx_sync": (C.c_int32, [vp]),
+    "gl355_last_error": (C.c_char_p, [vp]),
+    "gl355_version": (C.c_char_p, []),
+    "gl355_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
+    "gl355_malloc": (C.c_int32, [vp, C.c_size_t, C.POINTER(vp)]),
+    "gl355_free": (C.c_int32, [vp, vp]),
+    "gl355_memcpy_h2d": (C.c_int32, [vp, vp, vp, C.c_size_t]),
+    "gl355_memcpy_d2h": (C.c_int32, [vp, vp, vp, C.c_size_t]),
+    "gl355_timer_start": (C.c_int32, [vp]),
+    "gl355_timer_stop": (C.c_int32, [vp, C.POINTER(C.c_float)]),
+    "gl355_field_batch": (C.c_int32, [vp, C.c_int32, vp, vp, vp, C.c_uint64]),
+    "gl355_ntt": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int32]),
+    "gl355_coset_ntt": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32]),
+    "gl355_lde": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, vp]),
+    "gl355_lde_bitrev": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, vp]),
+    "gl355_transpose": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, vp]),
+    "gl355_reverse_index_bits": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32]),
+    "gl355_poseidon_permute": (C.c_int32, [vp, vp, C.c_uint64]),
+    "gl355_hash_no_pad": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
+    "gl355_hash_leaves": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
+    "gl355_two_to_one": (C.c_int32, [vp, vp, vp, C.c_uint64, vp]),
+    "gl355_merkle_build": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp]),
+    "gl355_merkle_prove": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint64, vp]),
+    "gl355_commit": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp, C.c_uint32, C.POINTER(vp)]),
+    "gl355_oracle_destroy": (C.c_int32, [vp]),
+    "gl355_oracle_info": (C.c_int32, [vp] + [C.POINTER(C.c_uint32)] * 5),
+    "gl355_oracle_cap": (C.c_int32, [vp, vp]),
+    "gl355_oracle_coeffs": (C.c_int32, [vp, vp]),
+    "gl355_oracle_leaves": (C.c_int32, [vp, vp]),
+    "gl355_oracle_digests": (C.c_int32, [vp, vp]),
+    "gl355_oracle_lde_ptr": (vp, [vp]),
+    "gl355_oracle_coeffs_ptr": (vp, [vp]),
+    "gl355_oracle_open": (C.c_int32, [vp, C.c_uint64, vp, vp]),
+    "gl355_deep_batch": (C.c_int32, [vp, C.POINTER(PolyRef), C.c_uint32, vp, vp, vp]),
+    "gl355_eval_polys": (C.c_int32, [vp, C.POINTER(PolyRef), C.c_uint32, vp, vp]),
+    "gl355_lde_ext": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, vp]),
+    "gl355_fri_fold": (C.c_int32, [vp, vp, C.c_uint64, vp, vp]),
+    "gl355_fri_layer_commit": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
+    "gl355_pow_grind": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "gl355_zs_partial_products": (C.c_int32, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                              C.c_uint64, vp, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgl355.so and attach signatures.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libgl355.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C stark-verifier_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

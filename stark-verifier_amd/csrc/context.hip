@@ -1,0 +1,229 @@
+// Context, stream, scratch allocator, host/device buffer staging and cached tables of libgl355.
+#include "gl355_internal.h"
+
+namespace gl355 {
+
+int32_t Ctx::fail(int32_t code, const char* msg) {
+    err = msg ? msg : "";
+    return code;
+}
+int32_t Ctx::fail_hip(hipError_t e, const char* expr, const char* file, int line) {
+    err = std::string("HIP error '") + hipGetErrorString(e) + "' in " + expr + " at " + file + ":" + std::to_string(line);
+    if (e == hipErrorOutOfMemory) return GL355_E_OOM;
+    return GL355_E_HIP;
+}
+
+int32_t Ctx::alloc(size_t bytes, void** out) {
+    if (bytes == 0) bytes = 256;
+    bytes = (bytes + 255) & ~size_t(255);
+    // best fit among free cached blocks (at most 2x waste)
+    int best = -1;
+    for (size_t i = 0; i < blocks.size(); i++) {
+        if (!blocks[i].used && blocks[i].size >= bytes && blocks[i].size <= 2 * bytes + (1 << 20)) {
+            if (best < 0 || blocks[i].size < blocks[best].size) best = (int)i;
+        }
+    }
+    if (best >= 0) { blocks[best].used = true; *out = blocks[best].p; return GL355_OK; }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        (void)hipGetLastError();
+        for (auto it = blocks.begin(); it != blocks.end();) {
+            if (!it->used) { (void)hipFree(it->p); it = blocks.erase(it); } else ++it;
+        }
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail_hip(e, "hipMalloc(scratch)", __FILE__, __LINE__); }
+    }
+    blocks.push_back({p, bytes, true});
+    *out = p;
+    return GL355_OK;
+}
+void Ctx::release(void* p) {
+    for (auto& b : blocks)
+        if (b.p == p) { b.used = false; return; }
+}
+void Ctx::release_all() {
+    for (auto& b : blocks) (void)hipFree(b.p);
+    blocks.clear();
+}
+
+int32_t Ctx::pow_tables_multi(const std::vector<uint64_t>& bases, const uint64_t** lo, const uint64_t** hi) {
+    auto it = pow_cache.find(bases);
+    if (it != pow_cache.end()) { *lo = it->second.lo; *hi = it->second.hi; return GL355_OK; }
+    const size_t nb = bases.size();
+    std::vector<uint64_t> h(2 * nb * 4096);
+    for (size_t c = 0; c < nb; c++) {
+        uint64_t x = 1;
+        const uint64_t g = bases[c];
+        uint64_t* l = h.data() + c * 4096;
+        for (int j = 0; j < 4096; j++) { l[j] = gl_canon(x); x = gl_mul(x, g); }
+        const uint64_t g4096 = x;  // g^4096
+        uint64_t* hh = h.data() + (nb + c) * 4096;
+        uint64_t y = 1;
+        for (int j = 0; j < 4096; j++) { hh[j] = gl_canon(y); y = gl_mul(y, g4096); }
+    }
+    uint64_t* d = nullptr;
+    GL355_HIP(this, hipMalloc((void**)&d, h.size() * 8));
+    GL355_HIP(this, hipMemcpyAsync(d, h.data(), h.size() * 8, hipMemcpyHostToDevice, stream));
+    GL355_HIP(this, hipStreamSynchronize(stream));
+    PowTab t{d, d + nb * 4096};
+    pow_cache[bases] = t;
+    *lo = t.lo; *hi = t.hi;
+    return GL355_OK;
+}
+
+bool ptr_is_device(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+int32_t Staged::open(const void* ptr, size_t nbytes, int dir) {
+    user = const_cast<void*>(ptr);
+    bytes = nbytes;
+    if (!ptr || nbytes == 0) { dev = user; is_host = false; return GL355_OK; }
+    if (ptr_is_device(ptr)) { dev = user; is_host = false; return GL355_OK; }
+    is_host = true;
+    copy_back = (dir & 2) != 0;
+    GL355_TRY(ctx->alloc(nbytes, &dev));
+    if (dir & 1) GL355_HIP(ctx, hipMemcpyAsync(dev, ptr, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    return GL355_OK;
+}
+int32_t Staged::finish() {
+    if (is_host && copy_back) {
+        GL355_HIP(ctx, hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (is_host) GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GL355_OK;
+}
+
+static int32_t ctx_init(Ctx* c) {
+    GL355_HIP(c, hipSetDevice(c->device));
+    if (!c->external_stream) {
+        GL355_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    GL355_HIP(c, hipEventCreate(&c->ev0));
+    GL355_HIP(c, hipEventCreate(&c->ev1));
+    // omega_{2^14}^(+-e) tables for the in-tile twiddles
+    std::vector<uint64_t> h(2 * 16384);
+    const uint64_t w = gl_root_of_unity(14), wi = gl_inv(w);
+    uint64_t x = 1, y = 1;
+    for (int e = 0; e < 16384; e++) { h[e] = gl_canon(x); h[16384 + e] = gl_canon(y); x = gl_mul(x, w); y = gl_mul(y, wi); }
+    GL355_HIP(c, hipMalloc((void**)&c->tw_fwd, h.size() * 8));
+    c->tw_inv = c->tw_fwd + 16384;
+    GL355_HIP(c, hipMemcpyAsync(c->tw_fwd, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream));
+    GL355_HIP(c, hipStreamSynchronize(c->stream));
+    return ntt_init_constants(c);
+}
+
+}  // namespace gl355
+
+using namespace gl355;
+
+struct gl355_ctx {
+    Ctx c;
+};
+
+static std::string g_create_error;
+
+extern "C" {
+
+const char* gl355_version(void) { return "gl355 0.1 (gfx950)"; }
+
+int32_t gl355_device_count(int32_t* out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); *out = 0; return GL355_E_NO_DEVICE; }
+    *out = n;
+    return GL355_OK;
+}
+
+static int32_t create_common(int32_t device, void* stream, bool external, gl355_ctx** out) {
+    if (!out) return GL355_E_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); g_create_error = "no HIP device"; return GL355_E_NO_DEVICE; }
+    if (device < 0 || device >= n) { g_create_error = "device index out of range"; return GL355_E_INVALID_ARG; }
+    gl355_ctx* h = new (std::nothrow) gl355_ctx();
+    if (!h) return GL355_E_OOM;
+    h->c.device = device;
+    h->c.stream = reinterpret_cast<hipStream_t>(stream);
+    h->c.own_stream = false;
+    h->c.external_stream = external;
+    int32_t rc = ctx_init(&h->c);
+    if (rc != GL355_OK) { g_create_error = h->c.err; delete h; return rc; }
+    *out = h;
+    return GL355_OK;
+}
+int32_t gl355_ctx_create(int32_t device, gl355_ctx** out) { return create_common(device, nullptr, false, out); }
+// hip_stream may be NULL (the legacy default stream, which is what torch uses unless told otherwise)
+int32_t gl355_ctx_create_on_stream(int32_t device, void* hip_stream, gl355_ctx** out) {
+    return create_common(device, hip_stream, true, out);
+}
+int32_t gl355_ctx_destroy(gl355_ctx* ctx) {
+    if (!ctx) return GL355_OK;
+    Ctx& c = ctx->c;
+    (void)hipSetDevice(c.device);
+    (void)hipStreamSynchronize(c.stream);
+    c.release_all();
+    for (auto& kv : c.pow_cache) (void)hipFree(kv.second.lo);
+    if (c.tw_fwd) (void)hipFree(c.tw_fwd);
+    if (c.ev0) (void)hipEventDestroy(c.ev0);
+    if (c.ev1) (void)hipEventDestroy(c.ev1);
+    if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
+    delete ctx;
+    return GL355_OK;
+}
+int32_t gl355_ctx_sync(gl355_ctx* ctx) {
+    if (!ctx) return GL355_E_INVALID_ARG;
+    GL355_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    return GL355_OK;
+}
+const char* gl355_last_error(gl355_ctx* ctx) { return ctx ? ctx->c.err.c_str() : g_create_error.c_str(); }
+
+int32_t gl355_malloc(gl355_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return GL355_E_INVALID_ARG;
+    GL355_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 256);
+    if (e != hipSuccess) { (void)hipGetLastError(); return ctx->c.fail_hip(e, "hipMalloc", __FILE__, __LINE__); }
+    return GL355_OK;
+}
+int32_t gl355_free(gl355_ctx* ctx, void* dptr) {
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (dptr) { GL355_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream)); GL355_HIP(&ctx->c, hipFree(dptr)); }
+    return GL355_OK;
+}
+int32_t gl355_memcpy_h2d(gl355_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return GL355_E_INVALID_ARG;
+    GL355_HIP(&ctx->c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->c.stream));
+    GL355_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    return GL355_OK;
+}
+int32_t gl355_memcpy_d2h(gl355_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return GL355_E_INVALID_ARG;
+    GL355_HIP(&ctx->c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->c.stream));
+    GL355_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    return GL355_OK;
+}
+int32_t gl355_timer_start(gl355_ctx* ctx) {
+    if (!ctx) return GL355_E_INVALID_ARG;
+    GL355_HIP(&ctx->c, hipEventRecord(ctx->c.ev0, ctx->c.stream));
+    return GL355_OK;
+}
+int32_t gl355_timer_stop(gl355_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return GL355_E_INVALID_ARG;
+    GL355_HIP(&ctx->c, hipEventRecord(ctx->c.ev1, ctx->c.stream));
+    GL355_HIP(&ctx->c, hipEventSynchronize(ctx->c.ev1));
+    GL355_HIP(&ctx->c, hipEventElapsedTime(ms, ctx->c.ev0, ctx->c.ev1));
+    return GL355_OK;
+}
+
+}  // extern "C"
+
+namespace gl355 {
+Ctx* ctx_of(gl355_ctx* h) { return h ? &h->c : nullptr; }
+}

@@ -1,0 +1,161 @@
+// Internal C++ declarations shared by the HIP translation units of libgl355.  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gl355.h"
+#include "gl_field.cuh"
+
+namespace gl355 {
+
+struct Ctx;
+
+// evaluate a HIP call, record the error on the context and return GL355_E_HIP from the caller
+#define GL355_HIP(ctx, expr)                                                          \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) return (ctx)->fail_hip(_e, #expr, __FILE__, __LINE__);  \
+    } while (0)
+#define GL355_TRY(expr)          \
+    do {                         \
+        int32_t _rc = (expr);    \
+        if (_rc != GL355_OK) return _rc; \
+    } while (0)
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool external_stream = false;
+    std::string err;
+    uint64_t* tw_fwd = nullptr;  // omega_{2^14}^e, e < 2^14
+    uint64_t* tw_inv = nullptr;  // omega_{2^14}^-e
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // cached two-level power tables, keyed by the list of bases
+    struct PowTab { uint64_t* lo; uint64_t* hi; };
+    std::map<std::vector<uint64_t>, PowTab> pow_cache;
+
+    // trivial caching device allocator (per context => per stream, so reuse is stream-ordered)
+    struct Block { void* p; size_t size; bool used; };
+    std::vector<Block> blocks;
+
+    int32_t fail(int32_t code, const char* msg);
+    int32_t fail_hip(hipError_t e, const char* expr, const char* file, int line);
+    int32_t alloc(size_t bytes, void** out);
+    void release(void* p);
+    void release_all();
+    // lo[c*4096 + j] = bases[c]^j, hi[c*4096 + j] = bases[c]^(4096 j)
+    int32_t pow_tables_multi(const std::vector<uint64_t>& bases, const uint64_t** lo, const uint64_t** hi);
+    int32_t pow_tables(uint64_t base, const uint64_t** lo, const uint64_t** hi) {
+        return pow_tables_multi(std::vector<uint64_t>{gl_canon(base)}, lo, hi);
+    }
+};
+
+// RAII scratch buffer from the context allocator
+struct Scratch {
+    Ctx* ctx;
+    void* p = nullptr;
+    explicit Scratch(Ctx* c) : ctx(c) {}
+    ~Scratch() { if (p) ctx->release(p); }
+    int32_t get(size_t bytes) { return ctx->alloc(bytes, &p); }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+    Scratch(const Scratch&) = delete;
+    Scratch& operator=(const Scratch&) = delete;
+};
+
+// A caller buffer that may live on the host or on the device.  Host buffers are staged through a
+// scratch allocation (H2D before, D2H after); device buffers are used in place.
+struct Staged {
+    Ctx* ctx;
+    void* user = nullptr;
+    void* dev = nullptr;
+    size_t bytes = 0;
+    bool is_host = false, copy_back = false;
+    explicit Staged(Ctx* c) : ctx(c) {}
+    ~Staged() { if (is_host && dev) ctx->release(dev); }
+    // dir: bit0 = read by the kernels (copy in), bit1 = written (copy out at finish())
+    int32_t open(const void* ptr, size_t nbytes, int dir);
+    int32_t finish();  // enqueue D2H if needed, then sync
+    template <typename T> T* as() const { return reinterpret_cast<T*>(dev); }
+    Staged(const Staged&) = delete;
+    Staged& operator=(const Staged&) = delete;
+};
+bool ptr_is_device(const void* p);
+
+// ---- ntt.hip -------------------------------------------------------------------------------
+struct NttPlan {
+    const uint64_t* in = nullptr;
+    uint64_t* out = nullptr;
+    uint64_t in_col_stride = 0, out_col_stride = 0;
+    uint32_t log_n = 0, batch = 1;
+    bool inverse = false;      // use omega^-1 (no scaling unless `scale` says so)
+    bool in_bitrev = false;    // input is in bit-reversed order
+    bool out_bitrev = false;   // leave output in bit-reversed order
+    uint32_t n_cosets = 1;     // > 1: LDE-style, coset c reads tables c and writes slot coset_slot[c]
+    uint8_t coset_slot[16] = {0};
+    uint64_t coset_out_stride = 0;
+    const uint64_t* pre_lo = nullptr;  // multiplier tables on natural-order input index
+    const uint64_t* pre_hi = nullptr;
+    const uint64_t* post_lo = nullptr; // multiplier tables on natural-order output index
+    const uint64_t* post_hi = nullptr;
+    uint64_t scale = 1;
+};
+int32_t ntt_init_constants(Ctx* ctx);
+int32_t ntt_run(Ctx* ctx, const NttPlan& p);
+int32_t bitrev_permute(Ctx* ctx, const uint64_t* in, uint64_t* out, uint32_t log_n, uint32_t width,
+                       uint64_t in_col_stride, uint64_t out_col_stride, uint32_t batch);
+int32_t transpose_cols_to_rows(Ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t rows, uint32_t cols,
+                               uint64_t in_col_stride, uint32_t out_row_stride, uint32_t log_rows_brev);
+// device-resident building blocks used by the C ABI layer and the commit pipeline
+int32_t ntt_dev(Ctx* ctx, uint64_t* data, uint32_t log_n, uint32_t batch, uint64_t stride, bool inverse,
+                uint64_t coset_shift /* 0 = none */);
+int32_t lde_dev(Ctx* ctx, const uint64_t* coeffs, uint64_t in_stride, uint32_t log_n, uint32_t rate_bits,
+                uint64_t shift, uint32_t batch, uint64_t* out, uint64_t out_stride, bool out_bitrev);
+
+// ---- merkle.hip ----------------------------------------------------------------------------
+int32_t poseidon_permute_dev(Ctx* ctx, uint64_t* states, uint64_t count);
+// leaves: row-major [n][leaf_len] (row_stride = leaf_len) when col_major == false, else
+// column-major: element (leaf i, column c) at leaves[c * col_stride + i].
+int32_t hash_leaves_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, bool col_major,
+                        uint64_t col_stride, uint64_t* digests /* n_leaves * 4, linear order */);
+int32_t merkle_build_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, bool col_major,
+                         uint64_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap);
+int32_t hash_no_pad_dev(Ctx* ctx, const uint64_t* inputs, uint64_t n, uint32_t len, uint64_t* digests);
+int32_t two_to_one_dev(Ctx* ctx, const uint64_t* l, const uint64_t* r, uint64_t n, uint64_t* out);
+int32_t pow_grind_dev(Ctx* ctx, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t start,
+                      uint64_t* witness_host);
+
+// ---- fri.hip -------------------------------------------------------------------------------
+int32_t deep_batch_dev(Ctx* ctx, const uint64_t* const* poly_ptrs_host, uint32_t n_polys, uint32_t log_n,
+                       const uint64_t alpha[2], const uint64_t z[2], uint64_t* acc /* n ext */);
+int32_t eval_polys_ext_dev(Ctx* ctx, const uint64_t* const* poly_ptrs_host, uint32_t n_polys, uint32_t log_n,
+                           const uint64_t z[2], uint64_t* out_host_or_dev);
+int32_t fri_fold_dev(Ctx* ctx, const uint64_t* coeffs, uint64_t n, const uint64_t beta[2], uint64_t* out);
+int32_t fri_layer_leaves_dev(Ctx* ctx, const uint64_t* values, uint64_t n, uint64_t* leaves);
+int32_t lde_ext_dev(Ctx* ctx, const uint64_t* coeffs, uint32_t log_n, uint32_t rate_bits, uint64_t shift, uint64_t* out,
+                    bool out_bitrev);
+int32_t field_batch_dev(Ctx* ctx, int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n);
+int32_t zs_partial_products_dev(Ctx* ctx, const uint64_t* wires, const uint64_t* sigmas, const uint64_t* k_is,
+                                uint32_t log_n, uint32_t n_routed, uint32_t max_degree, uint64_t beta, uint64_t gamma,
+                                uint64_t* z_out, uint64_t* pp_out);
+int32_t canon_dev(Ctx* ctx, uint64_t* a, uint64_t n);
+int32_t intt_from_bitrev_dev(Ctx* ctx, const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t out_stride,
+                             uint32_t log_n, uint32_t batch, uint64_t coset_shift);
+Ctx* ctx_of(gl355_ctx* h);
+
+static inline uint32_t log2_u64(uint64_t n) { uint32_t l = 0; while ((1ull << l) < n) l++; return l; }
+static inline uint32_t host_brev(uint32_t x, uint32_t bits) {
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+
+}  // namespace gl355

@@ -1,0 +1,130 @@
+// Goldilocks field (p = 2^64 - 2^32 + 1) and its quadratic extension F_p[X]/(X^2 - 7) for gfx950.
+//
+// Replaces plonky2_field::goldilocks_field::GoldilocksField / QuadraticExtension, reached from the
+// reference at src/plonky2_semaphore/signal.rs:1,5; modulus pinned at
+// src/plonky2_verifier/chip/native_chip/arithmetic_chip.rs:19, non-residue W = 7 at :122-125.
+//
+// Representation: a field element is ANY uint64_t (values >= p are legal, "non-canonical"); every
+// routine accepts any u64 and returns some u64 congruent to the result.  gl_canon() maps to [0, p)
+// and is applied wherever a value leaves the device or is compared.
+//
+// gfx950 notes (tools/ubench/ubench_alu.hip, measured): v_mad_u64_u32 issues at half rate
+// (~4.9 cyc/wave), a carry-chained add_co/addc pair costs ~9 cyc while the single v_lshl_add_u64
+// costs ~4.6, so 64-bit adds are written as plain u64 arithmetic with compare-based carry detection.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GL_P 0xFFFFFFFF00000001ull
+#define GL_EPS 0xFFFFFFFFull  // 2^64 mod p
+
+#define GL_DEV __device__ __forceinline__
+#define GL_HD __host__ __device__ __forceinline__
+
+GL_HD uint64_t gl_canon(uint64_t a) { return a >= GL_P ? a - GL_P : a; }
+
+GL_HD uint64_t gl_add(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    if (s < a) {                 // true sum = s + 2^64 == s + EPS
+        s += GL_EPS;
+        if (s < GL_EPS) s += GL_EPS;
+    }
+    return s;
+}
+
+GL_HD uint64_t gl_sub(uint64_t a, uint64_t b) {
+    uint64_t d = a - b;
+    if (a < b) {                 // true diff = d - 2^64 == d - EPS
+        uint64_t e = d - GL_EPS;
+        if (d < GL_EPS) e -= GL_EPS;
+        d = e;
+    }
+    return d;
+}
+
+GL_HD uint64_t gl_neg(uint64_t a) { return gl_sub(0, a); }
+
+// (lo, hi) = hi*2^64 + lo  ->  lo - hi_hi + hi_lo*(2^32 - 1)      [2^64 = 2^32-1, 2^96 = -1 mod p]
+GL_HD uint64_t gl_reduce128(uint64_t lo, uint64_t hi) {
+    uint32_t hi_hi = (uint32_t)(hi >> 32), hi_lo = (uint32_t)hi;
+    uint64_t t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= GL_EPS;
+    uint64_t t1 = ((uint64_t)hi_lo << 32) - hi_lo;
+    uint64_t r = t0 + t1;
+    if (r < t1) r += GL_EPS;
+    return r;
+}
+
+GL_HD uint64_t gl_mul(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // four chained 32x32+64 multiply-adds (v_mad_u64_u32); no intermediate can overflow 64 bits
+    uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    uint64_t t = (uint64_t)a0 * b0;
+    uint64_t u = (uint64_t)a0 * b1 + (t >> 32);
+    uint64_t v = (uint64_t)a1 * b0 + (uint32_t)u;
+    uint64_t w = (uint64_t)a1 * b1 + (u >> 32) + (v >> 32);
+    uint64_t lo = (v << 32) | (uint32_t)t;
+    return gl_reduce128(lo, w);
+#else
+    unsigned __int128 pr = (unsigned __int128)a * b;
+    return gl_reduce128((uint64_t)pr, (uint64_t)(pr >> 64));
+#endif
+}
+
+GL_HD uint64_t gl_sqr(uint64_t a) { return gl_mul(a, a); }
+
+// a * c for a small constant c < 2^32 (MDS entries, W = 7, ...): two mads instead of four
+GL_HD uint64_t gl_mul_small(uint64_t a, uint32_t c) {
+    uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
+    uint64_t t = (uint64_t)a0 * c;
+    uint64_t u = (uint64_t)a1 * c + (t >> 32);   // < 2^64
+    uint64_t lo = (u << 32) | (uint32_t)t;
+    uint32_t hi = (uint32_t)(u >> 32);           // product = hi*2^64 + lo, hi < 2^32
+    uint64_t t1 = ((uint64_t)hi << 32) - hi;
+    uint64_t r = lo + t1;
+    if (r < t1) r += GL_EPS;
+    return r;
+}
+
+GL_HD uint64_t gl_pow(uint64_t a, uint64_t e) {
+    uint64_t r = 1;
+    while (e) {
+        if (e & 1) r = gl_mul(r, a);
+        a = gl_mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+GL_HD uint64_t gl_inv(uint64_t a) { return gl_pow(a, GL_P - 2); }
+
+// omega_N = 7^((p-1)/N): src/plonky2_verifier/chip/fri_chip.rs:162-163
+GL_HD uint64_t gl_root_of_unity(uint32_t log_n) { return gl_pow(7, (GL_P - 1) >> log_n); }
+
+// ---- quadratic extension, X^2 = 7 (arithmetic_chip.rs:109-132) -------------------------------
+struct gl2 {
+    uint64_t c0, c1;
+};
+GL_HD gl2 gl2_make(uint64_t a, uint64_t b) { gl2 r; r.c0 = a; r.c1 = b; return r; }
+GL_HD gl2 gl2_add(gl2 a, gl2 b) { return gl2_make(gl_add(a.c0, b.c0), gl_add(a.c1, b.c1)); }
+GL_HD gl2 gl2_sub(gl2 a, gl2 b) { return gl2_make(gl_sub(a.c0, b.c0), gl_sub(a.c1, b.c1)); }
+GL_HD gl2 gl2_mul(gl2 a, gl2 b) {
+    uint64_t c0 = gl_add(gl_mul(a.c0, b.c0), gl_mul_small(gl_mul(a.c1, b.c1), 7));
+    uint64_t c1 = gl_add(gl_mul(a.c0, b.c1), gl_mul(a.c1, b.c0));
+    return gl2_make(c0, c1);
+}
+GL_HD gl2 gl2_mul_base(gl2 a, uint64_t b) { return gl2_make(gl_mul(a.c0, b), gl_mul(a.c1, b)); }
+GL_HD gl2 gl2_canon(gl2 a) { return gl2_make(gl_canon(a.c0), gl_canon(a.c1)); }
+GL_HD gl2 gl2_inv(gl2 a) {
+    uint64_t norm = gl_sub(gl_mul(a.c0, a.c0), gl_mul_small(gl_mul(a.c1, a.c1), 7));
+    uint64_t ni = gl_inv(norm);
+    return gl2_make(gl_mul(a.c0, ni), gl_mul(gl_neg(a.c1), ni));
+}
+GL_HD gl2 gl2_pow(gl2 a, uint64_t e) {
+    gl2 r = gl2_make(1, 0);
+    while (e) {
+        if (e & 1) r = gl2_mul(r, a);
+        a = gl2_mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}

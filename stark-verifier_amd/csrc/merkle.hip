@@ -1,0 +1,224 @@
+// Poseidon sponge, Merkle tree with cap and proof-of-work grinding for gfx950 (a6, a7, a8, a13).
+//
+// Replaces plonky2::hash::hashing::{hash_n_to_m_no_pad, compress}, Hasher::{hash_or_noop,
+// two_to_one}, plonky2::hash::merkle_tree::{MerkleTree::new, fill_digests_buf, fill_subtree} and
+// plonky2::fri::prover::fri_proof_of_work; reached from the reference at
+// src/plonky2_semaphore/signal.rs:40, access_set.rs:67,205, recursion.rs:360 and inside every
+// PolynomialBatch commitment.  Semantics pinned by chip/hasher_chip.rs:122-148 (overwrite sponge,
+// rate 8), chip/merkle_proof_chip.rs:39-87 (leaf <= 4 elements is its own digest; bit k of the
+// index = 1 means "current node is the right child") and chip/fri_chip.rs:364-376 (PoW).
+//
+// Design: these kernels are integer-VALU bound (one permutation ~ 1.1 k 64-bit modmuls), not HBM
+// bound, so the layout goal is only "never waste a load": leaves are read straight from the
+// column-major LDE the NTT wrote (lane i reads element i of a column: perfectly coalesced; the
+// row-major transpose plonky2 performs is never materialised on the commit path), and the digests
+// are written directly into plonky2's recursive `digests` layout so no later shuffle is needed.
+#include "gl355_internal.h"
+#include "poseidon.cuh"
+
+namespace gl355 {
+
+// index of node k of layer `layer` (0 = leaf digests) inside one cap-subtree's digest buffer:
+// pair p = k>>1 of layer i sits at pair slot (p << (i+1)) + 2^i - 1 (MerkleTree::prove's formula).
+__host__ __device__ __forceinline__ uint64_t digest_slot(uint32_t layer, uint64_t k) {
+    return 2 * (((k >> 1) << (layer + 1)) + (1ull << layer) - 1) + (k & 1);
+}
+
+__global__ void __launch_bounds__(256) poseidon_permute_kernel(uint64_t* states, uint64_t count) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = states[i * 12 + k];
+    psd_permute(s);
+#pragma unroll
+    for (int k = 0; k < 12; k++) states[i * 12 + k] = gl_canon(s[k]);
+}
+
+struct LeafArgs {
+    const uint64_t* leaves;
+    uint64_t n_leaves;
+    uint32_t leaf_len;
+    uint32_t col_major;
+    uint64_t stride;        // col-major: elements between columns; row-major: elements between rows
+    uint64_t* out;          // digest destination
+    uint32_t sub_bits;      // log2(leaves per cap subtree); layout = subtree t at out + t*sub_dig*4
+    uint32_t linear;        // 1: out[i*4..] (no layout)
+    uint32_t always_hash;   // hash_no_pad semantics (no <=4 shortcut)
+    uint64_t* cap;          // used when sub_bits == 0 (tree is all cap)
+};
+
+// one lane = one leaf: overwrite-mode sponge over ceil(len/8) chunks
+__global__ void __launch_bounds__(256) hash_leaves_kernel(LeafArgs a) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= a.n_leaves) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = 0;
+    const uint32_t len = a.leaf_len;
+    uint64_t d[4];
+    if (len <= 4 && !a.always_hash) {
+        for (uint32_t k = 0; k < 4; k++) {
+            uint64_t v = 0;
+            if (k < len) v = a.col_major ? a.leaves[(uint64_t)k * a.stride + i] : a.leaves[i * a.stride + k];
+            d[k] = gl_canon(v);
+        }
+    } else {
+        for (uint32_t off = 0; off < len; off += 8) {
+            const uint32_t m = min(8u, len - off);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                if (k < m) s[k] = a.col_major ? a.leaves[(uint64_t)(off + k) * a.stride + i]
+                                              : a.leaves[i * a.stride + off + k];
+            }
+            psd_permute(s);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = gl_canon(s[k]);
+    }
+    uint64_t* dst;
+    if (a.linear) dst = a.out + i * 4;
+    else if (a.sub_bits == 0) dst = a.cap + i * 4;
+    else {
+        const uint64_t sub_leaves = 1ull << a.sub_bits;
+        const uint64_t t = i >> a.sub_bits, k = i & (sub_leaves - 1);
+        dst = a.out + (t * 2 * (sub_leaves - 1) + digest_slot(0, k)) * 4;
+    }
+    *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(d[0], d[1]);
+    *reinterpret_cast<ulonglong2*>(dst + 2) = make_ulonglong2(d[2], d[3]);
+}
+
+// one lane = one parent node of layer `layer` (>= 1): two_to_one of its children in layer-1
+__global__ void __launch_bounds__(256) merkle_level_kernel(uint64_t* digests, uint64_t* cap, uint32_t sub_bits,
+                                                          uint32_t layer, uint64_t n_nodes /* all subtrees */) {
+    const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (g >= n_nodes) return;
+    const uint64_t sub_leaves = 1ull << sub_bits;
+    const uint64_t per = sub_leaves >> layer;
+    const uint64_t t = g / per, k = g % per;
+    uint64_t* tree = digests + t * 2 * (sub_leaves - 1) * 4;
+    const uint64_t child = digest_slot(layer - 1, 2 * k);  // left child; right child is +1
+    const ulonglong2 l0 = *reinterpret_cast<const ulonglong2*>(tree + child * 4);
+    const ulonglong2 l1 = *reinterpret_cast<const ulonglong2*>(tree + child * 4 + 2);
+    const ulonglong2 r0 = *reinterpret_cast<const ulonglong2*>(tree + child * 4 + 4);
+    const ulonglong2 r1 = *reinterpret_cast<const ulonglong2*>(tree + child * 4 + 6);
+    uint64_t s[12] = {l0.x, l0.y, l1.x, l1.y, r0.x, r0.y, r1.x, r1.y, 0, 0, 0, 0};
+    psd_permute(s);
+    uint64_t* dst = (layer == sub_bits) ? cap + t * 4 : tree + digest_slot(layer, k) * 4;
+    *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(gl_canon(s[0]), gl_canon(s[1]));
+    *reinterpret_cast<ulonglong2*>(dst + 2) = make_ulonglong2(gl_canon(s[2]), gl_canon(s[3]));
+}
+
+__global__ void __launch_bounds__(256) two_to_one_kernel(const uint64_t* l, const uint64_t* r, uint64_t n, uint64_t* out) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s[12] = {l[4 * i], l[4 * i + 1], l[4 * i + 2], l[4 * i + 3],
+                      r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3], 0, 0, 0, 0};
+    psd_permute(s);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[4 * i + k] = gl_canon(s[k]);
+}
+
+// proof of work: candidates start + g; the smallest passing candidate of the launch wins (atomicMin)
+__global__ void __launch_bounds__(256) pow_grind_kernel(const uint64_t* state, uint32_t pos, uint32_t bits,
+                                                       uint64_t start, unsigned long long* best) {
+    const uint64_t w = start + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint64_t s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = state[k];
+#pragma unroll
+    for (int k = 0; k < 12; k++) if ((uint32_t)k == pos) s[k] = w;
+    psd_permute(s);
+    const uint64_t resp = gl_canon(s[7]);
+    if (bits == 0 || (resp >> (64 - bits)) == 0) atomicMin(best, (unsigned long long)w);
+}
+
+// ------------------------------------------------------------------------------------------------
+int32_t poseidon_permute_dev(Ctx* ctx, uint64_t* states, uint64_t count) {
+    if (count == 0) return GL355_OK;
+    hipLaunchKernelGGL(poseidon_permute_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, states, count);
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+
+static int32_t launch_leaves(Ctx* ctx, const LeafArgs& a) {
+    if (a.n_leaves == 0) return GL355_OK;
+    hipLaunchKernelGGL(hash_leaves_kernel, dim3((uint32_t)((a.n_leaves + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+
+int32_t hash_leaves_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, bool col_major,
+                        uint64_t col_stride, uint64_t* digests) {
+    LeafArgs a;
+    memset(&a, 0, sizeof a);
+    a.leaves = leaves; a.n_leaves = n_leaves; a.leaf_len = leaf_len; a.col_major = col_major;
+    a.stride = col_major ? col_stride : leaf_len;
+    a.out = digests; a.linear = 1;
+    return launch_leaves(ctx, a);
+}
+
+int32_t hash_no_pad_dev(Ctx* ctx, const uint64_t* inputs, uint64_t n, uint32_t len, uint64_t* digests) {
+    LeafArgs a;
+    memset(&a, 0, sizeof a);
+    a.leaves = inputs; a.n_leaves = n; a.leaf_len = len; a.col_major = 0; a.stride = len;
+    a.out = digests; a.linear = 1; a.always_hash = 1;
+    return launch_leaves(ctx, a);
+}
+
+int32_t two_to_one_dev(Ctx* ctx, const uint64_t* l, const uint64_t* r, uint64_t n, uint64_t* out) {
+    if (n == 0) return GL355_OK;
+    hipLaunchKernelGGL(two_to_one_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, l, r, n, out);
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+
+int32_t merkle_build_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, bool col_major,
+                         uint64_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap) {
+    const uint32_t log_n = log2_u64(n_leaves);
+    if ((1ull << log_n) != n_leaves) return ctx->fail(GL355_E_INVALID_ARG, "merkle: n_leaves must be a power of two");
+    if (cap_height > log_n) return ctx->fail(GL355_E_INVALID_ARG, "merkle: cap_height > log2(n_leaves)");
+    const uint32_t sub_bits = log_n - cap_height;
+    LeafArgs a;
+    memset(&a, 0, sizeof a);
+    a.leaves = leaves; a.n_leaves = n_leaves; a.leaf_len = leaf_len; a.col_major = col_major;
+    a.stride = col_major ? col_stride : leaf_len;
+    a.out = digests; a.cap = cap; a.sub_bits = sub_bits;
+    GL355_TRY(launch_leaves(ctx, a));
+    for (uint32_t layer = 1; layer <= sub_bits; layer++) {
+        const uint64_t n_nodes = n_leaves >> layer;
+        hipLaunchKernelGGL(merkle_level_kernel, dim3((uint32_t)((n_nodes + 255) / 256)), dim3(256), 0, ctx->stream,
+                           digests, cap, sub_bits, layer, n_nodes);
+        GL355_HIP(ctx, hipGetLastError());
+    }
+    return GL355_OK;
+}
+
+int32_t pow_grind_dev(Ctx* ctx, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t start,
+                      uint64_t* witness_host) {
+    if (pos >= 8) return ctx->fail(GL355_E_INVALID_ARG, "pow: witness position must be in the rate part");
+    if (bits > 40) return ctx->fail(GL355_E_UNSUPPORTED, "pow: more than 40 bits of grinding refused");
+    Scratch sc(ctx);
+    GL355_TRY(sc.get(13 * sizeof(uint64_t)));
+    uint64_t* d_state = sc.as<uint64_t>();
+    unsigned long long* d_best = reinterpret_cast<unsigned long long*>(d_state + 12);
+    uint64_t host[13];
+    for (int i = 0; i < 12; i++) host[i] = gl_canon(state[i]);
+    host[12] = ~0ull;
+    GL355_HIP(ctx, hipMemcpyAsync(d_state, host, sizeof host, hipMemcpyHostToDevice, ctx->stream));
+    // batches of 2^20 candidates until one launch contains a solution; within a launch the
+    // minimum wins, and earlier launches found nothing, so the result is the global minimum.
+    const uint64_t per_launch = 1ull << 20;
+    for (uint64_t base = start;; base += per_launch) {
+        hipLaunchKernelGGL(pow_grind_kernel, dim3((uint32_t)(per_launch / 256)), dim3(256), 0, ctx->stream, d_state, pos,
+                           bits, base, d_best);
+        GL355_HIP(ctx, hipGetLastError());
+        unsigned long long best;
+        GL355_HIP(ctx, hipMemcpyAsync(&best, d_best, sizeof best, hipMemcpyDeviceToHost, ctx->stream));
+        GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (best != ~0ull) { *witness_host = best; return GL355_OK; }
+        if (base - start > (1ull << 44)) return ctx->fail(GL355_E_UNSUPPORTED, "pow: no witness found in 2^44 candidates");
+    }
+}
+
+}  // namespace gl355

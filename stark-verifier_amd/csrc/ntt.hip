@@ -1,0 +1,499 @@
+// Batched radix-2 Goldilocks NTT / inverse NTT / coset NTT / LDE for gfx950 (a2, a3, a5 of SURVEY.md 8).
+//
+// Replaces plonky2_field::fft::{fft_with_options, ifft_with_options}, PolynomialCoeffs::{lde,
+// coset_fft_with_options}, PolynomialValues::{ifft, coset_ifft} and plonky2_util::{transpose,
+// reverse_index_bits_in_place}, reached from the reference inside CircuitBuilder::build /
+// CircuitData::prove (src/plonky2_semaphore/access_set.rs:91,94; recursion.rs:167-168).
+// Conventions pinned by the reference's verifier: omega_N = 7^((p-1)/N) (chip/fri_chip.rs:162-163),
+// coset generator 7 (chip/plonk/plonk_verifier_chip.rs:225-227), bit-reversed evaluation order
+// (chip/fri_chip.rs:245-264).
+//
+// Design (MI355X-first, not plonky2's layer-by-layer loop):
+//   * one workgroup owns a TILE of 2^LT elements (LT = 12..14) held in LDS (160 KiB/CU);
+//     each thread keeps 16 elements in VGPRs and runs radix-16 decimation-in-frequency rounds
+//     (4 butterfly layers per LDS round-trip), so a 2^12 tile needs 3 LDS exchanges, not 12;
+//   * sizes up to 2^14 are ONE pass over HBM; larger sizes use the 4-step split N = N1*N2:
+//     a "column" pass (tiles of N1 rows x TC adjacent columns, every global access a full
+//     TC*8-byte segment) and a "row" pass (contiguous rows), each a single read + single write;
+//   * DIF produces bit-reversed order for free, which is exactly the Merkle-leaf order the FRI
+//     commit wants, so the commit path never runs a separate permutation or transpose;
+//   * coset scaling, the 1/n of the inverse transform and the 4-step twiddles are fused into the
+//     load / store of the passes (two-level power tables: g^e = lo[e & 4095] * hi[e >> 12]);
+//   * the LDE runs the 2^rate_bits cosets as independent size-n transforms (the first rate_bits
+//     layers of the zero-padded size-N transform are trivial); coset c's output is the contiguous
+//     block bitrev(c) of the bit-reversed result, and workgroup id % n_cosets selects the coset so
+//     that with 8 cosets each XCD's L2 keeps exactly one coset's power table.
+#include "gl355_internal.h"
+
+namespace gl355 {
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+GL_DEV uint32_t brev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+// LDS index padding: one extra element every 16 keeps the stride-16 / stride-256 register rounds
+// conflict-free for ds_read_b64 (NTT section)
+GL_DEV uint32_t lds_phys(uint32_t idx) { return idx + (idx >> 4); }
+
+// g^e from a two-level table: lo[j] = g^j (j < 4096), hi[j] = g^(4096 j)
+GL_DEV uint64_t pow2lvl(const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi, uint64_t e) {
+    uint64_t v = lo[e & 4095];
+    if (hi) v = gl_mul(v, hi[e >> 12]);
+    return v;
+}
+
+// omega_16^j for the in-register radix-16 butterflies (forward / inverse), filled at ctx creation
+__constant__ uint64_t c_w16[2][8];
+
+// In-register DIF butterfly network on 2^RHO values: x[pos] <- X[bitrev(pos)].
+template <int RHO, bool INV>
+GL_DEV void dif_regs(uint64_t (&x)[16]) {
+#pragma unroll
+    for (int s = 0; s < RHO; s++) {
+        const int half = 1 << (RHO - 1 - s);
+#pragma unroll
+        for (int blk = 0; blk < (1 << s); blk++) {
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                const int i0 = blk * 2 * half + j, i1 = i0 + half;
+                uint64_t a = x[i0], b = x[i1];
+                x[i0] = gl_add(a, b);
+                uint64_t d = gl_sub(a, b);
+                // twiddle omega_{2*half}^j = omega_16^(j * 8 / half)
+                const int e = j * (8 / half);
+                x[i1] = (e == 0) ? d : gl_mul(d, c_w16[INV ? 1 : 0][e]);
+            }
+        }
+    }
+}
+
+// One DIF round of radix 2^RHO on an LDS tile.  The transform currently consists of independent
+// blocks of 2^m (transform units); transform bit 0 sits at tile-index bit LO.  `tw` holds
+// omega_{2^14}^e (forward or inverse) for e < 2^14.
+template <int LT, int RHO, bool INV>
+GL_DEV void dif_round(uint64_t* lds, const uint64_t* __restrict__ tw, int m, int LO, int tid, int nthreads) {
+    constexpr int R = 1 << RHO;
+    const int tasks = (1 << LT) >> RHO;
+    const int fbit = LO + m - RHO;  // lowest tile-index bit of the radix field
+    for (int t = tid; t < tasks; t += nthreads) {
+        const uint32_t low = t & ((1u << fbit) - 1), high = t >> fbit;
+        const uint32_t idx0 = (high << (fbit + RHO)) | low;
+        uint64_t x[16];
+#pragma unroll
+        for (int q = 0; q < R; q++) x[q] = lds[lds_phys(idx0 + ((uint32_t)q << fbit))];
+        dif_regs<RHO, INV>(x);
+        if (m > RHO) {
+            // output k0 = bitrev(q) of this butterfly is multiplied by omega_{2^m}^(r*k0)
+            const uint32_t r = (idx0 >> LO) & ((1u << (m - RHO)) - 1);
+#pragma unroll
+            for (int q = 1; q < R; q++) {
+                const uint32_t k0 = brev(q, RHO);
+                const uint32_t e = (r * k0) << (14 - m);
+                x[q] = gl_mul(x[q], tw[e]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; q++) lds[lds_phys(idx0 + ((uint32_t)q << fbit))] = x[q];
+    }
+}
+
+// all rounds for LOG_T transform bits starting at tile bit LO
+template <int LT, int LOG_T, bool INV>
+GL_DEV void dif_tile(uint64_t* lds, const uint64_t* __restrict__ tw, int LO, int tid, int nthreads) {
+    int m = LOG_T;
+#pragma unroll
+    for (int round = 0; round < LOG_T / 4; round++) {
+        dif_round<LT, 4, INV>(lds, tw, m, LO, tid, nthreads);
+        m -= 4;
+        __syncthreads();
+    }
+    constexpr int REM = LOG_T % 4;
+    if constexpr (REM == 3) dif_round<LT, 3, INV>(lds, tw, 3, LO, tid, nthreads);
+    if constexpr (REM == 2) dif_round<LT, 2, INV>(lds, tw, 2, LO, tid, nthreads);
+    if constexpr (REM == 1) dif_round<LT, 1, INV>(lds, tw, 1, LO, tid, nthreads);
+    if constexpr (REM != 0) __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass kernels
+// ------------------------------------------------------------------------------------------------
+struct PassArgs {
+    const uint64_t* in;
+    uint64_t* out;
+    uint64_t in_col_stride;    // elements between polynomial columns (input)
+    uint64_t out_col_stride;   // elements between polynomial columns (output)
+    uint32_t batch;            // polynomial columns
+    uint32_t n_cosets;         // independent (table, output-offset) variants per column (LDE); >= 1
+    uint64_t coset_out_stride; // output offset of coset c = coset_slot[c] * coset_out_stride
+    uint8_t coset_slot[16];
+    uint32_t log_n;            // log2 of the whole transform (per column, per coset)
+    uint32_t log_rows;         // row kernel: rows per column = 2^log_rows; col kernel: log2(N2)
+    const uint64_t* tw;        // omega_{2^14}^(+-e), e < 2^14
+    const uint64_t* pre_lo;    // optional multiplier g^i on natural-order INPUT index i
+    const uint64_t* pre_hi;    //   tables of coset c at pre_lo + c*4096, pre_hi + c*4096
+    const uint64_t* post_lo;   // optional multiplier on natural-order OUTPUT index
+    const uint64_t* post_hi;
+    const uint64_t* step_lo;   // 4-step twiddle omega_N^(+-e): lo/hi tables (col kernel only)
+    const uint64_t* step_hi;
+    uint64_t scale;            // constant multiplier at store (1 = none)
+    uint32_t in_bitrev;        // input transform index is bit-reversed in memory
+    uint32_t out_natural;      // write natural order (else DIF-native bit-reversed order)
+    uint32_t canon;            // canonicalise at store (last pass)
+};
+
+// Row pass: each row = 2^LOG_T contiguous elements; a tile packs 2^(LT-LOG_T) rows.
+template <int LT, int LOG_T, bool INV>
+__global__ void __launch_bounds__(1 << (LT - 4)) ntt_rows_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    constexpr int NT = 1 << (LT - 4);
+    constexpr int RPT = 1 << (LT - LOG_T);  // rows per tile
+    const int tid = threadIdx.x;
+    const uint32_t coset = blockIdx.x % a.n_cosets;
+    const uint64_t tile = blockIdx.x / a.n_cosets;
+    const uint64_t row0 = tile * RPT;  // global row id over (column, row-in-column)
+    const uint64_t rows_per_col = 1ull << a.log_rows;
+    const uint64_t total_rows = rows_per_col * a.batch;
+    const uint64_t* pre_lo = a.pre_lo ? a.pre_lo + (uint64_t)coset * 4096 : nullptr;
+    const uint64_t* pre_hi = (a.pre_lo && a.pre_hi) ? a.pre_hi + (uint64_t)coset * 4096 : nullptr;
+
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t g = tid + i * NT;
+        const uint32_t lr = g >> LOG_T, e = g & ((1u << LOG_T) - 1);
+        const uint64_t row = row0 + lr;
+        uint64_t v = 0;
+        if (row < total_rows) {
+            const uint64_t col = row >> a.log_rows, rin = row & (rows_per_col - 1);
+            v = a.in[col * a.in_col_stride + (rin << LOG_T) + e];
+            if (pre_lo) v = gl_mul(v, pow2lvl(pre_lo, pre_hi, (rin << LOG_T) + e));
+        }
+        const uint32_t le = a.in_bitrev ? brev(e, LOG_T) : e;
+        lds[lds_phys((lr << LOG_T) | le)] = v;
+    }
+    __syncthreads();
+    dif_tile<LT, LOG_T, INV>(lds, a.tw, 0, tid, NT);
+    const uint64_t out_base = (uint64_t)a.coset_slot[coset] * a.coset_out_stride;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t g = tid + i * NT;
+        const uint32_t lr = g >> LOG_T, e = g & ((1u << LOG_T) - 1);
+        const uint64_t row = row0 + lr;
+        if (row < total_rows) {
+            const uint64_t col = row >> a.log_rows, rin = row & (rows_per_col - 1);
+            const uint32_t le = a.out_natural ? brev(e, LOG_T) : e;
+            uint64_t v = lds[lds_phys((lr << LOG_T) | le)];
+            if (a.post_lo) v = gl_mul(v, pow2lvl(a.post_lo, a.post_hi, (rin << LOG_T) + e));
+            if (a.scale != 1) v = gl_mul(v, a.scale);
+            if (a.canon) v = gl_canon(v);
+            a.out[out_base + col * a.out_col_stride + (rin << LOG_T) + e] = v;
+        }
+    }
+}
+
+// Column pass: transform over the row index of an [2^LOG_T][N2] matrix (N2 = 2^log_rows... here
+// a.log_rows holds log2(N2)); a tile is all 2^LOG_T rows x TC = 2^(12-LOG_T) adjacent columns.
+template <int LOG_T, bool INV>
+__global__ void __launch_bounds__(256) ntt_cols_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    constexpr int LT = 12, NT = 256;
+    constexpr int LOG_TC = LT - LOG_T, TC = 1 << LOG_TC;
+    const int tid = threadIdx.x;
+    const uint32_t log_n2 = a.log_rows;
+    const uint64_t n2 = 1ull << log_n2;
+    const uint32_t coset = blockIdx.x % a.n_cosets;
+    const uint64_t tile = blockIdx.x / a.n_cosets;
+    const uint64_t tiles_per_col = n2 >> LOG_TC;
+    const uint64_t col = tile / tiles_per_col;
+    const uint64_t c0 = (tile % tiles_per_col) << LOG_TC;  // first matrix column of the tile
+    const uint64_t* in = a.in + col * a.in_col_stride;
+    uint64_t* out = a.out + (uint64_t)a.coset_slot[coset] * a.coset_out_stride + col * a.out_col_stride;
+    const uint64_t* pre_lo = a.pre_lo ? a.pre_lo + (uint64_t)coset * 4096 : nullptr;
+    const uint64_t* pre_hi = (a.pre_lo && a.pre_hi) ? a.pre_hi + (uint64_t)coset * 4096 : nullptr;
+    const bool step_at_load = a.in_bitrev != 0;  // second pass of the bitrev -> natural flow
+
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t g = tid + i * NT;
+        const uint32_t r = g >> LOG_TC, cc = g & (TC - 1);
+        const uint64_t gi = ((uint64_t)r << log_n2) + c0 + cc;
+        uint64_t v = in[gi];
+        const uint32_t lr = a.in_bitrev ? brev(r, LOG_T) : r;  // logical transform index
+        if (pre_lo) v = gl_mul(v, pow2lvl(pre_lo, pre_hi, gi));
+        if (step_at_load && a.step_lo) v = gl_mul(v, pow2lvl(a.step_lo, a.step_hi, (uint64_t)lr * (c0 + cc)));
+        lds[lds_phys((lr << LOG_TC) | cc)] = v;
+    }
+    __syncthreads();
+    dif_tile<LT, LOG_T, INV>(lds, a.tw, LOG_TC, tid, NT);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t g = tid + i * NT;
+        const uint32_t r = g >> LOG_TC, cc = g & (TC - 1);
+        const uint32_t lr = a.out_natural ? brev(r, LOG_T) : r;  // LDS row holding output row r
+        uint64_t v = lds[lds_phys((lr << LOG_TC) | cc)];
+        const uint64_t go = ((uint64_t)r << log_n2) + c0 + cc;
+        if (!step_at_load && a.step_lo) {
+            const uint32_t k1 = a.out_natural ? r : brev(r, LOG_T);  // transform output index
+            v = gl_mul(v, pow2lvl(a.step_lo, a.step_hi, (uint64_t)k1 * (c0 + cc)));
+        }
+        if (a.post_lo) v = gl_mul(v, pow2lvl(a.post_lo, a.post_hi, go));
+        if (a.scale != 1) v = gl_mul(v, a.scale);
+        if (a.canon) v = gl_canon(v);
+        out[go] = v;
+    }
+}
+
+// out[c][i] = in[c][bitrev(i)] over 2^log_n entries of `width` u64 each (a5:
+// reverse_index_bits_in_place; out-of-place, or in place via swap when in == out).
+__global__ void bitrev_permute_kernel(const uint64_t* in, uint64_t* out, uint32_t log_n, uint32_t width,
+                                      uint64_t in_col_stride, uint64_t out_col_stride, uint32_t batch) {
+    const uint64_t n = 1ull << log_n;
+    const uint64_t total = n * batch;
+    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < total;
+         g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t col = g >> log_n, i = g & (n - 1);
+        const uint64_t j = brev((uint32_t)i, log_n);
+        if (in == out) {
+            if (i < j) {
+                for (uint32_t w = 0; w < width; w++) {
+                    uint64_t* pa = out + col * out_col_stride + i * width + w;
+                    uint64_t* pb = out + col * out_col_stride + j * width + w;
+                    uint64_t ta = *pa, tb = *pb;
+                    *pa = tb; *pb = ta;
+                }
+            }
+        } else {
+            for (uint32_t w = 0; w < width; w++)
+                out[col * out_col_stride + i * width + w] = in[col * in_col_stride + j * width + w];
+        }
+    }
+}
+
+// out[r][c] = in[c][perm(r)] : column-major [cols][rows] -> row-major [rows][cols], optionally
+// reading row bitrev(r) (a5: transpose; used to export plonky2-layout leaves).  32x32 LDS tiles.
+__global__ void transpose_kernel(const uint64_t* in, uint64_t* out, uint64_t rows, uint32_t cols,
+                                 uint64_t in_col_stride, uint32_t out_row_stride, uint32_t log_rows_brev) {
+    __shared__ uint64_t tile[32][33];
+    const uint64_t r0 = (uint64_t)blockIdx.x * 32;
+    const uint32_t c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const uint32_t c = c0 + k;
+        const uint64_t r = r0 + tx;
+        if (c < cols && r < rows) {
+            const uint64_t rr = log_rows_brev ? brev((uint32_t)r, log_rows_brev) : r;
+            tile[k][tx] = in[(uint64_t)c * in_col_stride + rr];
+        }
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const uint64_t r = r0 + k;
+        const uint32_t c = c0 + tx;
+        if (c < cols && r < rows) out[r * out_row_stride + c] = tile[tx][k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int LT, int LOG_T>
+static hipError_t launch_rows_lt(const PassArgs& a, bool inv, uint64_t blocks, hipStream_t s) {
+    const size_t shmem = ((1u << LT) + (1u << (LT - 4))) * sizeof(uint64_t);
+    constexpr int NT = 1 << (LT - 4);
+    if (inv) {
+        auto k = ntt_rows_kernel<LT, LOG_T, true>;
+        if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
+    } else {
+        auto k = ntt_rows_kernel<LT, LOG_T, false>;
+        if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
+    }
+    return hipGetLastError();
+}
+
+static hipError_t launch_rows(const PassArgs& a, uint32_t log_t, bool inv, hipStream_t s) {
+    const uint64_t total_rows = ((uint64_t)a.batch) << a.log_rows;
+    const int lt = log_t <= 12 ? 12 : (int)log_t;
+    const uint64_t rpt = 1ull << (lt - log_t);
+    const uint64_t blocks = ((total_rows + rpt - 1) / rpt) * a.n_cosets;
+    switch (log_t) {
+#define GL355_ROW_CASE(L) case L: return launch_rows_lt<12, L>(a, inv, blocks, s);
+        GL355_ROW_CASE(1) GL355_ROW_CASE(2) GL355_ROW_CASE(3) GL355_ROW_CASE(4) GL355_ROW_CASE(5)
+        GL355_ROW_CASE(6) GL355_ROW_CASE(7) GL355_ROW_CASE(8) GL355_ROW_CASE(9) GL355_ROW_CASE(10)
+        GL355_ROW_CASE(11) GL355_ROW_CASE(12)
+#undef GL355_ROW_CASE
+        case 13: return launch_rows_lt<13, 13>(a, inv, blocks, s);
+        case 14: return launch_rows_lt<14, 14>(a, inv, blocks, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int LOG_T>
+static hipError_t launch_cols_t(const PassArgs& a, bool inv, uint64_t blocks, hipStream_t s) {
+    const size_t shmem = (4096 + 256) * sizeof(uint64_t);
+    if (inv) hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, true>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
+    else hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, false>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
+    return hipGetLastError();
+}
+
+static hipError_t launch_cols(const PassArgs& a, uint32_t log_t, bool inv, hipStream_t s) {
+    const uint64_t n2 = 1ull << a.log_rows;
+    const uint64_t tc = 1ull << (12 - log_t);
+    const uint64_t blocks = (n2 / tc) * a.batch * a.n_cosets;
+    switch (log_t) {
+#define GL355_COL_CASE(L) case L: return launch_cols_t<L>(a, inv, blocks, s);
+        GL355_COL_CASE(1) GL355_COL_CASE(2) GL355_COL_CASE(3) GL355_COL_CASE(4) GL355_COL_CASE(5)
+        GL355_COL_CASE(6) GL355_COL_CASE(7) GL355_COL_CASE(8) GL355_COL_CASE(9) GL355_COL_CASE(10)
+        GL355_COL_CASE(11) GL355_COL_CASE(12)
+#undef GL355_COL_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// Split of a two-pass transform: N = N1 * N2, first-pass dimension N1 (columns kernel in the
+// natural->bitrev flow, rows kernel in the bitrev->natural flow).
+static void split_two_pass(uint32_t log_n, bool natural_in, uint32_t* log_n1, uint32_t* log_n2) {
+    if (natural_in) {  // cols over N1 (<= 2^12, prefers >= 16 cols per tile), rows over N2 <= 2^12
+        uint32_t l2 = 12;
+        uint32_t l1 = log_n - l2;
+        *log_n1 = l1; *log_n2 = l2;
+    } else {           // rows over N1 (contiguous, <= 2^12), then cols over N2 (<= 2^12)
+        uint32_t l1 = 12;
+        uint32_t l2 = log_n - l1;
+        *log_n1 = l1; *log_n2 = l2;
+    }
+}
+
+int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
+    if (p.log_n == 0) {
+        if (p.in != p.out) GL355_HIP(ctx, hipMemcpyAsync(p.out, p.in, sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+        return GL355_OK;
+    }
+    if (p.log_n > 24) return ctx->fail(GL355_E_UNSUPPORTED, "ntt: log_n > 24 unsupported");
+    if (p.n_cosets > 16 || p.n_cosets == 0) return ctx->fail(GL355_E_INVALID_ARG, "ntt: bad coset count");
+    const bool inv = p.inverse;
+    PassArgs a;
+    memset(&a, 0, sizeof a);
+    a.batch = p.batch;
+    a.n_cosets = p.n_cosets;
+    a.coset_out_stride = p.coset_out_stride;
+    for (uint32_t c = 0; c < 16; c++) a.coset_slot[c] = c < p.n_cosets ? p.coset_slot[c] : 0;
+    a.log_n = p.log_n;
+    a.tw = inv ? ctx->tw_inv : ctx->tw_fwd;
+    a.scale = 1;
+
+    if (p.log_n <= 14) {
+        // single pass over HBM
+        a.in = p.in; a.out = p.out;
+        a.in_col_stride = p.in_col_stride; a.out_col_stride = p.out_col_stride;
+        a.log_rows = 0;
+        a.pre_lo = p.pre_lo; a.pre_hi = p.log_n > 12 ? p.pre_hi : nullptr;
+        a.post_lo = p.post_lo; a.post_hi = p.log_n > 12 ? p.post_hi : nullptr;
+        a.scale = p.scale;
+        a.in_bitrev = p.in_bitrev; a.out_natural = p.out_bitrev ? 0 : 1;
+        a.canon = 1;
+        GL355_HIP(ctx, launch_rows(a, p.log_n, inv, ctx->stream));
+        return GL355_OK;
+    }
+
+    // two passes; 4-step twiddle omega_N^(+-e) tables
+    const uint64_t* step_lo; const uint64_t* step_hi;
+    int32_t rc = ctx->pow_tables(inv ? gl_inv(gl_root_of_unity(p.log_n)) : gl_root_of_unity(p.log_n), &step_lo, &step_hi);
+    if (rc) return rc;
+    uint32_t l1, l2;
+    if (!p.in_bitrev) {
+        // natural in -> (cols over N1, twiddle at store) -> (rows over N2) -> bit-reversed out
+        split_two_pass(p.log_n, true, &l1, &l2);
+        a.in = p.in; a.out = p.out;
+        a.in_col_stride = p.in_col_stride; a.out_col_stride = p.out_col_stride;
+        a.log_rows = l2;  // log2(N2): row stride of the N1 x N2 matrix
+        a.pre_lo = p.pre_lo; a.pre_hi = p.pre_hi;
+        a.step_lo = step_lo; a.step_hi = step_hi;
+        a.in_bitrev = 0; a.out_natural = 0; a.canon = 0;
+        GL355_HIP(ctx, launch_cols(a, l1, inv, ctx->stream));
+        PassArgs b = a;
+        b.in = p.out; b.in_col_stride = p.out_col_stride;
+        // each coset's intermediate lives in its own output block: rows pass runs per coset slot
+        b.pre_lo = b.pre_hi = nullptr; b.step_lo = b.step_hi = nullptr;
+        b.log_rows = l1;  // rows per column = N1
+        b.scale = p.scale; b.canon = 1;
+        if (p.n_cosets == 1) {
+            b.in = p.out + (uint64_t)a.coset_slot[0] * a.coset_out_stride;
+            GL355_HIP(ctx, launch_rows(b, l2, inv, ctx->stream));
+        } else {
+            // the coset blocks are contiguous sub-ranges of every output column: treat (column,
+            // coset) pairs as 2^(l1) * n_cosets rows per column -- requires the blocks to tile the
+            // column, which is how the LDE lays them out (coset_out_stride == n).
+            if (p.coset_out_stride != (1ull << p.log_n))
+                return ctx->fail(GL355_E_INVALID_ARG, "ntt: multi-coset two-pass needs contiguous coset blocks");
+            uint32_t lc = 0;
+            while ((1u << lc) < p.n_cosets) lc++;
+            b.n_cosets = 1; b.coset_slot[0] = 0; b.coset_out_stride = 0;
+            b.log_rows = l1 + lc;
+            GL355_HIP(ctx, launch_rows(b, l2, inv, ctx->stream));
+        }
+        if (!p.out_bitrev) {
+            // natural order requested: one extra permutation pass (not used on the commit path)
+            const uint64_t total = ((uint64_t)p.batch * p.n_cosets) << p.log_n;
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 16);
+            if (p.n_cosets != 1) return ctx->fail(GL355_E_UNSUPPORTED, "ntt: natural-order multi-coset output is done by the caller");
+            hipLaunchKernelGGL(bitrev_permute_kernel, dim3(blocks), dim3(256), 0, ctx->stream, p.out, p.out,
+                               p.log_n, 1u, p.out_col_stride, p.out_col_stride, p.batch);
+            GL355_HIP(ctx, hipGetLastError());
+        }
+        if (p.post_lo) return ctx->fail(GL355_E_UNSUPPORTED, "ntt: post-multiplier needs natural-order output from the bitrev-input flow");
+        return GL355_OK;
+    }
+    // bit-reversed in -> (rows over N1, natural within row) -> (cols over N2, twiddle at load) -> natural out
+    if (p.n_cosets != 1) return ctx->fail(GL355_E_UNSUPPORTED, "ntt: bitrev-input flow is single-coset");
+    if (p.out_bitrev) return ctx->fail(GL355_E_UNSUPPORTED, "ntt: bitrev -> bitrev not provided");
+    split_two_pass(p.log_n, false, &l1, &l2);
+    a.in = p.in; a.out = p.out;
+    a.in_col_stride = p.in_col_stride; a.out_col_stride = p.out_col_stride;
+    a.log_rows = l2;  // rows per column = N2 (row index = bitrev(i2))
+    a.in_bitrev = 1; a.out_natural = 1; a.canon = 0;
+    GL355_HIP(ctx, launch_rows(a, l1, inv, ctx->stream));
+    PassArgs b = a;
+    b.in = p.out; b.in_col_stride = p.out_col_stride;
+    b.log_rows = l1;  // matrix is [N2 rows][N1 columns]
+    b.step_lo = step_lo; b.step_hi = step_hi;
+    b.post_lo = p.post_lo; b.post_hi = p.post_hi;
+    b.scale = p.scale; b.canon = 1;
+    b.in_bitrev = 1; b.out_natural = 1;
+    GL355_HIP(ctx, launch_cols(b, l2, inv, ctx->stream));
+    return GL355_OK;
+}
+
+int32_t bitrev_permute(Ctx* ctx, const uint64_t* in, uint64_t* out, uint32_t log_n, uint32_t width,
+                       uint64_t in_col_stride, uint64_t out_col_stride, uint32_t batch) {
+    const uint64_t total = ((uint64_t)batch) << log_n;
+    if (total == 0) return GL355_OK;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(bitrev_permute_kernel, dim3(blocks), dim3(256), 0, ctx->stream, in, out, log_n, width,
+                       in_col_stride, out_col_stride, batch);
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+
+int32_t transpose_cols_to_rows(Ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t rows, uint32_t cols,
+                               uint64_t in_col_stride, uint32_t out_row_stride, uint32_t log_rows_brev) {
+    if (rows == 0 || cols == 0) return GL355_OK;
+    dim3 grid((uint32_t)((rows + 31) / 32), (cols + 31) / 32);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, in, out, rows, cols, in_col_stride,
+                       out_row_stride, log_rows_brev);
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+
+int32_t ntt_init_constants(Ctx* ctx) {
+    uint64_t w16[2][8];
+    const uint64_t w = gl_root_of_unity(4), wi = gl_inv(w);
+    uint64_t x = 1, y = 1;
+    for (int j = 0; j < 8; j++) { w16[0][j] = gl_canon(x); w16[1][j] = gl_canon(y); x = gl_mul(x, w); y = gl_mul(y, wi); }
+    GL355_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_w16), w16, sizeof w16, 0, hipMemcpyHostToDevice, ctx->stream));
+    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GL355_OK;
+}
+
+}  // namespace gl355

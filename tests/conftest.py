@@ -1,0 +1,31 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle_lib import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def gl():
+    return importlib.import_module("stark-verifier_amd")
+
+
+@pytest.fixture(scope="session")
+def ctx(gl):
+    c = gl.Context(0)
+    yield c
+    c.close()

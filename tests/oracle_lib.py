@@ -1,0 +1,232 @@
+"""ctypes wrapper around oracle/libgl_oracle.so (the CPU restatement; test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libgl_oracle.so")
+P = (1 << 64) - (1 << 32) + 1
+u64p = C.POINTER(C.c_uint64)
+
+
+def _p(a):
+    return a.ctypes.data_as(u64p)
+
+
+def u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class Challenger(C.Structure):
+    _fields_ = [("state", C.c_uint64 * 12), ("in_buf", C.c_uint64 * 8), ("in_len", C.c_uint32),
+                ("out_buf", C.c_uint64 * 8), ("out_len", C.c_uint32)]
+
+
+class Oracle:
+    def __init__(self):
+        if not os.path.exists(LIB):
+            subprocess.check_call(["make", "-C", ORACLE_DIR])
+        L = self.L = C.CDLL(LIB)
+        for name in ("orc_add", "orc_sub", "orc_mul", "orc_mul_ref", "orc_pow"):
+            getattr(L, name).restype = C.c_uint64
+            getattr(L, name).argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_inv.restype = C.c_uint64
+        L.orc_inv.argtypes = [C.c_uint64]
+        L.orc_root_of_unity.restype = C.c_uint64
+        L.orc_root_of_unity.argtypes = [C.c_uint32]
+        L.orc_pow_grind.restype = C.c_uint64
+        L.orc_pow_grind.argtypes = [u64p, C.c_uint32, C.c_uint32, C.c_uint64]
+        L.orc_challenger_squeeze.restype = C.c_uint64
+        L.orc_merkle_verify.restype = C.c_int
+        L.orc_num_threads.restype = C.c_int
+
+    # field
+    def add(self, a, b): return self.L.orc_add(a, b)
+    def sub(self, a, b): return self.L.orc_sub(a, b)
+    def mul(self, a, b): return self.L.orc_mul(a, b)
+    def mul_ref(self, a, b): return self.L.orc_mul_ref(a, b)
+    def pow(self, a, e): return self.L.orc_pow(a, e)
+    def inv(self, a): return self.L.orc_inv(a)
+    def root_of_unity(self, log_n): return self.L.orc_root_of_unity(log_n)
+
+    def ext_mul(self, a, b):
+        a, b, o = u64(a), u64(b), np.zeros(2, np.uint64)
+        self.L.orc_ext_mul(_p(a), _p(b), _p(o))
+        return o
+
+    def ext_inv(self, a):
+        a, o = u64(a), np.zeros(2, np.uint64)
+        self.L.orc_ext_inv(_p(a), _p(o))
+        return o
+
+    # ntt
+    def _cols(self, data):
+        d = u64(data).copy()
+        d2 = d.reshape(1, -1) if d.ndim == 1 else d
+        return d, d2, d2.shape[0], d2.shape[1], int(d2.shape[1]).bit_length() - 1
+
+    def ntt(self, data, inverse=False, shift=None):
+        d, d2, batch, n, lg = self._cols(data)
+        if shift is None:
+            (self.L.orc_intt if inverse else self.L.orc_ntt)(_p(d2), C.c_uint32(lg), C.c_uint32(batch), C.c_size_t(n))
+        else:
+            (self.L.orc_coset_intt if inverse else self.L.orc_coset_ntt)(_p(d2), C.c_uint32(lg), C.c_uint64(shift),
+                                                                       C.c_uint32(batch), C.c_size_t(n))
+        return d
+
+    def lde(self, coeffs, rate_bits, shift=7):
+        c, c2, batch, n, lg = self._cols(coeffs)
+        out = np.zeros((batch, n << rate_bits), np.uint64)
+        self.L.orc_lde(_p(c2), C.c_uint32(lg), C.c_uint32(rate_bits), C.c_uint64(shift), C.c_uint32(batch), _p(out))
+        return out.reshape(-1) if c.ndim == 1 else out
+
+    def lde_ext(self, coeffs, rate_bits, shift=7):
+        c = u64(coeffs)
+        n = c.size // 2
+        out = np.zeros(2 * (n << rate_bits), np.uint64)
+        self.L.orc_lde_ext(_p(c), C.c_uint32(int(n).bit_length() - 1), C.c_uint32(rate_bits), C.c_uint64(shift), _p(out))
+        return out
+
+    def transpose(self, m):
+        m = u64(m)
+        out = np.zeros((m.shape[1], m.shape[0]), np.uint64)
+        self.L.orc_transpose(_p(m), C.c_size_t(m.shape[0]), C.c_size_t(m.shape[1]), _p(out))
+        return out
+
+    def reverse_index_bits(self, rows):
+        r = u64(rows).copy()
+        r2 = r.reshape(-1, 1) if r.ndim == 1 else r
+        self.L.orc_reverse_index_bits(_p(r2), C.c_size_t(r2.shape[0]), C.c_size_t(r2.shape[1]))
+        return r
+
+    # poseidon
+    def permute(self, states):
+        s = u64(states).copy()
+        s2 = s.reshape(-1, 12)
+        for i in range(s2.shape[0]):
+            row = np.ascontiguousarray(s2[i])
+            self.L.orc_poseidon_permute(_p(row))
+            s2[i] = row
+        return s
+
+    def hash_no_pad(self, x):
+        x = u64(x)
+        o = np.zeros(4, np.uint64)
+        self.L.orc_hash_no_pad(_p(x), C.c_size_t(x.size), _p(o))
+        return o
+
+    def hash_or_noop(self, x):
+        x = u64(x)
+        o = np.zeros(4, np.uint64)
+        self.L.orc_hash_or_noop(_p(x), C.c_size_t(x.size), _p(o))
+        return o
+
+    def two_to_one(self, l, r):
+        l, r, o = u64(l), u64(r), np.zeros(4, np.uint64)
+        self.L.orc_two_to_one(_p(l), _p(r), _p(o))
+        return o
+
+    # merkle
+    def merkle_build(self, leaves, cap_height, variant=""):
+        lv = u64(leaves)
+        n, ll = lv.shape
+        dig = np.zeros((2 * (n - (1 << cap_height)), 4), np.uint64)
+        cap = np.zeros((1 << cap_height, 4), np.uint64)
+        fn = getattr(self.L, "orc_merkle_build" + variant)
+        fn(_p(lv), C.c_size_t(n), C.c_uint32(ll), C.c_uint32(cap_height), _p(dig), _p(cap))
+        return dig, cap
+
+    def merkle_prove(self, digests, n_leaves, cap_height, index):
+        d = u64(digests)
+        layers = (int(n_leaves).bit_length() - 1) - cap_height
+        sib = np.zeros((layers, 4), np.uint64)
+        self.L.orc_merkle_prove(_p(d), C.c_size_t(n_leaves), C.c_uint32(cap_height), C.c_size_t(index), _p(sib))
+        return sib
+
+    def merkle_verify(self, leaf, index, siblings, cap, cap_height):
+        leaf, sib, cap = u64(leaf), u64(siblings), u64(cap)
+        return bool(self.L.orc_merkle_verify(_p(leaf), C.c_uint32(leaf.size), C.c_size_t(index), _p(sib),
+                                             C.c_uint32(sib.size // 4), _p(cap), C.c_uint32(cap_height)))
+
+    def commit(self, values, rate_bits, cap_height, salt=None, is_coeffs=False):
+        v = u64(values)
+        batch, n = v.shape
+        lg = int(n).bit_length() - 1
+        N = n << rate_bits
+        width = batch + (4 if salt is not None else 0)
+        coeffs = np.zeros((batch, n), np.uint64)
+        leaves = np.zeros((N, width), np.uint64)
+        dig = np.zeros((2 * (N - (1 << cap_height)), 4), np.uint64)
+        cap = np.zeros((1 << cap_height, 4), np.uint64)
+        s = u64(salt) if salt is not None else None
+        self.L.orc_commit(_p(v), C.c_uint32(lg), C.c_uint32(batch), C.c_uint32(rate_bits), C.c_int(int(is_coeffs)),
+                          _p(s) if s is not None else None, C.c_uint32(cap_height), _p(coeffs), _p(leaves), _p(dig), _p(cap))
+        return coeffs, leaves, dig, cap
+
+    # deep / fri
+    def deep_batch(self, polys, alpha, z, acc):
+        p = u64(polys)
+        n_polys, n = p.shape
+        a, zz, acc = u64(alpha), u64(z), u64(acc).copy()
+        self.L.orc_deep_batch(_p(p), C.c_uint32(int(n).bit_length() - 1), C.c_uint32(n_polys), C.c_size_t(n), _p(a), _p(zz), _p(acc))
+        return acc
+
+    def eval_polys_ext(self, polys, z):
+        p = u64(polys)
+        n_polys, n = p.shape
+        zz, out = u64(z), np.zeros((n_polys, 2), np.uint64)
+        self.L.orc_eval_polys_ext(_p(p), C.c_uint32(int(n).bit_length() - 1), C.c_uint32(n_polys), C.c_size_t(n), _p(zz), _p(out))
+        return out
+
+    def fri_fold(self, coeffs, beta):
+        c, b = u64(coeffs), u64(beta)
+        n = c.size // 2
+        out = np.zeros(n, np.uint64)
+        self.L.orc_fri_fold(_p(c), C.c_size_t(n), _p(b), _p(out))
+        return out
+
+    def fri_layer_leaves(self, values):
+        v = u64(values)
+        n = v.size // 2
+        out = np.zeros((n // 2, 4), np.uint64)
+        self.L.orc_fri_layer_leaves(_p(v), C.c_size_t(n), _p(out))
+        return out
+
+    def pow_grind(self, state, pos, bits, start=0):
+        s = u64(state)
+        return self.L.orc_pow_grind(_p(s), C.c_uint32(pos), C.c_uint32(bits), C.c_uint64(start))
+
+    def challenger(self):
+        c = Challenger()
+        self.L.orc_challenger_init(C.byref(c))
+        return c
+
+    def observe(self, ch, elems):
+        e = u64(elems).reshape(-1)
+        self.L.orc_challenger_observe(C.byref(ch), _p(e), C.c_size_t(e.size))
+
+    def squeeze(self, ch):
+        return self.L.orc_challenger_squeeze(C.byref(ch))
+
+    def zs_partial_products(self, wires, sigmas, k_is, max_degree, beta, gamma):
+        w, s, k = u64(wires), u64(sigmas), u64(k_is)
+        n_routed, n = w.shape
+        n_chunks = (n_routed + max_degree - 1) // max_degree
+        z = np.zeros(n, np.uint64)
+        pp = np.zeros((n_chunks - 1, n), np.uint64)
+        self.L.orc_zs_partial_products(_p(w), _p(s), _p(k), C.c_uint32(int(n).bit_length() - 1), C.c_uint32(n_routed),
+                                       C.c_uint32(max_degree), C.c_uint64(beta), C.c_uint64(gamma), _p(z), _p(pp))
+        return z, pp
+
+
+def rand_field(rng, shape):
+    """uniform in [0, p) by rejection (SplitMix-style seeds, values < p)."""
+    a = rng.integers(0, 1 << 64, size=shape, dtype=np.uint64, endpoint=False)
+    bad = a >= np.uint64(P)
+    while bad.any():
+        a[bad] = rng.integers(0, 1 << 64, size=int(bad.sum()), dtype=np.uint64, endpoint=False)
+        bad = a >= np.uint64(P)
+    return a
