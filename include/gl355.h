@@ -63,6 +63,9 @@ int32_t gl355_memcpy_d2h(gl355_ctx* ctx, void* dst_host, const void* src_dev, si
 /* HIP-event timer on the context's stream (what bench.py times kernels with) */
 int32_t gl355_timer_start(gl355_ctx* ctx);
 int32_t gl355_timer_stop(gl355_ctx* ctx, float* ms);
+/* per-kernel-group HIP-event timing: enable, run, then read "name count total_ms" lines */
+int32_t gl355_profile_enable(gl355_ctx* ctx, int32_t on);
+int32_t gl355_profile_read(gl355_ctx* ctx, char* buf, size_t buf_len);
 
 /* ---- a1: GoldilocksField / QuadraticExtension (plonky2_field; signal.rs:1,5) ---------------- */
 enum { GL355_OP_ADD = 0, GL355_OP_SUB = 1, GL355_OP_MUL = 2, GL355_OP_INV = 3,

@@ -30,18 +30,20 @@ int orc_num_threads(void) {
  * a1 -- Goldilocks field, p = 2^64 - 2^32 + 1 (chip/native_chip/arithmetic_chip.rs:19).
  * Values are kept canonical everywhere in the oracle: simplest possible model.
  * ---------------------------------------------------------------------------------------- */
-static inline uint64_t canon(uint64_t a) { return a >= P ? a - P : a; }
+static inline uint64_t canon(uint64_t a) { return a - (P & (uint64_t)(-(int64_t)(a >= P))); }
 
-uint64_t orc_add(uint64_t a, uint64_t b) {
+static inline uint64_t f_add(uint64_t a, uint64_t b) {
     a = canon(a); b = canon(b);
     uint64_t s = a + b;
     if (s < a || s >= P) s -= P;
     return s;
 }
-uint64_t orc_sub(uint64_t a, uint64_t b) {
+static inline uint64_t f_sub(uint64_t a, uint64_t b) {
     a = canon(a); b = canon(b);
     return a >= b ? a - b : a + (P - b);
 }
+uint64_t orc_add(uint64_t a, uint64_t b) { return f_add(a, b); }
+uint64_t orc_sub(uint64_t a, uint64_t b) { return f_sub(a, b); }
 /* textbook model, kept so tests can pin the fast reduction below against plain `% p` */
 uint64_t orc_mul_ref(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) % P); }
 /* 2^64 = 2^32 - 1, 2^96 = -1 (mod p): x = lo + 2^64*hi_lo + 2^96*hi_hi = lo - hi_hi + EPS*hi_lo */
@@ -49,16 +51,17 @@ static inline uint64_t reduce128(u128 x) {
     uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
     uint64_t hi_hi = hi >> 32, hi_lo = hi & EPS;
     uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= EPS;
+    t0 -= EPS & (uint64_t)(-(int64_t)(lo < hi_hi));        /* branch-free: data is random */
     uint64_t t1 = hi_lo * EPS;
     uint64_t r = t0 + t1;
-    if (r < t1) r += EPS;
+    r += EPS & (uint64_t)(-(int64_t)(r < t1));
     return canon(r);
 }
-uint64_t orc_mul(uint64_t a, uint64_t b) { return reduce128((u128)a * b); }
+static inline uint64_t f_mul(uint64_t a, uint64_t b) { return reduce128((u128)a * b); }
+uint64_t orc_mul(uint64_t a, uint64_t b) { return f_mul(a, b); }
 uint64_t orc_pow(uint64_t a, uint64_t e) {
     uint64_t r = 1; a = canon(a);
-    while (e) { if (e & 1) r = orc_mul(r, a); a = orc_mul(a, a); e >>= 1; }
+    while (e) { if (e & 1) r = f_mul(r, a); a = f_mul(a, a); e >>= 1; }
     return r;
 }
 uint64_t orc_inv(uint64_t a) { return orc_pow(a, P - 2); }
@@ -70,19 +73,19 @@ uint64_t orc_root_of_unity(uint32_t log_n) { return orc_pow(7, (P - 1) >> log_n)
 /* F_p^2 = F_p[X]/(X^2 - 7) (arithmetic_chip.rs:109-132: left_x = a_x b_x + 7 a_y b_y,
  * left_y = a_x b_y + a_y b_x). */
 void orc_ext_mul(const uint64_t a[2], const uint64_t b[2], uint64_t out[2]) {
-    uint64_t c0 = orc_add(orc_mul(a[0], b[0]), orc_mul(7, orc_mul(a[1], b[1])));
-    uint64_t c1 = orc_add(orc_mul(a[0], b[1]), orc_mul(a[1], b[0]));
+    uint64_t c0 = f_add(f_mul(a[0], b[0]), f_mul(7, f_mul(a[1], b[1])));
+    uint64_t c1 = f_add(f_mul(a[0], b[1]), f_mul(a[1], b[0]));
     out[0] = c0; out[1] = c1;
 }
 static void ext_add(const uint64_t a[2], const uint64_t b[2], uint64_t o[2]) {
-    o[0] = orc_add(a[0], b[0]); o[1] = orc_add(a[1], b[1]);
+    o[0] = f_add(a[0], b[0]); o[1] = f_add(a[1], b[1]);
 }
 /* 1/(a0 + a1 X) = (a0 - a1 X) / (a0^2 - 7 a1^2) */
 void orc_ext_inv(const uint64_t a[2], uint64_t out[2]) {
-    uint64_t norm = orc_sub(orc_mul(a[0], a[0]), orc_mul(7, orc_mul(a[1], a[1])));
+    uint64_t norm = f_sub(f_mul(a[0], a[0]), f_mul(7, f_mul(a[1], a[1])));
     uint64_t ni = orc_inv(norm);
-    out[0] = orc_mul(canon(a[0]), ni);
-    out[1] = orc_mul(orc_sub(0, a[1]), ni);
+    out[0] = f_mul(canon(a[0]), ni);
+    out[1] = f_mul(f_sub(0, a[1]), ni);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -120,29 +123,39 @@ void orc_transpose(const uint64_t *in, size_t rows, size_t cols, uint64_t *out) 
  * decimation-in-time layers, natural-order output; out[j] = sum_i in[i] * omega_n^(i*j).
  * Inverse = forward, then index reversal (i <-> n-i) and scaling by n^-1.
  * ---------------------------------------------------------------------------------------- */
-static void ntt_one(uint64_t *a, uint32_t log_n, const uint64_t *roots /* n/2 powers of omega_n */) {
+/* per-layer contiguous root tables, as plonky2's fft_root_table: layer s (block size 2^s) uses
+ * omega_{2^s}^j for j < 2^(s-1), stored back to back (total n-1 entries). */
+static void ntt_one(uint64_t *a, uint32_t log_n, const uint64_t *roots) {
     size_t n = (size_t)1 << log_n;
     for (size_t i = 0; i < n; i++) {
         a[i] = canon(a[i]);
         size_t j = bitrev(i, log_n);
         if (i < j) { uint64_t t = a[i]; a[i] = canon(a[j]); a[j] = t; }
     }
+    const uint64_t *layer = roots;
     for (uint32_t s = 1; s <= log_n; s++) {
-        size_t m = (size_t)1 << s, half = m >> 1, step = n >> s;
+        size_t m = (size_t)1 << s, half = m >> 1;
         for (size_t k = 0; k < n; k += m)
             for (size_t j = 0; j < half; j++) {
-                uint64_t w = roots[j * step];
-                uint64_t u = a[k + j], v = orc_mul(a[k + j + half], w);
-                a[k + j] = orc_add(u, v);
-                a[k + j + half] = orc_sub(u, v);
+                uint64_t u = a[k + j], v = f_mul(a[k + j + half], layer[j]);
+                uint64_t x = u + v;                      /* u, v canonical: one conditional subtract */
+                x -= P & (uint64_t)(-(int64_t)((x < u) | (x >= P)));
+                a[k + j] = x;
+                a[k + j + half] = (u - v) + (P & (uint64_t)(-(int64_t)(u < v)));
             }
+        layer += half;
     }
 }
 static uint64_t *root_table(uint32_t log_n) {
-    size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;
-    uint64_t *r = (uint64_t *)malloc(half * sizeof(uint64_t));
-    uint64_t w = orc_root_of_unity(log_n), x = 1;
-    for (size_t i = 0; i < half; i++) { r[i] = x; x = orc_mul(x, w); }
+    size_t n = (size_t)1 << log_n;
+    uint64_t *r = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+    uint64_t *layer = r;
+    for (uint32_t s = 1; s <= log_n; s++) {
+        size_t half = (size_t)1 << (s - 1);
+        uint64_t w = orc_root_of_unity(s), x = 1;
+        for (size_t i = 0; i < half; i++) { layer[i] = x; x = f_mul(x, w); }
+        layer += half;
+    }
     return r;
 }
 void orc_ntt(uint64_t *data, uint32_t log_n, uint32_t batch, size_t stride) {
@@ -159,11 +172,11 @@ void orc_intt(uint64_t *data, uint32_t log_n, uint32_t batch, size_t stride) {
     for (uint32_t c = 0; c < batch; c++) {
         uint64_t *a = data + (size_t)c * stride;
         ntt_one(a, log_n, roots);
-        a[0] = orc_mul(a[0], n_inv);
-        if (n > 1) a[n / 2] = orc_mul(a[n / 2], n_inv);
+        a[0] = f_mul(a[0], n_inv);
+        if (n > 1) a[n / 2] = f_mul(a[n / 2], n_inv);
         for (size_t i = 1; i < n / 2; i++) {
             size_t j = n - i;
-            uint64_t ci = orc_mul(a[j], n_inv), cj = orc_mul(a[i], n_inv);
+            uint64_t ci = f_mul(a[j], n_inv), cj = f_mul(a[i], n_inv);
             a[i] = ci; a[j] = cj;
         }
     }
@@ -173,9 +186,10 @@ void orc_intt(uint64_t *data, uint32_t log_n, uint32_t batch, size_t stride) {
  * the inverse one (coset generator 7: plonk_verifier_chip.rs:225-227, fri_chip.rs:264). */
 void orc_coset_ntt(uint64_t *data, uint32_t log_n, uint64_t shift, uint32_t batch, size_t stride) {
     size_t n = (size_t)1 << log_n;
+#pragma omp parallel for schedule(dynamic)
     for (uint32_t c = 0; c < batch; c++) {
         uint64_t *a = data + (size_t)c * stride, s = 1;
-        for (size_t i = 0; i < n; i++) { a[i] = orc_mul(canon(a[i]), s); s = orc_mul(s, shift); }
+        for (size_t i = 0; i < n; i++) { a[i] = f_mul(canon(a[i]), s); s = f_mul(s, shift); }
     }
     orc_ntt(data, log_n, batch, stride);
 }
@@ -183,15 +197,17 @@ void orc_coset_intt(uint64_t *data, uint32_t log_n, uint64_t shift, uint32_t bat
     size_t n = (size_t)1 << log_n;
     uint64_t si = orc_inv(shift);
     orc_intt(data, log_n, batch, stride);
+#pragma omp parallel for schedule(dynamic)
     for (uint32_t c = 0; c < batch; c++) {
         uint64_t *a = data + (size_t)c * stride, s = 1;
-        for (size_t i = 0; i < n; i++) { a[i] = orc_mul(a[i], s); s = orc_mul(s, si); }
+        for (size_t i = 0; i < n; i++) { a[i] = f_mul(a[i], s); s = f_mul(s, si); }
     }
 }
 /* a3 -- PolynomialCoeffs::lde + coset_fft: zero-pad to N = n << rate_bits, scale by shift^i, NTT. */
 void orc_lde(const uint64_t *coeffs, uint32_t log_n, uint32_t rate_bits, uint64_t shift,
              uint32_t batch, uint64_t *out) {
     size_t n = (size_t)1 << log_n, N = n << rate_bits;
+#pragma omp parallel for schedule(static)
     for (uint32_t c = 0; c < batch; c++) {
         memcpy(out + (size_t)c * N, coeffs + (size_t)c * n, n * 8);
         memset(out + (size_t)c * N + n, 0, (N - n) * 8);
@@ -207,13 +223,13 @@ void orc_lde(const uint64_t *coeffs, uint32_t log_n, uint32_t rate_bits, uint64_
  * the two also cross-checks the derived tables.
  * ---------------------------------------------------------------------------------------- */
 static inline uint64_t sbox7(uint64_t x) {
-    uint64_t x2 = orc_mul(x, x), x4 = orc_mul(x2, x2), x3 = orc_mul(x, x2);
-    return orc_mul(x3, x4);
+    uint64_t x2 = f_mul(x, x), x4 = f_mul(x2, x2), x3 = f_mul(x, x2);
+    return f_mul(x3, x4);
 }
 void orc_poseidon_permute(uint64_t s[12]) {
     for (int i = 0; i < 12; i++) s[i] = canon(s[i]);
     for (int r = 0; r < 30; r++) {
-        for (int i = 0; i < 12; i++) s[i] = orc_add(s[i], ORC_POSEIDON_RC[12 * r + i]);
+        for (int i = 0; i < 12; i++) s[i] = f_add(s[i], ORC_POSEIDON_RC[12 * r + i]);
         if (r < 4 || r >= 26) { for (int i = 0; i < 12; i++) s[i] = sbox7(s[i]); }
         else s[0] = sbox7(s[0]);
         uint64_t t[12];
@@ -382,8 +398,8 @@ void orc_deep_batch(const uint64_t *polys, uint32_t log_n, uint32_t n_polys, siz
         const uint64_t *p = polys + (size_t)i * stride;
         for (size_t k = 0; k < n; k++) {
             uint64_t c = canon(p[k]);
-            comp[2 * k] = orc_add(comp[2 * k], orc_mul(ap[0], c));
-            comp[2 * k + 1] = orc_add(comp[2 * k + 1], orc_mul(ap[1], c));
+            comp[2 * k] = f_add(comp[2 * k], f_mul(ap[0], c));
+            comp[2 * k + 1] = f_add(comp[2 * k + 1], f_mul(ap[1], c));
         }
         orc_ext_mul(ap, alpha, ap);
     }
@@ -414,7 +430,7 @@ void orc_eval_polys_ext(const uint64_t *polys, uint32_t log_n, uint32_t n_polys,
         for (size_t k = n; k-- > 0;) {
             uint64_t t[2];
             orc_ext_mul(acc, z, t);
-            acc[0] = orc_add(t[0], canon(p[k])); acc[1] = t[1];
+            acc[0] = f_add(t[0], canon(p[k])); acc[1] = t[1];
         }
         out[2 * i] = acc[0]; out[2 * i + 1] = acc[1];
     }
@@ -511,14 +527,14 @@ void orc_zs_partial_products(const uint64_t *wires, const uint64_t *sigmas, cons
             uint64_t num = 1, den = 1;
             for (uint32_t j = ch * max_degree; j < (ch + 1) * max_degree && j < n_routed; j++) {
                 uint64_t w = canon(wires[(size_t)j * n + i]);
-                uint64_t s_id = orc_mul(k_is[j], x);
-                num = orc_mul(num, orc_add(orc_add(w, orc_mul(beta, s_id)), gamma));
-                den = orc_mul(den, orc_add(orc_add(w, orc_mul(beta, canon(sigmas[(size_t)j * n + i]))), gamma));
+                uint64_t s_id = f_mul(k_is[j], x);
+                num = f_mul(num, f_add(f_add(w, f_mul(beta, s_id)), gamma));
+                den = f_mul(den, f_add(f_add(w, f_mul(beta, canon(sigmas[(size_t)j * n + i]))), gamma));
             }
-            acc = orc_mul(acc, orc_mul(num, orc_inv(den)));
+            acc = f_mul(acc, f_mul(num, orc_inv(den)));
             if (ch + 1 < n_chunks) pp_out[(size_t)ch * n + i] = acc;
         }
         z = acc;
-        x = orc_mul(x, g);
+        x = f_mul(x, g);
     }
 }

@@ -36,6 +36,8 @@ SIGNATURES = {
     "gl355_memcpy_d2h": (C.c_int32, [vp, vp, vp, C.c_size_t]),
     "gl355_timer_start": (C.c_int32, [vp]),
     "gl355_timer_stop": (C.c_int32, [vp, C.POINTER(C.c_float)]),
+    "gl355_profile_enable": (C.c_int32, [vp, C.c_int32]),
+    "gl355_profile_read": (C.c_int32, [vp, C.c_char_p, C.c_size_t]),
     "gl355_field_batch": (C.c_int32, [vp, C.c_int32, vp, vp, vp, C.c_uint64]),
     "gl355_ntt": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int32]),
     "gl355_coset_ntt": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32]),

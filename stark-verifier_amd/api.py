@@ -87,6 +87,19 @@ class Context:
         self.check(self.lib.gl355_timer_stop(self.h, C.byref(ms)))
         return ms.value
 
+    def profile_enable(self, on=True):
+        self.check(self.lib.gl355_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        """{name: (count, total_ms)} of the kernel groups run since the last read."""
+        buf = C.create_string_buffer(1 << 16)
+        self.check(self.lib.gl355_profile_read(self.h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            out[name] = (int(cnt), float(ms))
+        return out
+
     # ---- a1 --------------------------------------------------------------------------------
     def field_batch(self, op, a, b=None):
         a = _u64(a)

@@ -13,6 +13,13 @@ int32_t Ctx::fail_hip(hipError_t e, const char* expr, const char* file, int line
     return GL355_E_HIP;
 }
 
+hipEvent_t Ctx::prof_event() {
+    if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return e;
+}
+
 int32_t Ctx::alloc(size_t bytes, void** out) {
     if (bytes == 0) bytes = 256;
     bytes = (bytes + 255) & ~size_t(255);
@@ -174,6 +181,8 @@ int32_t gl355_ctx_destroy(gl355_ctx* ctx) {
     if (c.tw_fwd) (void)hipFree(c.tw_fwd);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
+    for (auto& r : c.prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : c.ev_pool) (void)hipEventDestroy(e);
     if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
     delete ctx;
     return GL355_OK;
@@ -219,6 +228,32 @@ int32_t gl355_timer_stop(gl355_ctx* ctx, float* ms) {
     GL355_HIP(&ctx->c, hipEventRecord(ctx->c.ev1, ctx->c.stream));
     GL355_HIP(&ctx->c, hipEventSynchronize(ctx->c.ev1));
     GL355_HIP(&ctx->c, hipEventElapsedTime(ms, ctx->c.ev0, ctx->c.ev1));
+    return GL355_OK;
+}
+
+int32_t gl355_profile_enable(gl355_ctx* ctx, int32_t on) {
+    if (!ctx) return GL355_E_INVALID_ARG;
+    ctx->c.prof_on = on != 0;
+    return GL355_OK;
+}
+// Aggregates the recorded scopes by name into `buf` as lines "name count total_ms\n" and clears them.
+int32_t gl355_profile_read(gl355_ctx* ctx, char* buf, size_t buf_len) {
+    if (!ctx || !buf || buf_len == 0) return GL355_E_INVALID_ARG;
+    Ctx& c = ctx->c;
+    GL355_HIP(&c, hipStreamSynchronize(c.stream));
+    std::map<std::string, std::pair<uint64_t, double>> agg;
+    for (auto& r : c.prof) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { (void)hipGetLastError(); ms = 0; }
+        auto& a = agg[r.name];
+        a.first++; a.second += ms;
+        c.ev_pool.push_back(r.e0); c.ev_pool.push_back(r.e1);
+    }
+    c.prof.clear();
+    std::string out;
+    for (auto& kv : agg) out += kv.first + " " + std::to_string(kv.second.first) + " " + std::to_string(kv.second.second) + "\n";
+    if (out.size() + 1 > buf_len) out.resize(buf_len - 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
     return GL355_OK;
 }
 

@@ -47,6 +47,13 @@ struct Ctx {
     struct Block { void* p; size_t size; bool used; };
     std::vector<Block> blocks;
 
+    // optional per-kernel timing (gl355_profile_enable): HIP events around every launch group
+    struct ProfRec { const char* name; hipEvent_t e0, e1; };
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t prof_event();
+
     int32_t fail(int32_t code, const char* msg);
     int32_t fail_hip(hipError_t e, const char* expr, const char* file, int line);
     int32_t alloc(size_t bytes, void** out);
@@ -57,6 +64,20 @@ struct Ctx {
     int32_t pow_tables(uint64_t base, const uint64_t** lo, const uint64_t** hi) {
         return pow_tables_multi(std::vector<uint64_t>{gl_canon(base)}, lo, hi);
     }
+};
+
+// RAII: times everything enqueued on the context stream during its lifetime under `name`
+struct ProfScope {
+    Ctx* ctx; int idx = -1;
+    ProfScope(Ctx* c, const char* name) : ctx(c) {
+        if (!c->prof_on) return;
+        Ctx::ProfRec r{name, c->prof_event(), c->prof_event()};
+        if (!r.e0 || !r.e1) return;
+        (void)hipEventRecord(r.e0, c->stream);
+        idx = (int)c->prof.size();
+        c->prof.push_back(r);
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(ctx->prof[idx].e1, ctx->stream); }
 };
 
 // RAII scratch buffer from the context allocator

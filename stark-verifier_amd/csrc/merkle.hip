@@ -184,7 +184,8 @@ int32_t merkle_build_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, ui
     a.leaves = leaves; a.n_leaves = n_leaves; a.leaf_len = leaf_len; a.col_major = col_major;
     a.stride = col_major ? col_stride : leaf_len;
     a.out = digests; a.cap = cap; a.sub_bits = sub_bits;
-    GL355_TRY(launch_leaves(ctx, a));
+    { ProfScope ps(ctx, "merkle_hash_leaves"); GL355_TRY(launch_leaves(ctx, a)); }
+    ProfScope ps(ctx, "merkle_levels");
     for (uint32_t layer = 1; layer <= sub_bits; layer++) {
         const uint64_t n_nodes = n_leaves >> layer;
         hipLaunchKernelGGL(merkle_level_kernel, dim3((uint32_t)((n_nodes + 255) / 256)), dim3(256), 0, ctx->stream,

@@ -393,6 +393,7 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         a.scale = p.scale;
         a.in_bitrev = p.in_bitrev; a.out_natural = p.out_bitrev ? 0 : 1;
         a.canon = 1;
+        ProfScope ps(ctx, "ntt_rows_single_pass");
         GL355_HIP(ctx, launch_rows(a, p.log_n, inv, ctx->stream));
         return GL355_OK;
     }
@@ -411,7 +412,7 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         a.pre_lo = p.pre_lo; a.pre_hi = p.pre_hi;
         a.step_lo = step_lo; a.step_hi = step_hi;
         a.in_bitrev = 0; a.out_natural = 0; a.canon = 0;
-        GL355_HIP(ctx, launch_cols(a, l1, inv, ctx->stream));
+        { ProfScope ps(ctx, "ntt_cols_pass1"); GL355_HIP(ctx, launch_cols(a, l1, inv, ctx->stream)); }
         PassArgs b = a;
         b.in = p.out; b.in_col_stride = p.out_col_stride;
         // each coset's intermediate lives in its own output block: rows pass runs per coset slot
@@ -420,6 +421,7 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         b.scale = p.scale; b.canon = 1;
         if (p.n_cosets == 1) {
             b.in = p.out + (uint64_t)a.coset_slot[0] * a.coset_out_stride;
+            ProfScope ps(ctx, "ntt_rows_pass2");
             GL355_HIP(ctx, launch_rows(b, l2, inv, ctx->stream));
         } else {
             // the coset blocks are contiguous sub-ranges of every output column: treat (column,
@@ -431,6 +433,7 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
             while ((1u << lc) < p.n_cosets) lc++;
             b.n_cosets = 1; b.coset_slot[0] = 0; b.coset_out_stride = 0;
             b.log_rows = l1 + lc;
+            ProfScope ps(ctx, "ntt_rows_pass2");
             GL355_HIP(ctx, launch_rows(b, l2, inv, ctx->stream));
         }
         if (!p.out_bitrev) {

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Mints tests/golden/*.json.
+
+  poseidon_kat.json   the upstream plonky2 Poseidon-Goldilocks known-answer vectors (SURVEY.md 8(c);
+                      they are what plonky2's own poseidon_goldilocks tests assert), re-derived here
+                      by the big-integer model from the reference's constants -- the script refuses
+                      to write if the model disagrees with the transcribed expected words.
+  conventions.json    tiny convention vectors + small NTT / LDE / Merkle / FRI
+                      cases computed FROM THE DEFINITION by tests/pymodel.py (no oracle, no GPU).
+Run: python tests/golden/make_golden.py
+"""
+import json
+import os
+import random
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import pymodel as pm  # noqa: E402
+
+P = pm.P
+
+
+def hx(v):
+    return ["%016x" % x for x in v]
+
+
+UPSTREAM = {
+    "zeros": ([0] * 12, "3c18a9786cb0b359 c4055e3364a246c3 7953db0ab48808f4 c71603f33a1144ca d7709673896996dc 46a84e87642f44ed "
+                        "d032648251ee0b3c 1c687363b207df62 df8565563e8045fe 40f5b37ff4254dae d070f637b431067c 1792b1c4342109d7"),
+    "iota": (list(range(12)), "d64e1e3efc5b8e9e 53666633020aaa47 d40285597c6a8825 613a4f81e81231d2 414754bfebd051f0 cb1f8980294a023f "
+                               "6eb2a9e4d54a9d0f 1902bc3af467e056 f045d5eafdc6021f e4150f77caaa3be5 c9bfd01d39b50cce 5c0a27fcb0e1459b"),
+    "neg_one": ([P - 1] * 12, "be0085cfc57a8357 d95af71847d05c09 cf55a13d33c1c953 95803a74f4530e82 fcd99eb30a135df1 e095905e913a3029 "
+                               "de0392461b42919b 7d3260e24e81d031 10d3d0465d9deaa0 a87571083dfc2a47 e18263681e9958f8 e28e96f1ae5e60d3"),
+}
+
+
+def main():
+    kat = {"permute": []}
+    for name, (inp, want) in UPSTREAM.items():
+        got = pm.permute(inp)
+        assert hx(got) == want.split(), "model disagrees with upstream KAT %s" % name
+        kat["permute"].append({"name": name, "input": hx(inp), "output": hx(got)})
+    kat["hash_no_pad"] = [{"input": hx(list(range(1, k + 1))), "output": hx(pm.hash_no_pad(list(range(1, k + 1))))}
+                          for k in (1, 7, 8, 9, 16, 135)]
+    assert kat["hash_no_pad"][2]["output"] == "d110aa6a46373941 8f238fcceb658894 9cd4f8353866fb4f 274913f0007aa232".split()
+    json.dump(kat, open(os.path.join(HERE, "poseidon_kat.json"), "w"), indent=1)
+
+    rnd = random.Random(0x355)
+    conv = {"omega_8": "%016x" % pm.root_of_unity(3), "omega_2_16": "%016x" % pm.root_of_unity(16),
+            "omega_2_32": "%016x" % pm.root_of_unity(32)}
+    assert conv["omega_8"] == "fffffffeff000001" and conv["omega_2_32"] == "185629dcda58878c"
+    conv["ntt"] = []
+    for lg in (0, 1, 3, 5, 7):
+        c = list(range(1, 9)) if lg == 3 else [rnd.randrange(P) for _ in range(1 << lg)]
+        conv["ntt"].append({"input": hx(c), "forward": hx(pm.dft(c)), "inverse": hx(pm.dft(c, inverse=True))})
+    conv["lde"] = []
+    for lg, rb in ((2, 1), (3, 3), (5, 3), (4, 2)):
+        c = [1, 2, 3, 4] if lg == 2 else [rnd.randrange(P) for _ in range(1 << lg)]
+        conv["lde"].append({"coeffs": hx(c), "rate_bits": rb, "shift": 7, "natural": hx(pm.lde(c, rb))})
+    conv["merkle"] = []
+    for n, ll, cap in ((8, 4, 0), (8, 4, 1), (8, 9, 0), (16, 3, 2), (4, 135, 1), (2, 4, 1)):
+        leaves = [[4 * i + j for j in range(4)] for i in range(8)] if (n, ll) == (8, 4) else \
+                 [[9 * i + j for j in range(9)] for i in range(8)] if (n, ll) == (8, 9) else \
+                 [[rnd.randrange(P) for _ in range(ll)] for _ in range(n)]
+        dig, capv = pm.merkle(leaves, cap)
+        conv["merkle"].append({"leaves": [hx(l) for l in leaves], "cap_height": cap,
+                               "digests": [hx(d) for d in dig], "cap": [hx(c) for c in capv]})
+    a, b = (3, 5), (P - 2, 11)
+    conv["ext_mul"] = {"a": hx(a), "b": hx(b), "out": hx(pm.ext_mul(a, b))}
+    json.dump(conv, open(os.path.join(HERE, "conventions.json"), "w"), indent=1)
+    print("golden vectors written")
+
+
+if __name__ == "__main__":
+    main()

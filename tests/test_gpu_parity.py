@@ -268,3 +268,55 @@ def test_error_codes(gl, ctx):
         ctx.pow_grind(np.zeros(12, np.uint64), 9, 4)         # witness outside the rate part
     # the context stays usable after an error
     assert ctx.hash_no_pad(np.arange(1, 9, dtype=np.uint64))[0] == 0xD110AA6A46373941
+
+
+# ---- committed golden vectors through the C ABI ------------------------------------------------------
+def test_golden_vectors_on_gpu(gl, ctx):
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+
+    def ux(lst):
+        return np.array([int(x, 16) for x in lst], dtype=np.uint64)
+    kat = json.load(open(os.path.join(here, "golden", "poseidon_kat.json")))
+    for v in kat["permute"]:
+        eq(ctx.poseidon_permute(ux(v["input"])), ux(v["output"]))
+    for v in kat["hash_no_pad"]:
+        eq(ctx.hash_no_pad(ux(v["input"])), ux(v["output"]))
+    conv = json.load(open(os.path.join(here, "golden", "conventions.json")))
+    for v in conv["ntt"]:
+        eq(ctx.fft(ux(v["input"])), ux(v["forward"]))
+        eq(ctx.ifft(ux(v["input"])), ux(v["inverse"]))
+    for v in conv["lde"]:
+        if len(v["coeffs"]) > 1:
+            eq(ctx.lde(ux(v["coeffs"]), v["rate_bits"], v["shift"]), ux(v["natural"]))
+    for v in conv["merkle"]:
+        leaves = np.array([[int(x, 16) for x in l] for l in v["leaves"]], dtype=np.uint64)
+        t = gl.MerkleTree(ctx, leaves, v["cap_height"])
+        eq(t.cap, np.array([[int(x, 16) for x in d] for d in v["cap"]], dtype=np.uint64))
+        eq(t.digests, np.array([[int(x, 16) for x in d] for d in v["digests"]], dtype=np.uint64).reshape(-1, 4))
+
+
+def test_aggregation_root_on_gpu(gl, ctx, orc):
+    import importlib
+    par = importlib.import_module("stark-verifier_amd.parallel")
+    rng = np.random.default_rng(0x445)
+    leaves = rand_field(rng, (1000, 8))          # 1000 proofs x (nullifier || topic), padded to 1024
+    root = par.aggregation_root(ctx, leaves)
+    eq(root, orc.merkle_build(par.pad_pow2(leaves), 0)[1])
+
+
+def test_device_resident_buffers(gl, ctx, orc):
+    """device pointers (torch tensors) are used in place, no host staging: same results."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(0x455)
+    x = rand_field(rng, (4, 1 << 13))
+    t = torch.from_numpy(x.view(np.int64)).cuda()
+    out = torch.empty((4, 1 << 16), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.gl355_lde_bitrev(ctx.h, C.c_void_p(t.data_ptr()), 13, 3, 7, 4, C.c_void_p(out.data_ptr())))
+    ctx.sync()
+    want = orc.reverse_index_bits(orc.lde(x, 3).T.copy()).T
+    eq(out.cpu().numpy().view(np.uint64), want)
+    eq(t.cpu().numpy().view(np.uint64), x)       # input untouched
