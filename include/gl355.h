@@ -144,6 +144,46 @@ const uint64_t* gl355_oracle_coeffs_ptr(const gl355_oracle* o);
  * siblings [(log2 N - cap_height) x 4] to host buffers */
 int32_t gl355_oracle_open(const gl355_oracle* o, uint64_t index, uint64_t* leaf, uint64_t* siblings);
 
+/* ---- a10: compute_quotient_polys (vanishing_poly.rs:18-153, gates/mod.rs:87-132, gates/ evaluators) ------
+ * Circuit shape the constraint kernel needs (the host-side CommonCircuitData, types/common_data.rs:69-97).
+ * gates[] is the circuit's gate list in selector order; gate i is active on rows where
+ * constants[selector_index](row) == i; group = [group_start, group_end) are the gate indices sharing
+ * that selector polynomial. */
+#define GL355_MAX_GATES 16
+enum { GL355_GATE_NOOP = 0, GL355_GATE_CONSTANT = 1, GL355_GATE_PUBLIC_INPUT = 2, GL355_GATE_BASE_SUM = 3,
+       GL355_GATE_POSEIDON = 4, GL355_GATE_ARITHMETIC = 5 };
+typedef struct {
+    uint32_t type;            /* GL355_GATE_* */
+    uint32_t param;           /* CONSTANT: num_consts; BASE_SUM: num_limbs (base 2); ARITHMETIC: num_ops */
+    uint32_t selector_index;  /* which constants column is this gate's selector */
+    uint32_t group_start, group_end;
+} gl355_gate;
+typedef struct {
+    uint32_t degree_bits, rate_bits;
+    uint32_t num_wires, num_routed_wires;
+    uint32_t num_constants;         /* gate constants (columns after the selectors) */
+    uint32_t num_selectors;
+    uint32_t num_challenges;
+    uint32_t max_degree;            /* quotient_degree_factor = partial-product chunk size (8) */
+    uint32_t num_partial_products;  /* ceil(routed / max_degree) - 1 */
+    uint32_t num_gates;
+    gl355_gate gates[GL355_MAX_GATES];
+} gl355_circuit;
+/* Evaluates the combined vanishing polynomial / Z_H on the quotient coset for every challenge,
+ * interpolates (coset iNTT) and writes the quotient chunks: out[(c*max_degree + j)][n] coefficients.
+ * Oracles: constants_sigmas = [selectors | gate constants | sigmas], wires, zs_partial_products =
+ * [Z_c]_c | [pp_{c,k}]_{c,k}.  k_is[num_routed_wires], betas/gammas/alphas[num_challenges] base field. */
+int32_t gl355_quotient(gl355_ctx* ctx, const gl355_circuit* circuit, const gl355_oracle* constants_sigmas,
+                       const gl355_oracle* wires, const gl355_oracle* zs_partial_products, const uint64_t* k_is,
+                       const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas,
+                       const uint64_t pi_hash[4], uint64_t* quotient_coeffs);
+/* the vanishing values themselves (before interpolation), storage order = bit-reversed rows of the
+ * quotient coset: values[c][t]; for parity tests */
+int32_t gl355_quotient_values(gl355_ctx* ctx, const gl355_circuit* circuit, const gl355_oracle* constants_sigmas,
+                              const gl355_oracle* wires, const gl355_oracle* zs_partial_products, const uint64_t* k_is,
+                              const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas,
+                              const uint64_t pi_hash[4], uint64_t* values);
+
 /* ---- a11: PolynomialBatch::prove_openings (fri_chip.rs:112-149) ------------------------------
  * One opening batch over polynomials taken from resident oracles:
  *   C(X) = sum_i alpha^i p_i(X);  Q = (C - C(z)) / (X - z), padded to n;  acc = acc*alpha^k + Q
@@ -170,6 +210,27 @@ int32_t gl355_fri_layer_commit(gl355_ctx* ctx, const uint64_t* values, uint64_t 
 /* smallest w >= start such that permute(state with state[pos] = w)[7] has >= bits leading zeros */
 int32_t gl355_pow_grind(gl355_ctx* ctx, const uint64_t state[12], uint32_t pos, uint32_t bits,
                         uint64_t start, uint64_t* witness);
+
+/* ---- a15: Challenger (host, sequential; plonk_verifier_chip.rs:55-154, hasher_chip.rs:48-89) ----
+ * Plain host struct, no device involved: observe buffers inputs (absorbed 8 at a time by OVERWRITING
+ * the state), squeeze pops from the end of the rate part. */
+typedef struct {
+    uint64_t state[12];
+    uint64_t in_buf[8];
+    uint32_t in_len;
+    uint64_t out_buf[8];
+    uint32_t out_len;
+} gl355_challenger;
+int32_t gl355_challenger_init(gl355_challenger* c);
+int32_t gl355_challenger_observe(gl355_challenger* c, const uint64_t* elems, uint64_t n);
+int32_t gl355_challenger_squeeze(gl355_challenger* c, uint64_t* out, uint64_t n);
+/* sponge state + slot of the PoW witness candidate, to feed gl355_pow_grind */
+int32_t gl355_challenger_pow_state(const gl355_challenger* c, uint64_t state[12], uint32_t* pos);
+/* single host-side hashes (access_set.rs:67 hashes one 8-element input; the transcript) */
+int32_t gl355_host_poseidon_permute(uint64_t state[12]);
+int32_t gl355_host_hash_no_pad(const uint64_t* in, uint64_t len, uint64_t out[4]);
+/* witness generation of one PoseidonGate row (wire layout gates/poseidon.rs:329-380) */
+int32_t gl355_poseidon_gate_witness(const uint64_t inputs[12], uint64_t swap, uint64_t wires[135]);
 
 /* ---- a9: wires_permutation_partial_products_and_zs (vanishing_poly.rs:54-108,183-218) --------- */
 int32_t gl355_zs_partial_products(gl355_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas,

@@ -20,6 +20,27 @@ class PolyRef(C.Structure):
     _fields_ = [("oracle", vp), ("column", C.c_uint32)]
 
 
+class Challenger(C.Structure):
+    _fields_ = [("state", C.c_uint64 * 12), ("in_buf", C.c_uint64 * 8), ("in_len", C.c_uint32),
+                ("out_buf", C.c_uint64 * 8), ("out_len", C.c_uint32)]
+
+
+MAX_GATES = 16
+GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_BASE_SUM, GATE_POSEIDON, GATE_ARITHMETIC = range(6)
+
+
+class Gate(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("param", C.c_uint32), ("selector_index", C.c_uint32),
+                ("group_start", C.c_uint32), ("group_end", C.c_uint32)]
+
+
+class Circuit(C.Structure):
+    _fields_ = [("degree_bits", C.c_uint32), ("rate_bits", C.c_uint32), ("num_wires", C.c_uint32),
+                ("num_routed_wires", C.c_uint32), ("num_constants", C.c_uint32), ("num_selectors", C.c_uint32),
+                ("num_challenges", C.c_uint32), ("max_degree", C.c_uint32), ("num_partial_products", C.c_uint32),
+                ("num_gates", C.c_uint32), ("gates", Gate * MAX_GATES)]
+
+
 # name -> (restype, argtypes).  Data pointers are void* so numpy arrays, torch data_ptr() ints and
 # raw device pointers all pass through the same signature.
 SIGNATURES = {
@@ -61,6 +82,15 @@ SIGNATURES = {
     "gl355_oracle_lde_ptr": (vp, [vp]),
     "gl355_oracle_coeffs_ptr": (vp, [vp]),
     "gl355_oracle_open": (C.c_int32, [vp, C.c_uint64, vp, vp]),
+    "gl355_quotient": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gl355_quotient_values": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gl355_challenger_init": (C.c_int32, [C.POINTER(Challenger)]),
+    "gl355_challenger_observe": (C.c_int32, [C.POINTER(Challenger), vp, C.c_uint64]),
+    "gl355_challenger_squeeze": (C.c_int32, [C.POINTER(Challenger), vp, C.c_uint64]),
+    "gl355_challenger_pow_state": (C.c_int32, [C.POINTER(Challenger), vp, C.POINTER(C.c_uint32)]),
+    "gl355_host_poseidon_permute": (C.c_int32, [vp]),
+    "gl355_host_hash_no_pad": (C.c_int32, [vp, C.c_uint64, vp]),
+    "gl355_poseidon_gate_witness": (C.c_int32, [vp, C.c_uint64, vp]),
     "gl355_deep_batch": (C.c_int32, [vp, C.POINTER(PolyRef), C.c_uint32, vp, vp, vp]),
     "gl355_eval_polys": (C.c_int32, [vp, C.POINTER(PolyRef), C.c_uint32, vp, vp]),
     "gl355_lde_ext": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, vp]),

@@ -382,6 +382,55 @@ int32_t gl355_oracle_open(const gl355_oracle* o, uint64_t index, uint64_t* leaf,
     return prove_from(ctx, o->digests, N, o->cap_height, index, siblings);
 }
 
+// ---- a10 -------------------------------------------------------------------------------------
+static int32_t quotient_common(gl355_ctx* h, const gl355_circuit* c, const gl355_oracle* cs, const gl355_oracle* wires,
+                               const gl355_oracle* zs, const uint64_t* k_is, const uint64_t* betas, const uint64_t* gammas,
+                               const uint64_t* alphas, const uint64_t pi_hash[4], uint64_t* out, bool interpolate) {
+    CTX_OR_FAIL(h);
+    if (!c || !cs || !wires || !zs || !k_is || !betas || !gammas || !alphas || !pi_hash || !out)
+        return ctx->fail(GL355_E_INVALID_ARG, "quotient: null argument");
+    if (cs->log_n != c->degree_bits || wires->log_n != c->degree_bits || zs->log_n != c->degree_bits ||
+        cs->rate_bits != c->rate_bits || wires->rate_bits != c->rate_bits || zs->rate_bits != c->rate_bits)
+        return ctx->fail(GL355_E_INVALID_ARG, "quotient: oracle shapes do not match the circuit");
+    if (cs->batch != c->num_selectors + c->num_constants + c->num_routed_wires || wires->batch != c->num_wires ||
+        zs->batch != c->num_challenges * (1 + c->num_partial_products))
+        return ctx->fail(GL355_E_INVALID_ARG, "quotient: oracle widths do not match the circuit");
+    if (c->num_routed_wires > c->num_wires || c->max_degree == 0 ||
+        c->num_partial_products + 1 != (c->num_routed_wires + c->max_degree - 1) / c->max_degree)
+        return ctx->fail(GL355_E_INVALID_ARG, "quotient: inconsistent routed-wire / partial-product counts");
+    for (uint32_t g = 0; g < c->num_gates && g < GL355_MAX_GATES; g++) {
+        if (c->gates[g].type > GL355_GATE_ARITHMETIC) return ctx->fail(GL355_E_UNSUPPORTED, "quotient: unknown gate type");
+        if (c->gates[g].selector_index >= c->num_selectors || c->gates[g].group_end > c->num_gates)
+            return ctx->fail(GL355_E_INVALID_ARG, "quotient: bad selector group");
+    }
+    uint32_t qdb = 0;
+    while ((1u << qdb) < c->max_degree) qdb++;
+    const uint64_t N = 1ull << (c->degree_bits + c->rate_bits), nq = 1ull << (c->degree_bits + qdb);
+    const uint32_t nch = c->num_challenges;
+    Staged sk(ctx), so(ctx);
+    GL355_TRY(sk.open(k_is, (uint64_t)c->num_routed_wires * 8, 1));
+    GL355_TRY(so.open(out, (uint64_t)nch * nq * 8, 2));
+    if (!interpolate) {
+        GL355_TRY(quotient_dev(ctx, c, cs->lde, wires->lde, zs->lde, N, sk.as<uint64_t>(), betas, gammas, alphas, pi_hash, so.as<uint64_t>()));
+        return so.finish();
+    }
+    Scratch vals(ctx);
+    GL355_TRY(vals.get((uint64_t)nch * nq * 8));
+    GL355_TRY(quotient_dev(ctx, c, cs->lde, wires->lde, zs->lde, N, sk.as<uint64_t>(), betas, gammas, alphas, pi_hash, vals.as<uint64_t>()));
+    GL355_TRY(intt_from_bitrev_dev(ctx, vals.as<uint64_t>(), nq, so.as<uint64_t>(), nq, c->degree_bits + qdb, nch, GL355_COSET_SHIFT));
+    return so.finish();
+}
+int32_t gl355_quotient(gl355_ctx* h, const gl355_circuit* c, const gl355_oracle* cs, const gl355_oracle* wires,
+                       const gl355_oracle* zs, const uint64_t* k_is, const uint64_t* betas, const uint64_t* gammas,
+                       const uint64_t* alphas, const uint64_t pi_hash[4], uint64_t* quotient_coeffs) {
+    return quotient_common(h, c, cs, wires, zs, k_is, betas, gammas, alphas, pi_hash, quotient_coeffs, true);
+}
+int32_t gl355_quotient_values(gl355_ctx* h, const gl355_circuit* c, const gl355_oracle* cs, const gl355_oracle* wires,
+                              const gl355_oracle* zs, const uint64_t* k_is, const uint64_t* betas, const uint64_t* gammas,
+                              const uint64_t* alphas, const uint64_t pi_hash[4], uint64_t* values) {
+    return quotient_common(h, c, cs, wires, zs, k_is, betas, gammas, alphas, pi_hash, values, false);
+}
+
 // ---- a11 -------------------------------------------------------------------------------------
 static int32_t collect_polys(Ctx* ctx, const gl355_poly_ref* polys, uint32_t n_polys, std::vector<const uint64_t*>& ptrs,
                              uint32_t* log_n) {

@@ -170,6 +170,9 @@ int32_t zs_partial_products_dev(Ctx* ctx, const uint64_t* wires, const uint64_t*
 int32_t canon_dev(Ctx* ctx, uint64_t* a, uint64_t n);
 int32_t intt_from_bitrev_dev(Ctx* ctx, const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t out_stride,
                              uint32_t log_n, uint32_t batch, uint64_t coset_shift);
+int32_t quotient_dev(Ctx* ctx, const gl355_circuit* c, const uint64_t* cs_lde, const uint64_t* wires_lde,
+                     const uint64_t* zs_lde, uint64_t lde_stride, const uint64_t* k_is_dev, const uint64_t* betas,
+                     const uint64_t* gammas, const uint64_t* alphas, const uint64_t pi_hash[4], uint64_t* out_values);
 Ctx* ctx_of(gl355_ctx* h);
 
 static inline uint32_t log2_u64(uint64_t n) { uint32_t l = 0; while ((1ull << l) < n) l++; return l; }

@@ -1,0 +1,165 @@
+// Host-side (CPU, sequential) pieces of the prover that SURVEY.md 8(a) keeps on the host: the
+// Fiat-Shamir Challenger (a15) and the PoseidonGate witness row.  They are tiny and strictly
+// sequential (about 50 permutations per proof), so they run on the calling thread; the data-parallel
+// Poseidon work (leaf hashing, Merkle levels, PoW grinding) stays in merkle.hip.
+//
+// Replaces plonky2::iop::challenger::Challenger (transcript order pinned by
+// src/plonky2_verifier/chip/plonk/plonk_verifier_chip.rs:55-154, sponge mechanics by
+// chip/hasher_chip.rs:48-89) and plonky2::gates::poseidon::PoseidonGate's generator (wire layout
+// chip/plonk/gates/poseidon.rs:329-380, round structure :634-686).
+#include "gl355_internal.h"
+
+#define PSD_TABLE_QUAL static const
+#include "poseidon_tables.h"
+
+namespace gl355 {
+
+static inline uint64_t h_sbox(uint64_t x) {
+    uint64_t x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x, x2);
+    return gl_mul(x3, x4);
+}
+static void h_mds(uint64_t s[12]) {
+    static const uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    uint64_t t[12];
+    for (int r = 0; r < 12; r++) {
+        unsigned __int128 acc = 0;
+        for (int i = 0; i < 12; i++) acc += (unsigned __int128)gl_canon(s[(i + r) % 12]) * CIRC[i];
+        if (r == 0) acc += (unsigned __int128)gl_canon(s[0]) * 8;
+        t[r] = gl_reduce128((uint64_t)acc, (uint64_t)(acc >> 64));
+    }
+    memcpy(s, t, sizeof t);
+}
+// fast-partial form; sbox_in (optional) receives the 22 partial-round S-box inputs, full_in the
+// S-box inputs of the 8 full rounds (12 each) -- exactly the values PoseidonGate stores as wires
+static void h_permute(uint64_t s[12], uint64_t* full_in /*[8][12]*/, uint64_t* part_in /*[22]*/) {
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 12; i++) {
+            s[i] = gl_add(s[i], PSD_FULL_RC[12 * r + i]);
+            if (full_in) full_in[12 * r + i] = gl_canon(s[i]);
+            s[i] = h_sbox(s[i]);
+        }
+        h_mds(s);
+    }
+    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PSD_PART_FIRST[i]);
+    {
+        uint64_t t[12];
+        t[0] = s[0];
+        for (int c = 1; c < 12; c++) {
+            uint64_t acc = 0;
+            for (int r = 1; r < 12; r++) acc = gl_add(acc, gl_mul(s[r], PSD_PART_INIT[(r - 1) * 11 + (c - 1)]));
+            t[c] = acc;
+        }
+        memcpy(s, t, sizeof t);
+    }
+    for (int r = 0; r < 22; r++) {
+        if (part_in) part_in[r] = gl_canon(s[0]);
+        uint64_t s0 = gl_add(h_sbox(s[0]), PSD_PART_RC[r]);
+        uint64_t d = gl_mul_small(s0, 25);
+        for (int i = 1; i < 12; i++) {
+            d = gl_add(d, gl_mul(s[i], PSD_PART_WHAT[r * 11 + (i - 1)]));
+            s[i] = gl_add(s[i], gl_mul(s0, PSD_PART_VS[r * 11 + (i - 1)]));
+        }
+        s[0] = d;
+    }
+    for (int r = 4; r < 8; r++) {
+        for (int i = 0; i < 12; i++) {
+            s[i] = gl_add(s[i], PSD_FULL_RC[12 * r + i]);
+            if (full_in) full_in[12 * r + i] = gl_canon(s[i]);
+            s[i] = h_sbox(s[i]);
+        }
+        h_mds(s);
+    }
+    for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
+}
+
+}  // namespace gl355
+
+using namespace gl355;
+
+extern "C" {
+
+int32_t gl355_host_poseidon_permute(uint64_t state[12]) {
+    if (!state) return GL355_E_INVALID_ARG;
+    h_permute(state, nullptr, nullptr);
+    return GL355_OK;
+}
+
+int32_t gl355_host_hash_no_pad(const uint64_t* in, uint64_t len, uint64_t out[4]) {
+    if ((!in && len) || !out) return GL355_E_INVALID_ARG;
+    uint64_t st[12] = {0};
+    for (uint64_t off = 0; off < len; off += 8) {
+        const uint64_t m = len - off < 8 ? len - off : 8;
+        for (uint64_t i = 0; i < m; i++) st[i] = gl_canon(in[off + i]);
+        h_permute(st, nullptr, nullptr);
+    }
+    memcpy(out, st, 32);
+    return GL355_OK;
+}
+
+int32_t gl355_challenger_init(gl355_challenger* c) {
+    if (!c) return GL355_E_INVALID_ARG;
+    memset(c, 0, sizeof *c);
+    return GL355_OK;
+}
+static void duplex(gl355_challenger* c) {
+    for (uint32_t i = 0; i < c->in_len; i++) c->state[i] = c->in_buf[i];
+    c->in_len = 0;
+    h_permute(c->state, nullptr, nullptr);
+    memcpy(c->out_buf, c->state, 64);
+    c->out_len = 8;
+}
+int32_t gl355_challenger_observe(gl355_challenger* c, const uint64_t* elems, uint64_t n) {
+    if (!c || (!elems && n)) return GL355_E_INVALID_ARG;
+    for (uint64_t i = 0; i < n; i++) {
+        c->out_len = 0;  // any new input invalidates buffered outputs
+        c->in_buf[c->in_len++] = gl_canon(elems[i]);
+        if (c->in_len == 8) duplex(c);
+    }
+    return GL355_OK;
+}
+int32_t gl355_challenger_squeeze(gl355_challenger* c, uint64_t* out, uint64_t n) {
+    if (!c || !out) return GL355_E_INVALID_ARG;
+    for (uint64_t i = 0; i < n; i++) {
+        if (c->in_len > 0 || c->out_len == 0) duplex(c);
+        out[i] = c->out_buf[--c->out_len];  // pops from the END of the rate part
+    }
+    return GL355_OK;
+}
+// state and witness position for the PoW search: the pending inputs are written over the sponge state,
+// the candidate goes to slot in_len, then one permutation; the response is state[7]
+int32_t gl355_challenger_pow_state(const gl355_challenger* c, uint64_t state[12], uint32_t* pos) {
+    if (!c || !state || !pos) return GL355_E_INVALID_ARG;
+    if (c->in_len >= 8) return GL355_E_INVALID_ARG;
+    memcpy(state, c->state, 96);
+    for (uint32_t i = 0; i < c->in_len; i++) state[i] = c->in_buf[i];
+    *pos = c->in_len;
+    return GL355_OK;
+}
+
+// All 135 wires of one PoseidonGate row from its 12 inputs and the swap bit.
+int32_t gl355_poseidon_gate_witness(const uint64_t inputs[12], uint64_t swap, uint64_t wires[135]) {
+    if (!inputs || !wires || swap > 1) return GL355_E_INVALID_ARG;
+    for (int i = 0; i < 135; i++) wires[i] = 0;
+    for (int i = 0; i < 12; i++) wires[i] = gl_canon(inputs[i]);
+    wires[24] = swap;
+    uint64_t s[12];
+    for (int i = 0; i < 12; i++) s[i] = wires[i];
+    for (int i = 0; i < 4; i++) {
+        const uint64_t delta = swap ? gl_canon(gl_sub(wires[4 + i], wires[i])) : 0;  // swap * (rhs - lhs)
+        wires[25 + i] = delta;
+        s[i] = gl_add(wires[i], delta);
+        s[4 + i] = gl_sub(wires[4 + i], delta);
+    }
+    uint64_t full_in[96], part_in[22];
+    h_permute(s, full_in, part_in);
+    // first full round's S-box inputs are not wires; rounds 1..3 -> wires 29..64
+    for (int r = 1; r < 4; r++)
+        for (int i = 0; i < 12; i++) wires[29 + 12 * (r - 1) + i] = full_in[12 * r + i];
+    for (int r = 0; r < 22; r++) wires[65 + r] = part_in[r];
+    for (int r = 0; r < 4; r++)
+        for (int i = 0; i < 12; i++) wires[87 + 12 * r + i] = full_in[12 * (4 + r) + i];
+    for (int i = 0; i < 12; i++) wires[12 + i] = s[i];
+    return GL355_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,285 @@
+// Constraint / quotient batch evaluation for gfx950 (a10 of SURVEY.md 8).
+//
+// Replaces plonky2::plonk::prover::compute_quotient_polys ->
+// vanishing_poly::eval_vanishing_poly_base_batch -> Gate::eval_unfiltered_base_batch (+ ZeroPolyOnCoset),
+// reached from the reference through CircuitData::prove (src/plonky2_semaphore/access_set.rs:94,
+// recursion.rs:168, wrapper.rs:55).  The formula is the one the reference's verifier re-evaluates at
+// zeta: src/plonky2_verifier/chip/plonk/vanishing_poly.rs:18-153 (term order :110-123), gate filter
+// chip/plonk/gates/mod.rs:87-132, quotient identity chip/plonk/plonk_verifier_chip.rs:174-210, and
+// the gate evaluators chip/plonk/gates/{noop,constant,public_input,base_sum,arithmetic,poseidon}.rs.
+//
+// One lane = one point x = 7*omega^i of the quotient coset (size n * 2^qdb).  The three committed
+// oracles are column-major in bit-reversed row order, and lane t works on storage row t, so every
+// one of the ~240 column reads per point is a perfectly coalesced 512-byte wave access; nothing is
+// gathered except the 2 "next row" Z values.  All arithmetic is base field (the challenges alpha,
+// beta, gamma are base-field elements, plonk_verifier_chip.rs:64-96).  The term list
+//   [L0(x)(Z_c(x)-1)]_c || [prev*prod(num) - next*prod(den)]_{c,chunk} || [sum_g filter_g * constraint_{g,k}]_k
+// is reduced with powers of each alpha on the fly, so no per-lane constraint array exists.
+// Roofline: integer VALU (a PoseidonGate row costs about one permutation), not HBM.
+#include "gl355_internal.h"
+#include "poseidon.cuh"
+
+namespace gl355 {
+
+struct QuotArgs {
+    gl355_circuit c;
+    const uint64_t* cs;       // constants_sigmas LDE  [num_selectors + num_constants + routed][N]
+    const uint64_t* wires;    // wires LDE             [num_wires (+salt)][N]
+    const uint64_t* zs;       // Z + partial products  [num_challenges * (1 + num_pp) (+salt)][N]
+    uint64_t lde_stride;      // N
+    uint32_t qbits;           // log2 of the quotient domain
+    const uint64_t* k_is;     // [routed]
+    const uint64_t* xw_lo;    // omega_{Nq}^e two-level table
+    const uint64_t* xw_hi;
+    uint64_t zh_inv[16];      // 1 / (x^n - 1) for the 2^qdb classes of i mod 2^qdb
+    uint64_t zh[16];          // x^n - 1
+    uint64_t betas[4], gammas[4], alphas[4];
+    uint64_t pi_hash[4];
+    uint64_t n_inv;           // 1/n
+    uint64_t* out;            // [num_challenges][Nq], storage (bit-reversed) order
+};
+
+// running alpha-power accumulation of the constraint stream for up to 4 challenges
+struct AlphaAcc {
+    uint64_t acc[4], pw[4], alpha[4];
+    int nch;
+    GL_DEV void init(const QuotArgs& a) {
+        nch = a.c.num_challenges;
+        for (int c = 0; c < 4; c++) { acc[c] = 0; pw[c] = 1; alpha[c] = a.alphas[c]; }
+    }
+    GL_DEV void push(uint64_t term) {
+        for (int c = 0; c < nch; c++) {
+            acc[c] = gl_add(acc[c], gl_mul(term, pw[c]));
+            pw[c] = gl_mul(pw[c], alpha[c]);
+        }
+    }
+};
+
+// per-gate accumulation: sum_k alpha^(base+k) * c_k, later multiplied by the gate's filter
+struct GateAcc {
+    uint64_t acc[4], pw[4], alpha[4];
+    int nch;
+    GL_DEV void init(const uint64_t* alphas, const uint64_t* base_pw, int n) {
+        nch = n;
+        for (int c = 0; c < 4; c++) { acc[c] = 0; pw[c] = base_pw[c]; alpha[c] = alphas[c]; }
+    }
+    GL_DEV void push(uint64_t term) {
+        for (int c = 0; c < nch; c++) {
+            acc[c] = gl_add(acc[c], gl_mul(term, pw[c]));
+            pw[c] = gl_mul(pw[c], alpha[c]);
+        }
+    }
+};
+
+#define WIRE(j) (a.wires[(uint64_t)(j) * a.lde_stride + t])
+#define CONST(j) (a.cs[(uint64_t)(j) * a.lde_stride + t])
+
+// PoseidonGate: 123 constraints (gates/poseidon.rs:592-698); wire layout :329-380
+GL_DEV void gate_poseidon(const QuotArgs& a, uint64_t t, GateAcc& g) {
+    const uint64_t swap = WIRE(24);
+    g.push(gl_sub(gl_mul(swap, swap), swap));
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint64_t lhs = WIRE(i), rhs = WIRE(i + 4), delta = WIRE(25 + i);
+        g.push(gl_sub(gl_mul(swap, gl_sub(rhs, lhs)), delta));
+        s[i] = gl_add(lhs, delta);
+        s[i + 4] = gl_sub(rhs, delta);
+    }
+#pragma unroll
+    for (int i = 8; i < 12; i++) s[i] = WIRE(i);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            s[i] = gl_add(s[i], PSD_FULL_RC[12 * r + i]);
+            if (r != 0) {
+                const uint64_t sin = WIRE(29 + 12 * (r - 1) + i);
+                g.push(gl_sub(s[i], sin));
+                s[i] = sin;
+            }
+            s[i] = psd_sbox(s[i]);
+        }
+        psd_mds(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PSD_PART_FIRST[i]);
+    {
+        uint64_t u[12];
+        u[0] = s[0];
+#pragma unroll
+        for (int c = 1; c < 12; c++) u[c] = 0;
+#pragma unroll 1
+        for (int r = 1; r < 12; r++) {
+            const uint64_t sr = s[r];
+#pragma unroll
+            for (int c = 1; c < 12; c++) u[c] = gl_add(u[c], gl_mul(sr, PSD_PART_INIT[(r - 1) * 11 + (c - 1)]));
+        }
+#pragma unroll
+        for (int c = 0; c < 12; c++) s[c] = u[c];
+    }
+#pragma unroll 1
+    for (int r = 0; r < 22; r++) {
+        const uint64_t sin = WIRE(65 + r);
+        g.push(gl_sub(s[0], sin));
+        const uint64_t s0 = gl_add(psd_sbox(sin), PSD_PART_RC[r]);  // RC[21] == 0
+        uint64_t d = gl_mul_small(s0, 25);
+#pragma unroll
+        for (int i = 1; i < 12; i++) {
+            d = gl_add(d, gl_mul(s[i], PSD_PART_WHAT[r * 11 + (i - 1)]));
+            s[i] = gl_add(s[i], gl_mul(s0, PSD_PART_VS[r * 11 + (i - 1)]));
+        }
+        s[0] = d;
+    }
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            s[i] = gl_add(s[i], PSD_FULL_RC[48 + 12 * r + i]);
+            const uint64_t sin = WIRE(87 + 12 * r + i);
+            g.push(gl_sub(s[i], sin));
+            s[i] = psd_sbox(sin);
+        }
+        psd_mds(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) g.push(gl_sub(s[i], WIRE(12 + i)));
+}
+
+// BaseSumGate<2>{num_limbs}: sum_i limb_i 2^i - sum ; limb (limb - 1)   (gates/base_sum.rs:37-60)
+GL_DEV void gate_base_sum(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num_limbs) {
+    uint64_t acc = 0;
+    for (uint32_t i = num_limbs; i-- > 0;) acc = gl_add(gl_add(acc, acc), WIRE(1 + i));
+    g.push(gl_sub(acc, WIRE(0)));
+    for (uint32_t i = 0; i < num_limbs; i++) {
+        const uint64_t l = WIRE(1 + i);
+        g.push(gl_sub(gl_mul(l, l), l));
+    }
+}
+// ConstantGate{n}: const_i - wire_i   (gates/constant.rs:31-36); gate constants follow the selectors
+GL_DEV void gate_constant(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) g.push(gl_sub(CONST(a.c.num_selectors + i), WIRE(i)));
+}
+// PublicInputGate: wire_i - pi_hash_i   (gates/public_input.rs:32-39)
+GL_DEV void gate_public_input(const QuotArgs& a, uint64_t t, GateAcc& g) {
+    for (uint32_t i = 0; i < 4; i++) g.push(gl_sub(WIRE(i), a.pi_hash[i]));
+}
+// ArithmeticGate{num_ops}: out - (c0 m0 m1 + c1 addend)   (gates/arithmetic.rs:47-68)
+GL_DEV void gate_arithmetic(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num_ops) {
+    const uint64_t c0 = CONST(a.c.num_selectors), c1 = CONST(a.c.num_selectors + 1);
+    for (uint32_t i = 0; i < num_ops; i++) {
+        const uint64_t m0 = WIRE(4 * i), m1 = WIRE(4 * i + 1), ad = WIRE(4 * i + 2), out = WIRE(4 * i + 3);
+        g.push(gl_sub(out, gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(ad, c1))));
+    }
+}
+
+__global__ void __launch_bounds__(128) quotient_kernel(QuotArgs a) {
+    const uint64_t nq = 1ull << a.qbits;
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= nq) return;
+    const uint32_t qdb = a.qbits - a.c.degree_bits;
+    const uint64_t iq = __brevll(t) >> (64 - a.qbits);   // natural index of storage row t
+    const uint64_t x = gl_mul_small(gl_mul(a.xw_lo[iq & 4095], a.xw_hi[iq >> 12]), 7);
+    // next row: natural index iq + 2^qdb (g*x), its storage row is bitrev of that
+    const uint64_t iq_next = (iq + (1ull << qdb)) & (nq - 1);
+    const uint64_t t_next = __brevll(iq_next) >> (64 - a.qbits);
+    const uint32_t nch = a.c.num_challenges, npp = a.c.num_partial_products;
+    const uint32_t routed = a.c.num_routed_wires, chunk = a.c.max_degree;
+    const uint32_t n_sel = a.c.num_selectors, n_cst = a.c.num_constants;
+
+    AlphaAcc total;
+    total.init(a);
+    // ---- L0(x) (Z_c(x) - 1);  L0(x) = (x^n - 1) / (n (x - 1))  (vanishing_poly.rs:155-178) ---------
+    const uint64_t zh_inv = a.zh_inv[iq & ((1u << qdb) - 1)];
+    const uint64_t zh = a.zh[iq & ((1u << qdb) - 1)];  // x^n - 1 (never zero on the coset)
+    const uint64_t l0 = gl_mul(gl_mul(zh, a.n_inv), gl_inv(gl_sub(x, 1)));
+    for (uint32_t c = 0; c < nch; c++) {
+        const uint64_t z = a.zs[(uint64_t)c * a.lde_stride + t];
+        total.push(gl_sub(gl_mul(l0, z), l0));
+    }
+    // ---- partial products (vanishing_poly.rs:54-108, 183-218) -------------------------------------
+    for (uint32_t c = 0; c < nch; c++) {
+        const uint64_t beta = a.betas[c], gamma = a.gammas[c];
+        const uint64_t bx = gl_mul(beta, x);
+        uint64_t prev = a.zs[(uint64_t)c * a.lde_stride + t];
+        const uint32_t n_chunks = (routed + chunk - 1) / chunk;
+        for (uint32_t ch = 0; ch < n_chunks; ch++) {
+            uint64_t num = 1, den = 1;
+            for (uint32_t j = ch * chunk; j < (ch + 1) * chunk && j < routed; j++) {
+                const uint64_t w = gl_add(WIRE(j), gamma);
+                num = gl_mul(num, gl_add(w, gl_mul(bx, a.k_is[j])));
+                den = gl_mul(den, gl_add(w, gl_mul(beta, CONST(n_sel + n_cst + j))));
+            }
+            const uint64_t next = (ch + 1 < n_chunks)
+                                      ? a.zs[(uint64_t)(nch + c * npp + ch) * a.lde_stride + t]
+                                      : a.zs[(uint64_t)c * a.lde_stride + t_next];
+            total.push(gl_sub(gl_mul(prev, num), gl_mul(next, den)));
+            prev = next;
+        }
+    }
+    // ---- gate constraints, each gate's stream multiplied by its filter (gates/mod.rs:87-132) ---------
+    uint64_t gate_sum[4] = {0, 0, 0, 0};
+    for (uint32_t gi = 0; gi < a.c.num_gates; gi++) {
+        const gl355_gate gt = a.c.gates[gi];
+        if (gt.type == GL355_GATE_NOOP) continue;
+        GateAcc g;
+        g.init(a.alphas, total.pw, nch);
+        switch (gt.type) {
+            case GL355_GATE_POSEIDON: gate_poseidon(a, t, g); break;
+            case GL355_GATE_BASE_SUM: gate_base_sum(a, t, g, gt.param); break;
+            case GL355_GATE_CONSTANT: gate_constant(a, t, g, gt.param); break;
+            case GL355_GATE_PUBLIC_INPUT: gate_public_input(a, t, g); break;
+            case GL355_GATE_ARITHMETIC: gate_arithmetic(a, t, g, gt.param); break;
+            default: break;
+        }
+        const uint64_t sel = CONST(gt.selector_index);
+        uint64_t filter = 1;
+        for (uint32_t k = gt.group_start; k < gt.group_end; k++)
+            if (k != gi) filter = gl_mul(filter, gl_sub(k, sel));
+        if (n_sel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFull, sel));  // UNUSED_SELECTOR = u32::MAX
+        for (uint32_t c = 0; c < nch; c++) gate_sum[c] = gl_add(gate_sum[c], gl_mul(filter, g.acc[c]));
+    }
+    for (uint32_t c = 0; c < nch; c++) {
+        const uint64_t v = gl_mul(gl_add(total.acc[c], gate_sum[c]), zh_inv);
+        a.out[(uint64_t)c * nq + t] = gl_canon(v);
+    }
+}
+
+int32_t quotient_dev(Ctx* ctx, const gl355_circuit* c, const uint64_t* cs_lde, const uint64_t* wires_lde,
+                     const uint64_t* zs_lde, uint64_t lde_stride, const uint64_t* k_is_dev, const uint64_t* betas,
+                     const uint64_t* gammas, const uint64_t* alphas, const uint64_t pi_hash[4], uint64_t* out_values) {
+    uint32_t qdb = 0;
+    while ((1u << qdb) < c->max_degree) qdb++;
+    if ((1u << qdb) != c->max_degree || qdb > c->rate_bits || qdb > 4) return ctx->fail(GL355_E_UNSUPPORTED, "quotient: degree factor must be a power of two <= 2^rate_bits");
+    if (c->num_challenges == 0 || c->num_challenges > 4) return ctx->fail(GL355_E_UNSUPPORTED, "quotient: 1..4 challenges");
+    if (c->num_gates > GL355_MAX_GATES) return ctx->fail(GL355_E_INVALID_ARG, "quotient: too many gates");
+    QuotArgs a;
+    memset(&a, 0, sizeof a);
+    a.c = *c;
+    a.cs = cs_lde; a.wires = wires_lde; a.zs = zs_lde; a.lde_stride = lde_stride;
+    a.qbits = c->degree_bits + qdb;
+    a.k_is = k_is_dev;
+    GL355_TRY(ctx->pow_tables(gl_root_of_unity(a.qbits), &a.xw_lo, &a.xw_hi));
+    // x^n = 7^n * omega_{2^qdb}^(i mod 2^qdb)
+    const uint64_t sn = gl_pow(7, 1ull << c->degree_bits);
+    const uint64_t wq = gl_root_of_unity(qdb);
+    uint64_t w = 1;
+    for (uint32_t k = 0; k < (1u << qdb); k++) {
+        a.zh[k] = gl_canon(gl_sub(gl_mul(sn, w), 1));
+        a.zh_inv[k] = gl_canon(gl_inv(a.zh[k]));
+        w = gl_mul(w, wq);
+    }
+    for (uint32_t i = 0; i < c->num_challenges; i++) {
+        a.betas[i] = gl_canon(betas[i]); a.gammas[i] = gl_canon(gammas[i]); a.alphas[i] = gl_canon(alphas[i]);
+    }
+    for (int i = 0; i < 4; i++) a.pi_hash[i] = gl_canon(pi_hash[i]);
+    a.n_inv = gl_canon(gl_inv((1ull << c->degree_bits) % GL_P));
+    a.out = out_values;
+    const uint64_t nq = 1ull << a.qbits;
+    ProfScope ps(ctx, "quotient_kernel");
+    hipLaunchKernelGGL(quotient_kernel, dim3((uint32_t)((nq + 127) / 128)), dim3(128), 0, ctx->stream, a);
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+
+}  // namespace gl355

@@ -1,0 +1,407 @@
+"""Host-side prover driver: sequences one plonky2-style proof on top of the gl355 kernels.
+
+This is the host code the reference reaches through `CircuitBuilder::build` / `CircuitData::prove`
+(src/plonky2_semaphore/access_set.rs:85-94, recursion.rs:49,167-168, wrapper.rs:36-41,54-55), restated
+from the protocol the reference's in-tree verifier pins:
+  transcript order      chip/plonk/plonk_verifier_chip.rs:55-154
+  oracles / poly order  types/common_data.rs:100-222, types/assigned.rs:26-44
+  vanishing terms       chip/plonk/vanishing_poly.rs:18-153 (evaluated on the GPU: csrc/quotient.hip)
+  FRI                   chip/fri_chip.rs (batch combine :112-149, fold :168-226, queries :228-327, PoW :364-376)
+Every data-parallel stage is a libgl355 call (NTT/LDE/Merkle commit, Z/partial products, quotient,
+openings, DEEP quotient, FRI layers, PoW); only the Fiat-Shamir Challenger, the circuit bookkeeping
+and witness placement run on the host, as in the reference.
+The circuit builder below is this framework's own (gate placement and the circuit digest are not
+plonky2's -- its builder is not part of the reference tree), but the gate set, wire layouts,
+constraint formulas and proof structure are the reference's.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (GATE_ARITHMETIC, GATE_BASE_SUM, GATE_CONSTANT, GATE_NOOP, GATE_POSEIDON, GATE_PUBLIC_INPUT,
+                   Challenger as _CChallenger, Circuit as _CCircuit)
+from .api import COSET_SHIFT, P, SALT_SIZE, MerkleTree, PolynomialBatch, _ptr, _u64, deep_batch, eval_polys
+
+UNUSED_SELECTOR = 0xFFFFFFFF
+
+
+class CircuitConfig:
+    """plonky2's CircuitConfig with the values the reference uses (access_set.rs:68-84, recursion.rs:32-48)."""
+
+    def __init__(self, **kw):
+        self.num_wires = 135
+        self.num_routed_wires = 80
+        self.num_constants = 2
+        self.num_challenges = 2
+        self.max_quotient_degree_factor = 8
+        self.zero_knowledge = True
+        self.rate_bits = 3
+        self.cap_height = 4
+        self.proof_of_work_bits = 16
+        self.num_query_rounds = 28
+        self.reduction_arity_bits = 1      # FriReductionStrategy::ConstantArityBits(1, 5)
+        self.final_poly_bits = 5
+        self.__dict__.update(kw)
+
+    def fri_reduction_arity_bits(self, degree_bits):
+        """ConstantArityBits(a, f): push a while degree_bits > f and degree_bits + rate_bits - a >= cap_height."""
+        out, d = [], degree_bits
+        a, f = self.reduction_arity_bits, self.final_poly_bits
+        while d > f and d + self.rate_bits - a >= self.cap_height:
+            out.append(a)
+            d -= a
+        return out
+
+
+class Challenger:
+    """plonky2::iop::challenger::Challenger on the host (gl355_challenger_*)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.c = _CChallenger()
+        self.lib.gl355_challenger_init(C.byref(self.c))
+
+    def observe(self, elems):
+        e = _u64(elems).reshape(-1)
+        if e.size:
+            self.lib.gl355_challenger_observe(C.byref(self.c), _ptr(e), e.size)
+
+    def squeeze(self, n=1):
+        out = np.empty(n, dtype=np.uint64)
+        self.lib.gl355_challenger_squeeze(C.byref(self.c), _ptr(out), n)
+        return out
+
+    def get_extension_challenge(self):
+        return self.squeeze(2)
+
+    def pow_state(self):
+        st = np.empty(12, dtype=np.uint64)
+        pos = C.c_uint32()
+        rc = self.lib.gl355_challenger_pow_state(C.byref(self.c), _ptr(st), C.byref(pos))
+        assert rc == 0
+        return st, pos.value
+
+
+def host_hash_no_pad(x):
+    lib = _lib.load()
+    x = _u64(x).reshape(-1)
+    out = np.empty(4, dtype=np.uint64)
+    lib.gl355_host_hash_no_pad(_ptr(x) if x.size else None, x.size, _ptr(out))
+    return out
+
+
+def poseidon_gate_witness(inputs, swap):
+    lib = _lib.load()
+    w = np.empty(135, dtype=np.uint64)
+    rc = lib.gl355_poseidon_gate_witness(_ptr(_u64(inputs)), int(swap), _ptr(w))
+    assert rc == 0
+    return w
+
+
+class CircuitBuilder:
+    """Minimal gate-level builder: rows of gates, copy constraints between routed wires."""
+
+    def __init__(self, config=None):
+        self.config = config or CircuitConfig()
+        self.gate_types = []          # [(type, param)] in registration order
+        self.rows = []                # [(gate_type_index, [gate constants])]
+        self.copies = []              # [((row, col), (row, col))]
+        self.num_public_inputs = 0
+
+    def gate_type(self, gtype, param=0):
+        key = (gtype, param)
+        if key not in self.gate_types:
+            self.gate_types.append(key)
+        return self.gate_types.index(key)
+
+    def add_gate(self, gtype, param=0, constants=()):
+        gi = self.gate_type(gtype, param)
+        self.rows.append((gi, list(constants)))
+        return len(self.rows) - 1
+
+    def connect(self, a, b):
+        assert a[1] < self.config.num_routed_wires and b[1] < self.config.num_routed_wires, "only routed wires can be copied"
+        self.copies.append((a, b))
+
+    def build(self, ctx, rng, min_degree_bits=0):
+        """Pads (blinding rows + noops), computes selectors / sigmas and commits constants_sigmas."""
+        cfg = self.config
+        noop = self.gate_type(GATE_NOOP)
+        n_real = len(self.rows)
+        # zero-knowledge blinding: random unconstrained rows hide the wire openings,
+        # and pairs of rows sharing one random routed value randomise the Z polynomials
+        n_blind_wires = n_blind_z = 0
+        if cfg.zero_knowledge:
+            arities = cfg.fri_reduction_arity_bits(max(min_degree_bits, 13))
+            q = cfg.num_query_rounds * (1 + 2 * sum((1 << a) - 1 for a in arities) + 2 * (1 << cfg.final_poly_bits))
+            n_blind_wires = 2 + q
+            n_blind_z = 2 * (2 * 2 + q)
+        blind_start = len(self.rows)
+        for _ in range(n_blind_wires + n_blind_z):
+            self.add_gate(GATE_NOOP)
+        z_pairs = []
+        for k in range(n_blind_z // 2):
+            r0 = blind_start + n_blind_wires + 2 * k
+            self.connect((r0, 0), (r0 + 1, 0))
+            z_pairs.append((r0, r0 + 1))
+        degree_bits = max(min_degree_bits, 2, int(len(self.rows) - 1).bit_length())
+        n = 1 << degree_bits
+        while len(self.rows) < n:
+            self.add_gate(GATE_NOOP)
+        # selector groups: a gate of degree d may share a selector with g-1 others iff g-1+1+d <= 9
+        # -> PoseidonGate (degree 7) alone, everything else (degree <= 3) together
+        order = sorted(range(len(self.gate_types)), key=lambda i: 0 if self.gate_types[i][0] == GATE_POSEIDON else 1)
+        remap = {old: new for new, old in enumerate(order)}
+        gates = [self.gate_types[i] for i in order]
+        groups, sel_index = [], []
+        if any(g[0] == GATE_POSEIDON for g in gates):
+            k = sum(1 for g in gates if g[0] == GATE_POSEIDON)
+            groups.append((0, k))
+            if k < len(gates):
+                groups.append((k, len(gates)))
+        else:
+            groups.append((0, len(gates)))
+        for gi in range(len(gates)):
+            sel_index.append(next(s for s, (lo, hi) in enumerate(groups) if lo <= gi < hi))
+        num_selectors = len(groups)
+        consts = np.zeros((num_selectors + cfg.num_constants, n), dtype=np.uint64)
+        row_gate = np.zeros(n, dtype=np.int64)
+        for r, (gi_old, cs) in enumerate(self.rows):
+            gi = remap[gi_old]
+            row_gate[r] = gi
+            for s in range(num_selectors):
+                consts[s, r] = gi if sel_index[gi] == s else UNUSED_SELECTOR
+            for j, v in enumerate(cs):
+                consts[num_selectors + j, r] = v % P
+        # sigma: cyclic permutation inside every copy class, value = k_col * g^row
+        routed = cfg.num_routed_wires
+        parent = {}
+
+        def find(x):
+            while parent.setdefault(x, x) != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        for a, b in self.copies:
+            ra, rb = find(a), find(b)
+            if ra != rb:
+                parent[ra] = rb
+        classes = {}
+        for x in list(parent):
+            classes.setdefault(find(x), []).append(x)
+        sigma_map = {}
+        for members in classes.values():
+            members.sort()
+            for i, m in enumerate(members):
+                sigma_map[m] = members[(i + 1) % len(members)]
+        g = pow(7, (P - 1) >> degree_bits, P)
+        subgroup = np.empty(n, dtype=object)
+        x = 1
+        for i in range(n):
+            subgroup[i] = x
+            x = x * g % P
+        k_is = [pow(7, j, P) for j in range(routed)]
+        sigmas = np.empty((routed, n), dtype=np.uint64)
+        for j in range(routed):
+            col = [(k_is[j] * int(s)) % P for s in subgroup]
+            sigmas[j] = np.array(col, dtype=np.uint64)
+        for (r, c), (r2, c2) in sigma_map.items():
+            sigmas[c, r] = (k_is[c2] * int(subgroup[r2])) % P
+        cs_values = np.concatenate([consts, sigmas])
+        cs_batch = PolynomialBatch.from_values(ctx, cs_values, cfg.rate_bits, cfg.cap_height, salt=None)
+        data = CircuitData()
+        data.config, data.degree_bits, data.gates, data.groups, data.selector_indices = cfg, degree_bits, gates, groups, sel_index
+        data.num_selectors = num_selectors
+        data.k_is = np.array(k_is, dtype=np.uint64)
+        data.sigmas = sigmas
+        data.constants = consts
+        data.row_gate = row_gate
+        data.constants_sigmas = cs_batch
+        data.copy_classes = [m for m in classes.values() if len(m) > 1]
+        data.blind_rows = (blind_start, n_blind_wires, z_pairs, n_real)
+        data.num_partial_products = (routed + cfg.max_quotient_degree_factor - 1) // cfg.max_quotient_degree_factor - 1
+        data.num_gate_constraints = max([_GATE_CONSTRAINTS[t](p) for t, p in gates] + [0])
+        data.fri_arity_bits = cfg.fri_reduction_arity_bits(degree_bits)
+        # circuit digest: hash of the preprocessed commitment and the shape (this framework's own
+        # definition; plonky2's digest additionally covers its builder's domain separator)
+        shape = [degree_bits, len(gates), num_selectors] + [t * 1000 + p for t, p in gates]
+        data.circuit_digest = host_hash_no_pad(np.concatenate([cs_batch.cap.reshape(-1), np.array(shape, dtype=np.uint64)]))
+        cc = _CCircuit()
+        cc.degree_bits, cc.rate_bits = degree_bits, cfg.rate_bits
+        cc.num_wires, cc.num_routed_wires, cc.num_constants = cfg.num_wires, routed, cfg.num_constants
+        cc.num_selectors, cc.num_challenges = num_selectors, cfg.num_challenges
+        cc.max_degree, cc.num_partial_products, cc.num_gates = cfg.max_quotient_degree_factor, data.num_partial_products, len(gates)
+        for i, (t, p) in enumerate(gates):
+            cc.gates[i].type, cc.gates[i].param, cc.gates[i].selector_index = t, p, sel_index[i]
+            cc.gates[i].group_start, cc.gates[i].group_end = groups[sel_index[i]]
+        data.c_circuit = cc
+        return data
+
+
+_GATE_CONSTRAINTS = {
+    GATE_NOOP: lambda p: 0, GATE_CONSTANT: lambda p: p, GATE_PUBLIC_INPUT: lambda p: 4,
+    GATE_BASE_SUM: lambda p: 1 + p, GATE_POSEIDON: lambda p: 123, GATE_ARITHMETIC: lambda p: p,
+}
+
+
+class CircuitData:
+    """The prover/verifier data of one built circuit (plonky2 CircuitData / CommonCircuitData)."""
+
+    def common(self):
+        """Plain-dict common data for the verifier restatement in tests/."""
+        cfg = self.config
+        return dict(degree_bits=self.degree_bits, gates=list(self.gates), groups=list(self.groups),
+                    selector_indices=list(self.selector_indices), num_selectors=self.num_selectors,
+                    num_constants=cfg.num_constants, num_wires=cfg.num_wires, num_routed_wires=cfg.num_routed_wires,
+                    num_challenges=cfg.num_challenges, quotient_degree_factor=cfg.max_quotient_degree_factor,
+                    num_partial_products=self.num_partial_products, num_gate_constraints=self.num_gate_constraints,
+                    k_is=[int(k) for k in self.k_is], rate_bits=cfg.rate_bits, cap_height=cfg.cap_height,
+                    pow_bits=cfg.proof_of_work_bits, num_query_rounds=cfg.num_query_rounds,
+                    arity_bits=list(self.fri_arity_bits), hiding=cfg.zero_knowledge,
+                    circuit_digest=[int(x) for x in self.circuit_digest],
+                    constants_sigmas_cap=self.constants_sigmas.cap.copy())
+
+
+def fill_blinding(data, wires, rng):
+    """Random values on the blinding rows (all wires) and on the Z-blinding pairs (one shared value)."""
+    start, n_wires_rows, z_pairs, _ = data.blind_rows
+    if n_wires_rows:
+        wires[:, start:start + n_wires_rows] = rng.integers(0, P, size=(wires.shape[0], n_wires_rows), dtype=np.uint64)
+    for r0, r1 in z_pairs:
+        v = np.uint64(rng.integers(0, P, dtype=np.uint64))
+        wires[0, r0] = v
+        wires[0, r1] = v
+
+
+def check_copy_constraints(data, wires):
+    for members in data.copy_classes:
+        vals = {int(wires[c, r]) for r, c in members}
+        if len(vals) != 1:
+            raise AssertionError("copy constraint violated on %r" % (members[:4],))
+
+
+def _rand_salt(rng, n_cols):
+    return rng.integers(0, P, size=(SALT_SIZE, n_cols), dtype=np.uint64)
+
+
+def prove(ctx, data, wires, public_inputs, rng, timings=None):
+    """CircuitData::prove: wires[num_wires][n] is the full witness; returns the proof as a dict."""
+    import time
+    cfg = data.config
+    lib = ctx.lib
+    n = 1 << data.degree_bits
+    N = n << cfg.rate_bits
+    nch = cfg.num_challenges
+    salted = cfg.zero_knowledge
+    t_last = [time.perf_counter()]
+
+    def lap(name):
+        if timings is not None:
+            ctx.sync()
+            now = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + (now - t_last[0])
+            t_last[0] = now
+
+    pi = _u64(public_inputs)
+    pi_hash = host_hash_no_pad(pi)
+    ch = Challenger()
+    ch.observe(data.circuit_digest)
+    ch.observe(pi_hash)
+    # ---- wires ---------------------------------------------------------------------------------------
+    wires_batch = PolynomialBatch.from_values(ctx, wires, cfg.rate_bits, cfg.cap_height, salt=_rand_salt(rng, N) if salted else None)
+    wires_cap = wires_batch.cap
+    ch.observe(wires_cap)
+    betas, gammas = ch.squeeze(nch), ch.squeeze(nch)
+    lap("wires commit")
+    # ---- Z / partial products ---------------------------------------------------------------------------
+    routed = cfg.num_routed_wires
+    zs, pps = [], []
+    for c in range(nch):
+        z, pp = ctx.zs_partial_products(wires[:routed], data.sigmas, data.k_is, cfg.max_quotient_degree_factor, int(betas[c]), int(gammas[c]))
+        zs.append(z)
+        pps.append(pp)
+    zs_pp_values = np.concatenate([np.stack(zs)] + pps)
+    zs_batch = PolynomialBatch.from_values(ctx, zs_pp_values, cfg.rate_bits, cfg.cap_height, salt=_rand_salt(rng, N) if salted else None)
+    zs_cap = zs_batch.cap
+    ch.observe(zs_cap)
+    alphas = ch.squeeze(nch)
+    lap("Z/partial products + commit")
+    # ---- quotient -----------------------------------------------------------------------------------------
+    qdf = cfg.max_quotient_degree_factor
+    quot_coeffs = np.empty((nch * qdf, n), dtype=np.uint64)
+    ctx.check(lib.gl355_quotient(ctx.h, C.byref(data.c_circuit), data.constants_sigmas.h, wires_batch.h, zs_batch.h,
+                                 _ptr(data.k_is), _ptr(betas), _ptr(gammas), _ptr(alphas), _ptr(pi_hash), _ptr(quot_coeffs)))
+    quot_batch = PolynomialBatch.from_coeffs(ctx, quot_coeffs, cfg.rate_bits, cfg.cap_height, salt=_rand_salt(rng, N) if salted else None)
+    quot_cap = quot_batch.cap
+    ch.observe(quot_cap)
+    zeta = ch.get_extension_challenge()
+    lap("quotient + commit")
+    # ---- openings -------------------------------------------------------------------------------------------
+    g = pow(7, (P - 1) >> data.degree_bits, P)
+    zeta_next = np.array([int(zeta[0]) * g % P, int(zeta[1]) * g % P], dtype=np.uint64)
+    oracles = [data.constants_sigmas, wires_batch, zs_batch, quot_batch]
+    all_polys = [(o, i) for o in oracles for i in range(o.batch)]
+    zs_polys = [(zs_batch, i) for i in range(nch)]
+    ev = eval_polys(ctx, all_polys, zeta)
+    ev_next = eval_polys(ctx, zs_polys, zeta_next)
+    n_cs = data.constants_sigmas.batch
+    n_const = data.num_selectors + cfg.num_constants
+    openings = dict(constants=ev[:n_const], plonk_sigmas=ev[n_const:n_cs], wires=ev[n_cs:n_cs + cfg.num_wires],
+                    plonk_zs=ev[n_cs + cfg.num_wires:n_cs + cfg.num_wires + nch],
+                    partial_products=ev[n_cs + cfg.num_wires + nch:n_cs + cfg.num_wires + zs_batch.batch],
+                    quotient_polys=ev[n_cs + cfg.num_wires + zs_batch.batch:], plonk_zs_next=ev_next)
+    ch.observe(ev)
+    ch.observe(ev_next)
+    fri_alpha = ch.get_extension_challenge()
+    lap("openings")
+    # ---- DEEP quotient (prove_openings) ------------------------------------------------------------------------
+    acc = np.zeros(2 * n, dtype=np.uint64)
+    acc = deep_batch(ctx, all_polys, fri_alpha, zeta, acc)
+    acc = deep_batch(ctx, zs_polys, fri_alpha, zeta_next, acc)
+    final_values = ctx.lde_ext(acc, cfg.rate_bits)            # N ext values, natural order
+    coeffs = np.concatenate([acc, np.zeros(2 * (N - n), dtype=np.uint64)])   # final_poly.lde(rate_bits)
+    lap("DEEP quotient + final LDE")
+    # ---- FRI commit phase -----------------------------------------------------------------------------------------
+    trees, fri_betas = [], []
+    values, shift = final_values, COSET_SHIFT
+    for arity_bits in data.fri_arity_bits:
+        assert arity_bits == 1, "arity-2 folding only (the reference's verifier supports nothing else, fri_chip.rs:211)"
+        tree = ctx.fri_layer_commit(values, cfg.cap_height)
+        ch.observe(tree.cap)
+        trees.append(tree)
+        beta = ch.get_extension_challenge()
+        fri_betas.append(beta)
+        coeffs = ctx.fri_fold(coeffs, beta)
+        shift = shift * shift % P
+        values = ctx.lde_ext(coeffs, 0, shift)
+    final_poly = coeffs[: 2 * ((coeffs.size // 2) >> cfg.rate_bits)].copy()
+    assert not coeffs[final_poly.size:].any(), "FRI: the truncated coefficients must be zero"
+    ch.observe(final_poly)
+    lap("FRI commit phase")
+    # ---- proof of work ------------------------------------------------------------------------------------------------
+    st, pos = ch.pow_state()
+    pow_witness = ctx.pow_grind(st, pos, cfg.proof_of_work_bits)
+    ch.observe(np.array([pow_witness], dtype=np.uint64))
+    pow_response = int(ch.squeeze(1)[0])
+    assert cfg.proof_of_work_bits == 0 or pow_response >> (64 - cfg.proof_of_work_bits) == 0
+    lap("proof of work")
+    # ---- query rounds ----------------------------------------------------------------------------------------------------
+    queries = []
+    for _ in range(cfg.num_query_rounds):
+        x_index = int(ch.squeeze(1)[0]) % N
+        initial = [o.open(x_index) for o in oracles]
+        steps, idx = [], x_index
+        for tree in trees:
+            idx >>= 1
+            steps.append((tree.get(idx).copy(), tree.prove(idx)))
+        queries.append(dict(index=x_index, initial_trees=initial, steps=steps))
+    lap("query rounds")
+    proof = dict(wires_cap=wires_cap, plonk_zs_partial_products_cap=zs_cap, quotient_polys_cap=quot_cap,
+                 openings=openings,
+                 opening_proof=dict(commit_phase_merkle_caps=[t.cap for t in trees], query_round_proofs=queries,
+                                    final_poly=final_poly.reshape(-1, 2), pow_witness=pow_witness),
+                 public_inputs=pi.copy())
+    for o in (wires_batch, zs_batch, quot_batch):
+        o.close()
+    return proof

@@ -1,0 +1,147 @@
+"""GPU: a full Semaphore proof (make_signal, access_set.rs:61-104) produced by the HIP pipeline must pass
+the restatement of the reference's verifier (tests/plonk_verifier.py); the constraint kernel (a10) is
+additionally compared point-by-point with the big-integer evaluation of vanishing_poly.rs."""
+import importlib
+
+import numpy as np
+import pytest
+
+import plonk_verifier as pv
+import pymodel as pm
+from oracle_lib import P, rand_field
+
+pytestmark = pytest.mark.gpu
+
+
+def make_access_set(gl, ctx, log_members, seed):
+    sem = importlib.import_module("stark-verifier_amd.semaphore")
+    rng = np.random.default_rng(seed)
+    sks = rand_field(rng, (1 << log_members, 4))
+    keys = ctx.hash_no_pad(np.concatenate([sks, np.zeros_like(sks)], axis=1))     # signal.rs:32-39
+    return sem.AccessSet(ctx, keys), sks, rng
+
+
+def test_gate_witness_and_host_hash(gl, ctx, orc):
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    rng = np.random.default_rng(0x501)
+    x = rand_field(rng, 135)
+    assert np.array_equal(plonk.host_hash_no_pad(x), orc.hash_no_pad(x))
+    for swap in (0, 1):
+        inp = rand_field(rng, 12)
+        w = plonk.poseidon_gate_witness(inp, swap)
+        st = inp.copy()
+        if swap:
+            st[:4], st[4:8] = inp[4:8].copy(), inp[:4].copy()
+        assert np.array_equal(w[12:24], orc.permute(st))
+        cons = pv.eval_poseidon(None, [pv.base(v) for v in w], None)
+        assert all(c == (0, 0) for c in cons)
+        w2 = w.copy()
+        w2[70] ^= np.uint64(1)
+        assert any(c != (0, 0) for c in pv.eval_poseidon(None, [pv.base(v) for v in w2], None))
+    # challenger == oracle challenger
+    ch, oc = plonk.Challenger(), orc.challenger()
+    for chunk in (3, 8, 1, 13):
+        e = rand_field(rng, chunk)
+        ch.observe(e)
+        orc.observe(oc, e)
+        assert int(ch.squeeze(1)[0]) == orc.squeeze(oc)
+    st, pos = ch.pow_state()
+    ch.observe(rand_field(rng, 2))
+    st, pos = ch.pow_state()
+    assert pos == 2
+
+
+@pytest.mark.parametrize("log_members", [4])
+def test_semaphore_proof_verifies(gl, ctx, orc, log_members):
+    aset, sks, rng = make_access_set(gl, ctx, log_members, 0x357)
+    topic = rand_field(rng, 4)
+    signal, data = aset.make_signal(sks[12], topic, 12, np.random.default_rng(0x358), check=True)
+    cd = data.common()
+    ch = pv.verify(orc, cd, signal.proof)
+    assert len(ch["query_indices"]) == 28
+    # public inputs are root | nullifier | topic (access_set.rs:33-41)
+    pi = signal.proof["public_inputs"]
+    assert np.array_equal(pi[:4], aset.tree.cap[0]) and np.array_equal(pi[8:], topic)
+    assert np.array_equal(pi[4:8], orc.hash_no_pad(np.concatenate([sks[12], topic])))
+    # tampering is rejected
+    bad = dict(signal.proof)
+    bad["public_inputs"] = pi.copy()
+    bad["public_inputs"][9] ^= np.uint64(1)
+    with pytest.raises(pv.VerifyError):
+        pv.verify(orc, cd, bad)
+    bad = dict(signal.proof)
+    bad["openings"] = dict(signal.proof["openings"])
+    w = bad["openings"]["wires"].copy()
+    w[5][0] = (int(w[5][0]) + 1) % P
+    bad["openings"]["wires"] = w
+    with pytest.raises(pv.VerifyError):
+        pv.verify(orc, cd, bad)
+    # a second proof from the same circuit with a different member and fresh blinding also verifies
+    signal2, _ = aset.make_signal(sks[3], topic, 3, np.random.default_rng(0x359))
+    pv.verify(orc, cd, signal2.proof)
+    assert not np.array_equal(signal2.proof["wires_cap"], signal.proof["wires_cap"])
+
+
+def test_wrong_witness_fails_quotient(gl, ctx, orc):
+    """a witness that violates a gate constraint yields a 'quotient' of full degree: the proof must not verify."""
+    sem = importlib.import_module("stark-verifier_amd.semaphore")
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    aset, sks, rng = make_access_set(gl, ctx, 3, 0x35A)
+    data, rows = aset.build(rng)
+    wires, pi = aset.fill_semaphore_targets(data, rows, sks[1], rand_field(rng, 4), 1, rng)
+    wires[40, rows["null"]] ^= np.uint64(1)        # break one S-box wire
+    proof = plonk.prove(ctx, data, wires, pi, np.random.default_rng(1))
+    with pytest.raises(pv.VerifyError):
+        pv.verify(orc, data.common(), proof)
+
+
+def test_quotient_kernel_pointwise(gl, ctx, orc):
+    """a10: vanishing(x)/Z_H(x) from the HIP kernel == big-integer evaluation of vanishing_poly.rs at sample points."""
+    import ctypes as C
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    api = importlib.import_module("stark-verifier_amd.api")
+    aset, sks, rng = make_access_set(gl, ctx, 3, 0x35B)
+    data, rows = aset.build(rng)
+    cfg = data.config
+    wires, pi = aset.fill_semaphore_targets(data, rows, sks[5], rand_field(rng, 4), 5, rng)
+    n, N = 1 << data.degree_bits, 1 << (data.degree_bits + cfg.rate_bits)
+    wb = gl.PolynomialBatch.from_values(ctx, wires, cfg.rate_bits, cfg.cap_height, salt=rand_field(rng, (4, N)))
+    betas, gammas, alphas = rand_field(rng, 2), rand_field(rng, 2), rand_field(rng, 2)
+    zs, pps = [], []
+    for c in range(2):
+        z, pp = ctx.zs_partial_products(wires[:80], data.sigmas, data.k_is, 8, int(betas[c]), int(gammas[c]))
+        zs.append(z)
+        pps.append(pp)
+    zb = gl.PolynomialBatch.from_values(ctx, np.concatenate([np.stack(zs)] + pps), cfg.rate_bits, cfg.cap_height)
+    pi_hash = plonk.host_hash_no_pad(pi)
+    vals = np.empty((2, N), dtype=np.uint64)
+    ctx.check(ctx.lib.gl355_quotient_values(ctx.h, C.byref(data.c_circuit), data.constants_sigmas.h, wb.h, zb.h, api._ptr(data.k_is),
+                                            api._ptr(betas), api._ptr(gammas), api._ptr(alphas), api._ptr(pi_hash), api._ptr(vals)))
+    cs_leaves, w_leaves, z_leaves = data.constants_sigmas.leaves(), wb.leaves(), zb.leaves()
+    cd = data.common()
+    bits = data.degree_bits + cfg.rate_bits
+    omega = pm.root_of_unity(bits)
+    n_const = data.num_selectors + cfg.num_constants
+    for t in (0, 1, 77, N // 2 + 5, N - 1):
+        i = pm.bitrev(t, bits)
+        x = 7 * pow(omega, i, P) % P
+        t_next = pm.bitrev((i + 8) % N, bits)
+        op = dict(constants=[pv.base(v) for v in cs_leaves[t][:n_const]], plonk_sigmas=[pv.base(v) for v in cs_leaves[t][n_const:]],
+                  wires=[pv.base(v) for v in w_leaves[t][:135]], plonk_zs=[pv.base(v) for v in z_leaves[t][:2]],
+                  partial_products=[pv.base(v) for v in z_leaves[t][2:20]], plonk_zs_next=[pv.base(v) for v in z_leaves[t_next][:2]])
+        xn = pow(x, n, P)
+        van = pv.eval_vanishing_poly(cd, pv.base(x), pv.base(xn), op, [int(v) for v in pi_hash], [int(b) for b in betas],
+                                     [int(g) for g in gammas], [int(a) for a in alphas])
+        zh_inv = pow((xn - 1) % P, P - 2, P)
+        for c in range(2):
+            assert van[c][1] == 0
+            assert int(vals[c][t]) == van[c][0] * zh_inv % P, (t, c)
+    # and the interpolated quotient has degree < 8n by construction; its chunks recombine to the values
+    q = np.empty((16, n), dtype=np.uint64)
+    ctx.check(ctx.lib.gl355_quotient(ctx.h, C.byref(data.c_circuit), data.constants_sigmas.h, wb.h, zb.h, api._ptr(data.k_is),
+                                     api._ptr(betas), api._ptr(gammas), api._ptr(alphas), api._ptr(pi_hash), api._ptr(q)))
+    full = q.reshape(2, 8 * n)
+    back = ctx.coset_fft(full)            # natural order values on 7<omega_N>
+    assert np.array_equal(orc.reverse_index_bits(back.T.copy()).T, vals)
+    wb.close()
+    zb.close()
