@@ -144,6 +144,10 @@ const uint64_t* gl355_oracle_coeffs_ptr(const gl355_oracle* o);
  * siblings [(log2 N - cap_height) x 4] to host buffers */
 int32_t gl355_oracle_open(const gl355_oracle* o, uint64_t index, uint64_t* leaf, uint64_t* siblings);
 
+/* all FRI queries of one oracle at once: leaves[n_idx][leaf_len], siblings[n_idx][log2 N - cap_height][4] (host) */
+int32_t gl355_oracle_open_batch(const gl355_oracle* o, const uint64_t* indices, uint32_t n_idx, uint64_t* leaves,
+                                uint64_t* siblings);
+
 /* ---- a10: compute_quotient_polys (vanishing_poly.rs:18-153, gates/mod.rs:87-132, gates/ evaluators) ------
  * Circuit shape the constraint kernel needs (the host-side CommonCircuitData, types/common_data.rs:69-97).
  * gates[] is the circuit's gate list in selector order; gate i is active on rows where
@@ -231,6 +235,18 @@ int32_t gl355_host_poseidon_permute(uint64_t state[12]);
 int32_t gl355_host_hash_no_pad(const uint64_t* in, uint64_t len, uint64_t out[4]);
 /* witness generation of one PoseidonGate row (wire layout gates/poseidon.rs:329-380) */
 int32_t gl355_poseidon_gate_witness(const uint64_t inputs[12], uint64_t swap, uint64_t wires[135]);
+
+/* ---- a12 + a13 + a14 in one call: fri_proof (fri_chip.rs:168-226,275-327,364-376) ------------------
+ * final_coeffs: n = 2^log_n extension coefficients of the DEEP polynomial (host or device).  Runs the
+ * commit phase (n_layers arity-2 folds), observes the final polynomial, grinds the PoW, squeezes the
+ * query indices and opens every layer tree at every query; `ch` is advanced exactly as
+ * plonk_verifier_chip.rs:120-140 replays it.  Host outputs:
+ *   caps[n_layers][2^cap_height][4], final_poly[(n >> n_layers) ext], pow_witness, query_indices[num_queries],
+ *   step_evals[num_queries][n_layers][4], step_siblings[num_queries][sum_l (log_n+rate_bits-1-l-cap_height)][4]. */
+int32_t gl355_fri_prove(gl355_ctx* ctx, const uint64_t* final_coeffs, uint32_t log_n, uint32_t rate_bits,
+                        uint32_t cap_height, const uint32_t* arity_bits, uint32_t n_layers, uint32_t pow_bits,
+                        uint32_t num_queries, gl355_challenger* ch, uint64_t* caps, uint64_t* final_poly,
+                        uint64_t* pow_witness, uint64_t* query_indices, uint64_t* step_evals, uint64_t* step_siblings);
 
 /* ---- a9: wires_permutation_partial_products_and_zs (vanishing_poly.rs:54-108,183-218) --------- */
 int32_t gl355_zs_partial_products(gl355_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas,

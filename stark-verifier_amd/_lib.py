@@ -82,6 +82,9 @@ SIGNATURES = {
     "gl355_oracle_lde_ptr": (vp, [vp]),
     "gl355_oracle_coeffs_ptr": (vp, [vp]),
     "gl355_oracle_open": (C.c_int32, [vp, C.c_uint64, vp, vp]),
+    "gl355_oracle_open_batch": (C.c_int32, [vp, vp, C.c_uint32, vp, vp]),
+    "gl355_fri_prove": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.POINTER(Challenger), vp, vp, C.POINTER(C.c_uint64), vp, vp, vp]),
     "gl355_quotient": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gl355_quotient_values": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gl355_challenger_init": (C.c_int32, [C.POINTER(Challenger)]),

@@ -342,6 +342,15 @@ class PolynomialBatch:
         self.ctx.check(self.ctx.lib.gl355_oracle_open(self.h, index, _ptr(leaf), _ptr(sib)))
         return leaf, sib
 
+    def open_batch(self, indices):
+        """[(leaf, siblings)] for every index, one kernel + one copy (fri_prover_query_rounds)."""
+        idx = _u64(indices)
+        layers = self.degree_log + self.rate_bits - self.cap_height
+        leaves = np.empty((idx.size, self.leaf_len), dtype=np.uint64)
+        sib = np.empty((idx.size, layers, 4), dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.gl355_oracle_open_batch(self.h, _ptr(idx), idx.size, _ptr(leaves), _ptr(sib)))
+        return [(leaves[i], sib[i]) for i in range(idx.size)]
+
     def get_lde_values(self, index, step=1):
         """PolynomialBatch::get_lde_values: leaf bitrev(index*step) without the salt."""
         bits = self.degree_log + self.rate_bits

@@ -133,6 +133,47 @@ __global__ void __launch_bounds__(256) pow_grind_kernel(const uint64_t* state, u
     if (bits == 0 || (resp >> (64 - bits)) == 0) atomicMin(best, (unsigned long long)w);
 }
 
+// query openings: block q copies row idx[q] of a column-major matrix and its Merkle path (siblings
+// leaf -> cap, MerkleTree::prove's index walk) into dense output buffers -- one launch + one D2H per
+// oracle for all FRI queries instead of (1 + depth) tiny copies per query.
+__global__ void open_batch_kernel(const uint64_t* lde, uint64_t stride, uint32_t leaf_len, const uint64_t* digests,
+                                  uint32_t log_n, uint32_t cap_height, const uint64_t* idx, uint32_t idx_shift,
+                                  uint64_t* leaves_out, uint64_t leaf_out_stride, uint64_t* sib_out, uint64_t sib_out_stride) {
+    // stride == 0: leaves are row-major [n][leaf_len]; otherwise column-major with that column stride
+    const uint64_t index = idx[blockIdx.x] >> idx_shift;
+    const uint32_t layers = log_n - cap_height;
+    for (uint32_t c = threadIdx.x; c < leaf_len; c += blockDim.x)
+        leaves_out[(uint64_t)blockIdx.x * leaf_out_stride + c] = stride ? lde[(uint64_t)c * stride + index] : lde[index * leaf_len + c];
+    const uint64_t sub_leaves = 1ull << layers;
+    const uint64_t* tree = digests + (index >> layers) * 2 * (sub_leaves - 1) * 4;
+    const uint64_t k0 = index & (sub_leaves - 1);
+    for (uint32_t e = threadIdx.x; e < layers * 4; e += blockDim.x) {
+        const uint32_t layer = e >> 2;
+        const uint64_t k = (k0 >> layer) ^ 1;  // sibling of the node on the path at this layer
+        sib_out[(uint64_t)blockIdx.x * sib_out_stride + layer * 4 + (e & 3)] = tree[digest_slot(layer, k) * 4 + (e & 3)];
+    }
+}
+
+int32_t open_batch_dev(Ctx* ctx, const uint64_t* lde, uint64_t stride, uint32_t leaf_len, const uint64_t* digests,
+                       uint32_t log_n, uint32_t cap_height, const uint64_t* idx_dev, uint32_t n_idx, uint64_t* leaves_out,
+                       uint64_t* sib_out) {
+    if (n_idx == 0) return GL355_OK;
+    hipLaunchKernelGGL(open_batch_kernel, dim3(n_idx), dim3(64), 0, ctx->stream, lde, stride, leaf_len, digests, log_n,
+                       cap_height, idx_dev, 0u, leaves_out, (uint64_t)leaf_len, sib_out, (uint64_t)(log_n - cap_height) * 4);
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+// general form: index = idx[q] >> idx_shift, explicit output strides (FRI layer trees share one output row per query)
+int32_t open_batch_ex_dev(Ctx* ctx, const uint64_t* leaves, uint64_t stride, uint32_t leaf_len, const uint64_t* digests,
+                          uint32_t log_n, uint32_t cap_height, const uint64_t* idx_dev, uint32_t idx_shift, uint32_t n_idx,
+                          uint64_t* leaves_out, uint64_t leaf_out_stride, uint64_t* sib_out, uint64_t sib_out_stride) {
+    if (n_idx == 0) return GL355_OK;
+    hipLaunchKernelGGL(open_batch_kernel, dim3(n_idx), dim3(64), 0, ctx->stream, leaves, stride, leaf_len, digests, log_n,
+                       cap_height, idx_dev, idx_shift, leaves_out, leaf_out_stride, sib_out, sib_out_stride);
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 int32_t poseidon_permute_dev(Ctx* ctx, uint64_t* states, uint64_t count) {
     if (count == 0) return GL355_OK;

@@ -359,48 +359,39 @@ def prove(ctx, data, wires, public_inputs, rng, timings=None):
     acc = np.zeros(2 * n, dtype=np.uint64)
     acc = deep_batch(ctx, all_polys, fri_alpha, zeta, acc)
     acc = deep_batch(ctx, zs_polys, fri_alpha, zeta_next, acc)
-    final_values = ctx.lde_ext(acc, cfg.rate_bits)            # N ext values, natural order
-    coeffs = np.concatenate([acc, np.zeros(2 * (N - n), dtype=np.uint64)])   # final_poly.lde(rate_bits)
-    lap("DEEP quotient + final LDE")
-    # ---- FRI commit phase -----------------------------------------------------------------------------------------
-    trees, fri_betas = [], []
-    values, shift = final_values, COSET_SHIFT
-    for arity_bits in data.fri_arity_bits:
-        assert arity_bits == 1, "arity-2 folding only (the reference's verifier supports nothing else, fri_chip.rs:211)"
-        tree = ctx.fri_layer_commit(values, cfg.cap_height)
-        ch.observe(tree.cap)
-        trees.append(tree)
-        beta = ch.get_extension_challenge()
-        fri_betas.append(beta)
-        coeffs = ctx.fri_fold(coeffs, beta)
-        shift = shift * shift % P
-        values = ctx.lde_ext(coeffs, 0, shift)
-    final_poly = coeffs[: 2 * ((coeffs.size // 2) >> cfg.rate_bits)].copy()
-    assert not coeffs[final_poly.size:].any(), "FRI: the truncated coefficients must be zero"
-    ch.observe(final_poly)
-    lap("FRI commit phase")
-    # ---- proof of work ------------------------------------------------------------------------------------------------
-    st, pos = ch.pow_state()
-    pow_witness = ctx.pow_grind(st, pos, cfg.proof_of_work_bits)
-    ch.observe(np.array([pow_witness], dtype=np.uint64))
-    pow_response = int(ch.squeeze(1)[0])
-    assert cfg.proof_of_work_bits == 0 or pow_response >> (64 - cfg.proof_of_work_bits) == 0
-    lap("proof of work")
-    # ---- query rounds ----------------------------------------------------------------------------------------------------
+    lap("DEEP quotient")
+    # ---- FRI: commit phase, proof of work, layer openings (one resident call: csrc/prover.hip) ---------------------
+    arity = np.array(data.fri_arity_bits, dtype=np.uint32)
+    n_layers = arity.size
+    lde_bits = data.degree_bits + cfg.rate_bits
+    n_cap = 1 << cfg.cap_height
+    nq = cfg.num_query_rounds
+    depths = [lde_bits - 1 - l - cfg.cap_height for l in range(n_layers)]
+    caps = np.empty((n_layers, n_cap, 4), dtype=np.uint64)
+    final_poly = np.empty((n >> n_layers, 2), dtype=np.uint64)
+    pow_witness = C.c_uint64()
+    x_indices = np.empty(nq, dtype=np.uint64)
+    step_evals = np.empty((nq, n_layers, 4), dtype=np.uint64)
+    step_sibs = np.empty((nq, max(1, sum(depths)), 4), dtype=np.uint64)
+    ctx.check(lib.gl355_fri_prove(ctx.h, _ptr(acc), data.degree_bits, cfg.rate_bits, cfg.cap_height,
+                                  arity.ctypes.data_as(C.c_void_p), n_layers, cfg.proof_of_work_bits, nq, C.byref(ch.c),
+                                  _ptr(caps), _ptr(final_poly), C.byref(pow_witness), _ptr(x_indices), _ptr(step_evals),
+                                  _ptr(step_sibs)))
+    lap("FRI commit + PoW + layer openings")
+    # ---- initial-tree openings (fri_prover_query_round) -----------------------------------------------------------------
+    opened = [o.open_batch(x_indices) for o in oracles]
     queries = []
-    for _ in range(cfg.num_query_rounds):
-        x_index = int(ch.squeeze(1)[0]) % N
-        initial = [o.open(x_index) for o in oracles]
-        steps, idx = [], x_index
-        for tree in trees:
-            idx >>= 1
-            steps.append((tree.get(idx).copy(), tree.prove(idx)))
-        queries.append(dict(index=x_index, initial_trees=initial, steps=steps))
-    lap("query rounds")
+    offs = np.concatenate([[0], np.cumsum(depths)]).astype(int)
+    for qi in range(nq):
+        steps = [(step_evals[qi, l], step_sibs[qi, offs[l]:offs[l + 1]]) for l in range(n_layers)]
+        queries.append(dict(index=int(x_indices[qi]), initial_trees=[opened[o][qi] for o in range(len(oracles))], steps=steps))
+    lap("initial-tree openings")
+    trees_caps = [caps[l] for l in range(n_layers)]
+    pow_witness = pow_witness.value
     proof = dict(wires_cap=wires_cap, plonk_zs_partial_products_cap=zs_cap, quotient_polys_cap=quot_cap,
                  openings=openings,
-                 opening_proof=dict(commit_phase_merkle_caps=[t.cap for t in trees], query_round_proofs=queries,
-                                    final_poly=final_poly.reshape(-1, 2), pow_witness=pow_witness),
+                 opening_proof=dict(commit_phase_merkle_caps=trees_caps, query_round_proofs=queries,
+                                    final_poly=final_poly, pow_witness=pow_witness),
                  public_inputs=pi.copy())
     for o in (wires_batch, zs_batch, quot_batch):
         o.close()

@@ -320,3 +320,16 @@ def test_device_resident_buffers(gl, ctx, orc):
     want = orc.reverse_index_bits(orc.lde(x, 3).T.copy()).T
     eq(out.cpu().numpy().view(np.uint64), want)
     eq(t.cpu().numpy().view(np.uint64), x)       # input untouched
+
+
+def test_oracle_open_batch(gl, ctx, orc):
+    rng = np.random.default_rng(0x465)
+    vals = rand_field(rng, (7, 1 << 6))
+    pb = gl.PolynomialBatch.from_values(ctx, vals, 3, 2, salt=rand_field(rng, (4, 1 << 9)))
+    idx = [0, 511, 77, 77, 256]
+    for i, (leaf, sib) in zip(idx, pb.open_batch(idx)):
+        l2, s2 = pb.open(i)
+        eq(leaf, l2)
+        eq(sib, s2)
+        assert orc.merkle_verify(leaf, i, sib, pb.cap, 2)
+    pb.close()
