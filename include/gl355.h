@@ -155,10 +155,15 @@ int32_t gl355_oracle_open_batch(const gl355_oracle* o, const uint64_t* indices, 
  * that selector polynomial. */
 #define GL355_MAX_GATES 16
 enum { GL355_GATE_NOOP = 0, GL355_GATE_CONSTANT = 1, GL355_GATE_PUBLIC_INPUT = 2, GL355_GATE_BASE_SUM = 3,
-       GL355_GATE_POSEIDON = 4, GL355_GATE_ARITHMETIC = 5 };
+       GL355_GATE_POSEIDON = 4, GL355_GATE_ARITHMETIC = 5, GL355_GATE_ARITHMETIC_EXT = 6, GL355_GATE_MUL_EXT = 7,
+       GL355_GATE_POSEIDON_MDS = 8, GL355_GATE_RANDOM_ACCESS = 9, GL355_GATE_REDUCING = 10,
+       GL355_GATE_REDUCING_EXT = 11 };   /* the gate set of gates/mod.rs:141-196 */
+#define GL355_GATE_TYPE_MAX GL355_GATE_REDUCING_EXT
+/* RANDOM_ACCESS param = bits | num_copies << 8 | num_extra_constants << 16 */
 typedef struct {
     uint32_t type;            /* GL355_GATE_* */
-    uint32_t param;           /* CONSTANT: num_consts; BASE_SUM: num_limbs (base 2); ARITHMETIC: num_ops */
+    uint32_t param;           /* CONSTANT: num_consts; BASE_SUM: num_limbs (base 2); ARITHMETIC(_EXT) and MUL_EXT: num_ops;
+                                 REDUCING*: num_coeffs; RANDOM_ACCESS: packed (above) */
     uint32_t selector_index;  /* which constants column is this gate's selector */
     uint32_t group_start, group_end;
 } gl355_gate;

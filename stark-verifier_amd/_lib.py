@@ -26,7 +26,8 @@ class Challenger(C.Structure):
 
 
 MAX_GATES = 16
-GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_BASE_SUM, GATE_POSEIDON, GATE_ARITHMETIC = range(6)
+(GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_BASE_SUM, GATE_POSEIDON, GATE_ARITHMETIC, GATE_ARITHMETIC_EXT,
+ GATE_MUL_EXT, GATE_POSEIDON_MDS, GATE_RANDOM_ACCESS, GATE_REDUCING, GATE_REDUCING_EXT) = range(12)
 
 
 class Gate(C.Structure):

@@ -421,7 +421,7 @@ static int32_t quotient_common(gl355_ctx* h, const gl355_circuit* c, const gl355
         c->num_partial_products + 1 != (c->num_routed_wires + c->max_degree - 1) / c->max_degree)
         return ctx->fail(GL355_E_INVALID_ARG, "quotient: inconsistent routed-wire / partial-product counts");
     for (uint32_t g = 0; g < c->num_gates && g < GL355_MAX_GATES; g++) {
-        if (c->gates[g].type > GL355_GATE_ARITHMETIC) return ctx->fail(GL355_E_UNSUPPORTED, "quotient: unknown gate type");
+        if (c->gates[g].type > GL355_GATE_TYPE_MAX) return ctx->fail(GL355_E_UNSUPPORTED, "quotient: unknown gate type");
         if (c->gates[g].selector_index >= c->num_selectors || c->gates[g].group_end > c->num_gates)
             return ctx->fail(GL355_E_INVALID_ARG, "quotient: bad selector group");
     }

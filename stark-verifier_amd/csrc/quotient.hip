@@ -6,7 +6,7 @@
 // recursion.rs:168, wrapper.rs:55).  The formula is the one the reference's verifier re-evaluates at
 // zeta: src/plonky2_verifier/chip/plonk/vanishing_poly.rs:18-153 (term order :110-123), gate filter
 // chip/plonk/gates/mod.rs:87-132, quotient identity chip/plonk/plonk_verifier_chip.rs:174-210, and
-// the gate evaluators chip/plonk/gates/{noop,constant,public_input,base_sum,arithmetic,poseidon}.rs.
+// the gate evaluators chip/plonk/gates/*.rs (all 12 gate kinds of the dispatch table gates/mod.rs:141-196).
 //
 // One lane = one point x = 7*omega^i of the quotient coset (size n * 2^qdb).  The three committed
 // oracles are column-major in bit-reversed row order, and lane t works on storage row t, so every
@@ -173,6 +173,88 @@ GL_DEV void gate_arithmetic(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t 
     }
 }
 
+// ---- gates over the extension algebra: an F_p^2 element occupies two consecutive wires; on the coset
+// every wire value is a base-field number, so the algebra product is the plain F_p^2 product
+// (chip/goldilocks_extension_algebra_chip.rs:112-146).  Each algebra constraint yields 2 terms.
+#define WIRE2(j) gl2_make(WIRE(j), WIRE((j) + 1))
+GL_DEV void push2(GateAcc& g, gl2 v) { g.push(v.c0); g.push(v.c1); }
+
+// ArithmeticExtensionGate{num_ops}: out - (c0 m0 m1 + c1 addend)   (gates/arithmetic_extension.rs:22-80)
+GL_DEV void gate_arithmetic_ext(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num_ops) {
+    const uint64_t c0 = CONST(a.c.num_selectors), c1 = CONST(a.c.num_selectors + 1);
+    for (uint32_t i = 0; i < num_ops; i++) {
+        const gl2 m0 = WIRE2(8 * i), m1 = WIRE2(8 * i + 2), ad = WIRE2(8 * i + 4), out = WIRE2(8 * i + 6);
+        const gl2 comp = gl2_add(gl2_mul_base(gl2_mul(m0, m1), c0), gl2_mul_base(ad, c1));
+        push2(g, gl2_sub(out, comp));
+    }
+}
+// MulExtensionGate{num_ops}: out - c0 m0 m1   (gates/multiplication_extension.rs:22-68)
+GL_DEV void gate_mul_ext(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num_ops) {
+    const uint64_t c0 = CONST(a.c.num_selectors);
+    for (uint32_t i = 0; i < num_ops; i++) {
+        const gl2 m0 = WIRE2(6 * i), m1 = WIRE2(6 * i + 2), out = WIRE2(6 * i + 4);
+        push2(g, gl2_sub(out, gl2_mul_base(gl2_mul(m0, m1), c0)));
+    }
+}
+// PoseidonMdsGate: out_r - sum_i CIRC[i] in[(i+r)%12] - DIAG[r] in[r]   (gates/poseidon_mds.rs:26-126)
+GL_DEV void gate_poseidon_mds(const QuotArgs& a, uint64_t t, GateAcc& g) {
+    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    for (uint32_t r = 0; r < 12; r++) {
+        gl2 acc = gl2_make(0, 0);
+        for (uint32_t i = 0; i < 12; i++) {
+            const gl2 in = WIRE2(2 * ((i + r) % 12));
+            acc = gl2_add(acc, gl2_make(gl_mul_small(in.c0, CIRC[i]), gl_mul_small(in.c1, CIRC[i])));
+        }
+        if (r == 0) {
+            const gl2 in = WIRE2(0);
+            acc = gl2_add(acc, gl2_make(gl_mul_small(in.c0, 8), gl_mul_small(in.c1, 8)));
+        }
+        push2(g, gl2_sub(WIRE2(2 * (12 + r)), acc));
+    }
+}
+// RandomAccessGate{bits, copies, extra}   (gates/random_access.rs:27-147)
+GL_DEV void gate_random_access(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t param) {
+    const uint32_t bits = param & 0xFF, copies = (param >> 8) & 0xFF, extra = (param >> 16) & 0xFF;
+    const uint32_t vec = 1u << bits, routed = (2 + vec) * copies + extra;
+    for (uint32_t c = 0; c < copies; c++) {
+        const uint32_t base = (2 + vec) * c;
+        uint64_t recon = 0;
+        for (uint32_t i = 0; i < bits; i++) {
+            const uint64_t b = WIRE(routed + c * bits + i);
+            g.push(gl_sub(gl_mul(b, b), b));
+        }
+        for (uint32_t i = bits; i-- > 0;) recon = gl_add(gl_add(recon, recon), WIRE(routed + c * bits + i));
+        g.push(gl_sub(recon, WIRE(base)));
+        // fold the list: item = x + b (y - x) per pair, one bit per level (bits <= 4 => <= 16 items)
+        uint64_t items[16];
+        for (uint32_t i = 0; i < 16; i++) items[i] = i < vec ? WIRE(base + 2 + i) : 0;
+        uint32_t len = vec;
+        for (uint32_t lvl = 0; lvl < bits; lvl++) {
+            const uint64_t b = WIRE(routed + c * bits + lvl);
+            for (uint32_t k = 0; k < 8; k++) {
+                if (k < len / 2) items[k] = gl_add(gl_mul(b, gl_sub(items[2 * k + 1], items[2 * k])), items[2 * k]);
+            }
+            len >>= 1;
+        }
+        g.push(gl_sub(items[0], WIRE(base + 1)));
+    }
+    for (uint32_t i = 0; i < extra; i++) g.push(gl_sub(CONST(a.c.num_selectors + i), WIRE((2 + vec) * copies + i)));
+}
+// ReducingGate{n} / ReducingExtensionGate{n}: acc*alpha + coeff - acc_i   (gates/reducing.rs:20-85,
+// gates/reducing_extension.rs:20-87); the last accumulator is the output (wires 0..1)
+template <bool EXT>
+GL_DEV void gate_reducing(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t n) {
+    const gl2 alpha = WIRE2(2);
+    gl2 acc = WIRE2(4);
+    const uint32_t start_accs = 6 + (EXT ? 2 * n : n);
+    for (uint32_t i = 0; i < n; i++) {
+        const gl2 coeff = EXT ? WIRE2(6 + 2 * i) : gl2_make(WIRE(6 + i), 0);
+        const gl2 acc_i = (i == n - 1) ? WIRE2(0) : WIRE2(start_accs + 2 * i);
+        push2(g, gl2_sub(gl2_add(gl2_mul(acc, alpha), coeff), acc_i));
+        acc = acc_i;
+    }
+}
+
 __global__ void __launch_bounds__(128) quotient_kernel(QuotArgs a) {
     const uint64_t nq = 1ull << a.qbits;
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -230,6 +312,12 @@ __global__ void __launch_bounds__(128) quotient_kernel(QuotArgs a) {
             case GL355_GATE_CONSTANT: gate_constant(a, t, g, gt.param); break;
             case GL355_GATE_PUBLIC_INPUT: gate_public_input(a, t, g); break;
             case GL355_GATE_ARITHMETIC: gate_arithmetic(a, t, g, gt.param); break;
+            case GL355_GATE_ARITHMETIC_EXT: gate_arithmetic_ext(a, t, g, gt.param); break;
+            case GL355_GATE_MUL_EXT: gate_mul_ext(a, t, g, gt.param); break;
+            case GL355_GATE_POSEIDON_MDS: gate_poseidon_mds(a, t, g); break;
+            case GL355_GATE_RANDOM_ACCESS: gate_random_access(a, t, g, gt.param); break;
+            case GL355_GATE_REDUCING: gate_reducing<false>(a, t, g, gt.param); break;
+            case GL355_GATE_REDUCING_EXT: gate_reducing<true>(a, t, g, gt.param); break;
             default: break;
         }
         const uint64_t sel = CONST(gt.selector_index);

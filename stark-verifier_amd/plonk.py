@@ -19,7 +19,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (GATE_ARITHMETIC, GATE_BASE_SUM, GATE_CONSTANT, GATE_NOOP, GATE_POSEIDON, GATE_PUBLIC_INPUT,
+from ._lib import (GATE_ARITHMETIC, GATE_ARITHMETIC_EXT, GATE_BASE_SUM, GATE_CONSTANT, GATE_MUL_EXT, GATE_NOOP, GATE_POSEIDON,
+                   GATE_POSEIDON_MDS, GATE_PUBLIC_INPUT, GATE_RANDOM_ACCESS, GATE_REDUCING, GATE_REDUCING_EXT,
                    Challenger as _CChallenger, Circuit as _CCircuit)
 from .api import COSET_SHIFT, P, SALT_SIZE, MerkleTree, PolynomialBatch, _ptr, _u64, deep_batch, eval_polys
 
@@ -242,6 +243,9 @@ class CircuitBuilder:
 _GATE_CONSTRAINTS = {
     GATE_NOOP: lambda p: 0, GATE_CONSTANT: lambda p: p, GATE_PUBLIC_INPUT: lambda p: 4,
     GATE_BASE_SUM: lambda p: 1 + p, GATE_POSEIDON: lambda p: 123, GATE_ARITHMETIC: lambda p: p,
+    GATE_ARITHMETIC_EXT: lambda p: 2 * p, GATE_MUL_EXT: lambda p: 2 * p, GATE_POSEIDON_MDS: lambda p: 24,
+    GATE_RANDOM_ACCESS: lambda p: ((p >> 8) & 0xFF) * ((p & 0xFF) + 2) + ((p >> 16) & 0xFF),
+    GATE_REDUCING: lambda p: 2 * p, GATE_REDUCING_EXT: lambda p: 2 * p,
 }
 
 

@@ -22,7 +22,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gen_poseidon_tables as gpt  # noqa: E402
 
 P = pm.P
-NOOP, CONSTANT, PUBLIC_INPUT, BASE_SUM, POSEIDON, ARITHMETIC = range(6)
+(NOOP, CONSTANT, PUBLIC_INPUT, BASE_SUM, POSEIDON, ARITHMETIC, ARITHMETIC_EXT, MUL_EXT, POSEIDON_MDS, RANDOM_ACCESS,
+ REDUCING, REDUCING_EXT) = range(12)
 UNUSED_SELECTOR = 0xFFFFFFFF
 _RC = gpt.load_rc()
 _TB = gpt.derive(_RC)
@@ -155,6 +156,69 @@ def eval_gate(gate, consts, w, pi_hash):
         return [sub(w[4 * i + 3], add(mul(mul(w[4 * i], w[4 * i + 1]), consts[0]), mul(w[4 * i + 2], consts[1]))) for i in range(p)]
     if t == POSEIDON:
         return eval_poseidon(consts, w, pi_hash)
+    # ---- gates over the extension algebra (goldilocks_extension_algebra_chip.rs:112-146): an element is a
+    # pair of wires (A0, A1), product (A0 B0 + 7 A1 B1, A0 B1 + A1 B0) with component arithmetic in K
+    def alg(j):
+        return (w[j], w[j + 1])
+
+    def amul(a, b):
+        return (add(mul(a[0], b[0]), mul(base(7), mul(a[1], b[1]))), add(mul(a[0], b[1]), mul(a[1], b[0])))
+
+    def aadd(a, b):
+        return (add(a[0], b[0]), add(a[1], b[1]))
+
+    def asub(a, b):
+        return (sub(a[0], b[0]), sub(a[1], b[1]))
+
+    def ascal(c, a):
+        return (mul(c, a[0]), mul(c, a[1]))
+    if t == ARITHMETIC_EXT:
+        out = []
+        for i in range(p):
+            comp = aadd(ascal(consts[0], amul(alg(8 * i), alg(8 * i + 2))), ascal(consts[1], alg(8 * i + 4)))
+            out += list(asub(alg(8 * i + 6), comp))
+        return out
+    if t == MUL_EXT:
+        out = []
+        for i in range(p):
+            out += list(asub(alg(6 * i + 4), ascal(consts[0], amul(alg(6 * i), alg(6 * i + 2)))))
+        return out
+    if t == POSEIDON_MDS:
+        out = []
+        for r in range(12):
+            acc = (E0, E0)
+            for i in range(12):
+                acc = aadd(acc, ascal(base(gpt.CIRC[i]), alg(2 * ((i + r) % 12))))
+            acc = aadd(acc, ascal(base(gpt.DIAG[r]), alg(2 * r)))
+            out += list(asub(alg(2 * (12 + r)), acc))
+        return out
+    if t == RANDOM_ACCESS:
+        bits, copies, extra = p & 0xFF, (p >> 8) & 0xFF, (p >> 16) & 0xFF
+        vec = 1 << bits
+        routed = (2 + vec) * copies + extra
+        out = []
+        for c in range(copies):
+            b0 = (2 + vec) * c
+            bl = [w[routed + c * bits + i] for i in range(bits)]
+            out += [sub(mul(b, b), b) for b in bl]
+            out.append(sub(reduce_with_powers(bl, base(2)), w[b0]))
+            items = [w[b0 + 2 + i] for i in range(vec)]
+            for b in bl:
+                items = [add(mul(b, sub(items[2 * k + 1], items[2 * k])), items[2 * k]) for k in range(len(items) // 2)]
+            out.append(sub(items[0], w[b0 + 1]))
+        out += [sub(consts[i], w[(2 + vec) * copies + i]) for i in range(extra)]
+        return out
+    if t in (REDUCING, REDUCING_EXT):
+        isext = t == REDUCING_EXT
+        alpha, acc = alg(2), alg(4)
+        start_accs = 6 + (2 * p if isext else p)
+        out = []
+        for i in range(p):
+            coeff = alg(6 + 2 * i) if isext else (w[6 + i], E0)
+            acc_i = alg(0) if i == p - 1 else alg(start_accs + 2 * i)
+            out += list(asub(aadd(amul(acc, alpha), coeff), acc_i))
+            acc = acc_i
+        return out
     raise VerifyError("unknown gate")
 
 

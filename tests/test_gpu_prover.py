@@ -145,3 +145,62 @@ def test_quotient_kernel_pointwise(gl, ctx, orc):
     assert np.array_equal(orc.reverse_index_bits(back.T.copy()).T, vals)
     wb.close()
     zb.close()
+
+
+def test_gate_set_pointwise(gl, ctx):
+    """a10, the whole gate set of gates/mod.rs:141-196 (+ BaseSum{20} of circuit.rs:42): random wires / constants /
+    selectors, HIP kernel vs big-integer evaluation of the same formulas at sample points (the reference's
+    gate_test.rs methodology: random inputs, compare two evaluators)."""
+    import ctypes as C
+    lib = importlib.import_module("stark-verifier_amd._lib")
+    api = importlib.import_module("stark-verifier_amd.api")
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    rng = np.random.default_rng(0x35C)
+    gates = [(lib.GATE_POSEIDON, 0), (lib.GATE_ARITHMETIC, 20), (lib.GATE_PUBLIC_INPUT, 0), (lib.GATE_NOOP, 0), (lib.GATE_CONSTANT, 2),
+             (lib.GATE_BASE_SUM, 63), (lib.GATE_BASE_SUM, 4), (lib.GATE_BASE_SUM, 20), (lib.GATE_POSEIDON_MDS, 0),
+             (lib.GATE_RANDOM_ACCESS, 1 | 20 << 8), (lib.GATE_RANDOM_ACCESS, 4 | 4 << 8 | 2 << 16), (lib.GATE_REDUCING_EXT, 32),
+             (lib.GATE_REDUCING, 43), (lib.GATE_ARITHMETIC_EXT, 10), (lib.GATE_MUL_EXT, 13)]
+    groups = [(0, 1), (1, 6), (6, 11), (11, 15)]
+    sel_idx = [next(s for s, (lo, hi) in enumerate(groups) if lo <= g < hi) for g in range(len(gates))]
+    degree_bits, rate_bits, nch = 4, 3, 2
+    n, N = 1 << degree_bits, 1 << (degree_bits + rate_bits)
+    n_sel, n_cst, routed, nw, npp = len(groups), 2, 80, 135, 9
+    cs_vals = rand_field(rng, (n_sel + n_cst + routed, n))
+    cs_vals[:n_sel] = rng.integers(0, len(gates), size=(n_sel, n)).astype(np.uint64)   # selector-like small values
+    cs = gl.PolynomialBatch.from_values(ctx, cs_vals, rate_bits, 2)
+    wb = gl.PolynomialBatch.from_values(ctx, rand_field(rng, (nw, n)), rate_bits, 2)
+    zb = gl.PolynomialBatch.from_values(ctx, rand_field(rng, (nch * (1 + npp), n)), rate_bits, 2)
+    cc = lib.Circuit()
+    cc.degree_bits, cc.rate_bits, cc.num_wires, cc.num_routed_wires = degree_bits, rate_bits, nw, routed
+    cc.num_constants, cc.num_selectors, cc.num_challenges, cc.max_degree = n_cst, n_sel, nch, 8
+    cc.num_partial_products, cc.num_gates = npp, len(gates)
+    for i, (t, p) in enumerate(gates):
+        cc.gates[i].type, cc.gates[i].param, cc.gates[i].selector_index = t, p, sel_idx[i]
+        cc.gates[i].group_start, cc.gates[i].group_end = groups[sel_idx[i]]
+    k_is = np.array([pow(7, j, P) for j in range(routed)], dtype=np.uint64)
+    betas, gammas, alphas, pi_hash = rand_field(rng, 2), rand_field(rng, 2), rand_field(rng, 2), rand_field(rng, 4)
+    vals = np.empty((nch, N), dtype=np.uint64)
+    ctx.check(ctx.lib.gl355_quotient_values(ctx.h, C.byref(cc), cs.h, wb.h, zb.h, api._ptr(k_is), api._ptr(betas), api._ptr(gammas),
+                                            api._ptr(alphas), api._ptr(pi_hash), api._ptr(vals)))
+    cd = dict(degree_bits=degree_bits, gates=gates, groups=groups, selector_indices=sel_idx, num_selectors=n_sel,
+              num_constants=n_cst, num_wires=nw, num_routed_wires=routed, num_challenges=nch, quotient_degree_factor=8,
+              num_partial_products=npp, num_gate_constraints=max(plonk._GATE_CONSTRAINTS[t](p) for t, p in gates),
+              k_is=[int(k) for k in k_is])
+    cs_l, w_l, z_l = cs.leaves(), wb.leaves(), zb.leaves()
+    bits = degree_bits + rate_bits
+    omega = pm.root_of_unity(bits)
+    for t in (0, 3, 64, N - 1):
+        i = pm.bitrev(t, bits)
+        x = 7 * pow(omega, i, P) % P
+        t_next = pm.bitrev((i + 8) % N, bits)
+        op = dict(constants=[pv.base(v) for v in cs_l[t][:n_sel + n_cst]], plonk_sigmas=[pv.base(v) for v in cs_l[t][n_sel + n_cst:]],
+                  wires=[pv.base(v) for v in w_l[t]], plonk_zs=[pv.base(v) for v in z_l[t][:nch]],
+                  partial_products=[pv.base(v) for v in z_l[t][nch:]], plonk_zs_next=[pv.base(v) for v in z_l[t_next][:nch]])
+        xn = pow(x, n, P)
+        van = pv.eval_vanishing_poly(cd, pv.base(x), pv.base(xn), op, [int(v) for v in pi_hash], [int(b) for b in betas],
+                                     [int(g) for g in gammas], [int(a) for a in alphas])
+        zh_inv = pow((xn - 1) % P, P - 2, P)
+        for c in range(nch):
+            assert van[c][1] == 0 and int(vals[c][t]) == van[c][0] * zh_inv % P, (t, c)
+    for o in (cs, wb, zb):
+        o.close()
