@@ -253,6 +253,33 @@ int32_t gl355_fri_prove(gl355_ctx* ctx, const uint64_t* final_coeffs, uint32_t l
                         uint32_t num_queries, gl355_challenger* ch, uint64_t* caps, uint64_t* final_poly,
                         uint64_t* pow_witness, uint64_t* query_indices, uint64_t* step_evals, uint64_t* step_siblings);
 
+/* ---- CircuitData::prove in one call (access_set.rs:94, recursion.rs:168, wrapper.rs:55) ----------------
+ * Prover data of one built circuit (plonky2 ProverOnlyCircuitData + CommonCircuitData, the parts the hot
+ * path needs).  constants_sigmas is the preprocessed oracle committed at build time (not blinded);
+ * sigmas are the sigma VALUES sigma[j][i] = k_{j'} * g^{i'} ([num_routed_wires][n], host or device). */
+typedef struct {
+    const gl355_circuit* circuit;
+    const gl355_oracle* constants_sigmas;
+    const uint64_t* sigmas;
+    const uint64_t* k_is;
+    uint64_t circuit_digest[4];
+    uint32_t cap_height, pow_bits, num_queries, n_fri_layers;
+    int32_t zero_knowledge;      /* salt the wires / Z / quotient oracles with 4 pseudo-random columns */
+} gl355_prover_data;
+/* u64 words of the flat proof gl355_prove writes */
+uint64_t gl355_proof_words(const gl355_prover_data* pd);
+/* wires: the full witness [num_wires][n] (host or device), including the blinding rows.  seed drives the
+ * salt columns (counter-based PRNG on the device), so a (witness, seed) pair gives a reproducible proof.
+ * Flat proof layout (all u64; E = extension element = 2 words, H = digest = 4 words, C = 2^cap_height):
+ *   header[8] = {total_words, degree_bits, n_fri_layers, num_queries, n_public_inputs, zero_knowledge, cap_height, num_challenges}
+ *   wires_cap[C]H  zs_partial_products_cap[C]H  quotient_polys_cap[C]H
+ *   openings at zeta: constants | sigmas | wires | zs | partial_products | quotient_polys (E each), then zs at g*zeta
+ *   fri caps[n_fri_layers][C]H   final_poly[n >> n_fri_layers]E   pow_witness
+ *   per query: x_index; for oracle 0..3: leaf[leaf_len], siblings[log2 N - cap_height]H;
+ *              for layer l: evals[2]E, siblings[log2 N - 1 - l - cap_height]H */
+int32_t gl355_prove(gl355_ctx* ctx, const gl355_prover_data* pd, const uint64_t* wires, const uint64_t* public_inputs,
+                    uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words);
+
 /* ---- a9: wires_permutation_partial_products_and_zs (vanishing_poly.rs:54-108,183-218) --------- */
 int32_t gl355_zs_partial_products(gl355_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas,
                                   const uint64_t* k_is, uint32_t log_n, uint32_t n_routed,

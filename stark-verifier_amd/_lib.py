@@ -25,6 +25,12 @@ class Challenger(C.Structure):
                 ("out_buf", C.c_uint64 * 8), ("out_len", C.c_uint32)]
 
 
+class ProverData(C.Structure):
+    _fields_ = [("circuit", vp), ("constants_sigmas", vp), ("sigmas", vp), ("k_is", vp), ("circuit_digest", C.c_uint64 * 4),
+                ("cap_height", C.c_uint32), ("pow_bits", C.c_uint32), ("num_queries", C.c_uint32), ("n_fri_layers", C.c_uint32),
+                ("zero_knowledge", C.c_int32)]
+
+
 MAX_GATES = 16
 (GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_BASE_SUM, GATE_POSEIDON, GATE_ARITHMETIC, GATE_ARITHMETIC_EXT,
  GATE_MUL_EXT, GATE_POSEIDON_MDS, GATE_RANDOM_ACCESS, GATE_REDUCING, GATE_REDUCING_EXT) = range(12)
@@ -86,6 +92,8 @@ SIGNATURES = {
     "gl355_oracle_open_batch": (C.c_int32, [vp, vp, C.c_uint32, vp, vp]),
     "gl355_fri_prove": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.POINTER(Challenger), vp, vp, C.POINTER(C.c_uint64), vp, vp, vp]),
+    "gl355_proof_words": (C.c_uint64, [C.POINTER(ProverData)]),
+    "gl355_prove": (C.c_int32, [vp, C.POINTER(ProverData), vp, vp, C.c_uint32, C.c_uint64, vp, C.c_uint64]),
     "gl355_quotient": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gl355_quotient_values": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gl355_challenger_init": (C.c_int32, [C.POINTER(Challenger)]),

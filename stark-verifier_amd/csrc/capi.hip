@@ -86,15 +86,6 @@ int32_t lde_dev(Ctx* ctx, const uint64_t* coeffs, uint64_t in_stride, uint32_t l
 }  // namespace gl355
 
 // ---- oracle (PolynomialBatch) --------------------------------------------------------------
-struct gl355_oracle {
-    Ctx* ctx;
-    uint32_t log_n, rate_bits, batch, leaf_len, cap_height;
-    uint64_t* coeffs;   // [batch][n]
-    uint64_t* lde;      // [leaf_len][N], rows in bit-reversed order (salt columns last)
-    uint64_t* digests;  // plonky2 layout
-    uint64_t* cap;
-    uint64_t n_digests;
-};
 
 #define CTX_OR_FAIL(h)                      \
     Ctx* ctx = ctx_of(h);                   \
@@ -292,8 +283,14 @@ int32_t gl355_commit(gl355_ctx* h, const uint64_t* values, uint32_t log_n, uint3
     // one allocation: coeffs | lde | digests | cap
     const uint64_t total = (uint64_t)batch * n + (uint64_t)leaf_len * N + n_dig * 4 + n_cap * 4;
     uint64_t* base = nullptr;
-    hipError_t e = hipMalloc((void**)&base, total * 8);
-    if (e != hipSuccess) { (void)hipGetLastError(); delete o; return ctx->fail_hip(e, "hipMalloc(oracle)", __FILE__, __LINE__); }
+    hipError_t e = hipSuccess;
+    {
+        // from the context's caching allocator: repeated proofs reuse the same blocks (no hipMalloc/hipFree per commit)
+        void* p = nullptr;
+        int32_t arc = ctx->alloc(total * 8, &p);
+        if (arc != GL355_OK) { delete o; return arc; }
+        base = reinterpret_cast<uint64_t*>(p);
+    }
     o->coeffs = base; o->lde = base + (uint64_t)batch * n; o->digests = o->lde + (uint64_t)leaf_len * N; o->cap = o->digests + n_dig * 4;
     int32_t rc = GL355_OK;
     do {
@@ -319,7 +316,7 @@ int32_t gl355_commit(gl355_ctx* h, const uint64_t* values, uint32_t log_n, uint3
         e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { rc = ctx->fail_hip(e, "hipStreamSynchronize(commit)", __FILE__, __LINE__); break; }
     } while (0);
-    if (rc != GL355_OK) { (void)hipFree(base); delete o; return rc; }
+    if (rc != GL355_OK) { ctx->release(base); delete o; return rc; }
     *out = o;
     return GL355_OK;
 }
@@ -327,7 +324,7 @@ int32_t gl355_oracle_destroy(gl355_oracle* o) {
     if (!o) return GL355_OK;
     (void)hipSetDevice(o->ctx->device);
     (void)hipStreamSynchronize(o->ctx->stream);
-    (void)hipFree(o->coeffs);
+    o->ctx->release(o->coeffs);
     delete o;
     return GL355_OK;
 }

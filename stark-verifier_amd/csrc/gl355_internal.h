@@ -13,6 +13,19 @@
 #include "../../include/gl355.h"
 #include "gl_field.cuh"
 
+namespace gl355 { struct Ctx; }
+
+// a committed polynomial batch resident in HBM (PolynomialBatch); one allocation from the context pool
+struct gl355_oracle {
+    struct gl355::Ctx* ctx;
+    uint32_t log_n, rate_bits, batch, leaf_len, cap_height;
+    uint64_t* coeffs;   // [batch][n]
+    uint64_t* lde;      // [leaf_len][N], rows in bit-reversed order (salt columns last)
+    uint64_t* digests;  // plonky2 layout
+    uint64_t* cap;
+    uint64_t n_digests;
+};
+
 namespace gl355 {
 
 struct Ctx;

@@ -111,3 +111,213 @@ extern "C" int32_t gl355_fri_prove(gl355_ctx* h, const uint64_t* final_coeffs, u
     GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GL355_OK;
 }
+
+// ================================================================================================
+// gl355_prove: CircuitData::prove in one call (src/plonky2_semaphore/access_set.rs:94, recursion.rs:168,
+// wrapper.rs:55).  Stage order and transcript: chip/plonk/plonk_verifier_chip.rs:55-154; oracle and
+// opening order: types/common_data.rs:100-222, types/assigned.rs:26-44.  Everything between the
+// witness upload and the final proof download stays resident in HBM; the host only runs the
+// Challenger (about 50 permutations).  The proof is returned as one flat u64 buffer (layout in
+// include/gl355.h), which doubles as the wire format between aggregation levels.
+// ================================================================================================
+namespace gl355 {
+
+// counter-based blinding salt: SplitMix64(seed, index) folded into [0, p)
+__global__ void salt_kernel(uint64_t* out, uint64_t n, uint64_t seed) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    out[i] = gl_canon(z);
+}
+
+struct OracleGuard {
+    gl355_oracle* o = nullptr;
+    ~OracleGuard() { if (o) gl355_oracle_destroy(o); }
+};
+
+static int32_t observe_cap(Ctx* ctx, const gl355_oracle* o, gl355_challenger* ch, uint64_t* dst) {
+    const uint64_t words = 4ull << o->cap_height;
+    GL355_HIP(ctx, hipMemcpyAsync(dst, o->cap, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    gl355_challenger_observe(ch, dst, words);
+    return GL355_OK;
+}
+
+}  // namespace gl355
+
+extern "C" uint64_t gl355_proof_words(const gl355_prover_data* pd) {
+    if (!pd || !pd->circuit) return 0;
+    const gl355_circuit& c = *pd->circuit;
+    const uint64_t n_cap = 1ull << pd->cap_height;
+    const uint32_t nch = c.num_challenges, qdf = c.max_degree;
+    const uint32_t lde_bits = c.degree_bits + c.rate_bits;
+    const uint32_t widths[4] = {c.num_selectors + c.num_constants + c.num_routed_wires, c.num_wires,
+                                nch * (1 + c.num_partial_products), nch * qdf};
+    uint64_t w = 8;                                            // header
+    w += 3 * n_cap * 4;                                        // wires / zs / quotient caps
+    uint64_t n_open = 0;
+    for (int o = 0; o < 4; o++) n_open += widths[o];
+    w += 2 * (n_open + nch);                                   // openings at zeta, Z at g*zeta (ext)
+    w += (uint64_t)pd->n_fri_layers * n_cap * 4;               // commit-phase caps
+    w += 2 * ((1ull << c.degree_bits) >> pd->n_fri_layers);    // final polynomial (ext)
+    w += 1;                                                    // pow witness
+    uint64_t per_q = 1;
+    for (int o = 0; o < 4; o++) {
+        const uint32_t leaf = widths[o] + ((pd->zero_knowledge && o > 0) ? GL355_SALT_SIZE : 0);
+        per_q += leaf + (uint64_t)(lde_bits - pd->cap_height) * 4;
+    }
+    for (uint32_t l = 0; l < pd->n_fri_layers; l++) per_q += 4 + (uint64_t)(lde_bits - 1 - l - pd->cap_height) * 4;
+    w += per_q * pd->num_queries;
+    return w;
+}
+
+extern "C" int32_t gl355_prove(gl355_ctx* h, const gl355_prover_data* pd, const uint64_t* wires, const uint64_t* public_inputs,
+                               uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+    if (!pd || !pd->circuit || !pd->constants_sigmas || !pd->sigmas || !pd->k_is || !wires || !proof || (!public_inputs && n_public_inputs))
+        return ctx->fail(GL355_E_INVALID_ARG, "prove: null argument");
+    const gl355_circuit& c = *pd->circuit;
+    const uint32_t nch = c.num_challenges, qdf = c.max_degree, npp = c.num_partial_products, routed = c.num_routed_wires;
+    const uint32_t lde_bits = c.degree_bits + c.rate_bits, cap_h = pd->cap_height;
+    const uint64_t n = 1ull << c.degree_bits, N = 1ull << lde_bits, n_cap = 1ull << cap_h;
+    if (nch == 0 || nch > 4 || pd->n_fri_layers > 32) return ctx->fail(GL355_E_UNSUPPORTED, "prove: unsupported shape");
+    const uint64_t need = gl355_proof_words(pd);
+    if (proof_capacity_words < need) return ctx->fail(GL355_E_INVALID_ARG, "prove: proof buffer too small (see gl355_proof_words)");
+    const gl355_oracle* cs = pd->constants_sigmas;
+    if (cs->log_n != c.degree_bits || cs->rate_bits != c.rate_bits || cs->cap_height != cap_h)
+        return ctx->fail(GL355_E_INVALID_ARG, "prove: constants_sigmas oracle does not match the circuit");
+    const bool zk = pd->zero_knowledge != 0;
+
+    uint64_t* out = proof;
+    uint64_t* hdr = out; out += 8;
+    hdr[0] = need; hdr[1] = c.degree_bits; hdr[2] = pd->n_fri_layers; hdr[3] = pd->num_queries; hdr[4] = n_public_inputs;
+    hdr[5] = zk; hdr[6] = cap_h; hdr[7] = nch;
+
+    gl355_challenger ch;
+    gl355_challenger_init(&ch);
+    uint64_t pi_hash[4];
+    gl355_host_hash_no_pad(public_inputs, n_public_inputs, pi_hash);
+    gl355_challenger_observe(&ch, pd->circuit_digest, 4);
+    gl355_challenger_observe(&ch, pi_hash, 4);
+
+    // device staging: witness, sigma values, k_is, salt
+    Staged s_wires(ctx), s_sig(ctx), s_k(ctx);
+    GL355_TRY(s_wires.open(wires, (uint64_t)c.num_wires * n * 8, 1));
+    GL355_TRY(s_sig.open(pd->sigmas, (uint64_t)routed * n * 8, 1));
+    GL355_TRY(s_k.open(pd->k_is, (uint64_t)routed * 8, 1));
+    Scratch salt(ctx);
+    if (zk) GL355_TRY(salt.get((uint64_t)GL355_SALT_SIZE * N * 8));
+    auto fresh_salt = [&](uint64_t stream_id) -> int32_t {
+        const uint64_t cnt = (uint64_t)GL355_SALT_SIZE * N;
+        hipLaunchKernelGGL(salt_kernel, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, salt.as<uint64_t>(), cnt,
+                           seed * 0x100000001B3ull + stream_id * 0xD6E8FEB86659FD93ull);
+        GL355_HIP(ctx, hipGetLastError());
+        return GL355_OK;
+    };
+
+    // ---- wires ----------------------------------------------------------------------------------
+    OracleGuard g_w, g_z, g_q;
+    if (zk) GL355_TRY(fresh_salt(1));
+    GL355_TRY(gl355_commit(h, s_wires.as<uint64_t>(), c.degree_bits, c.num_wires, c.rate_bits, 0, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_w.o));
+    uint64_t* p_wires_cap = out; out += n_cap * 4;
+    GL355_TRY(observe_cap(ctx, g_w.o, &ch, p_wires_cap));
+    uint64_t betas[4], gammas[4], alphas[4];
+    gl355_challenger_squeeze(&ch, betas, nch);
+    gl355_challenger_squeeze(&ch, gammas, nch);
+    // ---- Z / partial products ----------------------------------------------------------------------
+    Scratch zbuf(ctx);
+    const uint32_t z_width = nch * (1 + npp);
+    GL355_TRY(zbuf.get((uint64_t)z_width * n * 8));
+    for (uint32_t k = 0; k < nch; k++) {
+        uint64_t* z = zbuf.as<uint64_t>() + (uint64_t)k * n;
+        uint64_t* pp = zbuf.as<uint64_t>() + ((uint64_t)nch + (uint64_t)k * npp) * n;
+        GL355_TRY(zs_partial_products_dev(ctx, s_wires.as<uint64_t>(), s_sig.as<uint64_t>(), s_k.as<uint64_t>(), c.degree_bits, routed, qdf,
+                                          betas[k], gammas[k], z, pp));
+    }
+    if (zk) GL355_TRY(fresh_salt(2));
+    GL355_TRY(gl355_commit(h, zbuf.as<uint64_t>(), c.degree_bits, z_width, c.rate_bits, 0, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_z.o));
+    uint64_t* p_zs_cap = out; out += n_cap * 4;
+    GL355_TRY(observe_cap(ctx, g_z.o, &ch, p_zs_cap));
+    gl355_challenger_squeeze(&ch, alphas, nch);
+    // ---- quotient ------------------------------------------------------------------------------------
+    uint32_t qdb = 0;
+    while ((1u << qdb) < qdf) qdb++;
+    const uint64_t nq = n << qdb;
+    Scratch qv(ctx), qc(ctx);
+    GL355_TRY(qv.get((uint64_t)nch * nq * 8));
+    GL355_TRY(qc.get((uint64_t)nch * nq * 8));
+    GL355_TRY(quotient_dev(ctx, &c, cs->lde, g_w.o->lde, g_z.o->lde, N, s_k.as<uint64_t>(), betas, gammas, alphas, pi_hash, qv.as<uint64_t>()));
+    GL355_TRY(intt_from_bitrev_dev(ctx, qv.as<uint64_t>(), nq, qc.as<uint64_t>(), nq, c.degree_bits + qdb, nch, GL355_COSET_SHIFT));
+    if (zk) GL355_TRY(fresh_salt(3));
+    GL355_TRY(gl355_commit(h, qc.as<uint64_t>(), c.degree_bits, nch * qdf, c.rate_bits, 1, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_q.o));
+    uint64_t* p_q_cap = out; out += n_cap * 4;
+    GL355_TRY(observe_cap(ctx, g_q.o, &ch, p_q_cap));
+    uint64_t zeta[2], zeta_next[2];
+    gl355_challenger_squeeze(&ch, zeta, 2);
+    const uint64_t g = gl_root_of_unity(c.degree_bits);
+    zeta_next[0] = gl_canon(gl_mul(zeta[0], g)); zeta_next[1] = gl_canon(gl_mul(zeta[1], g));
+    // ---- openings (OpeningSet::new): every polynomial at zeta, the Z polynomials at g*zeta ----------------
+    const gl355_oracle* oracles[4] = {cs, g_w.o, g_z.o, g_q.o};
+    std::vector<const uint64_t*> all_ptrs, z_ptrs;
+    for (int o = 0; o < 4; o++)
+        for (uint32_t i = 0; i < oracles[o]->batch; i++) all_ptrs.push_back(oracles[o]->coeffs + ((uint64_t)i << c.degree_bits));
+    for (uint32_t i = 0; i < nch; i++) z_ptrs.push_back(g_z.o->coeffs + ((uint64_t)i << c.degree_bits));
+    const uint64_t n_open = all_ptrs.size();
+    Scratch evb(ctx);
+    GL355_TRY(evb.get((n_open + nch) * 16));
+    GL355_TRY(eval_polys_ext_dev(ctx, all_ptrs.data(), (uint32_t)n_open, c.degree_bits, zeta, evb.as<uint64_t>()));
+    GL355_TRY(eval_polys_ext_dev(ctx, z_ptrs.data(), nch, c.degree_bits, zeta_next, evb.as<uint64_t>() + 2 * n_open));
+    uint64_t* p_open = out; out += 2 * (n_open + nch);
+    GL355_HIP(ctx, hipMemcpyAsync(p_open, evb.as<uint64_t>(), (n_open + nch) * 16, hipMemcpyDeviceToHost, ctx->stream));
+    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    gl355_challenger_observe(&ch, p_open, 2 * (n_open + nch));
+    uint64_t fri_alpha[2];
+    gl355_challenger_squeeze(&ch, fri_alpha, 2);
+    // ---- DEEP quotient (prove_openings) ----------------------------------------------------------------------
+    Scratch acc(ctx);
+    GL355_TRY(acc.get(n * 16));
+    GL355_HIP(ctx, hipMemsetAsync(acc.as<uint64_t>(), 0, n * 16, ctx->stream));
+    GL355_TRY(deep_batch_dev(ctx, all_ptrs.data(), (uint32_t)n_open, c.degree_bits, fri_alpha, zeta, acc.as<uint64_t>()));
+    GL355_TRY(deep_batch_dev(ctx, z_ptrs.data(), nch, c.degree_bits, fri_alpha, zeta_next, acc.as<uint64_t>()));
+    // ---- FRI ----------------------------------------------------------------------------------------------------
+    std::vector<uint32_t> arity(pd->n_fri_layers, 1);
+    uint64_t* p_fri_caps = out; out += (uint64_t)pd->n_fri_layers * n_cap * 4;
+    uint64_t* p_final = out; out += 2 * (n >> pd->n_fri_layers);
+    uint64_t* p_pow = out; out += 1;
+    std::vector<uint64_t> q_idx(pd->num_queries);
+    uint64_t sib_total = 0;
+    for (uint32_t l = 0; l < pd->n_fri_layers; l++) sib_total += (uint64_t)(lde_bits - 1 - l - cap_h) * 4;
+    std::vector<uint64_t> step_evals((uint64_t)pd->num_queries * pd->n_fri_layers * 4 + 4), step_sibs((uint64_t)pd->num_queries * sib_total + 4);
+    GL355_TRY(gl355_fri_prove(h, acc.as<uint64_t>(), c.degree_bits, c.rate_bits, cap_h, arity.data(), pd->n_fri_layers, pd->pow_bits,
+                              pd->num_queries, &ch, p_fri_caps, p_final, p_pow, q_idx.data(), step_evals.data(), step_sibs.data()));
+    // ---- initial-tree openings for every query ---------------------------------------------------------------------
+    const uint32_t depth0 = lde_bits - cap_h;
+    std::vector<std::vector<uint64_t>> leaves(4), sibs(4);
+    for (int o = 0; o < 4; o++) {
+        leaves[o].resize((uint64_t)pd->num_queries * oracles[o]->leaf_len + 4);
+        sibs[o].resize((uint64_t)pd->num_queries * depth0 * 4 + 4);
+        GL355_TRY(gl355_oracle_open_batch(oracles[o], q_idx.data(), pd->num_queries, leaves[o].data(), sibs[o].data()));
+    }
+    for (uint32_t q = 0; q < pd->num_queries; q++) {
+        *out++ = q_idx[q];
+        for (int o = 0; o < 4; o++) {
+            const uint32_t ll = oracles[o]->leaf_len;
+            memcpy(out, leaves[o].data() + (uint64_t)q * ll, (uint64_t)ll * 8); out += ll;
+            memcpy(out, sibs[o].data() + (uint64_t)q * depth0 * 4, (uint64_t)depth0 * 32); out += (uint64_t)depth0 * 4;
+        }
+        uint64_t so = 0;
+        for (uint32_t l = 0; l < pd->n_fri_layers; l++) {
+            memcpy(out, step_evals.data() + ((uint64_t)q * pd->n_fri_layers + l) * 4, 32); out += 4;
+            const uint64_t d = (uint64_t)(lde_bits - 1 - l - cap_h) * 4;
+            memcpy(out, step_sibs.data() + (uint64_t)q * sib_total + so, d * 8); out += d;
+            so += d;
+        }
+    }
+    if ((uint64_t)(out - proof) != need) return ctx->fail(GL355_E_HIP, "prove: internal proof-size mismatch");
+    return GL355_OK;
+}

@@ -252,6 +252,29 @@ _GATE_CONSTRAINTS = {
 class CircuitData:
     """The prover/verifier data of one built circuit (plonky2 CircuitData / CommonCircuitData)."""
 
+    def prover_data(self, ctx):
+        """gl355_prover_data with the sigma values and k_is resident on the device (uploaded once)."""
+        key = id(ctx)
+        cache = self.__dict__.setdefault("_pd_cache", {})
+        if key not in cache:
+            lib = ctx.lib
+            d_sig, d_k = C.c_void_p(), C.c_void_p()
+            ctx.check(lib.gl355_malloc(ctx.h, self.sigmas.nbytes, C.byref(d_sig)))
+            ctx.check(lib.gl355_malloc(ctx.h, self.k_is.nbytes, C.byref(d_k)))
+            ctx.check(lib.gl355_memcpy_h2d(ctx.h, d_sig, _ptr(self.sigmas), self.sigmas.nbytes))
+            ctx.check(lib.gl355_memcpy_h2d(ctx.h, d_k, _ptr(self.k_is), self.k_is.nbytes))
+            pd = _lib.ProverData()
+            pd.circuit = C.cast(C.pointer(self.c_circuit), C.c_void_p)
+            pd.constants_sigmas = self.constants_sigmas.h
+            pd.sigmas, pd.k_is = d_sig, d_k
+            for i in range(4):
+                pd.circuit_digest[i] = int(self.circuit_digest[i])
+            cfg = self.config
+            pd.cap_height, pd.pow_bits, pd.num_queries = cfg.cap_height, cfg.proof_of_work_bits, cfg.num_query_rounds
+            pd.n_fri_layers, pd.zero_knowledge = len(self.fri_arity_bits), int(cfg.zero_knowledge)
+            cache[key] = pd
+        return cache[key]
+
     def common(self):
         """Plain-dict common data for the verifier restatement in tests/."""
         cfg = self.config
@@ -289,8 +312,68 @@ def _rand_salt(rng, n_cols):
     return rng.integers(0, P, size=(SALT_SIZE, n_cols), dtype=np.uint64)
 
 
-def prove(ctx, data, wires, public_inputs, rng, timings=None):
-    """CircuitData::prove: wires[num_wires][n] is the full witness; returns the proof as a dict."""
+def parse_proof(data, flat):
+    """Flat u64 proof of gl355_prove (layout in include/gl355.h) -> the dict the verifier restatement reads."""
+    cfg = data.config
+    total, degree_bits, n_layers, nq, n_pi, zk, cap_h, nch = [int(v) for v in flat[:8]]
+    n_cap = 1 << cap_h
+    lde_bits = degree_bits + cfg.rate_bits
+    n = 1 << degree_bits
+    pos = [8]
+
+    def take(k, shape=None):
+        v = flat[pos[0]:pos[0] + k]
+        pos[0] += k
+        return v.reshape(shape) if shape else v
+    wires_cap, zs_cap, q_cap = take(4 * n_cap, (n_cap, 4)), take(4 * n_cap, (n_cap, 4)), take(4 * n_cap, (n_cap, 4))
+    n_const = data.num_selectors + cfg.num_constants
+    counts = [("constants", n_const), ("plonk_sigmas", cfg.num_routed_wires), ("wires", cfg.num_wires), ("plonk_zs", nch),
+              ("partial_products", nch * data.num_partial_products), ("quotient_polys", nch * cfg.max_quotient_degree_factor),
+              ("plonk_zs_next", nch)]
+    openings = {name: take(2 * k, (k, 2)) for name, k in counts}
+    caps = take(n_layers * n_cap * 4, (n_layers, n_cap, 4))
+    final_poly = take(2 * (n >> n_layers), (-1, 2))
+    pow_witness = int(take(1)[0])
+    widths = [n_const + cfg.num_routed_wires, cfg.num_wires, nch * (1 + data.num_partial_products), nch * cfg.max_quotient_degree_factor]
+    depth0 = lde_bits - cap_h
+    queries = []
+    for _ in range(nq):
+        x_index = int(take(1)[0])
+        initial = []
+        for o in range(4):
+            ll = widths[o] + (SALT_SIZE if (zk and o > 0) else 0)
+            initial.append((take(ll), take(depth0 * 4, (depth0, 4))))
+        steps = []
+        for l in range(n_layers):
+            d = lde_bits - 1 - l - cap_h
+            steps.append((take(4), take(d * 4, (d, 4))))
+        queries.append(dict(index=x_index, initial_trees=initial, steps=steps))
+    assert pos[0] == total == flat.size
+    return dict(wires_cap=wires_cap, plonk_zs_partial_products_cap=zs_cap, quotient_polys_cap=q_cap, openings=openings,
+                opening_proof=dict(commit_phase_merkle_caps=[caps[l] for l in range(n_layers)], query_round_proofs=queries,
+                                   final_poly=final_poly, pow_witness=pow_witness))
+
+
+def prove(ctx, data, wires, public_inputs, seed, flat_only=False):
+    """CircuitData::prove through the single resident C entry point gl355_prove (csrc/prover.hip)."""
+    lib = ctx.lib
+    cfg = data.config
+    pd = data.prover_data(ctx)
+    pi = _u64(public_inputs)
+    words = lib.gl355_proof_words(C.byref(pd))
+    flat = np.empty(words, dtype=np.uint64)
+    w = wires if hasattr(wires, "data_ptr") else np.ascontiguousarray(wires, dtype=np.uint64)
+    ctx.check(lib.gl355_prove(ctx.h, C.byref(pd), _ptr(w), _ptr(pi), pi.size, int(seed) & ((1 << 64) - 1), _ptr(flat), words))
+    if flat_only:
+        return flat
+    proof = parse_proof(data, flat)
+    proof["public_inputs"] = pi.copy()
+    return proof
+
+
+def prove_staged(ctx, data, wires, public_inputs, rng, timings=None):
+    """The same proof sequenced stage by stage from Python over the individual C-ABI entry points (used for
+    per-stage timings and to cross-check gl355_prove); wires[num_wires][n] is the full witness."""
     import time
     cfg = data.config
     lib = ctx.lib

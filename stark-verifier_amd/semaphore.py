@@ -10,7 +10,7 @@ import numpy as np
 from ._lib import GATE_BASE_SUM, GATE_CONSTANT, GATE_POSEIDON, GATE_PUBLIC_INPUT
 from .api import MerkleTree
 from .plonk import (CircuitBuilder, CircuitConfig, check_copy_constraints, fill_blinding, host_hash_no_pad,
-                    poseidon_gate_witness, prove)
+                    poseidon_gate_witness, prove, prove_staged)
 
 IN, OUT, SWAP = 0, 12, 24   # PoseidonGate wire offsets (chip/plonk/gates/poseidon.rs:329-345)
 
@@ -121,13 +121,16 @@ class AccessSet:
         return self._circuit
 
     # ---- access_set.rs:61-104 ---------------------------------------------------------------------------------
-    def make_signal(self, private_key, topic, public_key_index, rng, timings=None, check=False):
+    def make_signal(self, private_key, topic, public_key_index, rng, timings=None, check=False, staged=False):
         data, rows = self.build(rng)
         wires, public_inputs = self.fill_semaphore_targets(data, rows, private_key, topic, public_key_index, rng)
         assert np.array_equal(public_inputs[:4], self.tree.cap[0]), "witness root != access-set root"
         if check:
             check_copy_constraints(data, wires)
-        proof = prove(self.ctx, data, wires, public_inputs, rng, timings)
+        if staged or timings is not None:
+            proof = prove_staged(self.ctx, data, wires, public_inputs, rng, timings)
+        else:
+            proof = prove(self.ctx, data, wires, public_inputs, int(rng.integers(0, 1 << 62)))
         nullifier = host_hash_no_pad(np.concatenate([np.asarray(private_key, np.uint64), np.asarray(topic, np.uint64)]))
         assert np.array_equal(nullifier, public_inputs[4:8])
         return Signal([np.asarray(topic, np.uint64)], [nullifier], proof), data

@@ -80,6 +80,21 @@ def test_semaphore_proof_verifies(gl, ctx, orc, log_members):
     signal2, _ = aset.make_signal(sks[3], topic, 3, np.random.default_rng(0x359))
     pv.verify(orc, cd, signal2.proof)
     assert not np.array_equal(signal2.proof["wires_cap"], signal.proof["wires_cap"])
+    # the stage-by-stage Python sequencing over the individual entry points gives a valid proof too
+    signal3, _ = aset.make_signal(sks[7], topic, 7, np.random.default_rng(0x35A), staged=True)
+    pv.verify(orc, cd, signal3.proof)
+
+
+def test_prove_is_deterministic_in_witness_and_seed(gl, ctx):
+    """same witness + same seed => byte-identical proof (salt is counter-based, PoW takes the smallest witness)."""
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    aset, sks, rng = make_access_set(gl, ctx, 3, 0x35D)
+    data, rows = aset.build(rng)
+    wires, pi = aset.fill_semaphore_targets(data, rows, sks[2], rand_field(rng, 4), 2, np.random.default_rng(5))
+    a = plonk.prove(ctx, data, wires, pi, 42, flat_only=True)
+    b = plonk.prove(ctx, data, wires, pi, 42, flat_only=True)
+    c = plonk.prove(ctx, data, wires, pi, 43, flat_only=True)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
 
 
 def test_wrong_witness_fails_quotient(gl, ctx, orc):
@@ -90,9 +105,9 @@ def test_wrong_witness_fails_quotient(gl, ctx, orc):
     data, rows = aset.build(rng)
     wires, pi = aset.fill_semaphore_targets(data, rows, sks[1], rand_field(rng, 4), 1, rng)
     wires[40, rows["null"]] ^= np.uint64(1)        # break one S-box wire
-    proof = plonk.prove(ctx, data, wires, pi, np.random.default_rng(1))
-    with pytest.raises(pv.VerifyError):
-        pv.verify(orc, data.common(), proof)
+    for proof in (plonk.prove(ctx, data, wires, pi, 1), plonk.prove_staged(ctx, data, wires, pi, np.random.default_rng(1))):
+        with pytest.raises(pv.VerifyError):
+            pv.verify(orc, data.common(), proof)
 
 
 def test_quotient_kernel_pointwise(gl, ctx, orc):
