@@ -125,6 +125,15 @@ def load():
         raise RuntimeError(
             "libgl355.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C stark-verifier_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # If torch is in this process it must own the HIP runtime initialisation (it ships its own ROCm
+    # libraries; loading the system libamdhip64 first makes torch report "No HIP GPUs are available").
+    import sys
+    if "torch" in sys.modules:
+        try:
+            t = sys.modules["torch"]
+            t.cuda.is_available() and t.cuda.init()
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -178,6 +178,7 @@ int32_t gl355_ctx_destroy(gl355_ctx* ctx) {
     (void)hipStreamSynchronize(c.stream);
     c.release_all();
     for (auto& kv : c.pow_cache) (void)hipFree(kv.second.lo);
+    for (auto& kv : c.full_cache) (void)hipFree(kv.second);
     if (c.tw_fwd) (void)hipFree(c.tw_fwd);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);

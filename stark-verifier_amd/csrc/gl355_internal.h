@@ -55,6 +55,9 @@ struct Ctx {
     // cached two-level power tables, keyed by the list of bases
     struct PowTab { uint64_t* lo; uint64_t* hi; };
     std::map<std::vector<uint64_t>, PowTab> pow_cache;
+    std::map<std::vector<uint64_t>, uint64_t*> full_cache;   // full-size multiplier tables (ntt.hip)
+    int32_t full_pow_table(const uint64_t* lo, const uint64_t* hi, uint32_t n_cosets, uint32_t log_n, const uint64_t** out);
+    int32_t full_step_table(const uint64_t* lo, const uint64_t* hi, uint32_t l1, uint32_t l2, bool inv, const uint64_t** out);
 
     // trivial caching device allocator (per context => per stream, so reuse is stream-ordered)
     struct Block { void* p; size_t size; bool used; };

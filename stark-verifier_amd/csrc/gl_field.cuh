@@ -86,6 +86,28 @@ GL_HD uint64_t gl_mul_small(uint64_t a, uint32_t c) {
     return r;
 }
 
+// a * 2^S mod p for a compile-time 0 <= S < 96: powers of two are roots of unity in Goldilocks
+// (2^96 = -1), so the radix-16 butterflies' internal twiddles cost shifts instead of a 64x64 multiply.
+template <int S>
+GL_HD uint64_t gl_mul_2exp(uint64_t x) {
+    static_assert(S >= 0 && S < 96, "shift out of range");
+    if constexpr (S == 0) {
+        return x;
+    } else if constexpr (S <= 32) {
+        const uint32_t hi = (uint32_t)(x >> (64 - S));       // < 2^S <= 2^32
+        const uint64_t lo = x << S;
+        const uint64_t t = (uint64_t)hi * 0xFFFFFFFFu;        // hi * 2^64 == hi * EPS
+        uint64_t r = lo + t;
+        if (r < t) r += GL_EPS;
+        return r;
+    } else if constexpr (S < 64) {
+        return gl_reduce128(x << S, x >> (64 - S));
+    } else {
+        const uint64_t y = gl_mul_2exp<S - 64>(x);            // then * 2^64
+        return gl_reduce128(0, y);
+    }
+}
+
 GL_HD uint64_t gl_pow(uint64_t a, uint64_t e) {
     uint64_t r = 1;
     while (e) {

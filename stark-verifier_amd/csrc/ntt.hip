@@ -46,9 +46,25 @@ GL_DEV uint64_t pow2lvl(const uint64_t* __restrict__ lo, const uint64_t* __restr
 // omega_16^j for the in-register radix-16 butterflies (forward / inverse), filled at ctx creation
 __constant__ uint64_t c_w16[2][8];
 
+// (a - b) * omega_16^(+-E) with shifts only: omega_16 = 2^156 = -2^60, omega_16^-1 = 2^36, so
+//   forward  E=1..7: -2^60, -2^24, +2^84, +2^48, +2^12, -2^72, -2^36
+//   inverse  E=1..7: +2^36, +2^72, -2^12, -2^48, -2^84, +2^24, +2^60
+// (a negative sign is absorbed by computing b - a instead of a - b).
+template <bool INV, int E>
+GL_DEV uint64_t sub_mul_w16(uint64_t a, uint64_t b) {
+    constexpr int FWD_S[8] = {0, 60, 24, 84, 48, 12, 72, 36};
+    constexpr bool FWD_NEG[8] = {false, true, true, false, false, false, true, true};
+    constexpr int INV_S[8] = {0, 36, 72, 12, 48, 84, 24, 60};
+    constexpr bool INV_NEG[8] = {false, false, false, true, true, true, false, false};
+    constexpr int S = INV ? INV_S[E] : FWD_S[E];
+    constexpr bool NEG = INV ? INV_NEG[E] : FWD_NEG[E];
+    const uint64_t d = NEG ? gl_sub(b, a) : gl_sub(a, b);
+    return gl_mul_2exp<S>(d);
+}
+
 // In-register DIF butterfly network on 2^RHO values: x[pos] <- X[bitrev(pos)].
 template <int RHO, bool INV>
-GL_DEV void dif_regs(uint64_t (&x)[16]) {
+GL_DEV void dif_regs_generic(uint64_t (&x)[16]) {
 #pragma unroll
     for (int s = 0; s < RHO; s++) {
         const int half = 1 << (RHO - 1 - s);
@@ -66,6 +82,35 @@ GL_DEV void dif_regs(uint64_t (&x)[16]) {
             }
         }
     }
+}
+
+template <bool INV, int HALF, int J>
+GL_DEV void dif_pair(uint64_t (&x)[16], int i0) {
+    const uint64_t a = x[i0], b = x[i0 + HALF];
+    x[i0] = gl_add(a, b);
+    x[i0 + HALF] = sub_mul_w16<INV, J * (8 / HALF)>(a, b);
+}
+template <bool INV, int HALF, int BLK, int J>
+GL_DEV void dif_stage_unrolled(uint64_t (&x)[16]) {
+    if constexpr (J < HALF) {
+        dif_pair<INV, HALF, J>(x, BLK * 2 * HALF + J);
+        dif_stage_unrolled<INV, HALF, BLK, J + 1>(x);
+    }
+}
+template <bool INV, int HALF, int NBLK, int BLK>
+GL_DEV void dif_stage_blocks(uint64_t (&x)[16]) {
+    if constexpr (BLK < NBLK) {
+        dif_stage_unrolled<INV, HALF, BLK, 0>(x);
+        dif_stage_blocks<INV, HALF, NBLK, BLK + 1>(x);
+    }
+}
+// shift-twiddle version of the same network (all internal twiddles are powers of two)
+template <int RHO, bool INV>
+GL_DEV void dif_regs(uint64_t (&x)[16]) {
+    if constexpr (RHO >= 4) dif_stage_blocks<INV, 8, 1, 0>(x);
+    if constexpr (RHO >= 3) dif_stage_blocks<INV, 4, 1 << (RHO - 3), 0>(x);
+    if constexpr (RHO >= 2) dif_stage_blocks<INV, 2, 1 << (RHO - 2), 0>(x);
+    dif_stage_blocks<INV, 1, 1 << (RHO - 1), 0>(x);
 }
 
 // One DIF round of radix 2^RHO on an LDS tile.  The transform currently consists of independent
@@ -136,6 +181,9 @@ struct PassArgs {
     const uint64_t* post_hi;
     const uint64_t* step_lo;   // 4-step twiddle omega_N^(+-e): lo/hi tables (col kernel only)
     const uint64_t* step_hi;
+    const uint64_t* pre_full;  // optional full table g_c^i (coset c at + c*pre_full_stride): 1 load + 1 mul
+    uint64_t pre_full_stride;
+    const uint64_t* step_full; // optional full 4-step twiddle table in STORE order (col kernel, first pass)
     uint64_t scale;            // constant multiplier at store (1 = none)
     uint32_t in_bitrev;        // input transform index is bit-reversed in memory
     uint32_t out_natural;      // write natural order (else DIF-native bit-reversed order)
@@ -166,7 +214,8 @@ __global__ void __launch_bounds__(1 << (LT - 4)) ntt_rows_kernel(PassArgs a) {
         if (row < total_rows) {
             const uint64_t col = row >> a.log_rows, rin = row & (rows_per_col - 1);
             v = a.in[col * a.in_col_stride + (rin << LOG_T) + e];
-            if (pre_lo) v = gl_mul(v, pow2lvl(pre_lo, pre_hi, (rin << LOG_T) + e));
+            if (a.pre_full) v = gl_mul(v, a.pre_full[(uint64_t)coset * a.pre_full_stride + (rin << LOG_T) + e]);
+            else if (pre_lo) v = gl_mul(v, pow2lvl(pre_lo, pre_hi, (rin << LOG_T) + e));
         }
         const uint32_t le = a.in_bitrev ? brev(e, LOG_T) : e;
         lds[lds_phys((lr << LOG_T) | le)] = v;
@@ -219,7 +268,8 @@ __global__ void __launch_bounds__(256) ntt_cols_kernel(PassArgs a) {
         const uint64_t gi = ((uint64_t)r << log_n2) + c0 + cc;
         uint64_t v = in[gi];
         const uint32_t lr = a.in_bitrev ? brev(r, LOG_T) : r;  // logical transform index
-        if (pre_lo) v = gl_mul(v, pow2lvl(pre_lo, pre_hi, gi));
+        if (a.pre_full) v = gl_mul(v, a.pre_full[(uint64_t)coset * a.pre_full_stride + gi]);
+        else if (pre_lo) v = gl_mul(v, pow2lvl(pre_lo, pre_hi, gi));
         if (step_at_load && a.step_lo) v = gl_mul(v, pow2lvl(a.step_lo, a.step_hi, (uint64_t)lr * (c0 + cc)));
         lds[lds_phys((lr << LOG_TC) | cc)] = v;
     }
@@ -232,7 +282,8 @@ __global__ void __launch_bounds__(256) ntt_cols_kernel(PassArgs a) {
         const uint32_t lr = a.out_natural ? brev(r, LOG_T) : r;  // LDS row holding output row r
         uint64_t v = lds[lds_phys((lr << LOG_TC) | cc)];
         const uint64_t go = ((uint64_t)r << log_n2) + c0 + cc;
-        if (!step_at_load && a.step_lo) {
+        if (!step_at_load && a.step_full) v = gl_mul(v, a.step_full[go]);
+        else if (!step_at_load && a.step_lo) {
             const uint32_t k1 = a.out_natural ? r : brev(r, LOG_T);  // transform output index
             v = gl_mul(v, pow2lvl(a.step_lo, a.step_hi, (uint64_t)k1 * (c0 + cc)));
         }
@@ -291,6 +342,23 @@ __global__ void transpose_kernel(const uint64_t* in, uint64_t* out, uint64_t row
         const uint32_t c = c0 + tx;
         if (c < cols && r < rows) out[r * out_row_stride + c] = tile[tx][k];
     }
+}
+
+// full-size multiplier tables (built once per (bases, size), cached on the context): they trade one
+// modmul + one gather per element for a coalesced 8-byte read that stays L2-resident per XCD
+__global__ void build_pow_table_kernel(const uint64_t* lo, const uint64_t* hi, uint32_t n_cosets, uint64_t n, uint64_t* out) {
+    const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (g >= n * n_cosets) return;
+    const uint64_t c = g / n, i = g % n;
+    out[g] = gl_canon(gl_mul(lo[c * 4096 + (i & 4095)], hi[c * 4096 + (i >> 12)]));
+}
+// step_full[r * N2 + i2] = omega^(bitrev(r, l1) * i2): the 4-step twiddle in the column pass's store order
+__global__ void build_step_table_kernel(const uint64_t* lo, const uint64_t* hi, uint32_t l1, uint32_t l2, uint64_t* out) {
+    const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (g >= (1ull << (l1 + l2))) return;
+    const uint64_t r = g >> l2, i2 = g & ((1ull << l2) - 1);
+    const uint64_t e = (uint64_t)brev((uint32_t)r, l1) * i2;
+    out[g] = gl_canon(gl_mul(lo[e & 4095], hi[e >> 12]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -389,6 +457,10 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         a.in_col_stride = p.in_col_stride; a.out_col_stride = p.out_col_stride;
         a.log_rows = 0;
         a.pre_lo = p.pre_lo; a.pre_hi = p.log_n > 12 ? p.pre_hi : nullptr;
+        if (p.pre_lo && p.log_n > 12) {  // two-level lookups would cost an extra modmul per element
+            GL355_TRY(ctx->full_pow_table(p.pre_lo, p.pre_hi, p.n_cosets, p.log_n, &a.pre_full));
+            a.pre_full_stride = 1ull << p.log_n;
+        }
         a.post_lo = p.post_lo; a.post_hi = p.log_n > 12 ? p.post_hi : nullptr;
         a.scale = p.scale;
         a.in_bitrev = p.in_bitrev; a.out_natural = p.out_bitrev ? 0 : 1;
@@ -411,12 +483,20 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         a.log_rows = l2;  // log2(N2): row stride of the N1 x N2 matrix
         a.pre_lo = p.pre_lo; a.pre_hi = p.pre_hi;
         a.step_lo = step_lo; a.step_hi = step_hi;
+        if (p.log_n <= 20) {
+            // full-size tables (<= 8 MiB each): 1 load + 1 modmul per element instead of 2 + 2
+            if (p.pre_lo && ((uint64_t)p.n_cosets << p.log_n) <= (1ull << 21)) {
+                GL355_TRY(ctx->full_pow_table(p.pre_lo, p.pre_hi, p.n_cosets, p.log_n, &a.pre_full));
+                a.pre_full_stride = 1ull << p.log_n;
+            }
+            GL355_TRY(ctx->full_step_table(step_lo, step_hi, l1, l2, inv, &a.step_full));
+        }
         a.in_bitrev = 0; a.out_natural = 0; a.canon = 0;
         { ProfScope ps(ctx, "ntt_cols_pass1"); GL355_HIP(ctx, launch_cols(a, l1, inv, ctx->stream)); }
         PassArgs b = a;
         b.in = p.out; b.in_col_stride = p.out_col_stride;
         // each coset's intermediate lives in its own output block: rows pass runs per coset slot
-        b.pre_lo = b.pre_hi = nullptr; b.step_lo = b.step_hi = nullptr;
+        b.pre_lo = b.pre_hi = nullptr; b.step_lo = b.step_hi = nullptr; b.pre_full = nullptr; b.step_full = nullptr;
         b.log_rows = l1;  // rows per column = N1
         b.scale = p.scale; b.canon = 1;
         if (p.n_cosets == 1) {
@@ -486,6 +566,33 @@ int32_t transpose_cols_to_rows(Ctx* ctx, const uint64_t* in, uint64_t* out, uint
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, in, out, rows, cols, in_col_stride,
                        out_row_stride, log_rows_brev);
     GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+
+int32_t Ctx::full_pow_table(const uint64_t* lo, const uint64_t* hi, uint32_t n_cosets, uint32_t log_n, const uint64_t** out) {
+    const std::vector<uint64_t> key{1, (uint64_t)(uintptr_t)lo, n_cosets, log_n};
+    auto it = full_cache.find(key);
+    if (it != full_cache.end()) { *out = it->second; return GL355_OK; }
+    const uint64_t total = (uint64_t)n_cosets << log_n;
+    uint64_t* d = nullptr;
+    GL355_HIP(this, hipMalloc((void**)&d, total * 8));
+    hipLaunchKernelGGL(build_pow_table_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, lo, hi, n_cosets, 1ull << log_n, d);
+    GL355_HIP(this, hipGetLastError());
+    full_cache[key] = d;
+    *out = d;
+    return GL355_OK;
+}
+int32_t Ctx::full_step_table(const uint64_t* lo, const uint64_t* hi, uint32_t l1, uint32_t l2, bool inv, const uint64_t** out) {
+    const std::vector<uint64_t> key{2, l1, l2, inv ? 1ull : 0ull};
+    auto it = full_cache.find(key);
+    if (it != full_cache.end()) { *out = it->second; return GL355_OK; }
+    const uint64_t total = 1ull << (l1 + l2);
+    uint64_t* d = nullptr;
+    GL355_HIP(this, hipMalloc((void**)&d, total * 8));
+    hipLaunchKernelGGL(build_step_table_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, lo, hi, l1, l2, d);
+    GL355_HIP(this, hipGetLastError());
+    full_cache[key] = d;
+    *out = d;
     return GL355_OK;
 }
 

@@ -4,6 +4,14 @@ import sys
 
 import pytest
 
+# torch bundles its own ROCm runtime: let it initialise HIP BEFORE libgl355.so pulls in the system
+# libamdhip64, otherwise torch later reports "No HIP GPUs are available" in the same process.
+try:
+    import torch
+    torch.cuda.is_available() and torch.cuda.init()
+except Exception:  # CPU-only box / torch missing: the CPU tests do not need it
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
