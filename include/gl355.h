@@ -280,6 +280,20 @@ uint64_t gl355_proof_words(const gl355_prover_data* pd);
 int32_t gl355_prove(gl355_ctx* ctx, const gl355_prover_data* pd, const uint64_t* wires, const uint64_t* public_inputs,
                     uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words);
 
+/* the same proof from a SPARSE witness: only the n_rows non-trivial circuit rows are given (rows[r] = all
+ * num_wires values of circuit row row_idx[r]; all other rows are zero Noop rows), and the zero-knowledge
+ * blinding rows are filled on the device from `seed`: rows [blind_start, blind_start + n_blind) random on
+ * every wire, n_z_pairs consecutive row pairs from z_start sharing one random value on wire 0. */
+int32_t gl355_prove_sparse(gl355_ctx* ctx, const gl355_prover_data* pd, const uint32_t* row_idx, const uint64_t* rows,
+                           uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
+                           const uint64_t* public_inputs, uint32_t n_public_inputs, uint64_t seed, uint64_t* proof,
+                           uint64_t proof_capacity_words);
+/* host-side witness rows of the Semaphore circuit (circuit.rs:67-99): (height + 7) rows x 135 wires in the
+ * order PublicInput | pi-hash 1 | pi-hash 2 | BaseSum{height} | leaf hash | height Merkle levels | nullifier |
+ * Constant; public_inputs = merkle_root | nullifier | topic (circuit.rs:27-32). */
+int32_t gl355_semaphore_witness(const uint64_t private_key[4], const uint64_t topic[4], uint64_t index,
+                                const uint64_t* siblings, uint32_t height, uint64_t* rows, uint64_t public_inputs[12]);
+
 /* ---- a9: wires_permutation_partial_products_and_zs (vanishing_poly.rs:54-108,183-218) --------- */
 int32_t gl355_zs_partial_products(gl355_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas,
                                   const uint64_t* k_is, uint32_t log_n, uint32_t n_routed,

@@ -94,6 +94,9 @@ SIGNATURES = {
                                     C.POINTER(Challenger), vp, vp, C.POINTER(C.c_uint64), vp, vp, vp]),
     "gl355_proof_words": (C.c_uint64, [C.POINTER(ProverData)]),
     "gl355_prove": (C.c_int32, [vp, C.POINTER(ProverData), vp, vp, C.c_uint32, C.c_uint64, vp, C.c_uint64]),
+    "gl355_prove_sparse": (C.c_int32, [vp, C.POINTER(ProverData), vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       vp, C.c_uint32, C.c_uint64, vp, C.c_uint64]),
+    "gl355_semaphore_witness": (C.c_int32, [vp, vp, C.c_uint64, vp, C.c_uint32, vp, vp]),
     "gl355_quotient": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gl355_quotient_values": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gl355_challenger_init": (C.c_int32, [C.POINTER(Challenger)]),

@@ -163,3 +163,46 @@ int32_t gl355_poseidon_gate_witness(const uint64_t inputs[12], uint64_t swap, ui
 }
 
 }  // extern "C"
+
+// Witness rows of the Semaphore circuit (src/plonky2_semaphore/circuit.rs:67-99 fill_semaphore_targets +
+// the PoseidonGate / BaseSumGate generators), in the row order of stark-verifier_amd/semaphore.py:
+//   0 PublicInputGate | 1,2 public-input hash permutations | 3 BaseSum{h} (index bits) | 4 leaf hash |
+//   5..5+h-1 Merkle levels | 5+h nullifier hash | 6+h ConstantGate (zeros)
+// rows: (h + 7) x 135 values; public_inputs: root | nullifier | topic.
+extern "C" int32_t gl355_semaphore_witness(const uint64_t private_key[4], const uint64_t topic[4], uint64_t index,
+                                           const uint64_t* siblings, uint32_t height, uint64_t* rows, uint64_t public_inputs[12]) {
+    if (!private_key || !topic || (!siblings && height) || !rows || !public_inputs || height > 63) return GL355_E_INVALID_ARG;
+    const uint32_t n_rows = height + 7;
+    memset(rows, 0, (size_t)n_rows * 135 * 8);
+    uint64_t* r_pi = rows, *r_h1 = rows + 135, *r_h2 = rows + 2 * 135, *r_bits = rows + 3 * 135, *r_leaf = rows + 4 * 135;
+    uint64_t* r_null = rows + (size_t)(5 + height) * 135;
+    uint64_t in[12];
+    for (int i = 0; i < 4; i++) { in[i] = private_key[i]; in[4 + i] = 0; in[8 + i] = 0; }
+    gl355_poseidon_gate_witness(in, 0, r_leaf);
+    uint64_t state[4];
+    memcpy(state, r_leaf + 12, 32);
+    r_bits[0] = index;
+    for (uint32_t l = 0; l < height; l++) {
+        const uint64_t bit = (index >> l) & 1;
+        r_bits[1 + l] = bit;
+        for (int i = 0; i < 4; i++) { in[i] = state[i]; in[4 + i] = siblings[4 * l + i]; in[8 + i] = 0; }
+        uint64_t* row = rows + (size_t)(5 + l) * 135;
+        gl355_poseidon_gate_witness(in, bit, row);
+        memcpy(state, row + 12, 32);
+    }
+    for (int i = 0; i < 4; i++) { in[i] = private_key[i]; in[4 + i] = topic[i]; in[8 + i] = 0; }
+    gl355_poseidon_gate_witness(in, 0, r_null);
+    for (int i = 0; i < 4; i++) {
+        public_inputs[i] = state[i];
+        public_inputs[4 + i] = r_null[12 + i];
+        public_inputs[8 + i] = gl_canon(topic[i]);
+    }
+    for (int i = 0; i < 8; i++) in[i] = public_inputs[i];
+    for (int i = 8; i < 12; i++) in[i] = 0;
+    gl355_poseidon_gate_witness(in, 0, r_h1);
+    for (int i = 0; i < 4; i++) in[i] = public_inputs[8 + i];
+    for (int i = 4; i < 12; i++) in[i] = r_h1[12 + i];
+    gl355_poseidon_gate_witness(in, 0, r_h2);
+    for (int i = 0; i < 4; i++) r_pi[i] = r_h2[12 + i];
+    return GL355_OK;
+}

@@ -174,11 +174,91 @@ extern "C" uint64_t gl355_proof_words(const gl355_prover_data* pd) {
     return w;
 }
 
+// scatter the sparse witness rows into the column-major wire matrix and fill the blinding rows on the device
+__global__ void witness_rows_kernel(uint64_t* wires, uint64_t n, uint32_t num_wires, const uint32_t* row_idx,
+                                    const uint64_t* row_vals, uint32_t n_rows) {
+    const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (g >= (uint64_t)n_rows * num_wires) return;
+    const uint32_t r = g / num_wires, c = g % num_wires;
+    wires[(uint64_t)c * n + row_idx[r]] = gl_canon(row_vals[g]);
+}
+__global__ void witness_blind_kernel(uint64_t* wires, uint64_t n, uint32_t num_wires, uint32_t blind_start, uint32_t n_blind,
+                                     uint32_t z_start, uint32_t n_z_pairs, uint64_t seed) {
+    const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t n_a = (uint64_t)n_blind * num_wires;
+    if (g >= n_a + n_z_pairs) return;
+    uint64_t z = seed + (g + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = gl_canon(z ^ (z >> 31));
+    if (g < n_a) {
+        const uint32_t c = g / n_blind, r = g % n_blind;          // every wire of the wire-blinding rows
+        wires[(uint64_t)c * n + blind_start + r] = z;
+    } else {
+        const uint64_t k = g - n_a;                                 // one shared routed value per Z-blinding pair
+        wires[z_start + 2 * k] = z;
+        wires[z_start + 2 * k + 1] = z;
+    }
+}
+
+static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, const uint64_t* d_wires, const uint64_t* public_inputs,
+                          uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words);
+
 extern "C" int32_t gl355_prove(gl355_ctx* h, const gl355_prover_data* pd, const uint64_t* wires, const uint64_t* public_inputs,
                                uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words) {
     Ctx* ctx = ctx_of(h);
     if (!ctx) return GL355_E_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+    if (!pd || !pd->circuit || !wires) return ctx->fail(GL355_E_INVALID_ARG, "prove: null argument");
+    Staged s_wires(ctx);
+    GL355_TRY(s_wires.open(wires, ((uint64_t)pd->circuit->num_wires << pd->circuit->degree_bits) * 8, 1));
+    return prove_core(h, ctx, pd, s_wires.as<uint64_t>(), public_inputs, n_public_inputs, seed, proof, proof_capacity_words);
+}
+
+// Witness given as its non-zero rows only (the rest of the 2^degree_bits rows are Noop rows): rows[r] lists
+// all num_wires values of circuit row row_idx[r].  The zero-knowledge blinding rows are filled on the device:
+// rows [blind_start, blind_start+n_blind) get random values on every wire, and n_z_pairs consecutive row
+// pairs starting at z_start share one random value on routed wire 0 (the builder copy-constrains them).
+extern "C" int32_t gl355_prove_sparse(gl355_ctx* h, const gl355_prover_data* pd, const uint32_t* row_idx, const uint64_t* rows,
+                                      uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
+                                      const uint64_t* public_inputs, uint32_t n_public_inputs, uint64_t seed, uint64_t* proof,
+                                      uint64_t proof_capacity_words) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+    if (!pd || !pd->circuit || (!row_idx && n_rows) || (!rows && n_rows)) return ctx->fail(GL355_E_INVALID_ARG, "prove_sparse: null argument");
+    const uint32_t nw = pd->circuit->num_wires;
+    const uint64_t n = 1ull << pd->circuit->degree_bits;
+    if ((uint64_t)blind_start + n_blind > n || (uint64_t)z_start + 2ull * n_z_pairs > n) return ctx->fail(GL355_E_INVALID_ARG, "prove_sparse: blinding rows out of range");
+    for (uint32_t r = 0; r < n_rows; r++)
+        if (row_idx[r] >= n) return ctx->fail(GL355_E_INVALID_ARG, "prove_sparse: row index out of range");
+    Scratch w(ctx), rbuf(ctx);
+    GL355_TRY(w.get((uint64_t)nw * n * 8));
+    GL355_HIP(ctx, hipMemsetAsync(w.p, 0, (uint64_t)nw * n * 8, ctx->stream));
+    if (n_rows) {
+        GL355_TRY(rbuf.get((uint64_t)n_rows * nw * 8 + (uint64_t)n_rows * 4 + 16));
+        uint64_t* d_vals = rbuf.as<uint64_t>();
+        uint32_t* d_idx = reinterpret_cast<uint32_t*>(d_vals + (uint64_t)n_rows * nw);
+        GL355_HIP(ctx, hipMemcpyAsync(d_vals, rows, (uint64_t)n_rows * nw * 8, hipMemcpyHostToDevice, ctx->stream));
+        GL355_HIP(ctx, hipMemcpyAsync(d_idx, row_idx, (uint64_t)n_rows * 4, hipMemcpyHostToDevice, ctx->stream));
+        const uint64_t cnt = (uint64_t)n_rows * nw;
+        hipLaunchKernelGGL(witness_rows_kernel, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, w.as<uint64_t>(), n, nw,
+                           d_idx, d_vals, n_rows);
+        GL355_HIP(ctx, hipGetLastError());
+    }
+    const uint64_t cnt_b = (uint64_t)n_blind * nw + n_z_pairs;
+    if (cnt_b) {
+        hipLaunchKernelGGL(witness_blind_kernel, dim3((uint32_t)((cnt_b + 255) / 256)), dim3(256), 0, ctx->stream, w.as<uint64_t>(), n, nw,
+                           blind_start, n_blind, z_start, n_z_pairs, seed * 0xA24BAED4963EE407ull + 0x9FB21C651E98DF25ull);
+        GL355_HIP(ctx, hipGetLastError());
+    }
+    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host row buffers may be reused by the caller
+    return prove_core(h, ctx, pd, w.as<uint64_t>(), public_inputs, n_public_inputs, seed, proof, proof_capacity_words);
+}
+
+static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, const uint64_t* d_wires, const uint64_t* public_inputs,
+                          uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words) {
+    const uint64_t* wires = d_wires;
     if (!pd || !pd->circuit || !pd->constants_sigmas || !pd->sigmas || !pd->k_is || !wires || !proof || (!public_inputs && n_public_inputs))
         return ctx->fail(GL355_E_INVALID_ARG, "prove: null argument");
     const gl355_circuit& c = *pd->circuit;
@@ -205,9 +285,8 @@ extern "C" int32_t gl355_prove(gl355_ctx* h, const gl355_prover_data* pd, const 
     gl355_challenger_observe(&ch, pd->circuit_digest, 4);
     gl355_challenger_observe(&ch, pi_hash, 4);
 
-    // device staging: witness, sigma values, k_is, salt
-    Staged s_wires(ctx), s_sig(ctx), s_k(ctx);
-    GL355_TRY(s_wires.open(wires, (uint64_t)c.num_wires * n * 8, 1));
+    // device staging: sigma values, k_is, salt (the witness is already resident)
+    Staged s_sig(ctx), s_k(ctx);
     GL355_TRY(s_sig.open(pd->sigmas, (uint64_t)routed * n * 8, 1));
     GL355_TRY(s_k.open(pd->k_is, (uint64_t)routed * 8, 1));
     Scratch salt(ctx);
@@ -223,7 +302,7 @@ extern "C" int32_t gl355_prove(gl355_ctx* h, const gl355_prover_data* pd, const 
     // ---- wires ----------------------------------------------------------------------------------
     OracleGuard g_w, g_z, g_q;
     if (zk) GL355_TRY(fresh_salt(1));
-    GL355_TRY(gl355_commit(h, s_wires.as<uint64_t>(), c.degree_bits, c.num_wires, c.rate_bits, 0, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_w.o));
+    GL355_TRY(gl355_commit(h, wires, c.degree_bits, c.num_wires, c.rate_bits, 0, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_w.o));
     uint64_t* p_wires_cap = out; out += n_cap * 4;
     GL355_TRY(observe_cap(ctx, g_w.o, &ch, p_wires_cap));
     uint64_t betas[4], gammas[4], alphas[4];
@@ -236,7 +315,7 @@ extern "C" int32_t gl355_prove(gl355_ctx* h, const gl355_prover_data* pd, const 
     for (uint32_t k = 0; k < nch; k++) {
         uint64_t* z = zbuf.as<uint64_t>() + (uint64_t)k * n;
         uint64_t* pp = zbuf.as<uint64_t>() + ((uint64_t)nch + (uint64_t)k * npp) * n;
-        GL355_TRY(zs_partial_products_dev(ctx, s_wires.as<uint64_t>(), s_sig.as<uint64_t>(), s_k.as<uint64_t>(), c.degree_bits, routed, qdf,
+        GL355_TRY(zs_partial_products_dev(ctx, wires, s_sig.as<uint64_t>(), s_k.as<uint64_t>(), c.degree_bits, routed, qdf,
                                           betas[k], gammas[k], z, pp));
     }
     if (zk) GL355_TRY(fresh_salt(2));

@@ -371,6 +371,26 @@ def prove(ctx, data, wires, public_inputs, seed, flat_only=False):
     return proof
 
 
+def prove_sparse(ctx, data, row_idx, rows, public_inputs, seed, flat_only=False):
+    """gl355_prove_sparse: witness = its non-trivial rows; blinding rows are generated on the device."""
+    lib = ctx.lib
+    pd = data.prover_data(ctx)
+    pi = _u64(public_inputs)
+    words = lib.gl355_proof_words(C.byref(pd))
+    flat = np.empty(words, dtype=np.uint64)
+    idx = np.ascontiguousarray(row_idx, dtype=np.uint32)
+    rows = _u64(rows)
+    start, n_blind, z_pairs, _ = data.blind_rows
+    z_start = z_pairs[0][0] if z_pairs else 0
+    ctx.check(lib.gl355_prove_sparse(ctx.h, C.byref(pd), idx.ctypes.data_as(C.c_void_p), _ptr(rows), idx.size, start, n_blind,
+                                     z_start, len(z_pairs), _ptr(pi), pi.size, int(seed) & ((1 << 64) - 1), _ptr(flat), words))
+    if flat_only:
+        return flat
+    proof = parse_proof(data, flat)
+    proof["public_inputs"] = pi.copy()
+    return proof
+
+
 def prove_staged(ctx, data, wires, public_inputs, rng, timings=None):
     """The same proof sequenced stage by stage from Python over the individual C-ABI entry points (used for
     per-stage timings and to cross-check gl355_prove); wires[num_wires][n] is the full witness."""

@@ -9,8 +9,12 @@ import numpy as np
 
 from ._lib import GATE_BASE_SUM, GATE_CONSTANT, GATE_POSEIDON, GATE_PUBLIC_INPUT
 from .api import MerkleTree
+import ctypes as C
+
+from . import _lib
+from .api import _ptr
 from .plonk import (CircuitBuilder, CircuitConfig, check_copy_constraints, fill_blinding, host_hash_no_pad,
-                    poseidon_gate_witness, prove, prove_staged)
+                    poseidon_gate_witness, prove, prove_sparse, prove_staged)
 
 IN, OUT, SWAP = 0, 12, 24   # PoseidonGate wire offsets (chip/plonk/gates/poseidon.rs:329-345)
 
@@ -112,6 +116,22 @@ class AccessSet:
         fill_blinding(data, wires, rng)
         return wires, public_inputs
 
+    def witness_rows(self, rows, private_key, topic, public_key_index):
+        """the same witness as fill_semaphore_targets as sparse rows, computed by one C call
+        (gl355_semaphore_witness); returns (row_idx, rows[h+7][135], public_inputs)."""
+        h = self.tree_height()
+        lib = _lib.load()
+        sib = np.ascontiguousarray(self.tree.prove(public_key_index), dtype=np.uint64)
+        vals = np.empty((h + 7, 135), dtype=np.uint64)
+        pi = np.empty(12, dtype=np.uint64)
+        sk = np.ascontiguousarray(private_key, dtype=np.uint64)
+        tp = np.ascontiguousarray(topic, dtype=np.uint64)
+        rc = lib.gl355_semaphore_witness(_ptr(sk), _ptr(tp), int(public_key_index), _ptr(sib), h, _ptr(vals), _ptr(pi))
+        assert rc == 0
+        idx = np.array([rows["pi"], rows["h1"], rows["h2"], rows["bits"], rows["leaf"]] + list(rows["m"]) + [rows["null"], rows["zero"]],
+                       dtype=np.uint32)
+        return idx, vals, pi
+
     def build(self, rng, config=None):
         if self._circuit is None:
             builder = CircuitBuilder(config or CircuitConfig())
@@ -121,6 +141,13 @@ class AccessSet:
         return self._circuit
 
     # ---- access_set.rs:61-104 ---------------------------------------------------------------------------------
+    def make_signal_fast(self, private_key, topic, public_key_index, seed, flat_only=False):
+        """make_signal with the sparse witness path: 2 C calls per proof (witness rows, gl355_prove_sparse)."""
+        data, rows = self.build(None)
+        idx, vals, public_inputs = self.witness_rows(rows, private_key, topic, public_key_index)
+        proof = prove_sparse(self.ctx, data, idx, vals, public_inputs, seed, flat_only=flat_only)
+        return Signal([np.asarray(topic, np.uint64)], [public_inputs[4:8].copy()], proof), data
+
     def make_signal(self, private_key, topic, public_key_index, rng, timings=None, check=False, staged=False):
         data, rows = self.build(rng)
         wires, public_inputs = self.fill_semaphore_targets(data, rows, private_key, topic, public_key_index, rng)

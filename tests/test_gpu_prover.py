@@ -85,6 +85,22 @@ def test_semaphore_proof_verifies(gl, ctx, orc, log_members):
     pv.verify(orc, cd, signal3.proof)
 
 
+def test_sparse_witness_path(gl, ctx, orc):
+    """gl355_semaphore_witness + gl355_prove_sparse (device-side blinding) == the dense witness on the real rows, and
+    the proof verifies."""
+    aset, sks, rng = make_access_set(gl, ctx, 5, 0x35E)
+    data, rows = aset.build(rng)
+    topic = rand_field(rng, 4)
+    dense, pi = aset.fill_semaphore_targets(data, rows, sks[9], topic, 9, np.random.default_rng(3))
+    idx, vals, pi2 = aset.witness_rows(rows, sks[9], topic, 9)
+    assert np.array_equal(pi, pi2)
+    for k, r in enumerate(idx):
+        assert np.array_equal(dense[:, r], vals[k]), r
+    sig, _ = aset.make_signal_fast(sks[9], topic, 9, 77)
+    pv.verify(orc, data.common(), sig.proof)
+    assert np.array_equal(sig.nullifier[0], orc.hash_no_pad(np.concatenate([sks[9], topic])))
+
+
 def test_prove_is_deterministic_in_witness_and_seed(gl, ctx):
     """same witness + same seed => byte-identical proof (salt is counter-based, PoW takes the smallest witness)."""
     plonk = importlib.import_module("stark-verifier_amd.plonk")

@@ -20,13 +20,13 @@ def run(threads, per_thread, log_members):
         c = gl.Context(0)
         a = sem.AccessSet(c, keys)
         a.build(np.random.default_rng(1))
-        a.make_signal(sks[t], topic, t, np.random.default_rng(t))      # warm-up (tables, allocator)
+        a.make_signal_fast(sks[t], topic, t, t)      # warm-up (tables, allocator)
         sets.append(a)
     done = [0] * threads
     def worker(t):
         for k in range(per_thread):
             i = 100 + t * per_thread + k
-            sets[t].make_signal(sks[i], topic, i, np.random.default_rng(0x358 + i))
+            sets[t].make_signal_fast(sks[i], topic, i, 0x358 + i, flat_only=True)
             done[t] += 1
     ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
     t0 = time.perf_counter()
