@@ -91,9 +91,27 @@ GL_DEV void psd_partial_rounds(uint64_t (&s)[12]) {
     }
 }
 
+// partial rounds in the naive form (12 constants, lane-0 S-box, dense small-constant MDS): no 64-bit
+// constant multiplications at all; which form is faster is a measured choice (tools/kbench.py poseidon)
+GL_DEV void psd_partial_rounds_dense(uint64_t (&s)[12]) {
+#pragma unroll 1
+    for (int r = 0; r < 22; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PSD_ALL_RC[12 * (4 + r) + i]);
+        s[0] = psd_sbox(s[0]);
+        psd_mds(s);
+    }
+}
+
+// measured on MI355X (profiles/r01_poseidon_dense_vs_sparse.txt): dense partial rounds 1.56 G perm/s vs
+// 1.34 G perm/s for the sparse form -- v_mad_u64_u32 by a 6-bit constant is far cheaper than a 64x64 modmul
+#ifndef PSD_DENSE_PARTIAL
+#define PSD_DENSE_PARTIAL 1
+#endif
 GL_DEV void psd_permute(uint64_t (&s)[12]) {
     psd_full_rounds<true>(s);
-    psd_partial_rounds(s);
+    if (PSD_DENSE_PARTIAL) psd_partial_rounds_dense(s);
+    else psd_partial_rounds(s);
     psd_full_rounds<false>(s);
 }
 

@@ -16,4 +16,4 @@ aset = sem.AccessSet(ctx, keys)
 aset.build(np.random.default_rng(1))
 topic = rand_field(rng, 4)
 for k in range(n):
-    aset.make_signal(sks[k], topic, k, np.random.default_rng(k))
+    aset.make_signal_fast(sks[k], topic, k, k, flat_only=True)
