@@ -141,6 +141,75 @@ __global__ void k_fma_f64(uint64_t* out, uint32_t seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint64_t)s;
 }
 
+__global__ void k_dot2_u16(uint64_t* out, uint32_t seed) {
+    uint32_t acc[ILP];
+    uint32_t a = threadIdx.x * 2654435761u + seed, b = blockIdx.x * 40503u + 12345u;
+#pragma unroll
+    for (int j = 0; j < ILP; j++) acc[j] = a + j;
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int j = 0; j < ILP; j++) asm volatile("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(acc[j]) : "v"(acc[j]), "v"(b), "v"(acc[j]));
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < ILP; j++) s ^= acc[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_dot4_u8(uint64_t* out, uint32_t seed) {
+    uint32_t acc[ILP];
+    uint32_t a = threadIdx.x * 2654435761u + seed, b = blockIdx.x * 40503u + 12345u;
+#pragma unroll
+    for (int j = 0; j < ILP; j++) acc[j] = a + j;
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int j = 0; j < ILP; j++) asm volatile("v_dot4_u32_u8 %0, %1, %2, %3" : "=v"(acc[j]) : "v"(acc[j]), "v"(b), "v"(acc[j]));
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < ILP; j++) s ^= acc[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_perm(uint64_t* out, uint32_t seed) {
+    uint32_t acc[ILP];
+    uint32_t a = threadIdx.x * 2654435761u + seed, b = blockIdx.x * 40503u + 12345u;
+#pragma unroll
+    for (int j = 0; j < ILP; j++) acc[j] = a + j;
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int j = 0; j < ILP; j++) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(acc[j]) : "v"(acc[j]), "v"(b), "v"(0x05040100u));
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < ILP; j++) s ^= acc[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_cndmask(uint64_t* out, uint32_t seed) {
+    uint32_t acc[ILP];
+    uint32_t a = threadIdx.x * 2654435761u + seed, b = blockIdx.x * 40503u + 12345u;
+#pragma unroll
+    for (int j = 0; j < ILP; j++) acc[j] = a + j;
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int j = 0; j < ILP; j++) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(acc[j]) : "v"(acc[j]), "v"(b));
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < ILP; j++) s ^= acc[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_cmp64(uint64_t* out, uint32_t seed) {
+    uint64_t acc[ILP];
+    uint64_t a = threadIdx.x * 2654435761ull + seed, b = blockIdx.x * 40503ull + 0x123456789ull;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < ILP; j++) acc[j] = a + j;
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int j = 0; j < ILP; j++) asm volatile("v_cmp_lt_u64 vcc, %0, %1" :: "v"(acc[j]), "v"(b) : "vcc");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc[0] + cnt;
+}
+
 // full Goldilocks modmul, compiler-scheduled
 __device__ __forceinline__ uint64_t gl_mul(uint64_t a, uint64_t b) {
     uint32_t a0 = (uint32_t)a, a1 = a >> 32, b0 = (uint32_t)b, b1 = b >> 32;
@@ -208,6 +277,11 @@ int main() {
     run("v_mad_u32_u24", k_mad_u32_u24, n, d_out, blocks, threads);
     run("v_mad_u64_u32", k_mad_u64_u32, n, d_out, blocks, threads);
     run("v_fma_f64", k_fma_f64, n, d_out, blocks, threads);
+    run("v_dot2_u32_u16", k_dot2_u16, n, d_out, blocks, threads);
+    run("v_dot4_u32_u8", k_dot4_u8, n, d_out, blocks, threads);
+    run("v_perm_b32", k_perm, n, d_out, blocks, threads);
+    run("v_cndmask_b32", k_cndmask, n, d_out, blocks, threads);
+    run("v_cmp_lt_u64", k_cmp64, n, d_out, blocks, threads);
     run("gl_mul (full)", k_gl_mul, n / 4, d_out, blocks, threads);
     return 0;
 }
