@@ -150,19 +150,21 @@ class CircuitBuilder:
         n = 1 << degree_bits
         while len(self.rows) < n:
             self.add_gate(GATE_NOOP)
-        # selector groups: a gate of degree d may share a selector with g-1 others iff g-1+1+d <= 9
-        # -> PoseidonGate (degree 7) alone, everything else (degree <= 3) together
-        order = sorted(range(len(self.gate_types)), key=lambda i: 0 if self.gate_types[i][0] == GATE_POSEIDON else 1)
+        # selector groups (plonky2's selector_polynomials): a group of g gates sharing one selector column gets the
+        # filter prod_{k != i}(k - s) * (UNUSED - s) of degree g, so every member needs g + degree <= qdf + 1 = 9
+        max_deg = cfg.max_quotient_degree_factor + 1
+        order = sorted(range(len(self.gate_types)), key=lambda i: -_GATE_DEGREE[self.gate_types[i][0]](self.gate_types[i][1]))
         remap = {old: new for new, old in enumerate(order)}
         gates = [self.gate_types[i] for i in order]
         groups, sel_index = [], []
-        if any(g[0] == GATE_POSEIDON for g in gates):
-            k = sum(1 for g in gates if g[0] == GATE_POSEIDON)
-            groups.append((0, k))
-            if k < len(gates):
-                groups.append((k, len(gates)))
-        else:
-            groups.append((0, len(gates)))
+        start = 0
+        while start < len(gates):
+            end = start + 1
+            top = _GATE_DEGREE[gates[start][0]](gates[start][1])       # sorted: the first member has the largest degree
+            while end < len(gates) and (end - start + 1) + top <= max_deg:
+                end += 1
+            groups.append((start, end))
+            start = end
         for gi in range(len(gates)):
             sel_index.append(next(s for s, (lo, hi) in enumerate(groups) if lo <= gi < hi))
         num_selectors = len(groups)
@@ -240,6 +242,12 @@ class CircuitBuilder:
         return data
 
 
+_GATE_DEGREE = {
+    GATE_NOOP: lambda p: 0, GATE_CONSTANT: lambda p: 1, GATE_PUBLIC_INPUT: lambda p: 1, GATE_BASE_SUM: lambda p: 2,
+    GATE_POSEIDON: lambda p: 7, GATE_ARITHMETIC: lambda p: 3, GATE_ARITHMETIC_EXT: lambda p: 3, GATE_MUL_EXT: lambda p: 3,
+    GATE_POSEIDON_MDS: lambda p: 1, GATE_RANDOM_ACCESS: lambda p: (p & 0xFF) + 1, GATE_REDUCING: lambda p: 2,
+    GATE_REDUCING_EXT: lambda p: 2,
+}
 _GATE_CONSTRAINTS = {
     GATE_NOOP: lambda p: 0, GATE_CONSTANT: lambda p: p, GATE_PUBLIC_INPUT: lambda p: 4,
     GATE_BASE_SUM: lambda p: 1 + p, GATE_POSEIDON: lambda p: 123, GATE_ARITHMETIC: lambda p: p,

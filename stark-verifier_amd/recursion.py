@@ -1,0 +1,418 @@
+"""Recursive proof verification in-circuit and proof aggregation -- host mirror of
+src/plonky2_semaphore/recursion.rs (aggregate_signals :25-185, aggregate :187-247) and wrapper.rs:35-56,
+which call plonky2's `builder.verify_proof::<InnerC>()`.
+
+verify_proof() below emits, through gadgets.GadgetBuilder, exactly the checks the reference's own
+verifier performs on a proof (chip/plonk/plonk_verifier_chip.rs:55-242, chip/plonk/vanishing_poly.rs,
+chip/plonk/gates/*.rs, chip/fri_chip.rs, chip/merkle_proof_chip.rs) -- the same equations
+tests/plonk_verifier.py evaluates over big integers, here as gates over targets.  The resulting
+circuit is proved by the same GPU pipeline (gl355_prove_sparse) as any other circuit.
+"""
+import numpy as np
+
+from ._lib import (GATE_ARITHMETIC, GATE_ARITHMETIC_EXT, GATE_BASE_SUM, GATE_CONSTANT, GATE_NOOP, GATE_POSEIDON,
+                   GATE_POSEIDON_MDS, GATE_PUBLIC_INPUT, GATE_RANDOM_ACCESS, GATE_REDUCING, GATE_REDUCING_EXT)
+from .gadgets import CIRC, GadgetBuilder, T
+from .plonk import P, prove_sparse
+
+UNUSED_SELECTOR = 0xFFFFFFFF
+_RC = None
+
+
+def _round_constants():
+    global _RC
+    if _RC is None:
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "poseidon_goldilocks_round_constants.txt")
+        vals = [int(l, 16) for l in open(path).read().split("\n") if l and not l.startswith("#")]
+        _RC = [vals[12 * r:12 * (r + 1)] for r in range(30)]
+    return _RC
+
+
+class Challenger:
+    """in-circuit duplex sponge (hasher_chip.rs:48-89): buffered overwrite absorb, squeeze from the end of the rate"""
+
+    def __init__(self, b):
+        self.b = b
+        self.state = [b.zero()] * 12
+        self.inp, self.out = [], []
+
+    def observe(self, targets):
+        for t in targets:
+            self.out = []
+            self.inp.append(t)
+            if len(self.inp) == 8:
+                self._duplex()
+
+    def observe_ext(self, e):
+        self.observe([e[0], e[1]])
+
+    def _duplex(self):
+        st = list(self.inp) + self.state[len(self.inp):]
+        self.inp = []
+        self.state = self.b.permute_swapped(st)
+        self.out = list(self.state[:8])
+
+    def squeeze(self, n=1):
+        res = []
+        for _ in range(n):
+            if self.inp or not self.out:
+                self._duplex()
+            res.append(self.out.pop())
+        return res
+
+    def squeeze_ext(self):
+        v = self.squeeze(2)
+        return (v[0], v[1])
+
+
+# ---- gate constraint evaluators over extension targets (chip/plonk/gates/*.rs) -------------------------------
+def _sbox(b, x):
+    x2 = b.ext_mul(x, x)
+    x4 = b.ext_mul(x2, x2)
+    return b.ext_mul(b.ext_mul(x, x2), x4)
+
+
+def eval_poseidon(b, w):
+    rc = _round_constants()
+    c = []
+    swap = w[24]
+    c.append(b.ext_mul_sub(swap, swap, swap))
+    st = [None] * 12
+    for i in range(4):
+        lhs, rhs, delta = w[i], w[i + 4], w[25 + i]
+        c.append(b.ext_mul_sub(swap, b.ext_sub(rhs, lhs), delta))
+        st[i] = b.ext_add(lhs, delta)
+        st[i + 4] = b.ext_sub(rhs, delta)
+    for i in range(8, 12):
+        st[i] = w[i]
+
+    def add_rc(state, rnd):
+        return [b.ext_add(x, b.constant_ext((rc[rnd][i], 0))) for i, x in enumerate(state)]
+    for r in range(4):
+        st = add_rc(st, r)
+        if r != 0:
+            for i in range(12):
+                sin = w[29 + 12 * (r - 1) + i]
+                c.append(b.ext_sub(st[i], sin))
+                st[i] = sin
+        st = b.mds_ext([_sbox(b, x) for x in st])
+    # partial rounds, dense form: the S-box input of round r is state[0] + RC[4+r][0] in either formulation, so
+    # these are the same constraint polynomials as the reference's sparse evaluation (poseidon.rs:652-673)
+    for r in range(22):
+        st = add_rc(st, 4 + r)
+        sin = w[65 + r]
+        c.append(b.ext_sub(st[0], sin))
+        st[0] = _sbox(b, sin)
+        st = b.mds_ext(st)
+    for r in range(4):
+        st = add_rc(st, 26 + r)
+        for i in range(12):
+            sin = w[87 + 12 * r + i]
+            c.append(b.ext_sub(st[i], sin))
+            st[i] = sin
+        st = b.mds_ext([_sbox(b, x) for x in st])
+    for i in range(12):
+        c.append(b.ext_sub(st[i], w[12 + i]))
+    assert len(c) == 123
+    return c
+
+
+def _alg_mul(b, x, y):
+    """extension-algebra product of pairs of ext targets (goldilocks_extension_algebra_chip.rs:112-146)"""
+    w7 = b.constant_ext((7, 0))
+    c0 = b.ext_mul_add(b.ext_mul(x[1], y[1]), w7, b.ext_mul(x[0], y[0]))
+    c1 = b.ext_mul_add(x[0], y[1], b.ext_mul(x[1], y[0]))
+    return (c0, c1)
+
+
+def eval_gate(b, gate, consts, w, pi_hash):
+    t, p = gate
+    if t == GATE_NOOP:
+        return []
+    if t == GATE_CONSTANT:
+        return [b.ext_sub(consts[i], w[i]) for i in range(p)]
+    if t == GATE_PUBLIC_INPUT:
+        return [b.ext_sub(w[i], b.ext_from_base(pi_hash[i])) for i in range(4)]
+    if t == GATE_BASE_SUM:
+        limbs = w[1:1 + p]
+        two = b.constant_ext((2, 0))
+        acc = b.ext_zero()
+        for l in reversed(limbs):
+            acc = b.ext_mul_add(acc, two, l)
+        return [b.ext_sub(acc, w[0])] + [b.ext_mul_sub(l, l, l) for l in limbs]
+    if t == GATE_ARITHMETIC:
+        return [b.ext_sub(w[4 * i + 3], b.ext_mul_add(b.ext_mul(w[4 * i], w[4 * i + 1]), consts[0], b.ext_mul(w[4 * i + 2], consts[1])))
+                for i in range(p)]
+    if t == GATE_POSEIDON:
+        return eval_poseidon(b, w)
+
+    def alg(j):
+        return (w[j], w[j + 1])
+
+    def asub(x, y):
+        return (b.ext_sub(x[0], y[0]), b.ext_sub(x[1], y[1]))
+
+    def aadd(x, y):
+        return (b.ext_add(x[0], y[0]), b.ext_add(x[1], y[1]))
+
+    def ascal(s, x):
+        return (b.ext_mul(s, x[0]), b.ext_mul(s, x[1]))
+    if t == GATE_ARITHMETIC_EXT:
+        out = []
+        for i in range(p):
+            comp = aadd(ascal(consts[0], _alg_mul(b, alg(8 * i), alg(8 * i + 2))), ascal(consts[1], alg(8 * i + 4)))
+            out += list(asub(alg(8 * i + 6), comp))
+        return out
+    if t == GATE_POSEIDON_MDS:
+        out = []
+        cc = [b.constant_ext((c, 0)) for c in CIRC]
+        c8 = b.constant_ext((8, 0))
+        for r in range(12):
+            acc = (b.ext_zero(), b.ext_zero())
+            for i in range(12):
+                x = alg(2 * ((i + r) % 12))
+                acc = (b.ext_mul_add(cc[i], x[0], acc[0]), b.ext_mul_add(cc[i], x[1], acc[1]))
+            if r == 0:
+                x = alg(0)
+                acc = (b.ext_mul_add(c8, x[0], acc[0]), b.ext_mul_add(c8, x[1], acc[1]))
+            out += list(asub(alg(2 * (12 + r)), acc))
+        return out
+    if t == GATE_RANDOM_ACCESS:
+        bits, copies, extra = p & 0xFF, (p >> 8) & 0xFF, (p >> 16) & 0xFF
+        vec = 1 << bits
+        routed = (2 + vec) * copies + extra
+        two = b.constant_ext((2, 0))
+        out = []
+        for c in range(copies):
+            b0 = (2 + vec) * c
+            bl = [w[routed + c * bits + i] for i in range(bits)]
+            out += [b.ext_mul_sub(x, x, x) for x in bl]
+            acc = b.ext_zero()
+            for x in reversed(bl):
+                acc = b.ext_mul_add(acc, two, x)
+            out.append(b.ext_sub(acc, w[b0]))
+            items = [w[b0 + 2 + i] for i in range(vec)]
+            for x in bl:
+                items = [b.ext_mul_add(x, b.ext_sub(items[2 * k + 1], items[2 * k]), items[2 * k]) for k in range(len(items) // 2)]
+            out.append(b.ext_sub(items[0], w[b0 + 1]))
+        out += [b.ext_sub(consts[i], w[(2 + vec) * copies + i]) for i in range(extra)]
+        return out
+    if t in (GATE_REDUCING, GATE_REDUCING_EXT):
+        isext = t == GATE_REDUCING_EXT
+        alpha, acc = alg(2), alg(4)
+        start_accs = 6 + (2 * p if isext else p)
+        out = []
+        for i in range(p):
+            coeff = alg(6 + 2 * i) if isext else (w[6 + i], b.ext_zero())
+            acc_i = alg(0) if i == p - 1 else alg(start_accs + 2 * i)
+            out += list(asub(aadd(_alg_mul(b, acc, alpha), coeff), acc_i))
+            acc = acc_i
+        return out
+    raise NotImplementedError("gate %r has no in-circuit evaluator" % (gate,))
+
+
+def eval_vanishing_poly(b, cd, x, x_pow_n, op, pi_hash, betas, gammas, alphas):
+    """vanishing_poly.rs:18-153 over targets; returns one ext target per challenge"""
+    n = 1 << cd["degree_bits"]
+    consts, wires = op["constants"], op["wires"]
+    allc = [None] * cd["num_gate_constraints"]
+    for gi, gate in enumerate(cd["gates"]):
+        sel = cd["selector_indices"][gi]
+        lo, hi = cd["groups"][sel]
+        f = consts[sel]
+        filt = None
+        for k in [k for k in range(lo, hi) if k != gi] + ([UNUSED_SELECTOR] if cd["num_selectors"] > 1 else []):
+            term = b.ext_sub(b.constant_ext((k, 0)), f)
+            filt = term if filt is None else b.ext_mul(filt, term)
+        for k, c in enumerate(eval_gate(b, gate, consts[cd["num_selectors"]:], wires, pi_hash)):
+            fc = c if filt is None else b.ext_mul(filt, c)
+            allc[k] = fc if allc[k] is None else b.ext_add(allc[k], fc)
+    allc = [c if c is not None else b.ext_zero() for c in allc]
+    one = b.ext_one()
+    # L0(x) = (x^n - 1) / (n (x - 1))
+    l0 = b.ext_div(b.ext_sub(x_pow_n, one), b.arithmetic_ext(n, x, one, P - n, one))
+    z1_terms, pp_terms = [], []
+    routed, chunk, npp = cd["num_routed_wires"], cd["quotient_degree_factor"], cd["num_partial_products"]
+    s_ids = [b.ext_mul(x, b.constant_ext((k, 0))) for k in cd["k_is"]]
+    for i in range(cd["num_challenges"]):
+        z_x, z_gx = op["plonk_zs"][i], op["plonk_zs_next"][i]
+        z1_terms.append(b.ext_mul_sub(l0, z_x, l0))
+        beta, gamma = b.ext_from_base(betas[i]), b.ext_from_base(gammas[i])
+        nums, dens = [], []
+        for j in range(routed):
+            wg = b.ext_add(wires[j], gamma)
+            nums.append(b.ext_mul_add(beta, s_ids[j], wg))
+            dens.append(b.ext_mul_add(beta, op["plonk_sigmas"][j], wg))
+        accs = [z_x] + list(op["partial_products"][i * npp:(i + 1) * npp]) + [z_gx]
+        for ch in range(0, routed, chunk):
+            np_, dp = nums[ch], dens[ch]
+            for j in range(ch + 1, min(ch + chunk, routed)):
+                np_, dp = b.ext_mul(np_, nums[j]), b.ext_mul(dp, dens[j])
+            prev, nxt = accs[ch // chunk], accs[ch // chunk + 1]
+            pp_terms.append(b.ext_mul_sub(prev, np_, b.ext_mul(nxt, dp)))
+    terms = z1_terms + pp_terms + allc
+    return [b.reduce_with_powers_ext(terms, b.ext_from_base(a)) for a in alphas]
+
+
+def verify_merkle_proof(b, leaf, index_bits, cap_index, cap_targets, siblings):
+    """merkle_proof_chip.rs:39-87: fold the path with swap = index bit, look the root up in the cap"""
+    state = b.hash_or_noop(leaf)
+    z = b.zero()
+    for bit, sib in zip(index_bits, siblings):
+        state = b.permute_swapped(list(state) + list(sib) + [z] * 4, swap=bit)[:4]
+    n_cap = len(cap_targets)
+    for i in range(4):
+        items = [cap_targets[k][i] for k in range(n_cap)] + [z] * (16 - n_cap)
+        root_i = b.random_access(cap_index, items) if n_cap > 1 else cap_targets[0][i]
+        b.connect(root_i, state[i])
+
+
+def verify_proof(b, cd, proof, register_pis=True):
+    """builder.verify_proof: proof (dict as produced by plonk.parse_proof) becomes virtual targets; the inner
+    circuit's verifier data (constants_sigmas cap, circuit digest) are constants.  Returns the inner public-input
+    targets."""
+    nch = cd["num_challenges"]
+    tv = b.add_virtual_target
+
+    def ext_list(vals):
+        return [(tv(int(v[0])), tv(int(v[1]))) for v in vals]
+
+    def cap_targets(cap):
+        return [[tv(int(x)) for x in h] for h in cap]
+    pis = [tv(int(v)) for v in proof["public_inputs"]]
+    if register_pis:
+        b.register_public_inputs(pis)
+    op = {k: ext_list(v) for k, v in proof["openings"].items()}
+    wires_cap, zs_cap, q_cap = cap_targets(proof["wires_cap"]), cap_targets(proof["plonk_zs_partial_products_cap"]), cap_targets(proof["quotient_polys_cap"])
+    cs_cap = [[b.constant(int(x)) for x in h] for h in cd["constants_sigmas_cap"]]
+    fri = proof["opening_proof"]
+    fri_caps = [cap_targets(c) for c in fri["commit_phase_merkle_caps"]]
+    final_poly = ext_list(fri["final_poly"])
+    pow_witness = tv(int(fri["pow_witness"]))
+    # ---- challenges (plonk_verifier_chip.rs:55-154) -----------------------------------------------------------
+    pi_hash = b.hash_n_to_hash_no_pad(pis)
+    ch = Challenger(b)
+    ch.observe([b.constant(int(x)) for x in cd["circuit_digest"]])
+    ch.observe(pi_hash)
+    for h in wires_cap:
+        ch.observe(h)
+    betas, gammas = ch.squeeze(nch), ch.squeeze(nch)
+    for h in zs_cap:
+        ch.observe(h)
+    alphas = ch.squeeze(nch)
+    for h in q_cap:
+        ch.observe(h)
+    zeta = ch.squeeze_ext()
+    zeta_batch = op["constants"] + op["plonk_sigmas"] + op["wires"] + op["plonk_zs"] + op["partial_products"] + op["quotient_polys"]
+    next_batch = op["plonk_zs_next"]
+    for e in zeta_batch + next_batch:
+        ch.observe_ext(e)
+    fri_alpha = ch.squeeze_ext()
+    fri_betas = []
+    for cap in fri_caps:
+        for h in cap:
+            ch.observe(h)
+        fri_betas.append(ch.squeeze_ext())
+    for e in final_poly:
+        ch.observe_ext(e)
+    ch.observe([pow_witness])
+    pow_response = ch.squeeze(1)[0]
+    query_challenges = ch.squeeze(cd["num_query_rounds"])
+    # ---- vanishing identity (plonk_verifier_chip.rs:174-210) -----------------------------------------------------
+    zeta_pow_n = b.ext_exp_pow2(zeta, cd["degree_bits"])
+    van = eval_vanishing_poly(b, cd, zeta, zeta_pow_n, op, pi_hash, betas, gammas, alphas)
+    z_h = b.ext_sub(zeta_pow_n, b.ext_one())
+    qdf = cd["quotient_degree_factor"]
+    for i in range(nch):
+        chunk = op["quotient_polys"][i * qdf:(i + 1) * qdf]
+        b.connect_ext(b.ext_mul(z_h, b.reduce_with_powers_ext(chunk, zeta_pow_n)), van[i])
+    # ---- FRI (fri_chip.rs) -------------------------------------------------------------------------------------------
+    resp_bits = b.split_le_64(pow_response)
+    for bit in resp_bits[64 - cd["pow_bits"]:]:
+        b.assert_zero(bit)
+    lde_bits = cd["degree_bits"] + cd["rate_bits"]
+    cap_h = cd["cap_height"]
+    g = pow(7, (P - 1) >> cd["degree_bits"], P)
+    zeta_next = b.ext_mul(zeta, b.constant_ext((g, 0)))
+    widths = [cd["num_selectors"] + cd["num_constants"] + cd["num_routed_wires"], cd["num_wires"],
+              nch * (1 + cd["num_partial_products"]), nch * qdf]
+    red_open = [b.reduce_with_powers_ext(zeta_batch, fri_alpha), b.reduce_with_powers_ext(next_batch, fri_alpha)]
+    alpha_pows = [b.ext_exp_const(fri_alpha, len(zeta_batch)), b.ext_exp_const(fri_alpha, len(next_batch))]
+    caps = [cs_cap, wires_cap, zs_cap, q_cap]
+    omega = pow(7, (P - 1) >> lde_bits, P)
+    one, zero = b.one(), b.zero()
+    for q, rnd in zip(query_challenges, fri["query_round_proofs"]):
+        bits = b.split_le_64(q)[:lde_bits]
+        cap_index = b.le_sum(bits[lde_bits - cap_h:]) if cap_h else zero
+        leaves = [[tv(int(v)) for v in leaf] for leaf, _ in rnd["initial_trees"]]
+        for o in range(4):
+            sib = [[tv(int(v)) for v in s] for s in rnd["initial_trees"][o][1]]
+            verify_merkle_proof(b, leaves[o], bits[:lde_bits - cap_h], cap_index, caps[o], sib)
+        # x = 7 * omega^bitrev(index): bit j of the index contributes omega^(2^(lde_bits-1-j))
+        x = b.constant(7)
+        for j, bit in enumerate(bits):
+            f = pow(omega, 1 << (lde_bits - 1 - j), P)
+            x = b.mul(x, b.arithmetic(f - 1, bit, one, 1, one))       # bit ? f : 1
+        # batch_initial_polynomials (fri_chip.rs:112-149)
+        all_evals = [leaves[o][i] for o in range(4) for i in range(widths[o])]
+        z_evals = [leaves[2][i] for i in range(nch)]
+        xe = b.ext_from_base(x)
+        total = b.ext_zero()
+        for evals, red, apow, point in ((all_evals, red_open[0], alpha_pows[0], zeta), (z_evals, red_open[1], alpha_pows[1], zeta_next)):
+            num = b.ext_sub(b.reduce_with_powers_base(evals, fri_alpha), red)
+            den = b.ext_sub(xe, point)
+            total = b.ext_mul_add(total, apow, b.ext_div(num, den))
+        prev = total
+        neg_one = b.constant(P - 1)
+        idx_bits = bits
+        for l, arity_bits in enumerate(cd["arity_bits"]):
+            ev_flat, sib_vals = rnd["steps"][l]
+            ev = [tv(int(v)) for v in ev_flat]
+            e0, e1 = (ev[0], ev[1]), (ev[2], ev[3])
+            within = idx_bits[0]
+            coset_bits = idx_bits[1:]
+            picked = (b.select(within, e1[0], e0[0]), b.select(within, e1[1], e0[1]))
+            b.connect_ext(picked, prev)
+            # next_eval (fri_chip.rs:168-226): a0 = x * (-1)^within, b0 = -a0
+            a0 = b.mul(x, b.arithmetic(P - 2, within, one, 1, one))   # within ? -x : x
+            a0e = b.ext_from_base(a0)
+            numer = b.ext_mul(b.ext_sub(fri_betas[l], a0e), b.ext_sub(e1, e0))
+            denom = b.ext_from_base(b.mul_const(P - 2, a0))            # b0 - a0 = -2 a0
+            prev = b.ext_add(e0, b.ext_div(numer, denom))
+            sib = [[tv(int(v)) for v in s] for s in sib_vals]
+            verify_merkle_proof(b, ev, coset_bits[:len(coset_bits) - cap_h], cap_index, fri_caps[l], sib)
+            x = b.mul(x, x)
+            idx_bits = coset_bits
+        fin = b.reduce_with_powers_ext(final_poly, b.ext_from_base(x))
+        b.connect_ext(fin, prev)
+    return pis
+
+
+class RecursiveCircuit:
+    """wrapper.rs:35-56 WrapperCircuit / recursion.rs:25-185 aggregate_signals: a circuit that verifies k inner
+    proofs of one inner circuit.  The layout is fixed by the first proof set it sees; later calls only regenerate
+    the witness (same gate sequence) and prove."""
+
+    def __init__(self, ctx, inner_common, k=1, config=None):
+        self.ctx, self.cd, self.k, self.config = ctx, inner_common, k, config
+        self.data = None
+        self.structure = None
+
+    def _run(self, proofs):
+        b = GadgetBuilder(self.config)
+        for p in proofs:
+            verify_proof(b, self.cd, p)
+        pi_vals = b.finalize_public_inputs()
+        return b, pi_vals
+
+    def prove(self, proofs, seed, rng=None, flat_only=False):
+        assert len(proofs) == self.k
+        b, pi_vals = self._run(proofs)
+        sh = b.structure_hash()
+        if self.data is None:
+            self.data = b.cb.build(self.ctx, rng)
+            self.structure = sh
+        assert sh == self.structure, "recursive circuit layout depends on the proof values"
+        idx, vals = b.sparse_witness()
+        return prove_sparse(self.ctx, self.data, idx, vals, np.array(pi_vals, dtype=np.uint64), seed, flat_only=flat_only)
