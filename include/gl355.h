@@ -37,6 +37,7 @@ extern "C" {
 #define GL355_E_OOM (-3)
 #define GL355_E_HIP (-4)
 #define GL355_E_UNSUPPORTED (-5)
+#define GL355_E_WITNESS (-6)     /* witness generation hit an unsatisfiable constraint (invalid inner proof) */
 
 #define GL355_P UINT64_C(0xFFFFFFFF00000001) /* chip/native_chip/arithmetic_chip.rs:19 */
 #define GL355_COSET_SHIFT UINT64_C(7)        /* chip/plonk/plonk_verifier_chip.rs:225-227 */
@@ -293,6 +294,29 @@ int32_t gl355_prove_sparse(gl355_ctx* ctx, const gl355_prover_data* pd, const ui
  * Constant; public_inputs = merkle_root | nullifier | topic (circuit.rs:27-32). */
 int32_t gl355_semaphore_witness(const uint64_t private_key[4], const uint64_t topic[4], uint64_t index,
                                 const uint64_t* siblings, uint32_t height, uint64_t* rows, uint64_t public_inputs[12]);
+
+/* Witness tape: the host-side witness generation of a built circuit (plonky2's generators, run inside
+ * `data.prove(pw)` at recursion.rs:167-168 / wrapper.rs:55) as a recorded straight-line program.  tape is
+ * n_ops entries of 5 words {op, a, b, c, d}; wire operands are positions in `rows` (sparse row r, wire w ->
+ * r * num_wires + w, the layout gl355_prove_sparse takes); `inputs` is the flat input vector the INPUT
+ * entries index (for the recursive verifier: each inner proof's flat words followed by its public inputs).
+ *   CONST a <- b | INPUT a <- inputs[b] | COPY a <- [b] | ASSERT_EQ [a] == [b]
+ *   ARITH at a: {m0, m1, addend, out}, out = b*m0*m1 + c*addend            (gates/arithmetic.rs)
+ *   ARITH_EXT at a: the same over F_p^2, 8 wires                           (gates/arithmetic_extension.rs)
+ *   POSEIDON row a: inputs 0..11 and swap 24 set, fills the row            (gates/poseidon.rs:329-380)
+ *   MDS_EXT row a: 12 extension inputs -> 12 outputs at wire 24            (gates/poseidon_mds.rs)
+ *   BASE_SUM row a: wire 0 -> b little-endian bits at wire 1               (gates/base_sum.rs)
+ *   RANDOM_ACCESS row a, copy b: claimed element + index bits              (gates/random_access.rs)
+ *   REDUCING row a: b coefficients, c = 1 for the extension variant        (gates/reducing.rs, reducing_extension.rs)
+ *   LO32 / HI32 a <- halves of [b] | EXT_INV (a, b) <- ([c], [d])^-1
+ * rows is zeroed first.  Returns GL355_E_WITNESS (and the entry index in *failed_op) when an ASSERT_EQ or a
+ * range condition fails, i.e. the inputs do not satisfy the circuit. */
+enum { GL355_TAPE_CONST = 0, GL355_TAPE_INPUT = 1, GL355_TAPE_COPY = 2, GL355_TAPE_ASSERT_EQ = 3, GL355_TAPE_ARITH = 4,
+       GL355_TAPE_ARITH_EXT = 5, GL355_TAPE_POSEIDON = 6, GL355_TAPE_MDS_EXT = 7, GL355_TAPE_BASE_SUM = 8,
+       GL355_TAPE_RANDOM_ACCESS = 9, GL355_TAPE_REDUCING = 10, GL355_TAPE_LO32 = 11, GL355_TAPE_HI32 = 12,
+       GL355_TAPE_EXT_INV = 13 };
+int32_t gl355_witness_replay(const uint64_t* tape, uint64_t n_ops, const uint64_t* inputs, uint64_t n_inputs,
+                             uint64_t* rows, uint64_t n_words, uint32_t num_wires, uint64_t* failed_op);
 
 /* ---- a9: wires_permutation_partial_products_and_zs (vanishing_poly.rs:54-108,183-218) --------- */
 int32_t gl355_zs_partial_products(gl355_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas,

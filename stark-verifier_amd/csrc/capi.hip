@@ -83,6 +83,29 @@ int32_t lde_dev(Ctx* ctx, const uint64_t* coeffs, uint64_t in_stride, uint32_t l
     return GL355_OK;
 }
 
+// the same on an explicit context (stream + scratch): a read-only oracle such as a circuit's preprocessed
+// constants_sigmas may be opened concurrently by several prover contexts of one device
+int32_t oracle_open_batch_on(Ctx* ctx, const gl355_oracle* o, const uint64_t* indices, uint32_t n_idx, uint64_t* leaves,
+                                    uint64_t* siblings) {
+    const uint32_t bits = o->log_n + o->rate_bits, layers = bits - o->cap_height;
+    const uint64_t N = 1ull << bits;
+    for (uint32_t i = 0; i < n_idx; i++)
+        if (indices[i] >= N) return ctx->fail(GL355_E_INVALID_ARG, "oracle_open_batch: index out of range");
+    Scratch sc(ctx);
+    const uint64_t n_leaf = (uint64_t)n_idx * o->leaf_len, n_sib = (uint64_t)n_idx * layers * 4;
+    GL355_TRY(sc.get((n_idx + n_leaf + n_sib) * 8));
+    uint64_t* d_idx = sc.as<uint64_t>();
+    uint64_t* d_leaf = d_idx + n_idx;
+    uint64_t* d_sib = d_leaf + n_leaf;
+    GL355_HIP(ctx, hipMemcpyAsync(d_idx, indices, (uint64_t)n_idx * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL355_TRY(open_batch_dev(ctx, o->lde, N, o->leaf_len, o->digests, bits, o->cap_height, d_idx, n_idx, d_leaf, d_sib));
+    GL355_HIP(ctx, hipMemcpyAsync(leaves, d_leaf, n_leaf * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_sib) GL355_HIP(ctx, hipMemcpyAsync(siblings, d_sib, n_sib * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GL355_OK;
+}
+
+
 }  // namespace gl355
 
 // ---- oracle (PolynomialBatch) --------------------------------------------------------------
@@ -382,23 +405,7 @@ int32_t gl355_oracle_open(const gl355_oracle* o, uint64_t index, uint64_t* leaf,
 int32_t gl355_oracle_open_batch(const gl355_oracle* o, const uint64_t* indices, uint32_t n_idx, uint64_t* leaves,
                                 uint64_t* siblings) {
     if (!o || !indices || !leaves || !siblings) return GL355_E_INVALID_ARG;
-    Ctx* ctx = o->ctx;
-    const uint32_t bits = o->log_n + o->rate_bits, layers = bits - o->cap_height;
-    const uint64_t N = 1ull << bits;
-    for (uint32_t i = 0; i < n_idx; i++)
-        if (indices[i] >= N) return ctx->fail(GL355_E_INVALID_ARG, "oracle_open_batch: index out of range");
-    Scratch sc(ctx);
-    const uint64_t n_leaf = (uint64_t)n_idx * o->leaf_len, n_sib = (uint64_t)n_idx * layers * 4;
-    GL355_TRY(sc.get((n_idx + n_leaf + n_sib) * 8));
-    uint64_t* d_idx = sc.as<uint64_t>();
-    uint64_t* d_leaf = d_idx + n_idx;
-    uint64_t* d_sib = d_leaf + n_leaf;
-    GL355_HIP(ctx, hipMemcpyAsync(d_idx, indices, (uint64_t)n_idx * 8, hipMemcpyHostToDevice, ctx->stream));
-    GL355_TRY(open_batch_dev(ctx, o->lde, N, o->leaf_len, o->digests, bits, o->cap_height, d_idx, n_idx, d_leaf, d_sib));
-    GL355_HIP(ctx, hipMemcpyAsync(leaves, d_leaf, n_leaf * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (n_sib) GL355_HIP(ctx, hipMemcpyAsync(siblings, d_sib, n_sib * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return GL355_OK;
+    return gl355::oracle_open_batch_on(o->ctx, o, indices, n_idx, leaves, siblings);
 }
 
 // ---- a10 -------------------------------------------------------------------------------------

@@ -380,7 +380,7 @@ static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, c
     for (int o = 0; o < 4; o++) {
         leaves[o].resize((uint64_t)pd->num_queries * oracles[o]->leaf_len + 4);
         sibs[o].resize((uint64_t)pd->num_queries * depth0 * 4 + 4);
-        GL355_TRY(gl355_oracle_open_batch(oracles[o], q_idx.data(), pd->num_queries, leaves[o].data(), sibs[o].data()));
+        GL355_TRY(oracle_open_batch_on(ctx, oracles[o], q_idx.data(), pd->num_queries, leaves[o].data(), sibs[o].data()));
     }
     for (uint32_t q = 0; q < pd->num_queries; q++) {
         *out++ = q_idx[q];

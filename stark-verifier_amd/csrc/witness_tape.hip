@@ -1,0 +1,143 @@
+// Witness tape: a straight-line program that recomputes every wire of a circuit's non-trivial rows from
+// a flat input vector.  It plays the role of plonky2's witness generators (`generate_partial_witness`,
+// run inside `data.prove(pw)` at src/plonky2_semaphore/recursion.rs:167-168 and wrapper.rs:55): the
+// recursive-verifier circuit's ~6000 gate rows (Poseidon, Reducing, Arithmetic, RandomAccess, BaseSum,
+// ...) are a fixed function of the inner proofs' words.  The tape is recorded once by the host-side
+// builder (stark-verifier_amd/gadgets.py) and replayed here per proof: sequential host work
+// (about 5k Poseidon permutations with their S-box-input wires + ~0.5M field operations), single thread,
+// no device involvement -- callers overlap it with the GPU prove of the previous proof.
+//
+// Wire layouts of the gate rows follow the reference's chip/plonk/gates/*.rs (arithmetic.rs,
+// arithmetic_extension.rs, poseidon.rs:329-380, poseidon_mds.rs, base_sum.rs, random_access.rs,
+// reducing.rs, reducing_extension.rs).
+#include "gl355_internal.h"
+
+using namespace gl355;
+
+namespace {
+constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+}
+
+extern "C" int32_t gl355_witness_replay(const uint64_t* tape, uint64_t n_ops, const uint64_t* inputs, uint64_t n_inputs,
+                                        uint64_t* rows, uint64_t n_words, uint32_t num_wires, uint64_t* failed_op) {
+    if (!tape || !rows || (!inputs && n_inputs) || num_wires < 135) return GL355_E_INVALID_ARG;
+    if (failed_op) *failed_op = ~0ull;
+    memset(rows, 0, n_words * 8);
+    uint64_t* W = rows;
+#define CHK(i, span)                                                        \
+    if ((uint64_t)(i) + (span) > n_words) {                                   \
+        if (failed_op) *failed_op = t;                                        \
+        return GL355_E_INVALID_ARG;                                           \
+    }
+#define ROWCHK(i)                                                           \
+    CHK(i, num_wires)                                                        \
+    if ((i) % num_wires) {                                                    \
+        if (failed_op) *failed_op = t;                                        \
+        return GL355_E_INVALID_ARG;                                           \
+    }
+    for (uint64_t t = 0; t < n_ops; t++) {
+        const uint64_t* e = tape + 5 * t;
+        const uint64_t a = e[1], b = e[2], c = e[3], d = e[4];
+        switch (e[0]) {
+        case GL355_TAPE_CONST:
+            CHK(a, 1) W[a] = gl_canon(b);
+            break;
+        case GL355_TAPE_INPUT:
+            CHK(a, 1)
+            if (b >= n_inputs) { if (failed_op) *failed_op = t; return GL355_E_INVALID_ARG; }
+            W[a] = gl_canon(inputs[b]);
+            break;
+        case GL355_TAPE_COPY:
+            CHK(a, 1) CHK(b, 1) W[a] = W[b];
+            break;
+        case GL355_TAPE_ASSERT_EQ:
+            CHK(a, 1) CHK(b, 1)
+            if (W[a] != W[b]) { if (failed_op) *failed_op = t; return GL355_E_WITNESS; }
+            break;
+        case GL355_TAPE_ARITH:
+            CHK(a, 4)
+            W[a + 3] = gl_canon(gl_add(gl_mul(gl_mul(W[a], W[a + 1]), b), gl_mul(W[a + 2], c)));
+            break;
+        case GL355_TAPE_ARITH_EXT: {
+            CHK(a, 8)
+            gl2 pr = gl2_mul(gl2_make(W[a], W[a + 1]), gl2_make(W[a + 2], W[a + 3]));
+            gl2 r = gl2_add(gl2_mul_base(pr, b), gl2_mul_base(gl2_make(W[a + 4], W[a + 5]), c));
+            r = gl2_canon(r);
+            W[a + 6] = r.c0;
+            W[a + 7] = r.c1;
+            break;
+        }
+        case GL355_TAPE_POSEIDON: {
+            ROWCHK(a)
+            uint64_t in[12];
+            memcpy(in, W + a, sizeof in);
+            const uint64_t swap = W[a + 24];
+            if (swap > 1) { if (failed_op) *failed_op = t; return GL355_E_WITNESS; }
+            gl355_poseidon_gate_witness(in, swap, W + a);
+            break;
+        }
+        case GL355_TAPE_MDS_EXT: {
+            ROWCHK(a)
+            for (int r = 0; r < 12; r++)
+                for (int k = 0; k < 2; k++) {
+                    unsigned __int128 acc = 0;
+                    for (int i = 0; i < 12; i++) acc += (unsigned __int128)W[a + 2 * ((i + r) % 12) + k] * CIRC[i];
+                    if (r == 0) acc += (unsigned __int128)W[a + k] * 8;
+                    W[a + 2 * (12 + r) + k] = gl_canon(gl_reduce128((uint64_t)acc, (uint64_t)(acc >> 64)));
+                }
+            break;
+        }
+        case GL355_TAPE_BASE_SUM: {
+            ROWCHK(a)
+            if (b > 63 || 1 + b > num_wires || (W[a] >> b)) { if (failed_op) *failed_op = t; return b > 63 ? GL355_E_INVALID_ARG : GL355_E_WITNESS; }
+            for (uint64_t i = 0; i < b; i++) W[a + 1 + i] = (W[a] >> i) & 1;
+            break;
+        }
+        case GL355_TAPE_RANDOM_ACCESS: {   // RandomAccessGate{bits 4, copies 4, extra constants 2}
+            ROWCHK(a)
+            if (b >= 4) { if (failed_op) *failed_op = t; return GL355_E_INVALID_ARG; }
+            const uint64_t idx = W[a + 18 * b];
+            if (idx >= 16) { if (failed_op) *failed_op = t; return GL355_E_WITNESS; }
+            W[a + 18 * b + 1] = W[a + 18 * b + 2 + idx];
+            for (int k = 0; k < 4; k++) W[a + 74 + 4 * b + k] = (idx >> k) & 1;
+            break;
+        }
+        case GL355_TAPE_REDUCING: {   // b = number of coefficients, c = 1 for ReducingExtensionGate
+            ROWCHK(a)
+            const uint64_t n = b, ext = c;
+            const uint64_t start_accs = 6 + (ext ? 2 * n : n);
+            if (n == 0 || start_accs + 2 * (n - 1) > num_wires) { if (failed_op) *failed_op = t; return GL355_E_INVALID_ARG; }
+            const gl2 alpha = gl2_make(W[a + 2], W[a + 3]);
+            gl2 acc = gl2_make(W[a + 4], W[a + 5]);
+            for (uint64_t i = 0; i < n; i++) {
+                const gl2 cf = ext ? gl2_make(W[a + 6 + 2 * i], W[a + 7 + 2 * i]) : gl2_make(W[a + 6 + i], 0);
+                acc = gl2_canon(gl2_add(gl2_mul(acc, alpha), cf));
+                const uint64_t o = i == n - 1 ? 0 : start_accs + 2 * i;
+                W[a + o] = acc.c0;
+                W[a + o + 1] = acc.c1;
+            }
+            break;
+        }
+        case GL355_TAPE_LO32:
+            CHK(a, 1) CHK(b, 1) W[a] = W[b] & 0xFFFFFFFFull;
+            break;
+        case GL355_TAPE_HI32:
+            CHK(a, 1) CHK(b, 1) W[a] = W[b] >> 32;
+            break;
+        case GL355_TAPE_EXT_INV: {
+            CHK(a, 1) CHK(b, 1) CHK(c, 1) CHK(d, 1)
+            if (W[c] == 0 && W[d] == 0) { if (failed_op) *failed_op = t; return GL355_E_WITNESS; }
+            const gl2 r = gl2_canon(gl2_inv(gl2_make(W[c], W[d])));
+            W[a] = r.c0;
+            W[b] = r.c1;
+            break;
+        }
+        default:
+            if (failed_op) *failed_op = t;
+            return GL355_E_INVALID_ARG;
+        }
+    }
+#undef CHK
+#undef ROWCHK
+    return GL355_OK;
+}

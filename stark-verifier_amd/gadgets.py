@@ -25,6 +25,16 @@ from .plonk import CircuitBuilder, CircuitConfig, P, host_hash_no_pad, poseidon_
 RA_PARAM = 4 | 4 << 8 | 2 << 16
 CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
 
+# witness-tape opcodes (include/gl355.h GL355_TAPE_*, interpreter: csrc/witness_tape.hip).  Every builder
+# primitive appends the entries that recompute its wires from earlier wires, so a circuit built once can be
+# re-witnessed for new inputs by gl355_witness_replay without running the Python gadgets again.
+(TAPE_CONST, TAPE_INPUT, TAPE_COPY, TAPE_ASSERT_EQ, TAPE_ARITH, TAPE_ARITH_EXT, TAPE_POSEIDON, TAPE_MDS_EXT,
+ TAPE_BASE_SUM, TAPE_RANDOM_ACCESS, TAPE_REDUCING, TAPE_LO32, TAPE_HI32, TAPE_EXT_INV) = range(14)
+# which of the four operand fields of an entry are wire references (bit i = operand i)
+TAPE_WIRE_FIELDS = {TAPE_CONST: 1, TAPE_INPUT: 1, TAPE_COPY: 3, TAPE_ASSERT_EQ: 3, TAPE_ARITH: 1, TAPE_ARITH_EXT: 1,
+                    TAPE_POSEIDON: 1, TAPE_MDS_EXT: 1, TAPE_BASE_SUM: 1, TAPE_RANDOM_ACCESS: 1, TAPE_REDUCING: 1,
+                    TAPE_LO32: 3, TAPE_HI32: 3, TAPE_EXT_INV: 15}
+
 
 class T:
     """a base-field target: home wire + value"""
@@ -55,6 +65,13 @@ class GadgetBuilder:
         self.public_inputs = []
         self.trace = hashlib.sha256()
         self._free = None         # (row, next col) of the current Noop storage row
+        self.tape = []            # (op, a, b, c, d) with wire operands as row * num_wires + col
+
+    def _w(self, row, col):
+        return row * self.nw + col
+
+    def _rec(self, op, a=0, b=0, c=0, d=0):
+        self.tape.append((op, a, b, c, d))
 
     # ---- low level ------------------------------------------------------------------------------------
     def _new_row(self, gtype, param=0, constants=()):
@@ -72,25 +89,34 @@ class GadgetBuilder:
         self.rows[row][col] = src.v
         if (src.row, src.col) != (row, col):
             self.cb.connect((src.row, src.col), (row, col))
+            self._rec(TAPE_COPY, self._w(row, col), self._w(src.row, src.col))
 
     def connect(self, a, b):
         assert a.v == b.v, "connect() of targets with different values: %x != %x" % (a.v, b.v)
         self.cb.connect((a.row, a.col), (b.row, b.col))
+        self._rec(TAPE_ASSERT_EQ, self._w(a.row, a.col), self._w(b.row, b.col))
 
     def connect_ext(self, a, b):
         self.connect(a[0], b[0])
         self.connect(a[1], b[1])
 
-    def add_virtual_target(self, v):
-        """a free witness input (home: a routed wire of a Noop row)"""
+    def add_virtual_target(self, v, derived=False):
+        """a free witness input (home: a routed wire of a Noop row).  A value carrying `.src` (plonk.Src: its
+        position in the caller's flat input vector) is recorded on the tape as an INPUT; `derived` targets are
+        recorded by the caller (they are functions of other wires)."""
         if self._free is None or self._free[1] >= self.routed:
             self._free = [self._new_row(GATE_NOOP), 0]
-        t = self._set(self._free[0], self._free[1], v)
+        src = getattr(v, "src", None)
+        t = self._set(self._free[0], self._free[1], int(v))
         self._free[1] += 1
+        if src is not None:
+            self._rec(TAPE_INPUT, self._w(t.row, t.col), src)
+        elif not derived:
+            self.untagged_inputs = getattr(self, "untagged_inputs", 0) + 1
         return t
 
     def add_virtual_targets(self, vals):
-        return [self.add_virtual_target(int(v)) for v in vals]
+        return [self.add_virtual_target(v) for v in vals]
 
     def add_virtual_ext(self, v):
         return (self.add_virtual_target(v[0]), self.add_virtual_target(v[1]))
@@ -109,6 +135,7 @@ class GadgetBuilder:
             self.trace.update(b"c%d;" % v)        # constants are part of the circuit, not of the witness
             self.cb.rows[row][1][k] = v          # gate constant k of that row
             self.consts[v] = self._set(row, k, v)
+            self._rec(TAPE_CONST, self._w(row, k), v)
             slot[1] += 1
         return self.consts[v]
 
@@ -138,6 +165,7 @@ class GadgetBuilder:
         self._link(m0, row, 4 * i)
         self._link(m1, row, 4 * i + 1)
         self._link(addend, row, 4 * i + 2)
+        self._rec(TAPE_ARITH, self._w(row, 4 * i), c0, c1)
         return self._set(row, 4 * i + 3, c0 * m0.v * m1.v + c1 * addend.v)
 
     def mul(self, a, b):
@@ -182,6 +210,7 @@ class GadgetBuilder:
         pr = emul((m0[0].v, m0[1].v), (m1[0].v, m1[1].v))
         v0 = c0 * pr[0] + c1 * addend[0].v
         v1 = c0 * pr[1] + c1 * addend[1].v
+        self._rec(TAPE_ARITH_EXT, self._w(row, 8 * i), c0, c1)
         return (self._set(row, 8 * i + 6, v0), self._set(row, 8 * i + 7, v1))
 
     def ext_zero(self):
@@ -214,7 +243,9 @@ class GadgetBuilder:
     def ext_inverse(self, a):
         """witness the inverse and check a * inv == 1"""
         inv = einv((a[0].v, a[1].v))
-        t = self.add_virtual_ext(inv)
+        t = (self.add_virtual_target(inv[0], derived=True), self.add_virtual_target(inv[1], derived=True))
+        self._rec(TAPE_EXT_INV, self._w(t[0].row, t[0].col), self._w(t[1].row, t[1].col),
+                  self._w(a[0].row, a[0].col), self._w(a[1].row, a[1].col))
         prod = self.ext_mul(a, t)
         self.connect_ext(prod, self.ext_one())
         return t
@@ -247,7 +278,10 @@ class GadgetBuilder:
             self.rows[row][c] = int(w[c])
         for i, t in enumerate(inputs):
             self.cb.connect((t.row, t.col), (row, i))
+            self._rec(TAPE_COPY, self._w(row, i), self._w(t.row, t.col))
         self.cb.connect((sw.row, sw.col), (row, 24))
+        self._rec(TAPE_COPY, self._w(row, 24), self._w(sw.row, sw.col))
+        self._rec(TAPE_POSEIDON, self._w(row, 0))
         return [T(row, 12 + i, int(w[12 + i])) for i in range(12)]
 
     def hash_n_to_hash_no_pad(self, inputs):
@@ -271,6 +305,7 @@ class GadgetBuilder:
         for i, e in enumerate(state):
             self._link(e[0], row, 2 * i)
             self._link(e[1], row, 2 * i + 1)
+        self._rec(TAPE_MDS_EXT, self._w(row, 0))
         out = []
         for r in range(12):
             v0 = sum(CIRC[i] * state[(i + r) % 12][0].v for i in range(12)) + (8 * state[0][0].v if r == 0 else 0)
@@ -285,14 +320,17 @@ class GadgetBuilder:
         self._link(x, row, 0)
         v = x.v
         assert v < (1 << 32)
+        self._rec(TAPE_BASE_SUM, self._w(row, 0), 32)
         bits = [self._set(row, 1 + i, (v >> i) & 1) for i in range(32)]
         return bits[:n_used]
 
     def split_le_64(self, x):
         """all 64 bits of a field element: x = lo + 2^32 * hi with both halves range-checked by BaseSum{32}.
         (Like plonky2's split_le this does not exclude the non-canonical representation x + p < 2^64.)"""
-        lo = self.add_virtual_target(x.v & 0xFFFFFFFF)
-        hi = self.add_virtual_target(x.v >> 32)
+        lo = self.add_virtual_target(x.v & 0xFFFFFFFF, derived=True)
+        hi = self.add_virtual_target(x.v >> 32, derived=True)
+        self._rec(TAPE_LO32, self._w(lo.row, lo.col), self._w(x.row, x.col))
+        self._rec(TAPE_HI32, self._w(hi.row, hi.col), self._w(x.row, x.col))
         bits_lo = self.split_le_32(lo, 32)
         bits_hi = self.split_le_32(hi, 32)
         recomposed = self.arithmetic(1 << 32, hi, self.one(), 1, lo)
@@ -331,6 +369,7 @@ class GadgetBuilder:
             self._link(it, row, 18 * c + 2 + i)
         for k in range(4):
             self.rows[row][74 + 4 * c + k] = (idx.v >> k) & 1
+        self._rec(TAPE_RANDOM_ACCESS, self._w(row, 0), c)
         return self._set(row, 18 * c + 1, items[idx.v].v)
 
     # ---- ReducingGate{43} / ReducingExtensionGate{32} (gates/reducing.rs, reducing_extension.rs) ---------------------
@@ -352,10 +391,11 @@ class GadgetBuilder:
             if ext:
                 self._link(cf[0], row, 6 + 2 * i)
                 self._link(cf[1], row, 6 + 2 * i + 1)
-                cv = (cf[0].v, cf[1].v)
             else:
                 self._link(cf, row, 6 + i)
-                cv = (cf.v, 0)
+        self._rec(TAPE_REDUCING, self._w(row, 0), n, 1 if ext else 0)
+        for i, cf in enumerate(padded):
+            cv = (cf[0].v, cf[1].v) if ext else (cf.v, 0)
             pr = emul(acc, al)
             acc = ((pr[0] + cv[0]) % P, (pr[1] + cv[1]) % P)
             base = 0 if i == n - 1 else start_accs + 2 * i
@@ -412,6 +452,24 @@ class GadgetBuilder:
                 vals[k, c] = v
         return np.array(idx, dtype=np.uint32), vals
 
-    def check_gates(self):
-        """debug: evaluate every gate constraint on the witness with the big-integer model (tests only)."""
-        raise NotImplementedError
+    def witness_tape(self):
+        """The recorded witness program with wire operands renumbered to the sparse-row layout of
+        sparse_witness(): (tape uint64[n][5], row_idx uint32[k], public-input wire positions int64[n_pi])."""
+        idx = sorted(r for r, cols in self.rows.items() if cols)
+        rank = np.full(max(idx) + 1, -1, dtype=np.int64)
+        rank[idx] = np.arange(len(idx))
+        tape = np.array(self.tape, dtype=object)
+        ops = tape[:, 0].astype(np.int64)
+        out = np.zeros(tape.shape, dtype=np.uint64)
+        out[:, 0] = ops.astype(np.uint64)
+        masks = np.array([TAPE_WIRE_FIELDS[o] for o in range(14)], dtype=np.int64)[ops]
+        for f in range(4):
+            col = np.array([int(x) for x in tape[:, 1 + f]], dtype=np.uint64)
+            is_wire = (masks >> f) & 1 == 1
+            w = col[is_wire].astype(np.int64)
+            r = rank[w // self.nw]
+            assert (r >= 0).all()
+            col[is_wire] = (r * self.nw + w % self.nw).astype(np.uint64)
+            out[:, 1 + f] = col
+        pi_pos = np.array([rank[t.row] * self.nw + t.col for t in self.public_inputs], dtype=np.int64)
+        return out, np.array(idx, dtype=np.uint32), pi_pos

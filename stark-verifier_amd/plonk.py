@@ -320,12 +320,48 @@ def _rand_salt(rng, n_cols):
     return rng.integers(0, P, size=(SALT_SIZE, n_cols), dtype=np.uint64)
 
 
+class Src(int):
+    """an input value that remembers its position in a flat input vector (witness-tape recording)"""
+    def __new__(cls, v, src):
+        o = int.__new__(cls, int(v))
+        o.src = int(src)
+        return o
+
+
+def tag_proof(vals, idxs):
+    """zip a parsed proof with the identically parsed index vector: every leaf becomes a Src"""
+    if isinstance(vals, dict):
+        return {k: tag_proof(v, idxs[k]) for k, v in vals.items()}
+    if isinstance(vals, (list, tuple)):
+        return type(vals)(tag_proof(v, i) for v, i in zip(vals, idxs))
+    if isinstance(vals, np.ndarray):
+        return [tag_proof(v, i) for v, i in zip(vals, idxs)]
+    return Src(vals, idxs)
+
+
+def parse_proof_tagged(data, flat, public_inputs, offset=0):
+    """parse_proof whose leaves are Src(value, offset + position in flat ‖ public_inputs)"""
+    flat = _u64(flat)
+    idx = np.arange(offset, offset + flat.size, dtype=np.uint64)
+    idx[:8] = flat[:8]
+    proof = tag_proof(parse_proof(data, flat), parse_proof(data, idx))
+    proof["public_inputs"] = [Src(v, offset + flat.size + i) for i, v in enumerate(_u64(public_inputs))]
+    return proof
+
+
 def parse_proof(data, flat):
-    """Flat u64 proof of gl355_prove (layout in include/gl355.h) -> the dict the verifier restatement reads."""
-    cfg = data.config
+    """Flat u64 proof of gl355_prove (layout in include/gl355.h) -> the dict the verifier restatement reads.
+    data: CircuitData, or its common() dict."""
+    if isinstance(data, dict):
+        rate_bits, n_const, n_routed, n_wires = data["rate_bits"], data["num_selectors"] + data["num_constants"], data["num_routed_wires"], data["num_wires"]
+        n_pp, qdf = data["num_partial_products"], data["quotient_degree_factor"]
+    else:
+        cfg = data.config
+        rate_bits, n_const, n_routed, n_wires = cfg.rate_bits, data.num_selectors + cfg.num_constants, cfg.num_routed_wires, cfg.num_wires
+        n_pp, qdf = data.num_partial_products, cfg.max_quotient_degree_factor
     total, degree_bits, n_layers, nq, n_pi, zk, cap_h, nch = [int(v) for v in flat[:8]]
     n_cap = 1 << cap_h
-    lde_bits = degree_bits + cfg.rate_bits
+    lde_bits = degree_bits + rate_bits
     n = 1 << degree_bits
     pos = [8]
 
@@ -334,15 +370,13 @@ def parse_proof(data, flat):
         pos[0] += k
         return v.reshape(shape) if shape else v
     wires_cap, zs_cap, q_cap = take(4 * n_cap, (n_cap, 4)), take(4 * n_cap, (n_cap, 4)), take(4 * n_cap, (n_cap, 4))
-    n_const = data.num_selectors + cfg.num_constants
-    counts = [("constants", n_const), ("plonk_sigmas", cfg.num_routed_wires), ("wires", cfg.num_wires), ("plonk_zs", nch),
-              ("partial_products", nch * data.num_partial_products), ("quotient_polys", nch * cfg.max_quotient_degree_factor),
-              ("plonk_zs_next", nch)]
+    counts = [("constants", n_const), ("plonk_sigmas", n_routed), ("wires", n_wires), ("plonk_zs", nch),
+              ("partial_products", nch * n_pp), ("quotient_polys", nch * qdf), ("plonk_zs_next", nch)]
     openings = {name: take(2 * k, (k, 2)) for name, k in counts}
     caps = take(n_layers * n_cap * 4, (n_layers, n_cap, 4))
     final_poly = take(2 * (n >> n_layers), (-1, 2))
     pow_witness = int(take(1)[0])
-    widths = [n_const + cfg.num_routed_wires, cfg.num_wires, nch * (1 + data.num_partial_products), nch * cfg.max_quotient_degree_factor]
+    widths = [n_const + n_routed, n_wires, nch * (1 + n_pp), nch * qdf]
     depth0 = lde_bits - cap_h
     queries = []
     for _ in range(nq):

@@ -8,12 +8,14 @@ chip/plonk/gates/*.rs, chip/fri_chip.rs, chip/merkle_proof_chip.rs) -- the same 
 tests/plonk_verifier.py evaluates over big integers, here as gates over targets.  The resulting
 circuit is proved by the same GPU pipeline (gl355_prove_sparse) as any other circuit.
 """
+import ctypes as C
+
 import numpy as np
 
 from ._lib import (GATE_ARITHMETIC, GATE_ARITHMETIC_EXT, GATE_BASE_SUM, GATE_CONSTANT, GATE_NOOP, GATE_POSEIDON,
                    GATE_POSEIDON_MDS, GATE_PUBLIC_INPUT, GATE_RANDOM_ACCESS, GATE_REDUCING, GATE_REDUCING_EXT)
 from .gadgets import CIRC, GadgetBuilder, T
-from .plonk import P, prove_sparse
+from .plonk import P, _ptr, _u64, parse_proof_tagged, prove_sparse
 
 UNUSED_SELECTOR = 0xFFFFFFFF
 _RC = None
@@ -276,11 +278,11 @@ def verify_proof(b, cd, proof, register_pis=True):
     tv = b.add_virtual_target
 
     def ext_list(vals):
-        return [(tv(int(v[0])), tv(int(v[1]))) for v in vals]
+        return [(tv(v[0]), tv(v[1])) for v in vals]
 
     def cap_targets(cap):
-        return [[tv(int(x)) for x in h] for h in cap]
-    pis = [tv(int(v)) for v in proof["public_inputs"]]
+        return [[tv(x) for x in h] for h in cap]
+    pis = [tv(v) for v in proof["public_inputs"]]
     if register_pis:
         b.register_public_inputs(pis)
     op = {k: ext_list(v) for k, v in proof["openings"].items()}
@@ -289,7 +291,7 @@ def verify_proof(b, cd, proof, register_pis=True):
     fri = proof["opening_proof"]
     fri_caps = [cap_targets(c) for c in fri["commit_phase_merkle_caps"]]
     final_poly = ext_list(fri["final_poly"])
-    pow_witness = tv(int(fri["pow_witness"]))
+    pow_witness = tv(fri["pow_witness"])
     # ---- challenges (plonk_verifier_chip.rs:55-154) -----------------------------------------------------------
     pi_hash = b.hash_n_to_hash_no_pad(pis)
     ch = Challenger(b)
@@ -345,9 +347,9 @@ def verify_proof(b, cd, proof, register_pis=True):
     for q, rnd in zip(query_challenges, fri["query_round_proofs"]):
         bits = b.split_le_64(q)[:lde_bits]
         cap_index = b.le_sum(bits[lde_bits - cap_h:]) if cap_h else zero
-        leaves = [[tv(int(v)) for v in leaf] for leaf, _ in rnd["initial_trees"]]
+        leaves = [[tv(v) for v in leaf] for leaf, _ in rnd["initial_trees"]]
         for o in range(4):
-            sib = [[tv(int(v)) for v in s] for s in rnd["initial_trees"][o][1]]
+            sib = [[tv(v) for v in s] for s in rnd["initial_trees"][o][1]]
             verify_merkle_proof(b, leaves[o], bits[:lde_bits - cap_h], cap_index, caps[o], sib)
         # x = 7 * omega^bitrev(index): bit j of the index contributes omega^(2^(lde_bits-1-j))
         x = b.constant(7)
@@ -368,7 +370,7 @@ def verify_proof(b, cd, proof, register_pis=True):
         idx_bits = bits
         for l, arity_bits in enumerate(cd["arity_bits"]):
             ev_flat, sib_vals = rnd["steps"][l]
-            ev = [tv(int(v)) for v in ev_flat]
+            ev = [tv(v) for v in ev_flat]
             e0, e1 = (ev[0], ev[1]), (ev[2], ev[3])
             within = idx_bits[0]
             coset_bits = idx_bits[1:]
@@ -380,7 +382,7 @@ def verify_proof(b, cd, proof, register_pis=True):
             numer = b.ext_mul(b.ext_sub(fri_betas[l], a0e), b.ext_sub(e1, e0))
             denom = b.ext_from_base(b.mul_const(P - 2, a0))            # b0 - a0 = -2 a0
             prev = b.ext_add(e0, b.ext_div(numer, denom))
-            sib = [[tv(int(v)) for v in s] for s in sib_vals]
+            sib = [[tv(v) for v in s] for s in sib_vals]
             verify_merkle_proof(b, ev, coset_bits[:len(coset_bits) - cap_h], cap_index, fri_caps[l], sib)
             x = b.mul(x, x)
             idx_bits = coset_bits
@@ -389,23 +391,88 @@ def verify_proof(b, cd, proof, register_pis=True):
     return pis
 
 
+def wrap_public_inputs(b, inner_pis):
+    """wrapper.rs:35-47: the outer circuit re-exposes every inner public input, in order"""
+    for pis in inner_pis:
+        b.register_public_inputs(pis)
+
+
+def aggregate_public_inputs(b, inner_pis):
+    """recursion.rs:105-165: merkle_root | nullifiers(0 then 1) | topics(0 then 1).  Each inner proof exposes
+    root | its nullifiers | its topics.  (The reference leaves the outer root an unconstrained virtual hash;
+    here it IS inner proof 0's root and inner proof 1's root is connected to it -- same values, same layout,
+    strictly more constrained.)"""
+    root = inner_pis[0][:4]
+    for pis in inner_pis[1:]:
+        for j in range(4):
+            b.connect(pis[j], root[j])
+    b.register_public_inputs(root)
+    halves = [(len(pis) - 4) // 2 for pis in inner_pis]
+    for pis, h in zip(inner_pis, halves):
+        b.register_public_inputs(pis[4:4 + h])
+    for pis, h in zip(inner_pis, halves):
+        b.register_public_inputs(pis[4 + h:4 + 2 * h])
+
+
 class RecursiveCircuit:
     """wrapper.rs:35-56 WrapperCircuit / recursion.rs:25-185 aggregate_signals: a circuit that verifies k inner
-    proofs of one inner circuit.  The layout is fixed by the first proof set it sees; later calls only regenerate
-    the witness (same gate sequence) and prove."""
+    proofs of one inner circuit.  The first proof set fixes the layout (gate rows, selectors, sigmas) AND records
+    the witness tape; every later proof set is witnessed by gl355_witness_replay (C, about 10 ms) straight from
+    the inner proofs' flat words and proven by gl355_prove_sparse.  `prove_python` keeps the eager Python gadget
+    pass (tests cross-check the tape against it)."""
 
-    def __init__(self, ctx, inner_common, k=1, config=None):
+    def __init__(self, ctx, inner_common, k=1, config=None, public_inputs=wrap_public_inputs):
         self.ctx, self.cd, self.k, self.config = ctx, inner_common, k, config
+        self.pi_layout = public_inputs
         self.data = None
         self.structure = None
+        self.tape = None
 
     def _run(self, proofs):
         b = GadgetBuilder(self.config)
-        for p in proofs:
-            verify_proof(b, self.cd, p)
+        inner_pis = [verify_proof(b, self.cd, p, register_pis=False) for p in proofs]
+        self.pi_layout(b, inner_pis)
         pi_vals = b.finalize_public_inputs()
         return b, pi_vals
 
+    # ---- layout + tape from the first proof set ---------------------------------------------------------------
+    def build(self, flat_proofs, rng=None):
+        """flat_proofs: k pairs (flat proof words, public inputs) of VALID inner proofs"""
+        assert len(flat_proofs) == self.k and self.data is None
+        tagged, off = [], 0
+        for flat, pi in flat_proofs:
+            tagged.append(parse_proof_tagged(self.cd, flat, pi, off))
+            off += len(flat) + len(pi)
+        b, _ = self._run(tagged)
+        assert getattr(b, "untagged_inputs", 0) == 0
+        self.structure = b.structure_hash()
+        self.tape, self.row_idx, self.pi_pos = b.witness_tape()
+        self.data = b.cb.build(self.ctx, rng)
+        self.n_inputs = off
+        return self
+
+    def witness(self, flat_proofs):
+        """(rows uint64[n_rows][num_wires], public inputs) by tape replay; raises on an invalid inner proof"""
+        inputs = np.concatenate([np.concatenate([_u64(f), _u64(p)]) for f, p in flat_proofs])
+        assert inputs.size == self.n_inputs
+        nw = self.data.config.num_wires
+        rows = np.empty((self.row_idx.size, nw), dtype=np.uint64)
+        failed = C.c_uint64(0)
+        rc = self.ctx.lib.gl355_witness_replay(_ptr(self.tape), self.tape.shape[0], _ptr(inputs), inputs.size, _ptr(rows), rows.size,
+                                               nw, C.byref(failed))
+        if rc != 0:
+            raise AssertionError("witness generation failed (rc %d) at tape entry %d: %r" % (rc, failed.value, self.tape[failed.value] if failed.value < self.tape.shape[0] else None))
+        return rows, rows.reshape(-1)[self.pi_pos]
+
+    def prove_flat(self, flat_proofs, seed, rng=None, flat_only=True):
+        """-> (flat outer proof, outer public inputs) [or the parsed proof dict]"""
+        if self.data is None:
+            self.build(flat_proofs, rng)
+        rows, pis = self.witness(flat_proofs)
+        out = prove_sparse(self.ctx, self.data, self.row_idx, rows, pis, seed, flat_only=flat_only)
+        return (out, pis) if flat_only else out
+
+    # ---- the eager Python pass (parsed proof dicts) ---------------------------------------------------------
     def prove(self, proofs, seed, rng=None, flat_only=False):
         assert len(proofs) == self.k
         b, pi_vals = self._run(proofs)
@@ -416,3 +483,34 @@ class RecursiveCircuit:
         assert sh == self.structure, "recursive circuit layout depends on the proof values"
         idx, vals = b.sparse_witness()
         return prove_sparse(self.ctx, self.data, idx, vals, np.array(pi_vals, dtype=np.uint64), seed, flat_only=flat_only)
+
+
+class Aggregator:
+    """recursion.rs:187-247 `aggregate`: pairwise aggregation of 2^L signals into one proof.  Level l has its own
+    circuit (it verifies two proofs of level l-1; level 0 is the Semaphore circuit) built from the first pair it
+    sees; all pairs of a level are independent proofs."""
+
+    def __init__(self, ctx, signal_common, config=None):
+        self.ctx, self.config = ctx, config
+        self.levels = []            # RecursiveCircuit per level
+        self.commons = [signal_common]
+
+    def aggregate(self, signals, seed=1, rng=None):
+        """signals: list of (flat proof, public inputs), power-of-two many, all of the level-0 circuit and the
+        same Merkle root.  Returns (flat proof, public inputs, common data of the final circuit)."""
+        n = len(signals)
+        assert n >= 2 and n & (n - 1) == 0
+        level = 0
+        while len(signals) > 1:
+            if level == len(self.levels):
+                self.levels.append(RecursiveCircuit(self.ctx, self.commons[level], k=2, config=self.config,
+                                                    public_inputs=aggregate_public_inputs))
+            rc = self.levels[level]
+            nxt = []
+            for i in range(0, len(signals), 2):
+                nxt.append(rc.prove_flat(signals[i:i + 2], seed + i, rng))
+            if level + 1 == len(self.commons):
+                self.commons.append(rc.data.common())
+            signals = nxt
+            level += 1
+        return signals[0][0], signals[0][1], self.commons[level]

@@ -1,5 +1,6 @@
 """GPU: gadget builder + recursive verification (recursion.rs:25-185, wrapper.rs:35-56).  Every proof produced here
 must pass the restatement of the reference's verifier (tests/plonk_verifier.py)."""
+import ctypes as C
 import importlib
 
 import numpy as np
@@ -20,7 +21,10 @@ def test_gadget_circuit_proves_and_verifies(gl, ctx, orc):
     plonk = importlib.import_module("stark-verifier_amd.plonk")
     rng = np.random.default_rng(0x601)
     b = gad.GadgetBuilder()
-    xs = b.add_virtual_targets(rand_field(rng, 8))
+    inputs = rand_field(rng, 8 + 1 + 16 + 100)          # every free input is tagged with its position: the tape can replay them
+    inputs[8] = 1
+    tagged = [plonk.Src(v, i) for i, v in enumerate(inputs)]
+    xs = b.add_virtual_targets(tagged[:8])
     # base arithmetic
     s = b.add(b.mul(xs[0], xs[1]), xs[2])
     assert s.v == (xs[0].v * xs[1].v + xs[2].v) % P
@@ -36,7 +40,7 @@ def test_gadget_circuit_proves_and_verifies(gl, ctx, orc):
     # Poseidon sponge, swapped permutation
     h = b.hash_n_to_hash_no_pad(xs + xs[:3])
     assert [t.v for t in h] == [int(v) for v in orc.hash_no_pad(np.array([t.v for t in xs + xs[:3]], dtype=np.uint64))]
-    bit = b.add_virtual_target(1)
+    bit = b.add_virtual_target(tagged[8])
     b.assert_bool(bit)
     sw = b.permute_swapped(xs + [b.zero()] * 4, swap=bit)
     st = np.array([t.v for t in xs[4:8] + xs[0:4]] + [0] * 4, dtype=np.uint64)
@@ -45,11 +49,11 @@ def test_gadget_circuit_proves_and_verifies(gl, ctx, orc):
     bits = b.split_le_64(xs[5])
     assert sum(t.v << i for i, t in enumerate(bits)) == xs[5].v
     assert b.le_sum(bits[:12]).v == xs[5].v & 0xFFF
-    items = b.add_virtual_targets(rand_field(rng, 16))
+    items = b.add_virtual_targets(tagged[9:25])
     idx = b.le_sum(bits[:4])
     assert b.random_access(idx, items).v == items[idx.v].v
     alpha = (xs[6], xs[7])
-    coeffs = b.add_virtual_targets(rand_field(rng, 100))
+    coeffs = b.add_virtual_targets(tagged[25:125])
     red = b.reduce_with_powers_base(coeffs, alpha)
     assert (red[0].v, red[1].v) == pv.reduce_with_powers([pv.base(c.v) for c in coeffs], (alpha[0].v, alpha[1].v))
     ecoeffs = [(coeffs[2 * i], coeffs[2 * i + 1]) for i in range(40)]
@@ -62,6 +66,27 @@ def test_gadget_circuit_proves_and_verifies(gl, ctx, orc):
     idx_rows, vals = b.sparse_witness()
     proof = plonk.prove_sparse(ctx, data, idx_rows, vals, np.array(pi_vals, dtype=np.uint64), 7)
     pv.verify(orc, data.common(), proof)
+    # the recorded witness tape reproduces the witness (gl355_witness_replay), also for other inputs
+    tape, ridx, pi_pos = b.witness_tape()
+    assert np.array_equal(ridx, idx_rows) and getattr(b, "untagged_inputs", 0) == 0
+
+    def replay(inp):
+        rows = np.empty_like(vals)
+        failed = C.c_uint64(0)
+        rc = ctx.lib.gl355_witness_replay(tape.ctypes.data, tape.shape[0], inp.ctypes.data, inp.size, rows.ctypes.data, rows.size, 135, C.byref(failed))
+        return rc, rows, failed.value
+    rc, rows, _ = replay(inputs)
+    assert rc == 0 and np.array_equal(rows, vals)
+    assert [int(v) for v in rows.reshape(-1)[pi_pos]] == pi_vals
+    other = rand_field(rng, inputs.size)
+    other[8] = 0
+    rc, rows2, _ = replay(other)
+    assert rc == 0
+    pv.verify(orc, data.common(), plonk.prove_sparse(ctx, data, ridx, rows2, rows2.reshape(-1)[pi_pos], 8))
+    other[8] = 2                                        # not a bit: assert_bool's ASSERT_EQ entry fails
+    rc, _, failed = replay(other)
+    assert rc == -6 and tape[failed][0] == gad.TAPE_ASSERT_EQ
+    assert ctx.lib.gl355_witness_replay(tape.ctypes.data, tape.shape[0], inputs.ctypes.data, 5, rows.ctypes.data, rows.size, 135, None) == -1
     # a violated gate (wrong product in an ArithmeticGate slot) must not verify
     bad = vals.copy()
     arith_rows = [k for k, r in enumerate(idx_rows) if data.gates[data.row_gate[r]][0] == 5]
@@ -101,3 +126,70 @@ def test_recursive_proof_of_semaphore(gl, ctx, orc):
     pv.verify(orc, rc2.data.common(), p2)
     assert np.array_equal(p2["public_inputs"], sig.proof["public_inputs"])
     print("2nd-level recursive circuit: degree 2^%d" % rc2.data.degree_bits)
+
+
+def flat_signal(aset, sk, topic, index, seed):
+    sig, data = aset.make_signal_fast(sk, topic, index, seed, flat_only=True)
+    return (sig.proof, np.concatenate([aset.tree.cap[0], sig.nullifier[0], sig.topics[0]])), data
+
+
+def test_witness_tape_equals_python_pass(gl, ctx, orc):
+    """the recorded tape replayed in C on a new inner proof gives exactly the rows of the eager Python gadget pass;
+    an invalid inner proof is refused with GL355_E_WITNESS"""
+    rec = importlib.import_module("stark-verifier_amd.recursion")
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    aset, sks, rng = make_access_set(gl, ctx, 3, 0x603)
+    topic = rand_field(rng, 4)
+    s0, data = flat_signal(aset, sks[1], topic, 1, 5)
+    s1, _ = flat_signal(aset, sks[6], rand_field(rng, 4), 6, 6)
+    cd = data.common()
+    rc = rec.RecursiveCircuit(ctx, cd, k=1).build([s0], rng)
+    rows, pis = rc.witness([s1])
+    parsed = plonk.parse_proof(cd, s1[0])
+    parsed["public_inputs"] = s1[1]
+    b, pi_vals = rc._run([parsed])
+    assert b.structure_hash() == rc.structure
+    idx, vals = b.sparse_witness()
+    assert np.array_equal(idx, rc.row_idx) and np.array_equal(vals, rows)
+    assert [int(v) for v in pis] == pi_vals == [int(v) for v in s1[1]]
+    proof, pis2 = rc.prove_flat([s1], seed=9)
+    outer = plonk.parse_proof(rc.data, proof)
+    outer["public_inputs"] = pis2
+    pv.verify(orc, rc.data.common(), outer)
+    for word in (40, s1[0].size - 3):                   # a cap word / a Merkle sibling of the last query
+        bad = s1[0].copy()
+        bad[word] ^= np.uint64(1)
+        with pytest.raises(AssertionError):
+            rc.witness([(bad, s1[1])])
+    with pytest.raises(AssertionError):
+        badpi = s1[1].copy()
+        badpi[5] ^= np.uint64(4)
+        rc.witness([(s1[0], badpi)])
+
+
+def test_aggregate_four_signals(gl, ctx, orc):
+    """recursion.rs:187-247: 4 signals -> 2 level-1 proofs -> 1 level-2 proof; public inputs root | nullifiers | topics"""
+    rec = importlib.import_module("stark-verifier_amd.recursion")
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    aset, sks, rng = make_access_set(gl, ctx, 3, 0x604)
+    members = [2, 7, 0, 5]
+    topics = [rand_field(rng, 4) for _ in members]
+    sigs, data = [], None
+    for k, (m, t) in enumerate(zip(members, topics)):
+        s, data = flat_signal(aset, sks[m], t, m, 40 + k)
+        sigs.append(s)
+    agg = rec.Aggregator(ctx, data.common())
+    proof, pis, cd = agg.aggregate(sigs, seed=100, rng=rng)
+    outer = plonk.parse_proof(cd, proof)
+    outer["public_inputs"] = pis
+    pv.verify(orc, cd, outer)
+    assert pis.size == 4 + 16 + 16
+    assert np.array_equal(pis[:4], aset.tree.cap[0])
+    assert np.array_equal(pis[4:20], np.concatenate([s[1][4:8] for s in sigs]))
+    assert np.array_equal(pis[20:36], np.concatenate(topics))
+    print("aggregation circuits: level-1 degree 2^%d, level-2 degree 2^%d" % (agg.levels[0].data.degree_bits, agg.levels[1].data.degree_bits))
+    # a signal against another access set (different root) cannot be aggregated
+    aset2, sks2, _ = make_access_set(gl, ctx, 3, 0x605)
+    alien, _ = flat_signal(aset2, sks2[1], topics[0], 1, 77)
+    with pytest.raises(AssertionError):
+        agg.levels[0].witness([sigs[0], alien])
