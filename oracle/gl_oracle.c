@@ -6,6 +6,7 @@
  * Every function cites the reference location that pins its semantics.
  */
 #include "gl_oracle.h"
+#include "gl_inline.h"
 #include "poseidon_rc.h"
 
 #include <stdlib.h>
@@ -14,9 +15,6 @@
 #include <omp.h>
 #endif
 
-typedef unsigned __int128 u128;
-#define P ORC_P
-#define EPS UINT64_C(0xFFFFFFFF) /* 2^64 mod p */
 
 int orc_num_threads(void) {
 #ifdef _OPENMP
@@ -30,34 +28,10 @@ int orc_num_threads(void) {
  * a1 -- Goldilocks field, p = 2^64 - 2^32 + 1 (chip/native_chip/arithmetic_chip.rs:19).
  * Values are kept canonical everywhere in the oracle: simplest possible model.
  * ---------------------------------------------------------------------------------------- */
-static inline uint64_t canon(uint64_t a) { return a - (P & (uint64_t)(-(int64_t)(a >= P))); }
-
-static inline uint64_t f_add(uint64_t a, uint64_t b) {
-    a = canon(a); b = canon(b);
-    uint64_t s = a + b;
-    if (s < a || s >= P) s -= P;
-    return s;
-}
-static inline uint64_t f_sub(uint64_t a, uint64_t b) {
-    a = canon(a); b = canon(b);
-    return a >= b ? a - b : a + (P - b);
-}
 uint64_t orc_add(uint64_t a, uint64_t b) { return f_add(a, b); }
 uint64_t orc_sub(uint64_t a, uint64_t b) { return f_sub(a, b); }
 /* textbook model, kept so tests can pin the fast reduction below against plain `% p` */
 uint64_t orc_mul_ref(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) % P); }
-/* 2^64 = 2^32 - 1, 2^96 = -1 (mod p): x = lo + 2^64*hi_lo + 2^96*hi_hi = lo - hi_hi + EPS*hi_lo */
-static inline uint64_t reduce128(u128 x) {
-    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
-    uint64_t hi_hi = hi >> 32, hi_lo = hi & EPS;
-    uint64_t t0 = lo - hi_hi;
-    t0 -= EPS & (uint64_t)(-(int64_t)(lo < hi_hi));        /* branch-free: data is random */
-    uint64_t t1 = hi_lo * EPS;
-    uint64_t r = t0 + t1;
-    r += EPS & (uint64_t)(-(int64_t)(r < t1));
-    return canon(r);
-}
-static inline uint64_t f_mul(uint64_t a, uint64_t b) { return reduce128((u128)a * b); }
 uint64_t orc_mul(uint64_t a, uint64_t b) { return f_mul(a, b); }
 uint64_t orc_pow(uint64_t a, uint64_t e) {
     uint64_t r = 1; a = canon(a);
@@ -92,12 +66,6 @@ void orc_ext_inv(const uint64_t a[2], uint64_t out[2]) {
  * a5 -- bit reversal / transpose (plonky2_util; the reference calls reverse_index_bits_in_place
  * itself at chip/fri_chip.rs:6,189).
  * ---------------------------------------------------------------------------------------- */
-static inline size_t bitrev(size_t x, uint32_t bits) {
-    size_t r = 0;
-    for (uint32_t i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
-    return r;
-}
-static uint32_t log2_exact(size_t n) { uint32_t l = 0; while (((size_t)1 << l) < n) l++; return l; }
 
 void orc_reverse_index_bits(uint64_t *data, size_t n_rows, size_t row_len) {
     uint32_t bits = log2_exact(n_rows);

@@ -137,6 +137,49 @@ void orc_zs_partial_products(const uint64_t *wires, const uint64_t *sigmas, cons
                              uint32_t log_n, uint32_t n_routed, uint32_t max_degree,
                              uint64_t beta, uint64_t gamma, uint64_t *z_out, uint64_t *pp_out);
 
+/* ---- a9..a15 composite: the whole prove() on the CPU (gl_prover.c) -------------------------------
+ * Circuit shape: same fields and layout as the product's gl355_circuit (include/gl355.h), so a test can hand
+ * the same table to both sides. */
+#define ORC_MAX_GATES 16
+enum { ORC_GATE_NOOP = 0, ORC_GATE_CONSTANT = 1, ORC_GATE_PUBLIC_INPUT = 2, ORC_GATE_BASE_SUM = 3, ORC_GATE_POSEIDON = 4,
+       ORC_GATE_ARITHMETIC = 5, ORC_GATE_ARITHMETIC_EXT = 6, ORC_GATE_MUL_EXT = 7, ORC_GATE_POSEIDON_MDS = 8,
+       ORC_GATE_RANDOM_ACCESS = 9, ORC_GATE_REDUCING = 10, ORC_GATE_REDUCING_EXT = 11 };   /* gates/mod.rs:141-196 */
+typedef struct { uint32_t type, param, selector_index, group_start, group_end; } orc_gate;
+typedef struct {
+    uint32_t degree_bits, rate_bits, num_wires, num_routed_wires, num_constants, num_selectors, num_challenges, max_degree,
+        num_partial_products, num_gates;
+    orc_gate gates[ORC_MAX_GATES];
+} orc_circuit;
+/* a committed PolynomialBatch on the host: coeffs [batch][n], leaves [N][leaf_len] (row i = evaluations at
+ * 7 w^bitrev(i), salt last), digests / cap as orc_merkle_build */
+typedef struct {
+    uint32_t log_n, rate_bits, batch, leaf_len, cap_height;
+    uint64_t *coeffs, *leaves, *digests, *cap;
+} orc_batch;
+orc_batch *orc_batch_commit(const uint64_t *values, uint32_t log_n, uint32_t batch, uint32_t rate_bits, int is_coeffs,
+                            const uint64_t *salt, uint32_t cap_height);
+void orc_batch_free(orc_batch *b);
+typedef struct {
+    const orc_circuit *circuit;
+    const orc_batch *constants_sigmas;   /* [selectors | gate constants | sigmas], not salted */
+    const uint64_t *sigmas;              /* sigma values [num_routed_wires][n] */
+    const uint64_t *k_is;
+    uint64_t circuit_digest[4];
+    uint32_t cap_height, pow_bits, num_queries, n_fri_layers;
+    int32_t zero_knowledge;
+} orc_prover_data;
+/* vanishing polynomial / Z_H on the quotient coset, out[c][i] in NATURAL order of i (x = 7 w^i) */
+void orc_vanishing_values(const orc_circuit *c, const orc_batch *cs, const orc_batch *wires, const orc_batch *zs,
+                          const uint64_t *k_is, const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas,
+                          const uint64_t pi_hash[4], uint64_t *out);
+uint64_t orc_proof_words(const orc_prover_data *pd);
+/* flat proof in the layout of include/gl355.h; 0 on success */
+int orc_prove(const orc_prover_data *pd, const uint64_t *wires, const uint64_t *public_inputs, uint32_t n_pi, uint64_t seed,
+              uint64_t *proof);
+int orc_prove_sparse(const orc_prover_data *pd, const uint32_t *row_idx, const uint64_t *rows, uint32_t n_rows, uint32_t blind_start,
+                     uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs, const uint64_t *public_inputs, uint32_t n_pi,
+                     uint64_t seed, uint64_t *proof);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -230,3 +230,106 @@ def rand_field(rng, shape):
         a[bad] = rng.integers(0, 1 << 64, size=int(bad.sum()), dtype=np.uint64, endpoint=False)
         bad = a >= np.uint64(P)
     return a
+
+
+# ---- CPU prover (oracle/gl_prover.c) ---------------------------------------------------------------------
+class OrcGate(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("param", C.c_uint32), ("selector_index", C.c_uint32), ("group_start", C.c_uint32),
+                ("group_end", C.c_uint32)]
+
+
+class OrcCircuit(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("degree_bits", "rate_bits", "num_wires", "num_routed_wires", "num_constants",
+                                          "num_selectors", "num_challenges", "max_degree", "num_partial_products", "num_gates")] + \
+               [("gates", OrcGate * 16)]
+
+
+class OrcBatch(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("log_n", "rate_bits", "batch", "leaf_len", "cap_height")] + \
+               [(k, u64p) for k in ("coeffs", "leaves", "digests", "cap")]
+
+
+class OrcProverData(C.Structure):
+    _fields_ = [("circuit", C.POINTER(OrcCircuit)), ("constants_sigmas", C.POINTER(OrcBatch)), ("sigmas", u64p), ("k_is", u64p),
+                ("circuit_digest", C.c_uint64 * 4), ("cap_height", C.c_uint32), ("pow_bits", C.c_uint32), ("num_queries", C.c_uint32),
+                ("n_fri_layers", C.c_uint32), ("zero_knowledge", C.c_int32)]
+
+
+class CpuProver:
+    """orc_prove over the tables of a built circuit.  `shape`: the gl355_circuit-compatible ctypes struct (its bytes are
+    copied), constants [num_selectors + num_constants][n], sigmas [routed][n], k_is, circuit_digest and the FRI parameters."""
+
+    def __init__(self, orc, shape, constants, sigmas, k_is, circuit_digest, cap_height, pow_bits, num_queries, n_fri_layers,
+                 zero_knowledge, blind_rows=None):
+        L = self.L = orc.L
+        L.orc_batch_commit.restype = C.POINTER(OrcBatch)
+        L.orc_batch_commit.argtypes = [u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u64p, C.c_uint32]
+        L.orc_batch_free.argtypes = [C.POINTER(OrcBatch)]
+        L.orc_proof_words.restype = C.c_uint64
+        L.orc_proof_words.argtypes = [C.POINTER(OrcProverData)]
+        self.circuit = OrcCircuit.from_buffer_copy(bytes(shape))
+        self.sigmas, self.k_is = u64(sigmas), u64(k_is)
+        cs_values = u64(np.concatenate([u64(constants), self.sigmas]))
+        c = self.circuit
+        self.cs = L.orc_batch_commit(_p(cs_values), c.degree_bits, cs_values.shape[0], c.rate_bits, 0, None, cap_height)
+        pd = self.pd = OrcProverData()
+        pd.circuit = C.pointer(self.circuit)
+        pd.constants_sigmas = self.cs
+        pd.sigmas, pd.k_is = _p(self.sigmas), _p(self.k_is)
+        for i in range(4):
+            pd.circuit_digest[i] = int(circuit_digest[i])
+        pd.cap_height, pd.pow_bits, pd.num_queries, pd.n_fri_layers = cap_height, pow_bits, num_queries, n_fri_layers
+        pd.zero_knowledge = int(zero_knowledge)
+        self.blind_rows = blind_rows
+        self.words = L.orc_proof_words(C.byref(pd))
+
+    @classmethod
+    def from_circuit_data(cls, orc, data):
+        cfg = data.config
+        return cls(orc, data.c_circuit, data.constants, data.sigmas, data.k_is, data.circuit_digest, cfg.cap_height,
+                   cfg.proof_of_work_bits, cfg.num_query_rounds, len(data.fri_arity_bits), cfg.zero_knowledge, data.blind_rows)
+
+    def cap(self):
+        n_cap = 1 << self.pd.cap_height
+        return np.ctypeslib.as_array(self.cs.contents.cap, shape=(n_cap, 4)).copy()
+
+    def prove(self, wires, public_inputs, seed):
+        wires, pi = u64(wires), u64(public_inputs)
+        flat = np.zeros(self.words, dtype=np.uint64)
+        rc = self.L.orc_prove(C.byref(self.pd), _p(wires), _p(pi), C.c_uint32(pi.size), C.c_uint64(seed & ((1 << 64) - 1)), _p(flat))
+        assert rc == 0
+        return flat
+
+    def prove_sparse(self, row_idx, rows, public_inputs, seed):
+        idx = np.ascontiguousarray(row_idx, dtype=np.uint32)
+        rows, pi = u64(rows), u64(public_inputs)
+        start, n_blind, z_pairs, _ = self.blind_rows
+        z_start = z_pairs[0][0] if z_pairs else 0
+        flat = np.zeros(self.words, dtype=np.uint64)
+        rc = self.L.orc_prove_sparse(C.byref(self.pd), idx.ctypes.data_as(C.POINTER(C.c_uint32)), _p(rows), C.c_uint32(idx.size),
+                                     C.c_uint32(start), C.c_uint32(n_blind), C.c_uint32(z_start), C.c_uint32(len(z_pairs)), _p(pi),
+                                     C.c_uint32(pi.size), C.c_uint64(seed & ((1 << 64) - 1)), _p(flat))
+        assert rc == 0
+        return flat
+
+    def vanishing_values(self, wires_values, zs_values, betas, gammas, alphas, pi_hash, salt_w=None, salt_z=None):
+        """commits the given wire / Z value columns on the CPU and evaluates the quotient numerator / Z_H: [nch][n * max_degree]"""
+        c = self.circuit
+        L = self.L
+        wv, zv = u64(wires_values), u64(zs_values)
+        sw = _p(u64(salt_w)) if salt_w is not None else None
+        sz = _p(u64(salt_z)) if salt_z is not None else None
+        bw = L.orc_batch_commit(_p(wv), c.degree_bits, wv.shape[0], c.rate_bits, 0, sw, self.pd.cap_height)
+        bz = L.orc_batch_commit(_p(zv), c.degree_bits, zv.shape[0], c.rate_bits, 0, sz, self.pd.cap_height)
+        out = np.zeros((c.num_challenges, (1 << c.degree_bits) * c.max_degree), dtype=np.uint64)
+        L.orc_vanishing_values(C.byref(c), self.cs, bw, bz, _p(self.k_is), _p(u64(betas)), _p(u64(gammas)), _p(u64(alphas)),
+                               _p(u64(pi_hash)), _p(out))
+        L.orc_batch_free(bw)
+        L.orc_batch_free(bz)
+        return out
+
+    def __del__(self):
+        try:
+            self.L.orc_batch_free(self.cs)
+        except Exception:
+            pass

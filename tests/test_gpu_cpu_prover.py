@@ -1,0 +1,99 @@
+"""GPU: the flat proof of gl355_prove / gl355_prove_sparse is BYTE-IDENTICAL to the CPU restatement of plonky2's prove()
+(oracle/gl_prover.c) on the same circuit tables, witness and seed -- BASELINE.json configs[3]'s "bit-exact" requirement for
+the whole path (every oracle cap, every opening, FRI caps, final polynomial, PoW witness, all query openings)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+import plonk_verifier as pv
+from oracle_lib import CpuProver, rand_field
+from test_gpu_prover import make_access_set
+
+pytestmark = pytest.mark.gpu
+
+
+def first_diff(a, b):
+    d = np.nonzero(a != b)[0]
+    return "first differing word %d of %d (%d differ)" % (d[0], a.size, d.size) if d.size else "equal"
+
+
+@pytest.mark.parametrize("log_members", [2, 5])
+def test_semaphore_proof_byte_identical(gl, ctx, orc, log_members):
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    aset, sks, rng = make_access_set(gl, ctx, log_members, 0x701)
+    data, rows = aset.build(rng)
+    cpu = CpuProver.from_circuit_data(orc, data)
+    assert np.array_equal(cpu.cap(), data.constants_sigmas.cap)                     # preprocessed commitment
+    topic = rand_field(rng, 4)
+    # dense witness (blinding rows drawn by the caller)
+    wires, pi = aset.fill_semaphore_targets(data, rows, sks[1], topic, 1, np.random.default_rng(5))
+    g = plonk.prove(ctx, data, wires, pi, 42, flat_only=True)
+    c = cpu.prove(wires, pi, 42)
+    assert np.array_equal(g, c), first_diff(g, c)
+    # sparse witness (blinding rows derived from the seed on both sides)
+    idx, vals, pi2 = aset.witness_rows(rows, sks[3], topic, 3)
+    g = plonk.prove_sparse(ctx, data, idx, vals, pi2, 77, flat_only=True)
+    c = cpu.prove_sparse(idx, vals, pi2, 77)
+    assert np.array_equal(g, c), first_diff(g, c)
+    proof = plonk.parse_proof(data, c)
+    proof["public_inputs"] = pi2
+    pv.verify(orc, data.common(), proof)                                          # and the CPU proof verifies
+
+
+def test_quotient_values_equal_cpu_vanishing_values(gl, ctx, orc):
+    """a10 at full size: gl355_quotient_values (storage order = bit-reversed rows) == orc_vanishing_values on every point of
+    the quotient coset, salted oracles, Semaphore circuit."""
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    api = importlib.import_module("stark-verifier_amd.api")
+    aset, sks, rng = make_access_set(gl, ctx, 4, 0x702)
+    data, rows = aset.build(rng)
+    cfg = data.config
+    cpu = CpuProver.from_circuit_data(orc, data)
+    wires, pi = aset.fill_semaphore_targets(data, rows, sks[6], rand_field(rng, 4), 6, np.random.default_rng(6))
+    n, N = 1 << data.degree_bits, 1 << (data.degree_bits + cfg.rate_bits)
+    nch = cfg.num_challenges
+    betas, gammas, alphas = rand_field(rng, nch), rand_field(rng, nch), rand_field(rng, nch)
+    pi_hash = orc.hash_no_pad(pi)
+    zs = []
+    pps = []
+    for k in range(nch):
+        z, pp = orc.zs_partial_products(wires[:cfg.num_routed_wires], data.sigmas, data.k_is, cfg.max_quotient_degree_factor,
+                                        int(betas[k]), int(gammas[k]))
+        zs.append(z)
+        pps.append(pp)
+    zvals = np.concatenate([np.stack(zs)] + pps)
+    salt_w, salt_z = rand_field(rng, (4, N)), rand_field(rng, (4, N))
+    want = cpu.vanishing_values(wires, zvals, betas, gammas, alphas, pi_hash, salt_w, salt_z)
+    bw = api.PolynomialBatch.from_values(ctx, wires, cfg.rate_bits, cfg.cap_height, salt=salt_w)
+    bz = api.PolynomialBatch.from_values(ctx, zvals, cfg.rate_bits, cfg.cap_height, salt=salt_z)
+    nq = n * cfg.max_quotient_degree_factor
+    got = np.zeros((nch, nq), dtype=np.uint64)
+    lib = ctx.lib
+    k_is = np.ascontiguousarray(data.k_is)
+    ctx.check(lib.gl355_quotient_values(ctx.h, C.byref(data.c_circuit), data.constants_sigmas.h, bw.h, bz.h, k_is.ctypes.data,
+                                        betas.ctypes.data, gammas.ctypes.data, alphas.ctypes.data, pi_hash.ctypes.data, got.ctypes.data))
+    bits = nq.bit_length() - 1
+    rev = np.array([int(format(i, "0%db" % bits)[::-1], 2) for i in range(nq)])
+    assert np.array_equal(got[:, rev], want)
+    # the witness satisfies the circuit: the values are a polynomial of degree < nq - n ... checked end-to-end by the verifier
+    # tests; here additionally a broken witness changes the values
+    wires[30, rows["null"]] ^= np.uint64(1)
+    assert not np.array_equal(cpu.vanishing_values(wires, zvals, betas, gammas, alphas, pi_hash, salt_w, salt_z), want)
+
+
+def test_recursive_proof_byte_identical(gl, ctx, orc):
+    """the recursive verifier circuit (all 11 gate kinds, degree 2^14): GPU proof == CPU proof, byte for byte"""
+    rec = importlib.import_module("stark-verifier_amd.recursion")
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    aset, sks, rng = make_access_set(gl, ctx, 3, 0x703)
+    topic = rand_field(rng, 4)
+    sig, data = aset.make_signal_fast(sks[2], topic, 2, 5, flat_only=True)
+    inner = (sig.proof, np.concatenate([aset.tree.cap[0], sig.nullifier[0], sig.topics[0]]))
+    rc = rec.RecursiveCircuit(ctx, data.common(), k=1).build([inner], rng)
+    rows, pis = rc.witness([inner])
+    g = plonk.prove_sparse(ctx, rc.data, rc.row_idx, rows, pis, 11, flat_only=True)
+    cpu = CpuProver.from_circuit_data(orc, rc.data)
+    c = cpu.prove_sparse(rc.row_idx, rows, pis, 11)
+    assert np.array_equal(g, c), first_diff(g, c)
