@@ -126,7 +126,16 @@ class CircuitBuilder:
         self.copies.append((a, b))
 
     def build(self, ctx, rng, min_degree_bits=0):
-        """Pads (blinding rows + noops), computes selectors / sigmas and commits constants_sigmas."""
+        """Pads (blinding rows + noops), computes selectors / sigmas and commits constants_sigmas on the device."""
+        data = self.layout(min_degree_bits)
+        cs_values = np.concatenate([data.constants, data.sigmas])
+        data.constants_sigmas = PolynomialBatch.from_values(ctx, cs_values, self.config.rate_bits, self.config.cap_height, salt=None)
+        data.set_digest(data.constants_sigmas.cap)
+        return data
+
+    def layout(self, min_degree_bits=0):
+        """The host-only part of build(): padding, selector groups, constants and sigma tables, the gl355_circuit
+        shape.  No device work; the preprocessed commitment (and the digest that covers it) is added by build()."""
         cfg = self.config
         noop = self.gate_type(GATE_NOOP)
         n_real = len(self.rows)
@@ -211,8 +220,6 @@ class CircuitBuilder:
             sigmas[j] = np.array(col, dtype=np.uint64)
         for (r, c), (r2, c2) in sigma_map.items():
             sigmas[c, r] = (k_is[c2] * int(subgroup[r2])) % P
-        cs_values = np.concatenate([consts, sigmas])
-        cs_batch = PolynomialBatch.from_values(ctx, cs_values, cfg.rate_bits, cfg.cap_height, salt=None)
         data = CircuitData()
         data.config, data.degree_bits, data.gates, data.groups, data.selector_indices = cfg, degree_bits, gates, groups, sel_index
         data.num_selectors = num_selectors
@@ -220,16 +227,13 @@ class CircuitBuilder:
         data.sigmas = sigmas
         data.constants = consts
         data.row_gate = row_gate
-        data.constants_sigmas = cs_batch
+        data.constants_sigmas = None
         data.copy_classes = [m for m in classes.values() if len(m) > 1]
         data.blind_rows = (blind_start, n_blind_wires, z_pairs, n_real)
         data.num_partial_products = (routed + cfg.max_quotient_degree_factor - 1) // cfg.max_quotient_degree_factor - 1
         data.num_gate_constraints = max([_GATE_CONSTRAINTS[t](p) for t, p in gates] + [0])
         data.fri_arity_bits = cfg.fri_reduction_arity_bits(degree_bits)
-        # circuit digest: hash of the preprocessed commitment and the shape (this framework's own
-        # definition; plonky2's digest additionally covers its builder's domain separator)
-        shape = [degree_bits, len(gates), num_selectors] + [t * 1000 + p for t, p in gates]
-        data.circuit_digest = host_hash_no_pad(np.concatenate([cs_batch.cap.reshape(-1), np.array(shape, dtype=np.uint64)]))
+        data.circuit_digest = None
         cc = _CCircuit()
         cc.degree_bits, cc.rate_bits = degree_bits, cfg.rate_bits
         cc.num_wires, cc.num_routed_wires, cc.num_constants = cfg.num_wires, routed, cfg.num_constants
@@ -259,6 +263,14 @@ _GATE_CONSTRAINTS = {
 
 class CircuitData:
     """The prover/verifier data of one built circuit (plonky2 CircuitData / CommonCircuitData)."""
+
+    def set_digest(self, constants_sigmas_cap):
+        """circuit digest: hash of the preprocessed commitment and the shape (this framework's own definition;
+        plonky2's digest additionally covers its builder's domain separator)"""
+        shape = [self.degree_bits, len(self.gates), self.num_selectors] + [t * 1000 + p for t, p in self.gates]
+        self.constants_sigmas_cap = np.array(constants_sigmas_cap, dtype=np.uint64).reshape(-1, 4)
+        self.circuit_digest = host_hash_no_pad(np.concatenate([np.asarray(constants_sigmas_cap, dtype=np.uint64).reshape(-1),
+                                                               np.array(shape, dtype=np.uint64)]))
 
     def prover_data(self, ctx):
         """gl355_prover_data with the sigma values and k_is resident on the device (uploaded once)."""
@@ -295,7 +307,7 @@ class CircuitData:
                     pow_bits=cfg.proof_of_work_bits, num_query_rounds=cfg.num_query_rounds,
                     arity_bits=list(self.fri_arity_bits), hiding=cfg.zero_knowledge,
                     circuit_digest=[int(x) for x in self.circuit_digest],
-                    constants_sigmas_cap=self.constants_sigmas.cap.copy())
+                    constants_sigmas_cap=self.constants_sigmas_cap.copy())
 
 
 def fill_blinding(data, wires, rng):

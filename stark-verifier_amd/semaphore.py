@@ -19,6 +19,51 @@ from .plonk import (CircuitBuilder, CircuitConfig, check_copy_constraints, fill_
 IN, OUT, SWAP = 0, 12, 24   # PoseidonGate wire offsets (chip/plonk/gates/poseidon.rs:329-345)
 
 
+def semaphore_circuit(builder, h):
+    """circuit.rs:25-65 for a tree of height h: gate rows + copy constraints; returns the row map"""
+    b = builder
+    r = dict()
+    r["pi"] = b.add_gate(GATE_PUBLIC_INPUT)
+    r["h1"] = b.add_gate(GATE_POSEIDON)      # public-input hash, permutation 1 (inputs pi[0..8])
+    r["h2"] = b.add_gate(GATE_POSEIDON)      # permutation 2 (pi[8..12] overwrite lanes 0..3)
+    r["bits"] = b.add_gate(GATE_BASE_SUM, h)  # split_le(public_key_index, h)
+    r["leaf"] = b.add_gate(GATE_POSEIDON)    # public key = H(private_key | 0^4)
+    r["m"] = [b.add_gate(GATE_POSEIDON) for _ in range(h)]
+    r["null"] = b.add_gate(GATE_POSEIDON)    # nullifier = H(private_key | topic)
+    r["zero"] = b.add_gate(GATE_CONSTANT, 2, constants=(0, 0))
+    zero = (r["zero"], 0)
+    # public-input hash chain and PublicInputGate
+    for j in range(8, 12):
+        b.connect((r["h1"], IN + j), zero)
+    for j in range(4, 12):
+        b.connect((r["h1"], OUT + j), (r["h2"], IN + j))
+    for j in range(4):
+        b.connect((r["h2"], OUT + j), (r["pi"], j))
+    for row in (r["h1"], r["h2"], r["leaf"], r["null"]):
+        b.connect((row, SWAP), zero)
+    # leaf hash
+    for j in range(4, 12):
+        b.connect((r["leaf"], IN + j), zero)
+    # Merkle path: state in lanes 0..3, sibling in 4..7, swap = index bit (merkle_proof_chip.rs:58-70)
+    prev = r["leaf"]
+    for i, row in enumerate(r["m"]):
+        for j in range(4):
+            b.connect((row, IN + j), (prev, OUT + j))
+        for j in range(8, 12):
+            b.connect((row, IN + j), zero)
+        b.connect((row, SWAP), (r["bits"], 1 + i))
+        prev = row
+    # public inputs: root | nullifier | topic
+    for j in range(4):
+        b.connect((r["h1"], IN + j), (prev, OUT + j))                 # merkle_root
+        b.connect((r["h1"], IN + 4 + j), (r["null"], OUT + j))        # nullifier
+        b.connect((r["h2"], IN + j), (r["null"], IN + 4 + j))         # topic
+        b.connect((r["null"], IN + j), (r["leaf"], IN + j))           # private key
+    for j in range(8, 12):
+        b.connect((r["null"], IN + j), zero)
+    return r
+
+
 class Signal:
     """signal.rs:11-15"""
 
@@ -44,48 +89,7 @@ class AccessSet:
 
     # ---- circuit.rs:25-65 ------------------------------------------------------------------------------
     def semaphore_circuit(self, builder):
-        h = self.tree_height()
-        b = builder
-        r = dict()
-        r["pi"] = b.add_gate(GATE_PUBLIC_INPUT)
-        r["h1"] = b.add_gate(GATE_POSEIDON)      # public-input hash, permutation 1 (inputs pi[0..8])
-        r["h2"] = b.add_gate(GATE_POSEIDON)      # permutation 2 (pi[8..12] overwrite lanes 0..3)
-        r["bits"] = b.add_gate(GATE_BASE_SUM, h)  # split_le(public_key_index, h)
-        r["leaf"] = b.add_gate(GATE_POSEIDON)    # public key = H(private_key | 0^4)
-        r["m"] = [b.add_gate(GATE_POSEIDON) for _ in range(h)]
-        r["null"] = b.add_gate(GATE_POSEIDON)    # nullifier = H(private_key | topic)
-        r["zero"] = b.add_gate(GATE_CONSTANT, 2, constants=(0, 0))
-        zero = (r["zero"], 0)
-        # public-input hash chain and PublicInputGate
-        for j in range(8, 12):
-            b.connect((r["h1"], IN + j), zero)
-        for j in range(4, 12):
-            b.connect((r["h1"], OUT + j), (r["h2"], IN + j))
-        for j in range(4):
-            b.connect((r["h2"], OUT + j), (r["pi"], j))
-        for row in (r["h1"], r["h2"], r["leaf"], r["null"]):
-            b.connect((row, SWAP), zero)
-        # leaf hash
-        for j in range(4, 12):
-            b.connect((r["leaf"], IN + j), zero)
-        # Merkle path: state in lanes 0..3, sibling in 4..7, swap = index bit (merkle_proof_chip.rs:58-70)
-        prev = r["leaf"]
-        for i, row in enumerate(r["m"]):
-            for j in range(4):
-                b.connect((row, IN + j), (prev, OUT + j))
-            for j in range(8, 12):
-                b.connect((row, IN + j), zero)
-            b.connect((row, SWAP), (r["bits"], 1 + i))
-            prev = row
-        # public inputs: root | nullifier | topic
-        for j in range(4):
-            b.connect((r["h1"], IN + j), (prev, OUT + j))                 # merkle_root
-            b.connect((r["h1"], IN + 4 + j), (r["null"], OUT + j))        # nullifier
-            b.connect((r["h2"], IN + j), (r["null"], IN + 4 + j))         # topic
-            b.connect((r["null"], IN + j), (r["leaf"], IN + j))           # private key
-        for j in range(8, 12):
-            b.connect((r["null"], IN + j), zero)
-        return r
+        return semaphore_circuit(builder, self.tree_height())
 
     # ---- circuit.rs:67-99 ---------------------------------------------------------------------------------
     def fill_semaphore_targets(self, data, rows, private_key, topic, public_key_index, rng):

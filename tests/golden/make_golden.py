@@ -7,6 +7,9 @@
                       to write if the model disagrees with the transcribed expected words.
   conventions.json    tiny convention vectors + small NTT / LDE / Merkle / FRI
                       cases computed FROM THE DEFINITION by tests/pymodel.py (no oracle, no GPU).
+  semaphore_proof.json  SHA-256 of the flat proof of one depth-2 Semaphore signal (tests/cpu_semaphore.py GOLDEN_CASE),
+                      minted by the CPU restatement of prove() AFTER the restated reference verifier accepted it; the
+                      CPU suite re-derives it, the GPU suite requires the product's proof to hash to the same value.
 Run: python tests/golden/make_golden.py
 """
 import json
@@ -35,7 +38,22 @@ UPSTREAM = {
 }
 
 
+def mint_semaphore_proof():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import cpu_semaphore as cs
+    import plonk_verifier as pv
+    from oracle_lib import Oracle
+    orc = Oracle()
+    case, topic, (idx, vals, pi), flat = cs.golden_proof(orc)
+    proof = case["plonk"].parse_proof(case["data"], flat)
+    proof["public_inputs"] = pi
+    pv.verify(orc, case["data"].common(), proof)          # refuse to mint a proof the restated reference verifier rejects
+    json.dump({"case": cs.GOLDEN_CASE, "words": int(flat.size), "sha256": cs.digest_of(flat),
+               "public_inputs": ["%016x" % int(x) for x in pi]}, open(os.path.join(HERE, "semaphore_proof.json"), "w"), indent=1)
+
+
 def main():
+    mint_semaphore_proof()
     kat = {"permute": []}
     for name, (inp, want) in UPSTREAM.items():
         got = pm.permute(inp)

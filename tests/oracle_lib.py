@@ -277,7 +277,7 @@ class CpuProver:
         pd.constants_sigmas = self.cs
         pd.sigmas, pd.k_is = _p(self.sigmas), _p(self.k_is)
         for i in range(4):
-            pd.circuit_digest[i] = int(circuit_digest[i])
+            pd.circuit_digest[i] = int(circuit_digest[i]) if circuit_digest is not None else 0
         pd.cap_height, pd.pow_bits, pd.num_queries, pd.n_fri_layers = cap_height, pow_bits, num_queries, n_fri_layers
         pd.zero_knowledge = int(zero_knowledge)
         self.blind_rows = blind_rows

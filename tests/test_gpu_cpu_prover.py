@@ -97,3 +97,26 @@ def test_recursive_proof_byte_identical(gl, ctx, orc):
     cpu = CpuProver.from_circuit_data(orc, rc.data)
     c = cpu.prove_sparse(rc.row_idx, rows, pis, 11)
     assert np.array_equal(g, c), first_diff(g, c)
+
+
+def test_product_proof_hashes_to_the_committed_golden(gl, ctx, orc):
+    """tests/golden/semaphore_proof.json (minted by the CPU prover once the restated reference verifier accepted the proof):
+    the product, built and proven independently on the GPU for the same access set / member / topic / seed, must produce
+    exactly those bytes."""
+    import json
+    import os
+    import cpu_semaphore as cs
+    sem = importlib.import_module("stark-verifier_amd.semaphore")
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    g = cs.GOLDEN_CASE
+    rng = np.random.default_rng(g["seed"])
+    sks = rand_field(rng, (1 << g["log_members"], 4))
+    keys = ctx.hash_no_pad(np.concatenate([sks, np.zeros_like(sks)], axis=1))
+    aset = sem.AccessSet(ctx, keys)
+    topic = rand_field(rng, 4)
+    data, rows = aset.build(None)
+    idx, vals, pi = aset.witness_rows(rows, sks[g["member"]], topic, g["member"])
+    flat = plonk.prove_sparse(ctx, data, idx, vals, pi, g["proof_seed"], flat_only=True)
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "semaphore_proof.json")))
+    assert [int(x) for x in pi] == [int(x, 16) for x in golden["public_inputs"]]
+    assert int(flat.size) == golden["words"] and cs.digest_of(flat) == golden["sha256"]
