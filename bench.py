@@ -3,15 +3,18 @@
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-Workload (BASELINE.json configs[1]): 2^20-point Goldilocks LDE, blowup 8 -- B = 135 columns
-("wires"-shaped batch, access_set.rs:73) of n = 2^17 coefficients each are extended to N = 2^20
-evaluations on the coset 7<omega_N>, written in commitment (bit-reversed) order.  One step = one
-such batch per GPU, inputs and outputs resident in HBM.  value = algorithmic GB/s of the whole job:
-8*B*(n+N) bytes per step per GPU (one read of the coefficients + one write of the evaluations).
+Default workload `recursive` (BASELINE.json metric "recursive plonky2 proofs/sec (Semaphore d=20)", configs[3]; sharded
+over ranks it is configs[4]): one UNIT = one depth-20 Semaphore signal (make_signal, access_set.rs:61-104: witness, proof at
+n = 2^13, blowup 8, 28 queries, 16 PoW bits, zero-knowledge) PLUS the recursive proof that verifies it in-circuit
+(wrapper.rs:35-56 with the Poseidon-Goldilocks config; witness by tape replay, proof at n = 2^14).  One step = U units per
+GPU, proven by K concurrent prover contexts (one HIP stream + one host thread each), followed by the gather of the
+(nullifier | topic) leaves and the Poseidon aggregation root -- the job's only exchange (RCCL all_gather, 64 B per unit).
+value = units (= recursive proofs) per second of the whole job.  The roofline object is the kernel group with the largest
+HIP-event time inside the timed region: algorithmic bytes of its launches over their summed duration.
 
-Multi-GPU: the batch shards by columns/batches with no data-path collective (weak scaling); after
-the timed steps every rank contributes one Poseidon digest of its result and rank 0 folds the
-gathered digests into an aggregation root with the HIP Merkle kernel (RCCL all_gather of 32 B/rank).
+`--workload lde` (configs[1]): 2^20-point Goldilocks LDE, blowup 8, 135 columns, value in algorithmic GB/s; also run for a
+few steps after the default workload and reported as `ntt_lde` (the metric's "NTT HBM GB/s" half).
+`--workload semaphore`: the signals alone, no recursive proof.
 """
 import argparse
 import ctypes as C
@@ -59,8 +62,7 @@ def cpu_baseline(seconds=4.0):
 
 class SemaphoreProvers:
     """K concurrent prover contexts (one HIP stream each) on one GPU proving depth-20 Semaphore signals
-    (make_signal, access_set.rs:61-104): the unit of BASELINE's proofs/s metric, without the recursive wrap
-    (the recursive verifier circuit is not built yet -- DESIGN.md section 7)."""
+    (make_signal, access_set.rs:61-104), without the recursive proof."""
 
     def __init__(self, gl, device, threads, log_members=20, seed=0x357):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -99,20 +101,277 @@ class SemaphoreProvers:
         return leaves
 
 
+class RecursiveProvers(SemaphoreProvers):
+    """The same K contexts; a unit = a Semaphore signal + the recursive proof verifying it (wrapper.rs:35-56 over the
+    Poseidon-Goldilocks config).  The recursive circuit (layout, selectors, sigmas, preprocessed commitment) and its witness
+    tape are built once from the first signal and shared by all contexts; per unit the host thread runs
+    gl355_semaphore_witness -> gl355_prove_sparse (n = 2^13) -> gl355_witness_replay -> gl355_prove_sparse (n = 2^14)."""
+
+    def __init__(self, gl, device, threads, log_members=20, seed=0x357):
+        super().__init__(gl, device, threads, log_members, seed)
+        rec = importlib.import_module("stark-verifier_amd.recursion")
+        self.plonk = importlib.import_module("stark-verifier_amd.plonk")
+        a0 = self.sets[0]
+        sig, data = a0.make_signal_fast(self.sks[0], self.topic, 0, 1, flat_only=True)
+        self.inner_data = data
+        first = (sig.proof, np.concatenate([self.root, sig.nullifier[0], self.topic]))
+        self.rc = rec.RecursiveCircuit(a0.ctx, data.common(), k=1).build([first], np.random.default_rng(2))
+        self.last = None
+        self.units_done = [0] * threads
+        for t in range(threads):                              # per-context prover data + warm-up of the 2^14 pipeline
+            self.unit(t, t)
+
+    def unit(self, t, i):
+        a = self.sets[t]
+        sig, _ = a.make_signal_fast(self.sks[i], self.topic, i, 0x358 + i, flat_only=True)
+        inner = (sig.proof, np.concatenate([self.root, sig.nullifier[0], self.topic]))
+        rows, pis = self.rc.witness([inner])
+        outer = self.plonk.prove_sparse(a.ctx, self.rc.data, self.rc.row_idx, rows, pis, 0x359 + i, flat_only=True)
+        self.last = (inner, rows, pis, outer)
+        self.units_done[t] += 1
+        return pis[4:12]                                      # nullifier | topic, re-exposed by the recursive proof
+
+    def prove_batch(self, first, count):
+        import threading
+        k = len(self.sets)
+        leaves = np.zeros((count, 8), dtype=np.uint64)
+        errors = []
+
+        def worker(t):
+            try:
+                for j in range(t, count, k):
+                    leaves[j] = self.unit(t, (first + j) % self.sks.shape[0])
+            except Exception as exc:                          # surface worker failures in the main thread
+                errors.append(exc)
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(k)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        if errors:
+            raise errors[0]
+        return leaves
+
+    def profile(self, on, contexts=1):
+        """HIP-event scopes on the first `contexts` prover contexts only: an event pair per launch on all 12 streams costs
+        ~10 % throughput (extra barrier packets between back-to-back kernels); one stream's launches are a 1/12 sample of
+        the same timed region."""
+        self.prof_ctx = list(range(min(contexts, len(self.sets)))) if on else []
+        for t, a in enumerate(self.sets):
+            a.ctx.profile_enable(on and t in self.prof_ctx)
+            a.ctx.profile_read()
+        self.units_mark = list(self.units_done)
+
+    def profile_read(self):
+        """({kernel group: (launches, ms, algorithmic bytes)}, units proven by the profiled contexts since profile(True))"""
+        agg = {}
+        for t in self.prof_ctx:
+            for name, (cnt, ms, nbytes) in self.sets[t].ctx.profile_read().items():
+                c0, m0, b0 = agg.get(name, (0, 0.0, 0))
+                agg[name] = (c0 + cnt, m0 + ms, b0 + nbytes)
+        return agg, sum(self.units_done[t] - self.units_mark[t] for t in self.prof_ctx)
+
+
+def cpu_baseline_recursive(pr, units=1):
+    """The CPU restatement of prove() (oracle/gl_prover.c, OpenMP) on the same two circuits and witnesses: `units` signals +
+    recursive proofs, proofs only (the witnesses are handed over ready-made)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import CpuProver, Oracle
+    orc = Oracle()
+    threads = orc.L.orc_num_threads()
+    t_build = time.perf_counter()
+    cpu_in = CpuProver.from_circuit_data(orc, pr.inner_data)
+    cpu_out = CpuProver.from_circuit_data(orc, pr.rc.data)
+    t_build = time.perf_counter() - t_build
+    a = pr.sets[0]
+    _, rows = a.build(None)
+    idx, vals, pi = a.witness_rows(rows, pr.sks[5], pr.topic, 5)
+    inner, wrows, wpis, outer = pr.last
+    t0 = time.perf_counter()
+    same = True
+    for u in range(units):
+        flat_in = cpu_in.prove_sparse(idx, vals, pi, 7 + u)
+        flat_out = cpu_out.prove_sparse(pr.rc.row_idx, wrows, wpis, 9 + u)
+    dt = time.perf_counter() - t0
+    # bit-exactness of the product against this baseline on the very same inputs (seed of the last unit)
+    g_in = pr.plonk.prove_sparse(a.ctx, pr.inner_data, idx, vals, pi, 7 + units - 1, flat_only=True)
+    g_out = pr.plonk.prove_sparse(a.ctx, pr.rc.data, pr.rc.row_idx, wrows, wpis, 9 + units - 1, flat_only=True)
+    same = bool(np.array_equal(g_in, flat_in) and np.array_equal(g_out, flat_out))
+    return {"value": round(units / dt, 4), "unit": "recursive proofs/s", "cores": int(threads), "kind": "port",
+            "byte_identical_to_gpu_proofs": same,
+            "sample": "%d unit(s): Semaphore proof (n=2^13) + recursive proof (n=2^%d) by the C restatement of plonky2's prove() "
+                      "(oracle/gl_prover.c, OpenMP, %d threads), witnesses given, preprocessed commitments prebuilt (%.1f s, untimed); "
+                      "%.2f s wall.  Not the Rust binary (no Rust toolchain here); reference README: ~0.14 recursive proofs/s "
+                      "on 16 vCPU" % (units, pr.rc.data.degree_bits, threads, t_build, dt)}
+
+
+def lde_figure(gl, device, steps=8):
+    """BASELINE configs[1] on this GPU, a few steps: the metric's 'NTT HBM GB/s' half (full treatment: --workload lde)."""
+    import torch
+    ctx = gl.Context(device)
+    lib = ctx.lib
+    n, N = 1 << LOG_N, 1 << (LOG_N + RATE_BITS)
+    dev = torch.device("cuda", device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x355)
+    coeffs = torch.randint(0, (1 << 63) - 1, (BATCH, n), dtype=torch.int64, device=dev, generator=g)
+    out = torch.empty((BATCH, N), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.check(lib.gl355_lde_bitrev(ctx.h, C.c_void_p(coeffs.data_ptr()), LOG_N, RATE_BITS, 7, BATCH, C.c_void_p(out.data_ptr())))
+    for _ in range(2):
+        step()
+    ctx.sync()
+    ctx.profile_enable(True)
+    ctx.profile_read()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    alg = 8.0 * BATCH * (n + N)
+    kern_ms = sum(v[1] / max(1, v[0]) for k, v in prof.items() if k.startswith("ntt_"))
+    ach = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    del coeffs, out
+    ctx.close()
+    return {"value": round(alg * steps / dt / 1e9, 2), "unit": "GB/s", "steps": steps,
+            "workload": "lde n=2^17 -> N=2^20, 135 columns, bit-reversed output, resident operands",
+            "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "kernels_ms_per_launch": {k: round(v[1] / max(1, v[0]), 4) for k, v in prof.items()}}}
+
+
+def main_recursive(args):
+    """units sharded over ranks (recursion.rs:300-308: one block of members per GPU), no collective on the data path; one RCCL
+    all_gather of the (nullifier | topic) leaves per step and the aggregation root on rank 0."""
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    gl = importlib.import_module("stark-verifier_amd")
+    par = importlib.import_module("stark-verifier_amd.parallel")
+    pr = RecursiveProvers(gl, local_rank, args.threads, args.log_members)
+    per = args.proofs_per_step
+    total = per * world
+    lo, hi = par.shard_range(total, rank, world)
+    for w in range(args.warmup):
+        pr.prove_batch(1000 + w * total + lo, hi - lo)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    pr.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    root = None
+    for step in range(args.steps):
+        leaves = pr.prove_batch(5000 + step * total + lo, hi - lo)
+        lt = torch.from_numpy(leaves.view(np.int64)).to(dev)
+        allv = par.gather_leaves(lt, dist)
+        if rank == 0:
+            root = par.aggregation_root(pr.sets[0].ctx, allv.cpu().numpy().view(np.uint64))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, local_units = pr.profile_read()
+    pr.profile(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        units = total * args.steps
+        dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, 0.0, 0))
+        dname, (dcnt, dms, dbytes) = dom
+        ach = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+        gpu_ms = sum(v[1] for v in prof.values())
+        line = {
+            "metric": "recursive plonky2 proofs/sec (Semaphore d=%d)" % args.log_members,
+            "value": round(units / elapsed, 2), "unit": "recursive proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
+            "config": {"workload": "recursive: per unit one Semaphore signal (group 2^%d, n=2^13, blowup 8, 28 FRI queries, 16 PoW bits, "
+                                   "zk) + the recursive proof verifying it (n=2^%d, same FRI parameters); %d units per GPU per step, %d "
+                                   "prover contexts per GPU; all_gather of (nullifier|topic) + Poseidon aggregation root per step"
+                                   % (args.log_members, pr.rc.data.degree_bits, per, args.threads),
+                       "parallelism": "independent proofs sharded over ranks, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel": dname, "launches": dcnt, "avg_launch_ms": round(dms / max(1, dcnt), 4),
+                         "algorithmic_bytes_per_launch": round(dbytes / max(1, dcnt)),
+                         "note": "HIP events on 1 of the %d concurrent prover streams inside the timed region (durations include sharing the "
+                                 "GPU with the other streams); the kernel is integer-VALU bound (Poseidon: ~1.1k Goldilocks modmuls per "
+                                 "permutation, no MFMA form) -- DESIGN.md section 5" % args.threads,
+                         "gpu_ms_per_unit_all_kernels": round(gpu_ms / max(1, local_units), 3),
+                         "kernel_groups": {k: {"launches": v[0], "ms_per_unit": round(v[1] / max(1, local_units), 4),
+                                               "alg_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else None}
+                                           for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}},
+            "aggregation_root": ["%016x" % int(x) for x in root[0]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:    # the same kernels with the GPU to themselves: one context, 8 units, after the timed region
+                all_sets = pr.sets
+                pr.sets = all_sets[:1]
+                pr.profile(True)
+                pr.prove_batch(9000, 8)
+                iso, iso_units = pr.profile_read()
+                pr.profile(False)
+                pr.sets = all_sets
+                i_cnt, i_ms, i_bytes = iso.get(dname, (1, 0.0, 0))
+                i_ach = i_bytes / (i_ms * 1e-3) / 1e9 if i_ms > 0 else 0.0
+                line["roofline"]["isolated"] = {
+                    "what": "same kernel groups, single prover context (no other stream on the GPU), %d units" % iso_units,
+                    "kernel": dname, "avg_launch_ms": round(i_ms / max(1, i_cnt), 4), "achieved": round(i_ach, 2),
+                    "frac": round(i_ach / HBM_PEAK_GBS, 4), "gpu_ms_per_unit_all_kernels": round(sum(v[1] for v in iso.values()) / max(1, iso_units), 3),
+                    "kernel_groups": {k: {"ms_per_unit": round(v[1] / max(1, iso_units), 4), "alg_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else None}
+                                      for k, v in sorted(iso.items(), key=lambda kv: -kv[1][1])[:8]}}
+            except Exception as exc:
+                line["roofline"]["isolated"] = {"error": repr(exc)}
+            try:
+                line["cpu_baseline"] = cpu_baseline_recursive(pr)
+            except Exception as exc:
+                line["cpu_baseline"] = {"error": repr(exc)}
+            try:
+                del pr
+                line["ntt_lde"] = lde_figure(gl, local_rank)
+            except Exception as exc:
+                line["ntt_lde"] = {"error": repr(exc)}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["lde", "semaphore"], default="lde",
-                    help="lde = BASELINE configs[1] (default); semaphore = depth-20 proofs, sharded over the GPUs (configs[4] shape)")
-    ap.add_argument("--proofs-per-step", type=int, default=32, help="semaphore workload: proofs per GPU per step")
-    ap.add_argument("--threads", type=int, default=12, help="semaphore workload: concurrent prover contexts per GPU")
+    ap.add_argument("--workload", choices=["recursive", "lde", "semaphore"], default="recursive",
+                    help="recursive = Semaphore d=20 signal + recursive proof per unit (default; BASELINE configs[3]/[4]); "
+                         "lde = configs[1]; semaphore = the signals alone")
+    ap.add_argument("--proofs-per-step", type=int, default=24, help="units (recursive) / proofs (semaphore) per GPU per step")
+    ap.add_argument("--threads", type=int, default=12, help="concurrent prover contexts per GPU")
+    ap.add_argument("--log-members", type=int, default=20, help="log2 of the access-set size (tree depth)")
     args = ap.parse_args()
     if args.workload == "semaphore":
         return main_semaphore(args)
+    if args.workload == "recursive":
+        return main_recursive(args)
+    return main_lde(args)
 
+
+def main_lde(args):
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -197,7 +456,7 @@ def main():
         alg_bytes_step = 8.0 * BATCH * (n + N)
         value = alg_bytes_step * args.steps * world / elapsed / 1e9
         # dominant kernel = the kernel group with the largest HIP-event time in the timed region
-        dom_name, (dom_cnt, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, 0.0))
+        dom_name, (dom_cnt, dom_ms, _) = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, 0.0, 0))
         total_kernel_ms = sum(v[1] for v in prof.values())
         # algorithmic bytes of one launch of each pass (DESIGN.md "NTT"): pass 1 reads the n coefficients
         # once and owns the coset expansion; pass 2 turns them into the N evaluations.  A launch of either
@@ -232,19 +491,6 @@ def main():
             line["aggregation_root"] = ["%016x" % x for x in root]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-            # secondary figure (not the timed region): end-to-end Semaphore proofs/s on this GPU
-            try:
-                pr = SemaphoreProvers(gl, local_rank, 12)
-                pr.prove_batch(100, 16)
-                t_a = time.perf_counter()
-                pr.prove_batch(200, 128)
-                dt = time.perf_counter() - t_a
-                line["semaphore_proofs"] = {"value": round(128 / dt, 1), "unit": "proofs/s", "proofs": 128, "contexts": 12,
-                                            "what": "make_signal (depth-20 membership + nullifier, n = 2^13, blowup 8, 28 queries, "
-                                                    "16 PoW bits, zk) incl. witness generation, every proof bit-checked stage-wise in "
-                                                    "tests; no recursive wrap; reference README: ~1.05 proofs/s on an M1"}
-            except Exception as exc:  # the headline line must still be printed
-                line["semaphore_proofs"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

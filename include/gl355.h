@@ -64,7 +64,8 @@ int32_t gl355_memcpy_d2h(gl355_ctx* ctx, void* dst_host, const void* src_dev, si
 /* HIP-event timer on the context's stream (what bench.py times kernels with) */
 int32_t gl355_timer_start(gl355_ctx* ctx);
 int32_t gl355_timer_stop(gl355_ctx* ctx, float* ms);
-/* per-kernel-group HIP-event timing: enable, run, then read "name count total_ms" lines */
+/* per-kernel-group HIP-event timing: enable, run, then read "name count total_ms algorithmic_bytes" lines
+ * (algorithmic bytes = the compulsory HBM reads + writes of those launches, the numerator of the roofline) */
 int32_t gl355_profile_enable(gl355_ctx* ctx, int32_t on);
 int32_t gl355_profile_read(gl355_ctx* ctx, char* buf, size_t buf_len);
 

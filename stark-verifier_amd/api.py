@@ -91,13 +91,13 @@ class Context:
         self.check(self.lib.gl355_profile_enable(self.h, int(on)))
 
     def profile_read(self):
-        """{name: (count, total_ms)} of the kernel groups run since the last read."""
+        """{name: (count, total_ms, algorithmic_bytes)} of the kernel groups run since the last read."""
         buf = C.create_string_buffer(1 << 16)
         self.check(self.lib.gl355_profile_read(self.h, buf, len(buf)))
         out = {}
         for line in buf.value.decode().splitlines():
-            name, cnt, ms = line.split()
-            out[name] = (int(cnt), float(ms))
+            name, cnt, ms, nbytes = line.split()
+            out[name] = (int(cnt), float(ms), int(nbytes))
         return out
 
     # ---- a1 --------------------------------------------------------------------------------

@@ -237,22 +237,23 @@ int32_t gl355_profile_enable(gl355_ctx* ctx, int32_t on) {
     ctx->c.prof_on = on != 0;
     return GL355_OK;
 }
-// Aggregates the recorded scopes by name into `buf` as lines "name count total_ms\n" and clears them.
+// Aggregates the recorded scopes by name into `buf` as lines "name count total_ms total_algorithmic_bytes\n" and clears them.
 int32_t gl355_profile_read(gl355_ctx* ctx, char* buf, size_t buf_len) {
     if (!ctx || !buf || buf_len == 0) return GL355_E_INVALID_ARG;
     Ctx& c = ctx->c;
     GL355_HIP(&c, hipStreamSynchronize(c.stream));
-    std::map<std::string, std::pair<uint64_t, double>> agg;
+    struct Agg { uint64_t n = 0; double ms = 0; uint64_t bytes = 0; };
+    std::map<std::string, Agg> agg;
     for (auto& r : c.prof) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { (void)hipGetLastError(); ms = 0; }
         auto& a = agg[r.name];
-        a.first++; a.second += ms;
+        a.n++; a.ms += ms; a.bytes += r.bytes;
         c.ev_pool.push_back(r.e0); c.ev_pool.push_back(r.e1);
     }
     c.prof.clear();
     std::string out;
-    for (auto& kv : agg) out += kv.first + " " + std::to_string(kv.second.first) + " " + std::to_string(kv.second.second) + "\n";
+    for (auto& kv : agg) out += kv.first + " " + std::to_string(kv.second.n) + " " + std::to_string(kv.second.ms) + " " + std::to_string(kv.second.bytes) + "\n";
     if (out.size() + 1 > buf_len) out.resize(buf_len - 1);
     memcpy(buf, out.c_str(), out.size() + 1);
     return GL355_OK;

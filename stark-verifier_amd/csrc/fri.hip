@@ -150,6 +150,7 @@ int32_t deep_batch_dev(Ctx* ctx, const uint64_t* const* poly_ptrs_host, uint32_t
     uint64_t* d_v = vbuf.as<uint64_t>();
     uint64_t* d_tot = d_v + 2 * n;
     uint64_t* d_carry = d_tot + 2 * n_blocks;
+    ProfScope ps(ctx, "deep_batch", (uint64_t)n_polys * n * 8 + n * 32);   // every coefficient once + acc in/out
     hipLaunchKernelGGL(deep_reduce_scan_kernel, dim3((uint32_t)n_blocks), dim3(DEEP_B), 0, ctx->stream, d_ptrs, n_polys,
                        d_alpha, d_zpow2, n, d_v, d_tot);
     GL355_HIP(ctx, hipGetLastError());
@@ -201,6 +202,7 @@ int32_t eval_polys_ext_dev(Ctx* ctx, const uint64_t* const* poly_ptrs_host, uint
     GL355_HIP(ctx, hipMemcpyAsync(d_z, zc, 16, hipMemcpyHostToDevice, ctx->stream));
     GL355_HIP(ctx, hipMemcpyAsync(d_ptrs, poly_ptrs_host, sizeof(uint64_t*) * n_polys, hipMemcpyHostToDevice, ctx->stream));
     GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ProfScope ps(ctx, "eval_polys", ((uint64_t)n_polys << log_n) * 8);
     hipLaunchKernelGGL(eval_polys_kernel, dim3(n_polys), dim3(256), 0, ctx->stream, d_ptrs, 1ull << log_n, d_z, out_dev);
     GL355_HIP(ctx, hipGetLastError());
     return GL355_OK;
@@ -218,6 +220,7 @@ __global__ void fri_fold_kernel(const uint64_t* c, uint64_t half, uint64_t b0, u
 int32_t fri_fold_dev(Ctx* ctx, const uint64_t* coeffs, uint64_t n, const uint64_t beta[2], uint64_t* out) {
     const uint64_t half = n / 2;
     if (half == 0) return GL355_OK;
+    ProfScope ps(ctx, "fri_fold", n * 16 + half * 16);
     hipLaunchKernelGGL(fri_fold_kernel, dim3((uint32_t)((half + 255) / 256)), dim3(256), 0, ctx->stream, coeffs, half,
                        gl_canon(beta[0]), gl_canon(beta[1]), out);
     GL355_HIP(ctx, hipGetLastError());
@@ -235,6 +238,7 @@ __global__ void fri_layer_leaves_kernel(const uint64_t* values, uint32_t log_n, 
 }
 int32_t fri_layer_leaves_dev(Ctx* ctx, const uint64_t* values, uint64_t n, uint64_t* leaves) {
     if (n == 0) return GL355_OK;
+    ProfScope ps(ctx, "fri_layer_leaves", n * 32);
     hipLaunchKernelGGL(fri_layer_leaves_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, values,
                        log2_u64(n), leaves);
     GL355_HIP(ctx, hipGetLastError());
@@ -260,9 +264,11 @@ int32_t lde_ext_dev(Ctx* ctx, const uint64_t* coeffs, uint32_t log_n, uint32_t r
     GL355_TRY(sc.get((2 * n + 2 * N) * 8));
     uint64_t* cols = sc.as<uint64_t>();
     uint64_t* res = cols + 2 * n;
+    { ProfScope ps(ctx, "ext_split_join", n * 32);
     hipLaunchKernelGGL(ext_split_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, coeffs, n, cols, cols + n);
-    GL355_HIP(ctx, hipGetLastError());
+    GL355_HIP(ctx, hipGetLastError()); }
     GL355_TRY(lde_dev(ctx, cols, n, log_n, rate_bits, shift, 2, res, N, out_bitrev));
+    ProfScope ps(ctx, "ext_split_join", N * 32);
     hipLaunchKernelGGL(ext_join_kernel, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, ctx->stream, res, res + N, N, out);
     GL355_HIP(ctx, hipGetLastError());
     return GL355_OK;
@@ -338,6 +344,7 @@ int32_t zs_partial_products_dev(Ctx* ctx, const uint64_t* wires, const uint64_t*
     uint64_t* d_q = sc.as<uint64_t>();
     uint64_t* d_rp = d_q + (uint64_t)n_chunks * n;
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    ProfScope ps(ctx, "zs_partial_products", (uint64_t)n_routed * n * 16 + (uint64_t)n_chunks * n * 8);
     hipLaunchKernelGGL(zs_rows_kernel, dim3(blocks), dim3(256), 0, ctx->stream, wires, sigmas, k_is, log_n, n_routed,
                        max_degree, gl_canon(beta), gl_canon(gamma), gl_root_of_unity(log_n), d_q, d_rp);
     GL355_HIP(ctx, hipGetLastError());

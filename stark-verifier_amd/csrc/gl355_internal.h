@@ -64,7 +64,7 @@ struct Ctx {
     std::vector<Block> blocks;
 
     // optional per-kernel timing (gl355_profile_enable): HIP events around every launch group
-    struct ProfRec { const char* name; hipEvent_t e0, e1; };
+    struct ProfRec { const char* name; hipEvent_t e0, e1; uint64_t bytes; };
     bool prof_on = false;
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
@@ -85,9 +85,10 @@ struct Ctx {
 // RAII: times everything enqueued on the context stream during its lifetime under `name`
 struct ProfScope {
     Ctx* ctx; int idx = -1;
-    ProfScope(Ctx* c, const char* name) : ctx(c) {
+    // alg_bytes: the ALGORITHMIC HBM bytes of the launches in this scope (compulsory reads + writes)
+    ProfScope(Ctx* c, const char* name, uint64_t alg_bytes = 0) : ctx(c) {
         if (!c->prof_on) return;
-        Ctx::ProfRec r{name, c->prof_event(), c->prof_event()};
+        Ctx::ProfRec r{name, c->prof_event(), c->prof_event(), alg_bytes};
         if (!r.e0 || !r.e1) return;
         (void)hipEventRecord(r.e0, c->stream);
         idx = (int)c->prof.size();

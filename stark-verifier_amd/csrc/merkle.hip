@@ -227,6 +227,7 @@ int32_t open_batch_dev(Ctx* ctx, const uint64_t* lde, uint64_t stride, uint32_t 
                        uint32_t log_n, uint32_t cap_height, const uint64_t* idx_dev, uint32_t n_idx, uint64_t* leaves_out,
                        uint64_t* sib_out) {
     if (n_idx == 0) return GL355_OK;
+    ProfScope ps(ctx, "open_batch", (uint64_t)n_idx * (leaf_len * 16 + (log_n - cap_height) * 64));
     hipLaunchKernelGGL(open_batch_kernel, dim3(n_idx), dim3(64), 0, ctx->stream, lde, stride, leaf_len, digests, log_n,
                        cap_height, idx_dev, 0u, leaves_out, (uint64_t)leaf_len, sib_out, (uint64_t)(log_n - cap_height) * 4);
     GL355_HIP(ctx, hipGetLastError());
@@ -237,6 +238,7 @@ int32_t open_batch_ex_dev(Ctx* ctx, const uint64_t* leaves, uint64_t stride, uin
                           uint32_t log_n, uint32_t cap_height, const uint64_t* idx_dev, uint32_t idx_shift, uint32_t n_idx,
                           uint64_t* leaves_out, uint64_t leaf_out_stride, uint64_t* sib_out, uint64_t sib_out_stride) {
     if (n_idx == 0) return GL355_OK;
+    ProfScope ps(ctx, "open_batch", (uint64_t)n_idx * (leaf_len * 16 + (log_n - cap_height) * 64));
     hipLaunchKernelGGL(open_batch_kernel, dim3(n_idx), dim3(64), 0, ctx->stream, leaves, stride, leaf_len, digests, log_n,
                        cap_height, idx_dev, idx_shift, leaves_out, leaf_out_stride, sib_out, sib_out_stride);
     GL355_HIP(ctx, hipGetLastError());
@@ -294,10 +296,11 @@ int32_t merkle_build_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, ui
     a.leaves = leaves; a.n_leaves = n_leaves; a.leaf_len = leaf_len; a.col_major = col_major;
     a.stride = col_major ? col_stride : leaf_len;
     a.out = digests; a.cap = cap; a.sub_bits = sub_bits;
-    { ProfScope ps(ctx, "merkle_hash_leaves"); GL355_TRY(launch_leaves(ctx, a)); }
-    ProfScope ps(ctx, "merkle_levels");
+    { ProfScope ps(ctx, "hash_leaves_kernel", n_leaves * ((uint64_t)leaf_len * 8 + 32)); GL355_TRY(launch_leaves(ctx, a)); }
     for (uint32_t layer = 1; layer <= sub_bits; layer++) {
         const uint64_t n_nodes = n_leaves >> layer;
+        // one scope per level (= per launch): 2 child digests in, 1 out per node
+        ProfScope ps(ctx, n_nodes <= MERKLE_LANES_MAX_NODES ? "merkle_level_lanes_kernel" : "merkle_level_kernel", n_nodes * 96);
         if (n_nodes <= MERKLE_LANES_MAX_NODES) {
             // small level: 16 lanes per node (latency ~10x lower than one lane per node)
             hipLaunchKernelGGL(merkle_level_lanes_kernel, dim3((uint32_t)((n_nodes + 3) / 4)), dim3(64), 0, ctx->stream,
@@ -329,6 +332,7 @@ int32_t pow_grind_dev(Ctx* ctx, const uint64_t state[12], uint32_t pos, uint32_t
     uint64_t per_launch = 1ull << std::min<uint32_t>(std::max<uint32_t>(bits + 1, 12), 22);
     uint64_t base = start;
     for (;;) {
+        ProfScope ps(ctx, "pow_grind", 0);   // pure compute: one permutation per candidate, no HBM traffic
         hipLaunchKernelGGL(pow_grind_kernel, dim3((uint32_t)(per_launch / 256)), dim3(256), 0, ctx->stream, d_state, pos,
                            bits, base, d_best);
         GL355_HIP(ctx, hipGetLastError());

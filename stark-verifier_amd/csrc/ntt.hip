@@ -465,7 +465,7 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         a.scale = p.scale;
         a.in_bitrev = p.in_bitrev; a.out_natural = p.out_bitrev ? 0 : 1;
         a.canon = 1;
-        ProfScope ps(ctx, "ntt_rows_single_pass");
+        ProfScope ps(ctx, "ntt_rows_single_pass", ((uint64_t)p.batch << p.log_n) * 8 * (1 + p.n_cosets));
         GL355_HIP(ctx, launch_rows(a, p.log_n, inv, ctx->stream));
         return GL355_OK;
     }
@@ -492,7 +492,7 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
             GL355_TRY(ctx->full_step_table(step_lo, step_hi, l1, l2, inv, &a.step_full));
         }
         a.in_bitrev = 0; a.out_natural = 0; a.canon = 0;
-        { ProfScope ps(ctx, "ntt_cols_pass1"); GL355_HIP(ctx, launch_cols(a, l1, inv, ctx->stream)); }
+        { ProfScope ps(ctx, "ntt_cols_pass1", ((uint64_t)p.batch << p.log_n) * 8); GL355_HIP(ctx, launch_cols(a, l1, inv, ctx->stream)); }
         PassArgs b = a;
         b.in = p.out; b.in_col_stride = p.out_col_stride;
         // each coset's intermediate lives in its own output block: rows pass runs per coset slot
@@ -501,7 +501,7 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         b.scale = p.scale; b.canon = 1;
         if (p.n_cosets == 1) {
             b.in = p.out + (uint64_t)a.coset_slot[0] * a.coset_out_stride;
-            ProfScope ps(ctx, "ntt_rows_pass2");
+            ProfScope ps(ctx, "ntt_rows_pass2", ((uint64_t)p.batch << p.log_n) * 8);
             GL355_HIP(ctx, launch_rows(b, l2, inv, ctx->stream));
         } else {
             // the coset blocks are contiguous sub-ranges of every output column: treat (column,
@@ -513,7 +513,7 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
             while ((1u << lc) < p.n_cosets) lc++;
             b.n_cosets = 1; b.coset_slot[0] = 0; b.coset_out_stride = 0;
             b.log_rows = l1 + lc;
-            ProfScope ps(ctx, "ntt_rows_pass2");
+            ProfScope ps(ctx, "ntt_rows_pass2", ((uint64_t)p.batch * p.n_cosets << p.log_n) * 8);
             GL355_HIP(ctx, launch_rows(b, l2, inv, ctx->stream));
         }
         if (!p.out_bitrev) {
@@ -536,7 +536,7 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
     a.in_col_stride = p.in_col_stride; a.out_col_stride = p.out_col_stride;
     a.log_rows = l2;  // rows per column = N2 (row index = bitrev(i2))
     a.in_bitrev = 1; a.out_natural = 1; a.canon = 0;
-    GL355_HIP(ctx, launch_rows(a, l1, inv, ctx->stream));
+    { ProfScope ps(ctx, "ntt_bitrev_in_rows_pass1", ((uint64_t)p.batch << p.log_n) * 8); GL355_HIP(ctx, launch_rows(a, l1, inv, ctx->stream)); }
     PassArgs b = a;
     b.in = p.out; b.in_col_stride = p.out_col_stride;
     b.log_rows = l1;  // matrix is [N2 rows][N1 columns]
@@ -544,6 +544,7 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
     b.post_lo = p.post_lo; b.post_hi = p.post_hi;
     b.scale = p.scale; b.canon = 1;
     b.in_bitrev = 1; b.out_natural = 1;
+    ProfScope ps(ctx, "ntt_bitrev_in_cols_pass2", ((uint64_t)p.batch << p.log_n) * 8);
     GL355_HIP(ctx, launch_cols(b, l2, inv, ctx->stream));
     return GL355_OK;
 }
@@ -553,6 +554,7 @@ int32_t bitrev_permute(Ctx* ctx, const uint64_t* in, uint64_t* out, uint32_t log
     const uint64_t total = ((uint64_t)batch) << log_n;
     if (total == 0) return GL355_OK;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 16);
+    ProfScope ps(ctx, "bitrev_permute", total * 16);
     hipLaunchKernelGGL(bitrev_permute_kernel, dim3(blocks), dim3(256), 0, ctx->stream, in, out, log_n, width,
                        in_col_stride, out_col_stride, batch);
     GL355_HIP(ctx, hipGetLastError());
@@ -563,6 +565,7 @@ int32_t transpose_cols_to_rows(Ctx* ctx, const uint64_t* in, uint64_t* out, uint
                                uint64_t in_col_stride, uint32_t out_row_stride, uint32_t log_rows_brev) {
     if (rows == 0 || cols == 0) return GL355_OK;
     dim3 grid((uint32_t)((rows + 31) / 32), (cols + 31) / 32);
+    ProfScope ps(ctx, "transpose", rows * cols * 16);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, in, out, rows, cols, in_col_stride,
                        out_row_stride, log_rows_brev);
     GL355_HIP(ctx, hipGetLastError());

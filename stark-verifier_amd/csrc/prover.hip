@@ -242,12 +242,14 @@ extern "C" int32_t gl355_prove_sparse(gl355_ctx* h, const gl355_prover_data* pd,
         GL355_HIP(ctx, hipMemcpyAsync(d_vals, rows, (uint64_t)n_rows * nw * 8, hipMemcpyHostToDevice, ctx->stream));
         GL355_HIP(ctx, hipMemcpyAsync(d_idx, row_idx, (uint64_t)n_rows * 4, hipMemcpyHostToDevice, ctx->stream));
         const uint64_t cnt = (uint64_t)n_rows * nw;
+        ProfScope ps(ctx, "witness_scatter", cnt * 16);
         hipLaunchKernelGGL(witness_rows_kernel, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, w.as<uint64_t>(), n, nw,
                            d_idx, d_vals, n_rows);
         GL355_HIP(ctx, hipGetLastError());
     }
     const uint64_t cnt_b = (uint64_t)n_blind * nw + n_z_pairs;
     if (cnt_b) {
+        ProfScope ps(ctx, "witness_blind", cnt_b * 8);
         hipLaunchKernelGGL(witness_blind_kernel, dim3((uint32_t)((cnt_b + 255) / 256)), dim3(256), 0, ctx->stream, w.as<uint64_t>(), n, nw,
                            blind_start, n_blind, z_start, n_z_pairs, seed * 0xA24BAED4963EE407ull + 0x9FB21C651E98DF25ull);
         GL355_HIP(ctx, hipGetLastError());
@@ -293,6 +295,7 @@ static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, c
     if (zk) GL355_TRY(salt.get((uint64_t)GL355_SALT_SIZE * N * 8));
     auto fresh_salt = [&](uint64_t stream_id) -> int32_t {
         const uint64_t cnt = (uint64_t)GL355_SALT_SIZE * N;
+        ProfScope ps(ctx, "salt", cnt * 8);
         hipLaunchKernelGGL(salt_kernel, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, salt.as<uint64_t>(), cnt,
                            seed * 0x100000001B3ull + stream_id * 0xD6E8FEB86659FD93ull);
         GL355_HIP(ctx, hipGetLastError());

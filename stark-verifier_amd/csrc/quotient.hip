@@ -347,7 +347,9 @@ int32_t quotient_dev(Ctx* ctx, const gl355_circuit* c, const uint64_t* cs_lde, c
     a.n_inv = gl_canon(gl_inv((1ull << c->degree_bits) % GL_P));
     a.out = out_values;
     const uint64_t nq = 1ull << a.qbits;
-    ProfScope ps(ctx, "quotient_kernel");
+    // every column of the three oracles once per point of the quotient coset + the result
+    ProfScope ps(ctx, "quotient_kernel", nq * 8 * ((uint64_t)c->num_selectors + c->num_constants + c->num_routed_wires + c->num_wires +
+                                                   (uint64_t)c->num_challenges * (2 + c->num_partial_products)));
     hipLaunchKernelGGL(quotient_kernel, dim3((uint32_t)((nq + 127) / 128)), dim3(128), 0, ctx->stream, a);
     GL355_HIP(ctx, hipGetLastError());
     return GL355_OK;
