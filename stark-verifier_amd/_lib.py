@@ -55,6 +55,7 @@ SIGNATURES = {
     "gl355_ctx_create_on_stream": (C.c_int32, [C.c_int32, vp, C.POINTER(vp)]),
     "gl355_ctx_destroy": (C.c_int32, [vp]),
     "gl355_ctx_sync": (C.c_int32, [vp]),
+    "gl355_ctx_set_option": (C.c_int32, [vp, C.c_int32, C.c_int64]),
     "gl355_last_error": (C.c_char_p, [vp]),
     "gl355_version": (C.c_char_p, []),
     "gl355_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),

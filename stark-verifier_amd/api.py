@@ -87,6 +87,9 @@ class Context:
         self.check(self.lib.gl355_timer_stop(self.h, C.byref(ms)))
         return ms.value
 
+    def set_option(self, option, value):
+        self.check(self.lib.gl355_ctx_set_option(self.h, int(option), int(value)))
+
     def profile_enable(self, on=True):
         self.check(self.lib.gl355_profile_enable(self.h, int(on)))
 

@@ -188,6 +188,17 @@ int32_t gl355_ctx_destroy(gl355_ctx* ctx) {
     delete ctx;
     return GL355_OK;
 }
+int32_t gl355_ctx_set_option(gl355_ctx* ctx, int32_t option, int64_t value) {
+    if (!ctx) return GL355_E_INVALID_ARG;
+    switch (option) {
+    case GL355_OPT_MERKLE_LANES_LOG:
+        if (value < 0 || value > 30) return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: MERKLE_LANES_LOG must be in 0..30");
+        ctx->c.merkle_lanes_log = (uint32_t)value;
+        return GL355_OK;
+    default:
+        return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: unknown option");
+    }
+}
 int32_t gl355_ctx_sync(gl355_ctx* ctx) {
     if (!ctx) return GL355_E_INVALID_ARG;
     GL355_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));

@@ -65,6 +65,7 @@ struct Ctx {
 
     // optional per-kernel timing (gl355_profile_enable): HIP events around every launch group
     struct ProfRec { const char* name; hipEvent_t e0, e1; uint64_t bytes; };
+    uint32_t merkle_lanes_log = 14;   // Merkle levels with <= 2^this nodes use the 16-lanes-per-node kernel (GL355_OPT_MERKLE_LANES_LOG)
     bool prof_on = false;
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;

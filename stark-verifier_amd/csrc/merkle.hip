@@ -20,7 +20,7 @@ namespace gl355 {
 
 // levels with at most this many nodes use the lane-parallel kernel (4 nodes per wave): beyond ~2^14 nodes
 // the chip is full of waves either way and the one-lane-per-node kernel wins on instruction count
-constexpr uint64_t MERKLE_LANES_MAX_NODES = 1ull << 14;
+// the default of Ctx::merkle_lanes_log (gl355_ctx_set_option) is 14: see the lane-parallel kernel below
 
 // index of node k of layer `layer` (0 = leaf digests) inside one cap-subtree's digest buffer:
 // pair p = k>>1 of layer i sits at pair slot (p << (i+1)) + 2^i - 1 (MerkleTree::prove's formula).
@@ -125,17 +125,29 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(uint64_t* digests, ui
 // ------------------------------------------------------------------------------------------------
 __device__ __constant__ const uint32_t PSD_CIRC_DEV[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
 
+// the 16 lanes sharing a state sit in ONE wave, and a wave's LDS instructions complete in issue order: the ring
+// exchange only needs the compiler (and the LGKM counter) to keep write -> read -> next write ordered, not s_barrier
+#define GL_WAVE_LDS_SYNC()                                      \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+    } while (0)
 GL_DEV uint64_t psd_permute_lanes(uint64_t s, int li, uint64_t* ring /* 24 u64 of this 16-lane group */) {
     const bool active = li < 12;
     const int me = active ? li : 0;
+    // the constant index depends on the lane, so this is a vector load: fetch round r+1's constant while round r
+    // computes (a load issued and awaited inside the round costs an L2 round trip per round, ~40 % of the latency)
+    uint64_t rc = PSD_ALL_RC[me];
 #pragma unroll 1
     for (int r = 0; r < 30; r++) {
-        const uint64_t t = gl_add(s, PSD_ALL_RC[12 * r + me]);
+        const uint64_t rc_next = PSD_ALL_RC[12 * (r < 29 ? r + 1 : 29) + me];
+        const uint64_t t = gl_add(s, rc);
+        rc = rc_next;
         const bool full = r < 4 || r >= 26;
         const uint64_t sb = psd_sbox(t);
         s = (full || li == 0) ? sb : t;
         if (active) { ring[me] = s; ring[me + 12] = s; }
-        __syncthreads();
+        GL_WAVE_LDS_SYNC();
         uint64_t al = 0, ah = 0;
 #pragma unroll
         for (int j = 0; j < 12; j++) {
@@ -144,7 +156,7 @@ GL_DEV uint64_t psd_permute_lanes(uint64_t s, int li, uint64_t* ring /* 24 u64 o
             al += (uint64_t)(uint32_t)x * c;
             ah += (uint64_t)(uint32_t)(x >> 32) * c;
         }
-        __syncthreads();
+        GL_WAVE_LDS_SYNC();
         const uint64_t mid = ah << 32;
         const uint32_t top = (uint32_t)(ah >> 32);
         uint64_t r0 = al + mid;
@@ -297,11 +309,12 @@ int32_t merkle_build_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, ui
     a.stride = col_major ? col_stride : leaf_len;
     a.out = digests; a.cap = cap; a.sub_bits = sub_bits;
     { ProfScope ps(ctx, "hash_leaves_kernel", n_leaves * ((uint64_t)leaf_len * 8 + 32)); GL355_TRY(launch_leaves(ctx, a)); }
+    const uint64_t lanes_max = 1ull << ctx->merkle_lanes_log;
     for (uint32_t layer = 1; layer <= sub_bits; layer++) {
         const uint64_t n_nodes = n_leaves >> layer;
         // one scope per level (= per launch): 2 child digests in, 1 out per node
-        ProfScope ps(ctx, n_nodes <= MERKLE_LANES_MAX_NODES ? "merkle_level_lanes_kernel" : "merkle_level_kernel", n_nodes * 96);
-        if (n_nodes <= MERKLE_LANES_MAX_NODES) {
+        ProfScope ps(ctx, n_nodes <= lanes_max ? "merkle_level_lanes_kernel" : "merkle_level_kernel", n_nodes * 96);
+        if (n_nodes <= lanes_max) {
             // small level: 16 lanes per node (latency ~10x lower than one lane per node)
             hipLaunchKernelGGL(merkle_level_lanes_kernel, dim3((uint32_t)((n_nodes + 3) / 4)), dim3(64), 0, ctx->stream,
                                digests, cap, sub_bits, layer, n_nodes);

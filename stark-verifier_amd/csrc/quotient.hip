@@ -39,16 +39,19 @@ struct QuotArgs {
     uint64_t* out;            // [num_challenges][Nq], storage (bit-reversed) order
 };
 
-// running alpha-power accumulation of the constraint stream for up to 4 challenges
+// running alpha-power accumulation of the constraint stream; NCH (the number of challenges) is a template
+// parameter so that acc / pw stay in registers (a run-time bound puts the arrays in scratch memory and every
+// push() becomes scratch loads + stores)
+template <int NCH>
 struct AlphaAcc {
-    uint64_t acc[4], pw[4], alpha[4];
-    int nch;
+    uint64_t acc[NCH], pw[NCH], alpha[NCH];
     GL_DEV void init(const QuotArgs& a) {
-        nch = a.c.num_challenges;
-        for (int c = 0; c < 4; c++) { acc[c] = 0; pw[c] = 1; alpha[c] = a.alphas[c]; }
+#pragma unroll
+        for (int c = 0; c < NCH; c++) { acc[c] = 0; pw[c] = 1; alpha[c] = a.alphas[c]; }
     }
     GL_DEV void push(uint64_t term) {
-        for (int c = 0; c < nch; c++) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
             acc[c] = gl_add(acc[c], gl_mul(term, pw[c]));
             pw[c] = gl_mul(pw[c], alpha[c]);
         }
@@ -56,15 +59,16 @@ struct AlphaAcc {
 };
 
 // per-gate accumulation: sum_k alpha^(base+k) * c_k, later multiplied by the gate's filter
-struct GateAcc {
-    uint64_t acc[4], pw[4], alpha[4];
-    int nch;
-    GL_DEV void init(const uint64_t* alphas, const uint64_t* base_pw, int n) {
-        nch = n;
-        for (int c = 0; c < 4; c++) { acc[c] = 0; pw[c] = base_pw[c]; alpha[c] = alphas[c]; }
+template <int NCH>
+struct GateAccT {
+    uint64_t acc[NCH], pw[NCH], alpha[NCH];
+    GL_DEV void init(const uint64_t* alphas, const uint64_t* base_pw) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) { acc[c] = 0; pw[c] = base_pw[c]; alpha[c] = alphas[c]; }
     }
     GL_DEV void push(uint64_t term) {
-        for (int c = 0; c < nch; c++) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
             acc[c] = gl_add(acc[c], gl_mul(term, pw[c]));
             pw[c] = gl_mul(pw[c], alpha[c]);
         }
@@ -75,6 +79,7 @@ struct GateAcc {
 #define CONST(j) (a.cs[(uint64_t)(j) * a.lde_stride + t])
 
 // PoseidonGate: 123 constraints (gates/poseidon.rs:592-698); wire layout :329-380
+template <class GateAcc>
 GL_DEV void gate_poseidon(const QuotArgs& a, uint64_t t, GateAcc& g) {
     const uint64_t swap = WIRE(24);
     g.push(gl_sub(gl_mul(swap, swap), swap));
@@ -130,6 +135,7 @@ GL_DEV void gate_poseidon(const QuotArgs& a, uint64_t t, GateAcc& g) {
 }
 
 // BaseSumGate<2>{num_limbs}: sum_i limb_i 2^i - sum ; limb (limb - 1)   (gates/base_sum.rs:37-60)
+template <class GateAcc>
 GL_DEV void gate_base_sum(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num_limbs) {
     uint64_t acc = 0;
     for (uint32_t i = num_limbs; i-- > 0;) acc = gl_add(gl_add(acc, acc), WIRE(1 + i));
@@ -140,14 +146,17 @@ GL_DEV void gate_base_sum(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t nu
     }
 }
 // ConstantGate{n}: const_i - wire_i   (gates/constant.rs:31-36); gate constants follow the selectors
+template <class GateAcc>
 GL_DEV void gate_constant(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) g.push(gl_sub(CONST(a.c.num_selectors + i), WIRE(i)));
 }
 // PublicInputGate: wire_i - pi_hash_i   (gates/public_input.rs:32-39)
+template <class GateAcc>
 GL_DEV void gate_public_input(const QuotArgs& a, uint64_t t, GateAcc& g) {
     for (uint32_t i = 0; i < 4; i++) g.push(gl_sub(WIRE(i), a.pi_hash[i]));
 }
 // ArithmeticGate{num_ops}: out - (c0 m0 m1 + c1 addend)   (gates/arithmetic.rs:47-68)
+template <class GateAcc>
 GL_DEV void gate_arithmetic(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num_ops) {
     const uint64_t c0 = CONST(a.c.num_selectors), c1 = CONST(a.c.num_selectors + 1);
     for (uint32_t i = 0; i < num_ops; i++) {
@@ -160,9 +169,11 @@ GL_DEV void gate_arithmetic(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t 
 // every wire value is a base-field number, so the algebra product is the plain F_p^2 product
 // (chip/goldilocks_extension_algebra_chip.rs:112-146).  Each algebra constraint yields 2 terms.
 #define WIRE2(j) gl2_make(WIRE(j), WIRE((j) + 1))
+template <class GateAcc>
 GL_DEV void push2(GateAcc& g, gl2 v) { g.push(v.c0); g.push(v.c1); }
 
 // ArithmeticExtensionGate{num_ops}: out - (c0 m0 m1 + c1 addend)   (gates/arithmetic_extension.rs:22-80)
+template <class GateAcc>
 GL_DEV void gate_arithmetic_ext(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num_ops) {
     const uint64_t c0 = CONST(a.c.num_selectors), c1 = CONST(a.c.num_selectors + 1);
     for (uint32_t i = 0; i < num_ops; i++) {
@@ -172,6 +183,7 @@ GL_DEV void gate_arithmetic_ext(const QuotArgs& a, uint64_t t, GateAcc& g, uint3
     }
 }
 // MulExtensionGate{num_ops}: out - c0 m0 m1   (gates/multiplication_extension.rs:22-68)
+template <class GateAcc>
 GL_DEV void gate_mul_ext(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num_ops) {
     const uint64_t c0 = CONST(a.c.num_selectors);
     for (uint32_t i = 0; i < num_ops; i++) {
@@ -180,6 +192,7 @@ GL_DEV void gate_mul_ext(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num
     }
 }
 // PoseidonMdsGate: out_r - sum_i CIRC[i] in[(i+r)%12] - DIAG[r] in[r]   (gates/poseidon_mds.rs:26-126)
+template <class GateAcc>
 GL_DEV void gate_poseidon_mds(const QuotArgs& a, uint64_t t, GateAcc& g) {
     constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     for (uint32_t r = 0; r < 12; r++) {
@@ -196,6 +209,7 @@ GL_DEV void gate_poseidon_mds(const QuotArgs& a, uint64_t t, GateAcc& g) {
     }
 }
 // RandomAccessGate{bits, copies, extra}   (gates/random_access.rs:27-147)
+template <class GateAcc>
 GL_DEV void gate_random_access(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t param) {
     const uint32_t bits = param & 0xFF, copies = (param >> 8) & 0xFF, extra = (param >> 16) & 0xFF;
     const uint32_t vec = 1u << bits, routed = (2 + vec) * copies + extra;
@@ -225,7 +239,7 @@ GL_DEV void gate_random_access(const QuotArgs& a, uint64_t t, GateAcc& g, uint32
 }
 // ReducingGate{n} / ReducingExtensionGate{n}: acc*alpha + coeff - acc_i   (gates/reducing.rs:20-85,
 // gates/reducing_extension.rs:20-87); the last accumulator is the output (wires 0..1)
-template <bool EXT>
+template <bool EXT, class GateAcc>
 GL_DEV void gate_reducing(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t n) {
     const gl2 alpha = WIRE2(2);
     gl2 acc = WIRE2(4);
@@ -238,7 +252,8 @@ GL_DEV void gate_reducing(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t n)
     }
 }
 
-__global__ void __launch_bounds__(128) quotient_kernel(QuotArgs a) {
+template <int NCH>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) quotient_kernel(QuotArgs a) {
     const uint64_t nq = 1ull << a.qbits;
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= nq) return;
@@ -248,11 +263,12 @@ __global__ void __launch_bounds__(128) quotient_kernel(QuotArgs a) {
     // next row: natural index iq + 2^qdb (g*x), its storage row is bitrev of that
     const uint64_t iq_next = (iq + (1ull << qdb)) & (nq - 1);
     const uint64_t t_next = __brevll(iq_next) >> (64 - a.qbits);
-    const uint32_t nch = a.c.num_challenges, npp = a.c.num_partial_products;
+    constexpr uint32_t nch = NCH;
+    const uint32_t npp = a.c.num_partial_products;
     const uint32_t routed = a.c.num_routed_wires, chunk = a.c.max_degree;
     const uint32_t n_sel = a.c.num_selectors, n_cst = a.c.num_constants;
 
-    AlphaAcc total;
+    AlphaAcc<NCH> total;
     total.init(a);
     // ---- L0(x) (Z_c(x) - 1);  L0(x) = (x^n - 1) / (n (x - 1))  (vanishing_poly.rs:155-178) ---------
     const uint64_t zh_inv = a.zh_inv[iq & ((1u << qdb) - 1)];
@@ -283,12 +299,14 @@ __global__ void __launch_bounds__(128) quotient_kernel(QuotArgs a) {
         }
     }
     // ---- gate constraints, each gate's stream multiplied by its filter (gates/mod.rs:87-132) ---------
-    uint64_t gate_sum[4] = {0, 0, 0, 0};
+    uint64_t gate_sum[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) gate_sum[c] = 0;
     for (uint32_t gi = 0; gi < a.c.num_gates; gi++) {
         const gl355_gate gt = a.c.gates[gi];
         if (gt.type == GL355_GATE_NOOP) continue;
-        GateAcc g;
-        g.init(a.alphas, total.pw, nch);
+        GateAccT<NCH> g;
+        g.init(a.alphas, total.pw);
         switch (gt.type) {
             case GL355_GATE_POSEIDON: gate_poseidon(a, t, g); break;
             case GL355_GATE_BASE_SUM: gate_base_sum(a, t, g, gt.param); break;
@@ -308,6 +326,7 @@ __global__ void __launch_bounds__(128) quotient_kernel(QuotArgs a) {
         for (uint32_t k = gt.group_start; k < gt.group_end; k++)
             if (k != gi) filter = gl_mul(filter, gl_sub(k, sel));
         if (n_sel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFull, sel));  // UNUSED_SELECTOR = u32::MAX
+#pragma unroll
         for (uint32_t c = 0; c < nch; c++) gate_sum[c] = gl_add(gate_sum[c], gl_mul(filter, g.acc[c]));
     }
     for (uint32_t c = 0; c < nch; c++) {
@@ -350,7 +369,13 @@ int32_t quotient_dev(Ctx* ctx, const gl355_circuit* c, const uint64_t* cs_lde, c
     // every column of the three oracles once per point of the quotient coset + the result
     ProfScope ps(ctx, "quotient_kernel", nq * 8 * ((uint64_t)c->num_selectors + c->num_constants + c->num_routed_wires + c->num_wires +
                                                    (uint64_t)c->num_challenges * (2 + c->num_partial_products)));
-    hipLaunchKernelGGL(quotient_kernel, dim3((uint32_t)((nq + 127) / 128)), dim3(128), 0, ctx->stream, a);
+    const dim3 grid((uint32_t)((nq + 127) / 128));
+    switch (c->num_challenges) {
+        case 1: hipLaunchKernelGGL(quotient_kernel<1>, grid, dim3(128), 0, ctx->stream, a); break;
+        case 2: hipLaunchKernelGGL(quotient_kernel<2>, grid, dim3(128), 0, ctx->stream, a); break;
+        case 3: hipLaunchKernelGGL(quotient_kernel<3>, grid, dim3(128), 0, ctx->stream, a); break;
+        default: hipLaunchKernelGGL(quotient_kernel<4>, grid, dim3(128), 0, ctx->stream, a); break;
+    }
     GL355_HIP(ctx, hipGetLastError());
     return GL355_OK;
 }

@@ -11,6 +11,7 @@ import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--contexts", default="1,2,4,8,12,16")
 ap.add_argument("--units", type=int, default=48)
+ap.add_argument("--lanes-log", default="14")
 args = ap.parse_args()
 gl = importlib.import_module("stark-verifier_amd")
 counts = [int(x) for x in args.contexts.split(",")]
@@ -37,10 +38,14 @@ inner = (sig.proof, np.concatenate([pr.root, sig.nullifier[0], pr.topic]))
 t = time.perf_counter(); rows, pis = pr.rc.witness([inner]); t_rep = time.perf_counter() - t
 t = time.perf_counter(); pr.plonk.prove_sparse(a.ctx, pr.rc.data, pr.rc.row_idx, rows, pis, 1, flat_only=True); t_out = time.perf_counter() - t
 print("latency: signal %.2f ms, tape replay %.2f ms, recursive proof %.2f ms" % (t_in * 1e3, t_rep * 1e3, t_out * 1e3))
-for k in counts:
+for ll in [int(x) for x in args.lanes_log.split(",")]:
+  for a_ in sets:
+    a_.ctx.set_option(1, ll)
+  print("MERKLE_LANES_LOG", ll)
+  for k in counts:
     pr.sets = sets[:k]
     pr.prove_batch(300, 2 * k)
     t0 = time.perf_counter()
     pr.prove_batch(400, args.units)
     dt = time.perf_counter() - t0
-    print("contexts %2d: %.1f units/s" % (k, args.units / dt))
+    print("  contexts %2d: %.1f units/s" % (k, args.units / dt))
