@@ -205,6 +205,17 @@ def cpu_baseline_recursive(pr, units=1):
                       "on 16 vCPU" % (units, pr.rc.data.degree_bits, threads, t_build, dt)}
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (bench.py cannot collect PMC counters
+    itself); None when no pass covers the kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        return d["kernels"][kernel]["bytes_per_launch_corrected"], "profiles/r01_pmc_traffic.json: " + d["_source"]
+    except Exception:
+        return None, None
+
+
 def lde_figure(gl, device, steps=8):
     """BASELINE configs[1] on this GPU, a few steps: the metric's 'NTT HBM GB/s' half (full treatment: --workload lde)."""
     import torch
@@ -309,6 +320,7 @@ def main_recursive(args):
             items = sorted(p.items(), key=lambda kv: -kv[1][1])[:top]
             return {k: {"launches_per_unit": round(v[0] / max(1, n_units), 1), "ms_per_unit": round(v[1] / max(1, n_units), 4),
                         "alg_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else None} for k, v in items}
+        traffic, traffic_src = pmc_traffic(dname)
         line = {
             "metric": "recursive plonky2 proofs/sec (Semaphore d=%d)" % args.log_members,
             "value": round(units / elapsed, 2), "unit": "recursive proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -320,7 +332,7 @@ def main_recursive(args):
                                    % (args.log_members, pr.rc.data.degree_bits, per, args.threads),
                        "parallelism": "independent proofs sharded over ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel": dname, "launches_per_unit": round(dcnt / max(1, iso_units), 1),
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": dname, "launches_per_unit": round(dcnt / max(1, iso_units), 1),
                          "avg_launch_ms": round(dms / max(1, dcnt), 4), "algorithmic_bytes_per_launch": round(dbytes / max(1, dcnt)),
                          "how": "HIP events on the launching stream, one prover context, %d units, straight after the timed region; "
                                 "kernel = the scope group with the largest summed duration" % iso_units,
