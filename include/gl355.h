@@ -123,6 +123,20 @@ int32_t gl355_two_to_one(gl355_ctx* ctx, const uint64_t* left, const uint64_t* r
  * recursively) so MerkleTree::prove keeps working on it.  cap: 2^cap_height x 4. */
 int32_t gl355_merkle_build(gl355_ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len,
                            uint32_t cap_height, uint64_t* digests, uint64_t* cap);
+/* ---- the same entry points generic in the hasher `H` of plonky2's `Hasher<F>` / `GenericConfig::Hasher`
+ * (MerkleTree::new::<F, H>, H::hash_no_pad, H::two_to_one, H::Permutation::permute).  GL355_HASH_POSEIDON is
+ * PoseidonHash (the functions above); GL355_HASH_BN254_POSEIDON is the reference's Bn254PoseidonHash
+ * (src/plonky2_verifier/bn245_poseidon/plonky2_config.rs:38-75 over native.rs:16-77: three Goldilocks elements per BN254
+ * scalar, Poseidon t = 5 with 8 + 60 rounds and x^5, parameters constants.rs:5-404) -- the hasher of the outer wrap
+ * proof (wrapper.rs:35-56, access_set.rs:48-49, recursion.rs:333-335).  Same argument meaning and digest layout. */
+enum { GL355_HASH_POSEIDON = 0, GL355_HASH_BN254_POSEIDON = 1 };
+int32_t gl355_permute_h(gl355_ctx* ctx, int32_t hasher, uint64_t* states /* count x 12 */, uint64_t count);
+int32_t gl355_hash_no_pad_h(gl355_ctx* ctx, int32_t hasher, const uint64_t* inputs, uint64_t n, uint32_t len, uint64_t* digests);
+int32_t gl355_hash_leaves_h(gl355_ctx* ctx, int32_t hasher, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len,
+                            uint64_t* digests);
+int32_t gl355_two_to_one_h(gl355_ctx* ctx, int32_t hasher, const uint64_t* left, const uint64_t* right, uint64_t n, uint64_t* out);
+int32_t gl355_merkle_build_h(gl355_ctx* ctx, int32_t hasher, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len,
+                             uint32_t cap_height, uint64_t* digests, uint64_t* cap);
 /* siblings leaf -> cap: (log2(n_leaves) - cap_height) x 4 u64 (host buffer) */
 int32_t gl355_merkle_prove(gl355_ctx* ctx, const uint64_t* digests, uint64_t n_leaves, uint32_t cap_height,
                            uint64_t leaf_index, uint64_t* siblings);

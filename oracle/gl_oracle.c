@@ -264,20 +264,22 @@ void orc_merkle_build_recursive(const uint64_t *leaves, size_t n_leaves, uint32_
 /* same tree, level by level (parallel over nodes) using the closed-form slot of the layout:
  * node k of layer i (layer 0 = leaf digests) of a subtree lives at digest index
  * 2*(((k>>1) << (i+1)) + (1<<i) - 1) + (k&1).  Used for the multi-threaded CPU baseline. */
-void orc_merkle_build_layered(const uint64_t *leaves, size_t n_leaves, uint32_t leaf_len,
-                              uint32_t cap_height, uint64_t *digests, uint64_t *cap) {
+typedef void (*leaf_hash_fn)(const uint64_t *, size_t, uint64_t *);
+typedef void (*pair_hash_fn)(const uint64_t *, const uint64_t *, uint64_t *);
+static void merkle_layered(leaf_hash_fn leaf_hash, pair_hash_fn pair_hash, const uint64_t *leaves, size_t n_leaves,
+                           uint32_t leaf_len, uint32_t cap_height, uint64_t *digests, uint64_t *cap) {
     size_t n_cap = (size_t)1 << cap_height, sub_leaves = n_leaves >> cap_height;
     size_t sub_dig = 2 * (sub_leaves - 1);
     uint32_t sub_bits = log2_exact(sub_leaves);
     if (sub_bits == 0) {
-        for (size_t t = 0; t < n_cap; t++) orc_hash_or_noop(leaves + t * leaf_len, leaf_len, cap + t * 4);
+        for (size_t t = 0; t < n_cap; t++) leaf_hash(leaves + t * leaf_len, leaf_len, cap + t * 4);
         return;
     }
 #pragma omp parallel for schedule(static)
     for (size_t g = 0; g < n_leaves; g++) {
         size_t t = g >> sub_bits, k = g & (sub_leaves - 1);
         size_t pos = 2 * (((k >> 1) << 1) + 0) + (k & 1);
-        orc_hash_or_noop(leaves + g * leaf_len, leaf_len, digests + (t * sub_dig + pos) * 4);
+        leaf_hash(leaves + g * leaf_len, leaf_len, digests + (t * sub_dig + pos) * 4);
     }
     for (uint32_t i = 1; i <= sub_bits; i++) {
         size_t per = sub_leaves >> i; /* nodes of layer i per subtree */
@@ -290,9 +292,21 @@ void orc_merkle_build_layered(const uint64_t *leaves, size_t n_leaves, uint32_t 
             uint64_t *dst = (i == sub_bits)
                                 ? cap + t * 4
                                 : tree + (2 * (((k >> 1) << (i + 1)) + ((size_t)1 << i) - 1) + (k & 1)) * 4;
-            orc_two_to_one(l, r, dst);
+            pair_hash(l, r, dst);
         }
     }
+}
+void orc_merkle_build_layered(const uint64_t *leaves, size_t n_leaves, uint32_t leaf_len,
+                              uint32_t cap_height, uint64_t *digests, uint64_t *cap) {
+    merkle_layered(orc_hash_or_noop, orc_two_to_one, leaves, n_leaves, leaf_len, cap_height, digests, cap);
+}
+/* MerkleTree::new::<F, H> for H = PoseidonHash (ORC_HASH_POSEIDON) or the reference's Bn254PoseidonHash
+ * (ORC_HASH_BN254_POSEIDON, bn245_poseidon/plonky2_config.rs:57-75); same digest layout */
+void orc_merkle_build_h(int hasher, const uint64_t *leaves, size_t n_leaves, uint32_t leaf_len, uint32_t cap_height,
+                        uint64_t *digests, uint64_t *cap) {
+    if (hasher == ORC_HASH_BN254_POSEIDON)
+        merkle_layered(orc_bn254_hash_or_noop, orc_bn254_two_to_one, leaves, n_leaves, leaf_len, cap_height, digests, cap);
+    else orc_merkle_build(leaves, n_leaves, leaf_len, cap_height, digests, cap);
 }
 void orc_merkle_build(const uint64_t *leaves, size_t n_leaves, uint32_t leaf_len,
                       uint32_t cap_height, uint64_t *digests, uint64_t *cap) {

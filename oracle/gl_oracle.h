@@ -85,6 +85,17 @@ int orc_merkle_verify(const uint64_t *leaf, uint32_t leaf_len, size_t leaf_index
                       const uint64_t *siblings, uint32_t n_siblings, const uint64_t *cap,
                       uint32_t cap_height);
 
+/* ---- the reference's BN254-Poseidon hasher over Goldilocks elements (bn254_oracle.c) ------
+ * bn245_poseidon/native.rs:16-77, plonky2_config.rs:38-75.  permute_fr works on 5 canonical Fr values (4 limbs each). */
+enum { ORC_HASH_POSEIDON = 0, ORC_HASH_BN254_POSEIDON = 1 };
+void orc_bn254_permute_fr(uint64_t state[5][4]);
+void orc_bn254_permute(uint64_t state[12]);
+void orc_bn254_hash_no_pad(const uint64_t *in, size_t len, uint64_t out[4]);
+void orc_bn254_hash_or_noop(const uint64_t *in, size_t len, uint64_t out[4]);
+void orc_bn254_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]);
+void orc_merkle_build_h(int hasher, const uint64_t *leaves, size_t n_leaves, uint32_t leaf_len, uint32_t cap_height,
+                        uint64_t *digests, uint64_t *cap);
+
 /* ---- a4: FRI-commit pipeline (PolynomialBatch::from_values / from_coeffs) -------------- */
 /* values (or coeffs when is_coeffs != 0): batch columns of n.  salt: NULL or 4 columns of N
  * (natural order, as if they were extra LDE columns).  Outputs: coeffs_out [batch][n] (may be

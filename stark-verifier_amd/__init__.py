@@ -6,6 +6,7 @@ The directory name carries a hyphen (it mirrors the reference repository's name)
 include/gl355.h.  The HIP library is required: nothing in this package computes on the CPU.
 """
 from . import _lib  # noqa: F401
-from .api import (COSET_SHIFT, P, SALT_SIZE, Context, MerkleTree, PolynomialBatch, PoseidonHash,  # noqa: F401
+from .api import (COSET_SHIFT, HASH_BN254_POSEIDON, HASH_POSEIDON, P, SALT_SIZE, Bn254PoseidonHash, Context, MerkleTree,  # noqa: F401
+                  PolynomialBatch, PoseidonHash,
                   deep_batch, eval_polys)
 from ._lib import Gl355Error  # noqa: F401

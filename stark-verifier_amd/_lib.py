@@ -97,6 +97,11 @@ SIGNATURES = {
     "gl355_prove": (C.c_int32, [vp, C.POINTER(ProverData), vp, vp, C.c_uint32, C.c_uint64, vp, C.c_uint64]),
     "gl355_prove_sparse": (C.c_int32, [vp, C.POINTER(ProverData), vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        vp, C.c_uint32, C.c_uint64, vp, C.c_uint64]),
+    "gl355_permute_h": (C.c_int32, [vp, C.c_int32, vp, C.c_uint64]),
+    "gl355_hash_no_pad_h": (C.c_int32, [vp, C.c_int32, vp, C.c_uint64, C.c_uint32, vp]),
+    "gl355_hash_leaves_h": (C.c_int32, [vp, C.c_int32, vp, C.c_uint64, C.c_uint32, vp]),
+    "gl355_two_to_one_h": (C.c_int32, [vp, C.c_int32, vp, vp, C.c_uint64, vp]),
+    "gl355_merkle_build_h": (C.c_int32, [vp, C.c_int32, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp]),
     "gl355_semaphore_witness": (C.c_int32, [vp, vp, C.c_uint64, vp, C.c_uint32, vp, vp]),
     "gl355_witness_replay": (C.c_int32, [vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
     "gl355_quotient": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -228,33 +228,69 @@ class Context:
         return z, pp
 
 
-class PoseidonHash:
-    """plonky2::hash::poseidon::PoseidonHash (the reference's `C::Hasher`)."""
+HASH_POSEIDON, HASH_BN254_POSEIDON = 0, 1
+
+
+class _Hasher:
+    """plonky2 `Hasher<F>`: hash_no_pad, two_to_one, the permutation of the 12-element sponge state"""
+    ID = HASH_POSEIDON
 
     def __init__(self, ctx):
         self.ctx = ctx
 
+    def permute(self, states):
+        st = _u64(states).copy()
+        s2 = st.reshape(-1, 12)
+        self.ctx.check(self.ctx.lib.gl355_permute_h(self.ctx.h, self.ID, _ptr(s2), s2.shape[0]))
+        return st
+
     def hash_no_pad(self, inputs):
-        return self.ctx.hash_no_pad(inputs)
+        x = _u64(inputs)
+        x2 = x.reshape(1, -1) if x.ndim == 1 else x
+        out = np.empty((x2.shape[0], 4), dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.gl355_hash_no_pad_h(self.ctx.h, self.ID, _ptr(x2), x2.shape[0], x2.shape[1], _ptr(out)))
+        return out[0] if x.ndim == 1 else out
+
+    def hash_leaves(self, leaves):
+        x = _u64(leaves)
+        out = np.empty((x.shape[0], 4), dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.gl355_hash_leaves_h(self.ctx.h, self.ID, _ptr(x), x.shape[0], x.shape[1], _ptr(out)))
+        return out
 
     def two_to_one(self, left, right):
-        return self.ctx.two_to_one(left, right)
+        l, r = _u64(left).reshape(-1, 4), _u64(right).reshape(-1, 4)
+        out = np.empty_like(l)
+        self.ctx.check(self.ctx.lib.gl355_two_to_one_h(self.ctx.h, self.ID, _ptr(l), _ptr(r), l.shape[0], _ptr(out)))
+        return out
+
+
+class PoseidonHash(_Hasher):
+    """plonky2::hash::poseidon::PoseidonHash (the reference's `C::Hasher`)."""
+    ID = HASH_POSEIDON
+
+
+class Bn254PoseidonHash(_Hasher):
+    """the reference's Bn254PoseidonHash (src/plonky2_verifier/bn245_poseidon/plonky2_config.rs:57-75), the hasher of
+    `Bn254PoseidonGoldilocksConfig` = OuterC (access_set.rs:48-49, recursion.rs:333-335, wrapper.rs:35-56)"""
+    ID = HASH_BN254_POSEIDON
 
 
 class MerkleTree:
     """plonky2::hash::merkle_tree::MerkleTree { leaves, digests, cap } built on the GPU."""
 
-    def __init__(self, ctx, leaves, cap_height):
+    def __init__(self, ctx, leaves, cap_height, hasher=HASH_POSEIDON):
+        """MerkleTree::new::<F, H>(leaves, cap_height); hasher = HASH_POSEIDON | HASH_BN254_POSEIDON (or a _Hasher class)"""
         lv = _u64(leaves)
         n, leaf_len = lv.shape
+        self.hasher = getattr(hasher, "ID", hasher)
         self.ctx, self.leaves, self.cap_height = ctx, lv, cap_height
         self.digests = np.empty((max(0, 2 * (n - (1 << cap_height))), 4), dtype=np.uint64)
         self.cap = np.empty((1 << cap_height, 4), dtype=np.uint64)
-        ctx.check(ctx.lib.gl355_merkle_build(ctx.h, _ptr(lv), n, leaf_len, cap_height, _ptr(self.digests), _ptr(self.cap)))
+        ctx.check(ctx.lib.gl355_merkle_build_h(ctx.h, self.hasher, _ptr(lv), n, leaf_len, cap_height, _ptr(self.digests), _ptr(self.cap)))
 
     @classmethod
-    def new(cls, ctx, leaves, cap_height):
-        return cls(ctx, leaves, cap_height)
+    def new(cls, ctx, leaves, cap_height, hasher=HASH_POSEIDON):
+        return cls(ctx, leaves, cap_height, hasher)
 
     @classmethod
     def _from_parts(cls, ctx, leaves, digests, cap, cap_height):

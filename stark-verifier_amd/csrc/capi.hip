@@ -194,46 +194,73 @@ int32_t gl355_reverse_index_bits(gl355_ctx* h, uint64_t* data, uint64_t n_rows, 
     return s.finish();
 }
 
-int32_t gl355_poseidon_permute(gl355_ctx* h, uint64_t* states, uint64_t count) {
+#define HASHER_OR_FAIL(hs) \
+    if ((hs) != GL355_HASH_POSEIDON && (hs) != GL355_HASH_BN254_POSEIDON) return ctx->fail(GL355_E_INVALID_ARG, "unknown hasher")
+
+int32_t gl355_permute_h(gl355_ctx* h, int32_t hasher, uint64_t* states, uint64_t count) {
     CTX_OR_FAIL(h);
+    HASHER_OR_FAIL(hasher);
     if (count == 0) return GL355_OK;
     Staged s(ctx);
     GL355_TRY(s.open(states, count * 96, 3));
-    GL355_TRY(poseidon_permute_dev(ctx, s.as<uint64_t>(), count));
+    if (hasher == GL355_HASH_BN254_POSEIDON) GL355_TRY(bn254_permute_dev(ctx, s.as<uint64_t>(), count));
+    else GL355_TRY(poseidon_permute_dev(ctx, s.as<uint64_t>(), count));
     return s.finish();
 }
-int32_t gl355_hash_no_pad(gl355_ctx* h, const uint64_t* inputs, uint64_t n, uint32_t len, uint64_t* digests) {
+int32_t gl355_poseidon_permute(gl355_ctx* h, uint64_t* states, uint64_t count) { return gl355_permute_h(h, GL355_HASH_POSEIDON, states, count); }
+
+int32_t gl355_hash_no_pad_h(gl355_ctx* h, int32_t hasher, const uint64_t* inputs, uint64_t n, uint32_t len, uint64_t* digests) {
     CTX_OR_FAIL(h);
+    HASHER_OR_FAIL(hasher);
     if (n == 0) return GL355_OK;
     Staged si(ctx), so(ctx);
     GL355_TRY(si.open(inputs, n * len * 8, 1));
     GL355_TRY(so.open(digests, n * 32, 2));
-    GL355_TRY(hash_no_pad_dev(ctx, si.as<uint64_t>(), n, len, so.as<uint64_t>()));
+    if (hasher == GL355_HASH_BN254_POSEIDON) GL355_TRY(bn254_hash_leaves_dev(ctx, si.as<uint64_t>(), n, len, false, 0, so.as<uint64_t>(), true));
+    else GL355_TRY(hash_no_pad_dev(ctx, si.as<uint64_t>(), n, len, so.as<uint64_t>()));
     return so.finish();
 }
-int32_t gl355_hash_leaves(gl355_ctx* h, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, uint64_t* digests) {
+int32_t gl355_hash_no_pad(gl355_ctx* h, const uint64_t* inputs, uint64_t n, uint32_t len, uint64_t* digests) {
+    return gl355_hash_no_pad_h(h, GL355_HASH_POSEIDON, inputs, n, len, digests);
+}
+int32_t gl355_hash_leaves_h(gl355_ctx* h, int32_t hasher, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, uint64_t* digests) {
     CTX_OR_FAIL(h);
+    HASHER_OR_FAIL(hasher);
     if (n_leaves == 0) return GL355_OK;
     Staged si(ctx), so(ctx);
     GL355_TRY(si.open(leaves, n_leaves * leaf_len * 8, 1));
     GL355_TRY(so.open(digests, n_leaves * 32, 2));
-    GL355_TRY(hash_leaves_dev(ctx, si.as<uint64_t>(), n_leaves, leaf_len, false, 0, so.as<uint64_t>()));
+    if (hasher == GL355_HASH_BN254_POSEIDON) GL355_TRY(bn254_hash_leaves_dev(ctx, si.as<uint64_t>(), n_leaves, leaf_len, false, 0, so.as<uint64_t>(), false));
+    else GL355_TRY(hash_leaves_dev(ctx, si.as<uint64_t>(), n_leaves, leaf_len, false, 0, so.as<uint64_t>()));
     return so.finish();
 }
-int32_t gl355_two_to_one(gl355_ctx* h, const uint64_t* left, const uint64_t* right, uint64_t n, uint64_t* out) {
+int32_t gl355_hash_leaves(gl355_ctx* h, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, uint64_t* digests) {
+    return gl355_hash_leaves_h(h, GL355_HASH_POSEIDON, leaves, n_leaves, leaf_len, digests);
+}
+int32_t gl355_two_to_one_h(gl355_ctx* h, int32_t hasher, const uint64_t* left, const uint64_t* right, uint64_t n, uint64_t* out) {
     CTX_OR_FAIL(h);
+    HASHER_OR_FAIL(hasher);
     if (n == 0) return GL355_OK;
     Staged sl(ctx), sr(ctx), so(ctx);
     GL355_TRY(sl.open(left, n * 32, 1));
     GL355_TRY(sr.open(right, n * 32, 1));
     GL355_TRY(so.open(out, n * 32, 2));
-    GL355_TRY(two_to_one_dev(ctx, sl.as<uint64_t>(), sr.as<uint64_t>(), n, so.as<uint64_t>()));
+    if (hasher == GL355_HASH_BN254_POSEIDON) GL355_TRY(bn254_two_to_one_dev(ctx, sl.as<uint64_t>(), sr.as<uint64_t>(), n, so.as<uint64_t>()));
+    else GL355_TRY(two_to_one_dev(ctx, sl.as<uint64_t>(), sr.as<uint64_t>(), n, so.as<uint64_t>()));
     return so.finish();
+}
+int32_t gl355_two_to_one(gl355_ctx* h, const uint64_t* left, const uint64_t* right, uint64_t n, uint64_t* out) {
+    return gl355_two_to_one_h(h, GL355_HASH_POSEIDON, left, right, n, out);
 }
 
 int32_t gl355_merkle_build(gl355_ctx* h, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, uint32_t cap_height,
                            uint64_t* digests, uint64_t* cap) {
+    return gl355_merkle_build_h(h, GL355_HASH_POSEIDON, leaves, n_leaves, leaf_len, cap_height, digests, cap);
+}
+int32_t gl355_merkle_build_h(gl355_ctx* h, int32_t hasher, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, uint32_t cap_height,
+                             uint64_t* digests, uint64_t* cap) {
     CTX_OR_FAIL(h);
+    HASHER_OR_FAIL(hasher);
     if (n_leaves == 0) return ctx->fail(GL355_E_INVALID_ARG, "merkle: empty tree");
     const uint32_t lg = log2_u64(n_leaves);
     if ((1ull << lg) != n_leaves) return ctx->fail(GL355_E_INVALID_ARG, "merkle: n_leaves must be a power of two");
@@ -243,7 +270,10 @@ int32_t gl355_merkle_build(gl355_ctx* h, const uint64_t* leaves, uint64_t n_leav
     GL355_TRY(sl.open(leaves, n_leaves * leaf_len * 8, 1));
     GL355_TRY(sd.open(digests, n_dig * 32, 2));
     GL355_TRY(sc.open(cap, n_cap * 32, 2));
-    GL355_TRY(merkle_build_dev(ctx, sl.as<uint64_t>(), n_leaves, leaf_len, false, 0, cap_height, sd.as<uint64_t>(), sc.as<uint64_t>()));
+    if (hasher == GL355_HASH_BN254_POSEIDON)
+        GL355_TRY(bn254_merkle_build_dev(ctx, sl.as<uint64_t>(), n_leaves, leaf_len, false, 0, cap_height, sd.as<uint64_t>(), sc.as<uint64_t>()));
+    else
+        GL355_TRY(merkle_build_dev(ctx, sl.as<uint64_t>(), n_leaves, leaf_len, false, 0, cap_height, sd.as<uint64_t>(), sc.as<uint64_t>()));
     GL355_TRY(sd.finish());
     return sc.finish();
 }

@@ -15,18 +15,13 @@
 // are written directly into plonky2's recursive `digests` layout so no later shuffle is needed.
 #include "gl355_internal.h"
 #include "poseidon.cuh"
+#include "merkle_common.cuh"
 
 namespace gl355 {
 
 // levels with at most this many nodes use the lane-parallel kernel (4 nodes per wave): beyond ~2^14 nodes
 // the chip is full of waves either way and the one-lane-per-node kernel wins on instruction count
 // the default of Ctx::merkle_lanes_log (gl355_ctx_set_option) is 14: see the lane-parallel kernel below
-
-// index of node k of layer `layer` (0 = leaf digests) inside one cap-subtree's digest buffer:
-// pair p = k>>1 of layer i sits at pair slot (p << (i+1)) + 2^i - 1 (MerkleTree::prove's formula).
-__host__ __device__ __forceinline__ uint64_t digest_slot(uint32_t layer, uint64_t k) {
-    return 2 * (((k >> 1) << (layer + 1)) + (1ull << layer) - 1) + (k & 1);
-}
 
 __global__ void __launch_bounds__(256) poseidon_permute_kernel(uint64_t* states, uint64_t count) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -39,18 +34,6 @@ __global__ void __launch_bounds__(256) poseidon_permute_kernel(uint64_t* states,
     for (int k = 0; k < 12; k++) states[i * 12 + k] = gl_canon(s[k]);
 }
 
-struct LeafArgs {
-    const uint64_t* leaves;
-    uint64_t n_leaves;
-    uint32_t leaf_len;
-    uint32_t col_major;
-    uint64_t stride;        // col-major: elements between columns; row-major: elements between rows
-    uint64_t* out;          // digest destination
-    uint32_t sub_bits;      // log2(leaves per cap subtree); layout = subtree t at out + t*sub_dig*4
-    uint32_t linear;        // 1: out[i*4..] (no layout)
-    uint32_t always_hash;   // hash_no_pad semantics (no <=4 shortcut)
-    uint64_t* cap;          // used when sub_bits == 0 (tree is all cap)
-};
 
 // one lane = one leaf: overwrite-mode sponge over ceil(len/8) chunks
 __global__ void __launch_bounds__(256) hash_leaves_kernel(LeafArgs a) {

@@ -1,0 +1,145 @@
+// Second hash back-end: the reference's Bn254PoseidonHash (src/plonky2_verifier/bn245_poseidon/plonky2_config.rs:57-75
+// over native.rs:16-77) for permutation batches, leaf hashing, Merkle levels, two_to_one and PoW -- the hasher of the
+// final wrap proof (wrapper.rs:35-56 with OuterC = Bn254PoseidonGoldilocksConfig).  SURVEY 8(f) N1.
+//
+// Same launch shapes and the same plonky2 digest layout as merkle.hip; only the permutation differs (bn254.cuh).  One
+// lane = one sponge state: a permutation is ~2 000 254-bit Montgomery products (~0.9 M VALU instructions, ~35x the
+// Goldilocks Poseidon), so every level is throughput-bound down to a few hundred nodes and no lane-parallel variant is used.
+#include "gl355_internal.h"
+#include "bn254.cuh"
+#include "merkle_common.cuh"
+
+namespace gl355 {
+
+__global__ void __launch_bounds__(256) bn254_permute_kernel(uint64_t* states, uint64_t count) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = states[i * 12 + k];
+    bn254_permute(s);
+#pragma unroll
+    for (int k = 0; k < 12; k++) states[i * 12 + k] = s[k];
+}
+
+__global__ void __launch_bounds__(256) bn254_hash_leaves_kernel(LeafArgs a) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= a.n_leaves) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = 0;
+    const uint32_t len = a.leaf_len;
+    uint64_t d[4];
+    if (len <= 4 && !a.always_hash) {
+        for (uint32_t k = 0; k < 4; k++) {
+            uint64_t v = 0;
+            if (k < len) v = a.col_major ? a.leaves[(uint64_t)k * a.stride + i] : a.leaves[i * a.stride + k];
+            d[k] = gl_canon(v);
+        }
+    } else {
+#pragma unroll 1
+        for (uint32_t off = 0; off < len; off += 8) {
+            const uint32_t m = min(8u, len - off);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                if (k < m) s[k] = a.col_major ? a.leaves[(uint64_t)(off + k) * a.stride + i] : a.leaves[i * a.stride + off + k];
+            }
+            bn254_permute(s);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = s[k];
+    }
+    uint64_t* dst;
+    if (a.linear) dst = a.out + i * 4;
+    else if (a.sub_bits == 0) dst = a.cap + i * 4;
+    else {
+        const uint64_t sub_leaves = 1ull << a.sub_bits;
+        const uint64_t t = i >> a.sub_bits, k = i & (sub_leaves - 1);
+        dst = a.out + (t * 2 * (sub_leaves - 1) + digest_slot(0, k)) * 4;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst[k] = d[k];
+}
+
+__global__ void __launch_bounds__(256) bn254_merkle_level_kernel(uint64_t* digests, uint64_t* cap, uint32_t sub_bits, uint32_t layer,
+                                                                uint64_t n_nodes) {
+    const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (g >= n_nodes) return;
+    const uint64_t sub_leaves = 1ull << sub_bits;
+    const uint64_t per = sub_leaves >> layer;
+    const uint64_t t = g / per, k = g % per;
+    uint64_t* tree = digests + t * 2 * (sub_leaves - 1) * 4;
+    const uint64_t child = digest_slot(layer - 1, 2 * k);
+    uint64_t s[12];
+#pragma unroll
+    for (int e = 0; e < 8; e++) s[e] = tree[child * 4 + e];
+#pragma unroll
+    for (int e = 8; e < 12; e++) s[e] = 0;
+    bn254_permute(s);
+    uint64_t* dst = (layer == sub_bits) ? cap + t * 4 : tree + digest_slot(layer, k) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; e++) dst[e] = s[e];
+}
+
+__global__ void __launch_bounds__(256) bn254_two_to_one_kernel(const uint64_t* l, const uint64_t* r, uint64_t n, uint64_t* out) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s[12] = {gl_canon(l[4 * i]), gl_canon(l[4 * i + 1]), gl_canon(l[4 * i + 2]), gl_canon(l[4 * i + 3]),
+                      gl_canon(r[4 * i]), gl_canon(r[4 * i + 1]), gl_canon(r[4 * i + 2]), gl_canon(r[4 * i + 3]), 0, 0, 0, 0};
+    bn254_permute(s);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[4 * i + k] = s[k];
+}
+
+int32_t bn254_permute_dev(Ctx* ctx, uint64_t* states, uint64_t count) {
+    if (count == 0) return GL355_OK;
+    ProfScope ps(ctx, "bn254_permute_kernel", count * 192);
+    hipLaunchKernelGGL(bn254_permute_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, states, count);
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+static int32_t launch_leaves(Ctx* ctx, const LeafArgs& a) {
+    if (a.n_leaves == 0) return GL355_OK;
+    ProfScope ps(ctx, "bn254_hash_leaves_kernel", a.n_leaves * ((uint64_t)a.leaf_len * 8 + 32));
+    hipLaunchKernelGGL(bn254_hash_leaves_kernel, dim3((uint32_t)((a.n_leaves + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+int32_t bn254_hash_leaves_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, bool col_major, uint64_t col_stride,
+                              uint64_t* digests, bool always_hash) {
+    LeafArgs a;
+    memset(&a, 0, sizeof a);
+    a.leaves = leaves; a.n_leaves = n_leaves; a.leaf_len = leaf_len; a.col_major = col_major;
+    a.stride = col_major ? col_stride : leaf_len;
+    a.out = digests; a.linear = 1; a.always_hash = always_hash;
+    return launch_leaves(ctx, a);
+}
+int32_t bn254_two_to_one_dev(Ctx* ctx, const uint64_t* l, const uint64_t* r, uint64_t n, uint64_t* out) {
+    if (n == 0) return GL355_OK;
+    hipLaunchKernelGGL(bn254_two_to_one_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, l, r, n, out);
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+int32_t bn254_merkle_build_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, bool col_major, uint64_t col_stride,
+                               uint32_t cap_height, uint64_t* digests, uint64_t* cap) {
+    const uint32_t log_n = log2_u64(n_leaves);
+    if ((1ull << log_n) != n_leaves) return ctx->fail(GL355_E_INVALID_ARG, "merkle: n_leaves must be a power of two");
+    if (cap_height > log_n) return ctx->fail(GL355_E_INVALID_ARG, "merkle: cap_height > log2(n_leaves)");
+    const uint32_t sub_bits = log_n - cap_height;
+    LeafArgs a;
+    memset(&a, 0, sizeof a);
+    a.leaves = leaves; a.n_leaves = n_leaves; a.leaf_len = leaf_len; a.col_major = col_major;
+    a.stride = col_major ? col_stride : leaf_len;
+    a.out = digests; a.cap = cap; a.sub_bits = sub_bits;
+    GL355_TRY(launch_leaves(ctx, a));
+    for (uint32_t layer = 1; layer <= sub_bits; layer++) {
+        const uint64_t n_nodes = n_leaves >> layer;
+        ProfScope ps(ctx, "bn254_merkle_level_kernel", n_nodes * 96);
+        hipLaunchKernelGGL(bn254_merkle_level_kernel, dim3((uint32_t)((n_nodes + 255) / 256)), dim3(256), 0, ctx->stream, digests, cap,
+                           sub_bits, layer, n_nodes);
+        GL355_HIP(ctx, hipGetLastError());
+    }
+    return GL355_OK;
+}
+
+}  // namespace gl355

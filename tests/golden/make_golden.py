@@ -52,8 +52,31 @@ def mint_semaphore_proof():
                "public_inputs": ["%016x" % int(x) for x in pi]}, open(os.path.join(HERE, "semaphore_proof.json"), "w"), indent=1)
 
 
+def mint_bn254_kat():
+    """poseidon_bn254_kat.json: (1) the published circomlib known answer poseidon([1,2,3,4]) for t = 5 -- the script refuses to
+    write unless the big-integer model with the reference's parameters reproduces it; (2) permutation / hash vectors of the
+    reference's Goldilocks-packed hasher (bn245_poseidon/plonky2_config.rs:38-75) from that pinned model."""
+    import pymodel_bn254 as mb
+    circomlib = "299c867db6c1fdd79dcefa40e4510b9837e60ebb1ce0663dbaa525df65250465"
+    out = mb.permute_fr([0, 1, 2, 3, 4])
+    assert "%064x" % out[0] == circomlib, "model + reference parameters do not reproduce the circomlib known answer"
+    rnd = random.Random(0x254)
+    kat = {"circomlib_poseidon_1_2_3_4": circomlib,
+           "permute_fr": [{"input": ["%064x" % v for v in [0, 1, 2, 3, 4]], "output": ["%064x" % v for v in out]}],
+           "permute": [], "hash_no_pad": [], "two_to_one": []}
+    for name, st in (("zeros", [0] * 12), ("iota", list(range(12))), ("neg_one", [P - 1] * 12), ("random", [rnd.randrange(P) for _ in range(12)])):
+        kat["permute"].append({"name": name, "input": hx(st), "output": hx(mb.permute(st))})
+    for k in (1, 4, 7, 8, 9, 16, 135):
+        xs = [rnd.randrange(P) for _ in range(k)]
+        kat["hash_no_pad"].append({"input": hx(xs), "output": hx(mb.hash_no_pad(xs))})
+    l, r = [rnd.randrange(P) for _ in range(4)], [rnd.randrange(P) for _ in range(4)]
+    kat["two_to_one"].append({"left": hx(l), "right": hx(r), "output": hx(mb.two_to_one(l, r))})
+    json.dump(kat, open(os.path.join(HERE, "poseidon_bn254_kat.json"), "w"), indent=1)
+
+
 def main():
     mint_semaphore_proof()
+    mint_bn254_kat()
     kat = {"permute": []}
     for name, (inp, want) in UPSTREAM.items():
         got = pm.permute(inp)

@@ -333,3 +333,44 @@ class CpuProver:
             self.L.orc_batch_free(self.cs)
         except Exception:
             pass
+
+
+# ---- the reference's BN254-Poseidon hasher (oracle/bn254_oracle.c) ----------------------------------------
+class Bn254Oracle:
+    def __init__(self, orc):
+        self.L = orc.L
+
+    def permute_fr(self, vals5):
+        st = np.zeros((5, 4), dtype=np.uint64)
+        for i, v in enumerate(vals5):
+            for k in range(4):
+                st[i, k] = (int(v) >> (64 * k)) & ((1 << 64) - 1)
+        self.L.orc_bn254_permute_fr(_p(st))
+        return [sum(int(st[i, k]) << (64 * k) for k in range(4)) for i in range(5)]
+
+    def permute(self, states):
+        st = u64(states).copy()
+        s2 = st.reshape(-1, 12)
+        for i in range(s2.shape[0]):
+            row = np.ascontiguousarray(s2[i])
+            self.L.orc_bn254_permute(_p(row))
+            s2[i] = row
+        return st
+
+    def hash_no_pad(self, x):
+        x, out = u64(x), np.zeros(4, np.uint64)
+        self.L.orc_bn254_hash_no_pad(_p(x), C.c_size_t(x.size), _p(out))
+        return out
+
+    def two_to_one(self, l, r):
+        l, r, out = u64(l), u64(r), np.zeros(4, np.uint64)
+        self.L.orc_bn254_two_to_one(_p(l), _p(r), _p(out))
+        return out
+
+    def merkle_build(self, leaves, cap_height):
+        lv = u64(leaves)
+        n, ll = lv.shape
+        dig = np.zeros((max(0, 2 * (n - (1 << cap_height))), 4), np.uint64)
+        cap = np.zeros((1 << cap_height, 4), np.uint64)
+        self.L.orc_merkle_build_h(C.c_int(1), _p(lv), C.c_size_t(n), C.c_uint32(ll), C.c_uint32(cap_height), _p(dig), _p(cap))
+        return dig, cap

@@ -1,0 +1,75 @@
+"""GPU: the second hash back-end (GL355_HASH_BN254_POSEIDON = the reference's Bn254PoseidonHash) through the C ABI, bit-exact
+against the CPU restatement (oracle/bn254_oracle.c) and the committed known-answer vectors."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import Bn254Oracle, P, rand_field
+
+pytestmark = pytest.mark.gpu
+KAT = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "poseidon_bn254_kat.json")))
+
+
+def unhex(v):
+    return np.array([int(x, 16) for x in v], dtype=np.uint64)
+
+
+def test_known_answers(gl, ctx):
+    h = gl.Bn254PoseidonHash(ctx)
+    for case in KAT["permute"]:
+        assert np.array_equal(h.permute(unhex(case["input"])), unhex(case["output"])), case["name"]
+    for case in KAT["hash_no_pad"]:
+        assert np.array_equal(h.hash_no_pad(unhex(case["input"])), unhex(case["output"]))
+    c = KAT["two_to_one"][0]
+    assert np.array_equal(h.two_to_one(unhex(c["left"]), unhex(c["right"]))[0], unhex(c["output"]))
+
+
+def test_permute_batch_equals_oracle(gl, ctx, orc):
+    b, h = Bn254Oracle(orc), gl.Bn254PoseidonHash(ctx)
+    rng = np.random.default_rng(0x2541)
+    st = rand_field(rng, (300, 12))
+    st[0] = 0
+    st[1] = P - 1
+    st[2] = np.uint64((1 << 64) - 1)                     # non-canonical inputs are reduced first
+    st[3, :] = [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]
+    assert np.array_equal(h.permute(st), b.permute(st))
+
+
+@pytest.mark.parametrize("length", [1, 4, 5, 8, 9, 20, 135, 139])
+def test_hash_no_pad_and_leaves(gl, ctx, orc, length):
+    b, h = Bn254Oracle(orc), gl.Bn254PoseidonHash(ctx)
+    rng = np.random.default_rng(length)
+    x = rand_field(rng, (37, length))
+    want = np.stack([b.hash_no_pad(r) for r in x])
+    assert np.array_equal(h.hash_no_pad(x), want)
+    leaves = h.hash_leaves(x)                            # hash_or_noop: <= 4 elements are their own digest
+    if length <= 4:
+        assert np.array_equal(leaves[:, :length], x) and not leaves[:, length:].any()
+    else:
+        assert np.array_equal(leaves, want)
+
+
+@pytest.mark.parametrize("n,leaf_len,cap_h", [(1 << 10, 4, 4), (1 << 9, 20, 0), (1 << 8, 135, 4), (16, 7, 4), (2, 3, 0)])
+def test_merkle_tree_equals_oracle(gl, ctx, orc, n, leaf_len, cap_h):
+    b = Bn254Oracle(orc)
+    rng = np.random.default_rng(n + leaf_len)
+    leaves = rand_field(rng, (n, leaf_len))
+    tree = gl.MerkleTree(ctx, leaves, cap_h, hasher=gl.HASH_BN254_POSEIDON)
+    dig, cap = b.merkle_build(leaves, cap_h)
+    assert np.array_equal(tree.cap, cap) and np.array_equal(tree.digests, dig)
+    if n > (1 << cap_h):
+        assert np.array_equal(tree.prove(n - 1), orc.merkle_prove(dig, n, cap_h, n - 1))
+    other = gl.MerkleTree(ctx, leaves, cap_h)             # PoseidonHash tree over the same leaves differs
+    assert not np.array_equal(other.cap, tree.cap)
+
+
+def test_two_to_one_batch_and_errors(gl, ctx, orc):
+    b, h = Bn254Oracle(orc), gl.Bn254PoseidonHash(ctx)
+    rng = np.random.default_rng(7)
+    l, r = rand_field(rng, (50, 4)), rand_field(rng, (50, 4))
+    assert np.array_equal(h.two_to_one(l, r), np.stack([b.two_to_one(a, c) for a, c in zip(l, r)]))
+    st = np.zeros((1, 12), dtype=np.uint64)
+    assert ctx.lib.gl355_permute_h(ctx.h, 7, st.ctypes.data, 1) == -1       # unknown hasher
