@@ -147,6 +147,9 @@ int32_t gl355_merkle_prove(gl355_ctx* ctx, const uint64_t* digests, uint64_t n_l
  * random elements appended to every leaf when the oracle is blinded (natural order, i.e. exactly
  * what plonky2 appends to the LDE before its transpose).  The oracle keeps coefficients, the LDE
  * (column-major, bit-reversed row order), digests and cap resident on the device. */
+/* gl355_commit_h: the same with the Merkle hasher of the configuration (GL355_HASH_*); gl355_commit = GL355_HASH_POSEIDON */
+int32_t gl355_commit_h(gl355_ctx* ctx, int32_t hasher, const uint64_t* values, uint32_t log_n, uint32_t batch, uint32_t rate_bits,
+                       int32_t is_coeffs, const uint64_t* salt, uint32_t cap_height, gl355_oracle** out);
 int32_t gl355_commit(gl355_ctx* ctx, const uint64_t* values, uint32_t log_n, uint32_t batch,
                      uint32_t rate_bits, int32_t is_coeffs, const uint64_t* salt, uint32_t cap_height,
                      gl355_oracle** out);
@@ -233,11 +236,15 @@ int32_t gl355_lde_ext(gl355_ctx* ctx, const uint64_t* coeffs, uint32_t log_n, ui
 int32_t gl355_fri_fold(gl355_ctx* ctx, const uint64_t* coeffs, uint64_t n, const uint64_t beta[2], uint64_t* out);
 /* commit-phase layer tree from natural-order extension values (n ext): leaves = pairs in
  * bit-reversed order, flattened to 4 u64 (no leaf hash); outputs as gl355_merkle_build */
+int32_t gl355_fri_layer_commit_h(gl355_ctx* ctx, int32_t hasher, const uint64_t* values, uint64_t n, uint32_t cap_height,
+                                 uint64_t* leaves, uint64_t* digests, uint64_t* cap);
 int32_t gl355_fri_layer_commit(gl355_ctx* ctx, const uint64_t* values, uint64_t n, uint32_t cap_height,
                                uint64_t* leaves, uint64_t* digests, uint64_t* cap);
 
 /* ---- a13: fri_proof_of_work (fri_chip.rs:364-376, plonk_verifier_chip.rs:136-137) ------------- */
 /* smallest w >= start such that permute(state with state[pos] = w)[7] has >= bits leading zeros */
+int32_t gl355_pow_grind_h(gl355_ctx* ctx, int32_t hasher, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t start,
+                          uint64_t* witness);
 int32_t gl355_pow_grind(gl355_ctx* ctx, const uint64_t state[12], uint32_t pos, uint32_t bits,
                         uint64_t start, uint64_t* witness);
 
@@ -250,8 +257,10 @@ typedef struct {
     uint32_t in_len;
     uint64_t out_buf[8];
     uint32_t out_len;
+    int32_t hasher;          /* GL355_HASH_*: the sponge permutation (GenericConfig::Hasher); 0 after gl355_challenger_init */
 } gl355_challenger;
 int32_t gl355_challenger_init(gl355_challenger* c);
+int32_t gl355_challenger_init_h(gl355_challenger* c, int32_t hasher);
 int32_t gl355_challenger_observe(gl355_challenger* c, const uint64_t* elems, uint64_t n);
 int32_t gl355_challenger_squeeze(gl355_challenger* c, uint64_t* out, uint64_t n);
 /* sponge state + slot of the PoW witness candidate, to feed gl355_pow_grind */
@@ -259,6 +268,8 @@ int32_t gl355_challenger_pow_state(const gl355_challenger* c, uint64_t state[12]
 /* single host-side hashes (access_set.rs:67 hashes one 8-element input; the transcript) */
 int32_t gl355_host_poseidon_permute(uint64_t state[12]);
 int32_t gl355_host_hash_no_pad(const uint64_t* in, uint64_t len, uint64_t out[4]);
+int32_t gl355_host_permute_h(int32_t hasher, uint64_t state[12]);
+int32_t gl355_host_hash_no_pad_h(int32_t hasher, const uint64_t* in, uint64_t len, uint64_t out[4]);
 /* witness generation of one PoseidonGate row (wire layout gates/poseidon.rs:329-380) */
 int32_t gl355_poseidon_gate_witness(const uint64_t inputs[12], uint64_t swap, uint64_t wires[135]);
 
@@ -286,6 +297,9 @@ typedef struct {
     uint64_t circuit_digest[4];
     uint32_t cap_height, pow_bits, num_queries, n_fri_layers;
     int32_t zero_knowledge;      /* salt the wires / Z / quotient oracles with 4 pseudo-random columns */
+    int32_t hasher;              /* GL355_HASH_*: GenericConfig::Hasher = Merkle trees, transcript and PoW of this proof
+                                    (constants_sigmas must have been committed with it, gl355_commit_h).  Public inputs are
+                                    always hashed with Poseidon (GenericConfig::InnerHasher). */
 } gl355_prover_data;
 /* u64 words of the flat proof gl355_prove writes */
 uint64_t gl355_proof_words(const gl355_prover_data* pd);

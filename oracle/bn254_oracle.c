@@ -64,11 +64,15 @@ static fr fr_pow5(fr a) { fr a2 = fr_mul(a, a), a4 = fr_mul(a2, a2); return fr_m
 /* the Fr permutation on canonical (non-Montgomery) values: state[5][4] limbs */
 void orc_bn254_permute_fr(uint64_t state[5][4]) {
     static fr rc[340], mds[25];
-    static int init = 0;
+    static volatile int init = 0;
     if (!init) {
-        for (int i = 0; i < 340; i++) rc[i] = fr_to_mont(fr_from_limbs(ORC_BN254_RC[i]));
-        for (int i = 0; i < 25; i++) mds[i] = fr_to_mont(fr_from_limbs(ORC_BN254_MDS[i]));
-        init = 1;
+#pragma omp critical(orc_bn254_tables)
+        if (!init) {
+            for (int i = 0; i < 340; i++) rc[i] = fr_to_mont(fr_from_limbs(ORC_BN254_RC[i]));
+            for (int i = 0; i < 25; i++) mds[i] = fr_to_mont(fr_from_limbs(ORC_BN254_MDS[i]));
+            __sync_synchronize();
+            init = 1;
+        }
     }
     fr s[5];
     for (int i = 0; i < 5; i++) s[i] = fr_to_mont(fr_from_limbs(state[i]));

@@ -329,13 +329,19 @@ void orc_merkle_prove(const uint64_t *digests, size_t n_leaves, uint32_t cap_hei
 int orc_merkle_verify(const uint64_t *leaf, uint32_t leaf_len, size_t leaf_index,
                       const uint64_t *siblings, uint32_t n_siblings, const uint64_t *cap,
                       uint32_t cap_height) {
+    return orc_merkle_verify_h(ORC_HASH_POSEIDON, leaf, leaf_len, leaf_index, siblings, n_siblings, cap, cap_height);
+}
+int orc_merkle_verify_h(int hasher, const uint64_t *leaf, uint32_t leaf_len, size_t leaf_index,
+                        const uint64_t *siblings, uint32_t n_siblings, const uint64_t *cap, uint32_t cap_height) {
     (void)cap_height;
+    leaf_hash_fn leaf_hash = hasher == ORC_HASH_BN254_POSEIDON ? orc_bn254_hash_or_noop : orc_hash_or_noop;
+    pair_hash_fn pair_hash = hasher == ORC_HASH_BN254_POSEIDON ? orc_bn254_two_to_one : orc_two_to_one;
     uint64_t st[4], o[4];
-    orc_hash_or_noop(leaf, leaf_len, st);
+    leaf_hash(leaf, leaf_len, st);
     size_t idx = leaf_index;
     for (uint32_t i = 0; i < n_siblings; i++) {
-        if (idx & 1) orc_two_to_one(siblings + i * 4, st, o);
-        else orc_two_to_one(st, siblings + i * 4, o);
+        if (idx & 1) pair_hash(siblings + i * 4, st, o);
+        else pair_hash(st, siblings + i * 4, o);
         memcpy(st, o, 32);
         idx >>= 1;
     }
@@ -350,6 +356,11 @@ int orc_merkle_verify(const uint64_t *leaf, uint32_t leaf_len, size_t leaf_index
 void orc_commit(const uint64_t *values, uint32_t log_n, uint32_t batch, uint32_t rate_bits,
                 int is_coeffs, const uint64_t *salt, uint32_t cap_height, uint64_t *coeffs_out,
                 uint64_t *leaves, uint64_t *digests, uint64_t *cap) {
+    orc_commit_h(ORC_HASH_POSEIDON, values, log_n, batch, rate_bits, is_coeffs, salt, cap_height, coeffs_out, leaves, digests, cap);
+}
+void orc_commit_h(int hasher, const uint64_t *values, uint32_t log_n, uint32_t batch, uint32_t rate_bits,
+                  int is_coeffs, const uint64_t *salt, uint32_t cap_height, uint64_t *coeffs_out,
+                  uint64_t *leaves, uint64_t *digests, uint64_t *cap) {
     size_t n = (size_t)1 << log_n, N = n << rate_bits;
     uint32_t width = batch + (salt ? 4 : 0);
     uint64_t *coeffs = (uint64_t *)malloc((size_t)batch * n * 8);
@@ -362,7 +373,7 @@ void orc_commit(const uint64_t *values, uint32_t log_n, uint32_t batch, uint32_t
     if (salt) for (size_t i = 0; i < 4 * N; i++) lde[(size_t)batch * N + i] = canon(salt[i]);
     orc_transpose(lde, width, N, leaves); /* lde is [width][N] -> leaves [N][width] */
     orc_reverse_index_bits(leaves, N, width);
-    orc_merkle_build(leaves, N, width, cap_height, digests, cap);
+    orc_merkle_build_h(hasher, leaves, N, width, cap_height, digests, cap);
     free(lde); free(coeffs);
 }
 
@@ -473,7 +484,8 @@ void orc_challenger_init(orc_challenger *c) { memset(c, 0, sizeof *c); }
 static void challenger_duplex(orc_challenger *c) {
     for (uint32_t i = 0; i < c->in_len; i++) c->state[i] = c->in_buf[i];
     c->in_len = 0;
-    orc_poseidon_permute(c->state);
+    if (c->hasher == ORC_HASH_BN254_POSEIDON) orc_bn254_permute(c->state);
+    else orc_poseidon_permute(c->state);
     memcpy(c->out_buf, c->state, 64);
     c->out_len = 8;
 }

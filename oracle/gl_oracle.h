@@ -93,6 +93,11 @@ void orc_bn254_permute(uint64_t state[12]);
 void orc_bn254_hash_no_pad(const uint64_t *in, size_t len, uint64_t out[4]);
 void orc_bn254_hash_or_noop(const uint64_t *in, size_t len, uint64_t out[4]);
 void orc_bn254_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]);
+int orc_merkle_verify_h(int hasher, const uint64_t *leaf, uint32_t leaf_len, size_t leaf_index, const uint64_t *siblings,
+                        uint32_t n_siblings, const uint64_t *cap, uint32_t cap_height);
+void orc_commit_h(int hasher, const uint64_t *values, uint32_t log_n, uint32_t batch, uint32_t rate_bits, int is_coeffs,
+                  const uint64_t *salt, uint32_t cap_height, uint64_t *coeffs_out, uint64_t *leaves, uint64_t *digests,
+                  uint64_t *cap);
 void orc_merkle_build_h(int hasher, const uint64_t *leaves, size_t n_leaves, uint32_t leaf_len, uint32_t cap_height,
                         uint64_t *digests, uint64_t *cap);
 
@@ -136,6 +141,7 @@ typedef struct {
     uint32_t in_len;
     uint64_t out_buf[8];
     uint32_t out_len;
+    int32_t hasher;          /* ORC_HASH_*: the permutation of GenericConfig::Hasher; 0 after orc_challenger_init */
 } orc_challenger;
 void orc_challenger_init(orc_challenger *c);
 void orc_challenger_observe(orc_challenger *c, const uint64_t *elems, size_t n);
@@ -169,6 +175,8 @@ typedef struct {
 } orc_batch;
 orc_batch *orc_batch_commit(const uint64_t *values, uint32_t log_n, uint32_t batch, uint32_t rate_bits, int is_coeffs,
                             const uint64_t *salt, uint32_t cap_height);
+orc_batch *orc_batch_commit_h(int hasher, const uint64_t *values, uint32_t log_n, uint32_t batch, uint32_t rate_bits, int is_coeffs,
+                              const uint64_t *salt, uint32_t cap_height);
 void orc_batch_free(orc_batch *b);
 typedef struct {
     const orc_circuit *circuit;
@@ -178,6 +186,8 @@ typedef struct {
     uint64_t circuit_digest[4];
     uint32_t cap_height, pow_bits, num_queries, n_fri_layers;
     int32_t zero_knowledge;
+    int32_t hasher;          /* ORC_HASH_*: Merkle trees, transcript and PoW (GenericConfig::Hasher); public inputs are always
+                                hashed with Poseidon (GenericConfig::InnerHasher) */
 } orc_prover_data;
 /* vanishing polynomial / Z_H on the quotient coset, out[c][i] in NATURAL order of i (x = 7 w^i) */
 void orc_vanishing_values(const orc_circuit *c, const orc_batch *cs, const orc_batch *wires, const orc_batch *zs,

@@ -49,6 +49,10 @@ static inline uint64_t mix64(uint64_t seed, uint64_t i) {
 /* ---- committed batch (PolynomialBatch) ------------------------------------------------------------------ */
 orc_batch *orc_batch_commit(const uint64_t *values, uint32_t log_n, uint32_t batch, uint32_t rate_bits, int is_coeffs,
                             const uint64_t *salt, uint32_t cap_height) {
+    return orc_batch_commit_h(ORC_HASH_POSEIDON, values, log_n, batch, rate_bits, is_coeffs, salt, cap_height);
+}
+orc_batch *orc_batch_commit_h(int hasher, const uint64_t *values, uint32_t log_n, uint32_t batch, uint32_t rate_bits, int is_coeffs,
+                              const uint64_t *salt, uint32_t cap_height) {
     orc_batch *b = (orc_batch *)calloc(1, sizeof *b);
     size_t n = (size_t)1 << log_n, N = n << rate_bits;
     b->log_n = log_n; b->rate_bits = rate_bits; b->batch = batch; b->cap_height = cap_height;
@@ -57,7 +61,7 @@ orc_batch *orc_batch_commit(const uint64_t *values, uint32_t log_n, uint32_t bat
     b->leaves = (uint64_t *)malloc((size_t)b->leaf_len * N * 8);
     b->digests = (uint64_t *)malloc(2 * (N - ((size_t)1 << cap_height)) * 32 + 32);
     b->cap = (uint64_t *)malloc(((size_t)1 << cap_height) * 32);
-    orc_commit(values, log_n, batch, rate_bits, is_coeffs, salt, cap_height, b->coeffs, b->leaves, b->digests, b->cap);
+    orc_commit_h(hasher, values, log_n, batch, rate_bits, is_coeffs, salt, cap_height, b->coeffs, b->leaves, b->digests, b->cap);
     return b;
 }
 void orc_batch_free(orc_batch *b) {
@@ -353,7 +357,8 @@ static uint64_t grind(const orc_challenger *ch, uint32_t bits) {
             uint64_t t[12];
             memcpy(t, st, sizeof t);
             t[pos] = w;
-            orc_poseidon_permute(t);
+            if (ch->hasher == ORC_HASH_BN254_POSEIDON) orc_bn254_permute(t);
+            else orc_poseidon_permute(t);
             if ((t[7] >> (64 - bits)) == 0 && w < best) best = w;
         }
         if (best != UINT64_MAX) return best;
@@ -376,6 +381,8 @@ int orc_prove(const orc_prover_data *pd, const uint64_t *wires, const uint64_t *
 
     orc_challenger ch;
     orc_challenger_init(&ch);
+    ch.hasher = pd->hasher;
+    const int hs = pd->hasher;
     uint64_t pi_hash[4];
     orc_hash_no_pad(public_inputs, n_pi, pi_hash);
     orc_challenger_observe(&ch, pd->circuit_digest, 4);
@@ -389,7 +396,7 @@ int orc_prove(const orc_prover_data *pd, const uint64_t *wires, const uint64_t *
     }
     /* ---- wires ---- */
     FRESH_SALT(1)
-    orc_batch *b_w = orc_batch_commit(wires, c->degree_bits, c->num_wires, c->rate_bits, 0, salt, cap_h);
+    orc_batch *b_w = orc_batch_commit_h(hs, wires, c->degree_bits, c->num_wires, c->rate_bits, 0, salt, cap_h);
     memcpy(out, b_w->cap, n_cap * 32); orc_challenger_observe(&ch, out, n_cap * 4); out += n_cap * 4;
     uint64_t betas[4], gammas[4], alphas[4];
     squeeze_n(&ch, betas, nch);
@@ -401,7 +408,7 @@ int orc_prove(const orc_prover_data *pd, const uint64_t *wires, const uint64_t *
         orc_zs_partial_products(wires, pd->sigmas, pd->k_is, c->degree_bits, routed, qdf, betas[k], gammas[k], zbuf + (size_t)k * n,
                                 zbuf + ((size_t)nch + (size_t)k * npp) * n);
     FRESH_SALT(2)
-    orc_batch *b_z = orc_batch_commit(zbuf, c->degree_bits, z_width, c->rate_bits, 0, salt, cap_h);
+    orc_batch *b_z = orc_batch_commit_h(hs, zbuf, c->degree_bits, z_width, c->rate_bits, 0, salt, cap_h);
     memcpy(out, b_z->cap, n_cap * 32); orc_challenger_observe(&ch, out, n_cap * 4); out += n_cap * 4;
     squeeze_n(&ch, alphas, nch);
     /* ---- quotient: values on the coset -> coefficients -> max_degree chunks of degree < n ---- */
@@ -411,7 +418,7 @@ int orc_prove(const orc_prover_data *pd, const uint64_t *wires, const uint64_t *
     orc_vanishing_values(c, cs, b_w, b_z, pd->k_is, betas, gammas, alphas, pi_hash, qv);
     orc_coset_intt(qv, c->degree_bits + qdb, 7, nch, nq);
     FRESH_SALT(3)
-    orc_batch *b_q = orc_batch_commit(qv, c->degree_bits, nch * qdf, c->rate_bits, 1, salt, cap_h);
+    orc_batch *b_q = orc_batch_commit_h(hs, qv, c->degree_bits, nch * qdf, c->rate_bits, 1, salt, cap_h);
     memcpy(out, b_q->cap, n_cap * 32); orc_challenger_observe(&ch, out, n_cap * 4); out += n_cap * 4;
     uint64_t zeta[2], zeta_next[2];
     squeeze_n(&ch, zeta, 2);
@@ -448,7 +455,7 @@ int orc_prove(const orc_prover_data *pd, const uint64_t *wires, const uint64_t *
         lv[l] = (uint64_t *)malloc(len / 2 * 32);
         dg[l] = (uint64_t *)malloc(2 * (len / 2 - n_cap) * 32 + 32);
         orc_fri_layer_leaves(values, len, lv[l]);
-        orc_merkle_build(lv[l], len / 2, 4, cap_h, dg[l], p_caps + (size_t)l * n_cap * 4);
+        orc_merkle_build_h(hs, lv[l], len / 2, 4, cap_h, dg[l], p_caps + (size_t)l * n_cap * 4);
         orc_challenger_observe(&ch, p_caps + (size_t)l * n_cap * 4, n_cap * 4);
         uint64_t beta[2];
         squeeze_n(&ch, beta, 2);

@@ -22,13 +22,13 @@ class PolyRef(C.Structure):
 
 class Challenger(C.Structure):
     _fields_ = [("state", C.c_uint64 * 12), ("in_buf", C.c_uint64 * 8), ("in_len", C.c_uint32),
-                ("out_buf", C.c_uint64 * 8), ("out_len", C.c_uint32)]
+                ("out_buf", C.c_uint64 * 8), ("out_len", C.c_uint32), ("hasher", C.c_int32)]
 
 
 class ProverData(C.Structure):
     _fields_ = [("circuit", vp), ("constants_sigmas", vp), ("sigmas", vp), ("k_is", vp), ("circuit_digest", C.c_uint64 * 4),
                 ("cap_height", C.c_uint32), ("pow_bits", C.c_uint32), ("num_queries", C.c_uint32), ("n_fri_layers", C.c_uint32),
-                ("zero_knowledge", C.c_int32)]
+                ("zero_knowledge", C.c_int32), ("hasher", C.c_int32)]
 
 
 MAX_GATES = 16
@@ -80,6 +80,7 @@ SIGNATURES = {
     "gl355_two_to_one": (C.c_int32, [vp, vp, vp, C.c_uint64, vp]),
     "gl355_merkle_build": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp]),
     "gl355_merkle_prove": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint64, vp]),
+    "gl355_commit_h": (C.c_int32, [vp, C.c_int32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp, C.c_uint32, C.POINTER(vp)]),
     "gl355_commit": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp, C.c_uint32, C.POINTER(vp)]),
     "gl355_oracle_destroy": (C.c_int32, [vp]),
     "gl355_oracle_info": (C.c_int32, [vp] + [C.POINTER(C.c_uint32)] * 5),
@@ -107,17 +108,22 @@ SIGNATURES = {
     "gl355_quotient": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gl355_quotient_values": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gl355_challenger_init": (C.c_int32, [C.POINTER(Challenger)]),
+    "gl355_challenger_init_h": (C.c_int32, [C.POINTER(Challenger), C.c_int32]),
     "gl355_challenger_observe": (C.c_int32, [C.POINTER(Challenger), vp, C.c_uint64]),
     "gl355_challenger_squeeze": (C.c_int32, [C.POINTER(Challenger), vp, C.c_uint64]),
     "gl355_challenger_pow_state": (C.c_int32, [C.POINTER(Challenger), vp, C.POINTER(C.c_uint32)]),
     "gl355_host_poseidon_permute": (C.c_int32, [vp]),
     "gl355_host_hash_no_pad": (C.c_int32, [vp, C.c_uint64, vp]),
+    "gl355_host_hash_no_pad_h": (C.c_int32, [C.c_int32, vp, C.c_uint64, vp]),
+    "gl355_host_permute_h": (C.c_int32, [C.c_int32, vp]),
     "gl355_poseidon_gate_witness": (C.c_int32, [vp, C.c_uint64, vp]),
     "gl355_deep_batch": (C.c_int32, [vp, C.POINTER(PolyRef), C.c_uint32, vp, vp, vp]),
     "gl355_eval_polys": (C.c_int32, [vp, C.POINTER(PolyRef), C.c_uint32, vp, vp]),
     "gl355_lde_ext": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, vp]),
     "gl355_fri_fold": (C.c_int32, [vp, vp, C.c_uint64, vp, vp]),
+    "gl355_fri_layer_commit_h": (C.c_int32, [vp, C.c_int32, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
     "gl355_fri_layer_commit": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
+    "gl355_pow_grind_h": (C.c_int32, [vp, C.c_int32, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]),
     "gl355_pow_grind": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]),
     "gl355_zs_partial_products": (C.c_int32, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                               C.c_uint64, vp, vp]),

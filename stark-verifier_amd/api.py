@@ -46,6 +46,9 @@ def _u64(a):
     return np.ascontiguousarray(a, dtype=np.uint64)
 
 
+HASH_POSEIDON, HASH_BN254_POSEIDON = 0, 1   # GL355_HASH_*
+
+
 class Context:
     """One (device, stream) binding: gl355_ctx."""
 
@@ -228,9 +231,6 @@ class Context:
         return z, pp
 
 
-HASH_POSEIDON, HASH_BN254_POSEIDON = 0, 1
-
-
 class _Hasher:
     """plonky2 `Hasher<F>`: hash_no_pad, two_to_one, the permutation of the 12-element sponge state"""
     ID = HASH_POSEIDON
@@ -320,22 +320,22 @@ class PolynomialBatch:
         self.blinding = self.leaf_len != self.batch
 
     @classmethod
-    def _commit(cls, ctx, data, rate_bits, salt, cap_height, is_coeffs):
+    def _commit(cls, ctx, data, rate_bits, salt, cap_height, is_coeffs, hasher=HASH_POSEIDON):
         d = data if hasattr(data, "data_ptr") else _u64(data)
         batch, n = d.shape
         s = None if salt is None else (salt if hasattr(salt, "data_ptr") else _u64(salt))
         h = C.c_void_p()
-        ctx.check(ctx.lib.gl355_commit(ctx.h, _ptr(d), int(n).bit_length() - 1, batch, rate_bits, int(is_coeffs),
-                                       _ptr(s), cap_height, C.byref(h)))
+        ctx.check(ctx.lib.gl355_commit_h(ctx.h, getattr(hasher, "ID", hasher), _ptr(d), int(n).bit_length() - 1, batch, rate_bits,
+                                         int(is_coeffs), _ptr(s), cap_height, C.byref(h)))
         return cls(ctx, h)
 
     @classmethod
-    def from_values(cls, ctx, values, rate_bits, cap_height, salt=None):
-        return cls._commit(ctx, values, rate_bits, salt, cap_height, False)
+    def from_values(cls, ctx, values, rate_bits, cap_height, salt=None, hasher=HASH_POSEIDON):
+        return cls._commit(ctx, values, rate_bits, salt, cap_height, False, hasher)
 
     @classmethod
-    def from_coeffs(cls, ctx, coeffs, rate_bits, cap_height, salt=None):
-        return cls._commit(ctx, coeffs, rate_bits, salt, cap_height, True)
+    def from_coeffs(cls, ctx, coeffs, rate_bits, cap_height, salt=None, hasher=HASH_POSEIDON):
+        return cls._commit(ctx, coeffs, rate_bits, salt, cap_height, True, hasher)
 
     def close(self):
         if getattr(self, "h", None):

@@ -319,7 +319,12 @@ int32_t gl355_merkle_prove(gl355_ctx* h, const uint64_t* digests, uint64_t n_lea
 // ---- a4: commit -------------------------------------------------------------------------------
 int32_t gl355_commit(gl355_ctx* h, const uint64_t* values, uint32_t log_n, uint32_t batch, uint32_t rate_bits,
                      int32_t is_coeffs, const uint64_t* salt, uint32_t cap_height, gl355_oracle** out) {
+    return gl355_commit_h(h, GL355_HASH_POSEIDON, values, log_n, batch, rate_bits, is_coeffs, salt, cap_height, out);
+}
+int32_t gl355_commit_h(gl355_ctx* h, int32_t hasher, const uint64_t* values, uint32_t log_n, uint32_t batch, uint32_t rate_bits,
+                       int32_t is_coeffs, const uint64_t* salt, uint32_t cap_height, gl355_oracle** out) {
     CTX_OR_FAIL(h);
+    HASHER_OR_FAIL(hasher);
     if (!out) return ctx->fail(GL355_E_INVALID_ARG, "commit: null out");
     *out = nullptr;
     if (!values || batch == 0) return ctx->fail(GL355_E_INVALID_ARG, "commit: empty batch");
@@ -332,7 +337,7 @@ int32_t gl355_commit(gl355_ctx* h, const uint64_t* values, uint32_t log_n, uint3
     if (!o) return GL355_E_OOM;
     memset(o, 0, sizeof *o);
     o->ctx = ctx; o->log_n = log_n; o->rate_bits = rate_bits; o->batch = batch; o->leaf_len = leaf_len;
-    o->cap_height = cap_height; o->n_digests = n_dig;
+    o->cap_height = cap_height; o->n_digests = n_dig; o->hasher = hasher;
     // one allocation: coeffs | lde | digests | cap
     const uint64_t total = (uint64_t)batch * n + (uint64_t)leaf_len * N + n_dig * 4 + n_cap * 4;
     uint64_t* base = nullptr;
@@ -364,7 +369,7 @@ int32_t gl355_commit(gl355_ctx* h, const uint64_t* values, uint32_t log_n, uint3
             rc = bitrev_permute(ctx, ss.as<uint64_t>(), dst, log_n + rate_bits, 1, N, N, GL355_SALT_SIZE); if (rc) break;
             rc = ss.finish(); if (rc) break;
         }
-        rc = merkle_build_dev(ctx, o->lde, N, leaf_len, true, N, cap_height, o->digests, o->cap);
+        rc = merkle_build_any(ctx, hasher, o->lde, N, leaf_len, true, N, cap_height, o->digests, o->cap);
         if (rc) break;
         e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { rc = ctx->fail_hip(e, "hipStreamSynchronize(commit)", __FILE__, __LINE__); break; }
@@ -545,7 +550,12 @@ int32_t gl355_fri_fold(gl355_ctx* h, const uint64_t* coeffs, uint64_t n, const u
 }
 int32_t gl355_fri_layer_commit(gl355_ctx* h, const uint64_t* values, uint64_t n, uint32_t cap_height, uint64_t* leaves,
                                uint64_t* digests, uint64_t* cap) {
+    return gl355_fri_layer_commit_h(h, GL355_HASH_POSEIDON, values, n, cap_height, leaves, digests, cap);
+}
+int32_t gl355_fri_layer_commit_h(gl355_ctx* h, int32_t hasher, const uint64_t* values, uint64_t n, uint32_t cap_height, uint64_t* leaves,
+                                 uint64_t* digests, uint64_t* cap) {
     CTX_OR_FAIL(h);
+    HASHER_OR_FAIL(hasher);
     if (n < 2 || (n & (n - 1))) return ctx->fail(GL355_E_INVALID_ARG, "fri_layer_commit: n must be a power of two >= 2");
     const uint64_t n_leaves = n / 2;
     const uint32_t lg = log2_u64(n_leaves);
@@ -557,15 +567,20 @@ int32_t gl355_fri_layer_commit(gl355_ctx* h, const uint64_t* values, uint64_t n,
     GL355_TRY(sd.open(digests, n_dig * 32, 2));
     GL355_TRY(sc.open(cap, n_cap * 32, 2));
     GL355_TRY(fri_layer_leaves_dev(ctx, sv.as<uint64_t>(), n, sl.as<uint64_t>()));
-    GL355_TRY(merkle_build_dev(ctx, sl.as<uint64_t>(), n_leaves, 4, false, 0, cap_height, sd.as<uint64_t>(), sc.as<uint64_t>()));
+    GL355_TRY(merkle_build_any(ctx, hasher, sl.as<uint64_t>(), n_leaves, 4, false, 0, cap_height, sd.as<uint64_t>(), sc.as<uint64_t>()));
     GL355_TRY(sl.finish());
     GL355_TRY(sd.finish());
     return sc.finish();
 }
 int32_t gl355_pow_grind(gl355_ctx* h, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t start, uint64_t* witness) {
+    return gl355_pow_grind_h(h, GL355_HASH_POSEIDON, state, pos, bits, start, witness);
+}
+int32_t gl355_pow_grind_h(gl355_ctx* h, int32_t hasher, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t start,
+                          uint64_t* witness) {
     CTX_OR_FAIL(h);
-    if (!state || !witness) return ctx->fail(GL355_E_INVALID_ARG, "pow_grind: null argument");
-    return pow_grind_dev(ctx, state, pos, bits, start, witness);
+    HASHER_OR_FAIL(hasher);
+    if (!state || !witness || pos >= 8) return ctx->fail(GL355_E_INVALID_ARG, "pow_grind: bad argument");
+    return pow_grind_any(ctx, hasher, state, pos, bits, start, witness);
 }
 
 // ---- a9 --------------------------------------------------------------------------------------

@@ -84,16 +84,29 @@ int32_t gl355_host_poseidon_permute(uint64_t state[12]) {
     return GL355_OK;
 }
 
-int32_t gl355_host_hash_no_pad(const uint64_t* in, uint64_t len, uint64_t out[4]) {
-    if ((!in && len) || !out) return GL355_E_INVALID_ARG;
+static void permute_h(int32_t hasher, uint64_t st[12]) {
+    if (hasher == GL355_HASH_BN254_POSEIDON) host_bn254_permute(st);
+    else h_permute(st, nullptr, nullptr);
+}
+int32_t gl355_host_permute_h(int32_t hasher, uint64_t state[12]) {
+    if (!state || (hasher != GL355_HASH_POSEIDON && hasher != GL355_HASH_BN254_POSEIDON)) return GL355_E_INVALID_ARG;
+    for (int i = 0; i < 12; i++) state[i] = gl_canon(state[i]);
+    permute_h(hasher, state);
+    return GL355_OK;
+}
+int32_t gl355_host_hash_no_pad_h(int32_t hasher, const uint64_t* in, uint64_t len, uint64_t out[4]) {
+    if ((!in && len) || !out || (hasher != GL355_HASH_POSEIDON && hasher != GL355_HASH_BN254_POSEIDON)) return GL355_E_INVALID_ARG;
     uint64_t st[12] = {0};
     for (uint64_t off = 0; off < len; off += 8) {
         const uint64_t m = len - off < 8 ? len - off : 8;
         for (uint64_t i = 0; i < m; i++) st[i] = gl_canon(in[off + i]);
-        h_permute(st, nullptr, nullptr);
+        permute_h(hasher, st);
     }
     memcpy(out, st, 32);
     return GL355_OK;
+}
+int32_t gl355_host_hash_no_pad(const uint64_t* in, uint64_t len, uint64_t out[4]) {
+    return gl355_host_hash_no_pad_h(GL355_HASH_POSEIDON, in, len, out);
 }
 
 int32_t gl355_challenger_init(gl355_challenger* c) {
@@ -101,10 +114,16 @@ int32_t gl355_challenger_init(gl355_challenger* c) {
     memset(c, 0, sizeof *c);
     return GL355_OK;
 }
+int32_t gl355_challenger_init_h(gl355_challenger* c, int32_t hasher) {
+    if (!c || (hasher != GL355_HASH_POSEIDON && hasher != GL355_HASH_BN254_POSEIDON)) return GL355_E_INVALID_ARG;
+    memset(c, 0, sizeof *c);
+    c->hasher = hasher;
+    return GL355_OK;
+}
 static void duplex(gl355_challenger* c) {
     for (uint32_t i = 0; i < c->in_len; i++) c->state[i] = c->in_buf[i];
     c->in_len = 0;
-    h_permute(c->state, nullptr, nullptr);
+    permute_h(c->hasher, c->state);
     memcpy(c->out_buf, c->state, 64);
     c->out_len = 8;
 }

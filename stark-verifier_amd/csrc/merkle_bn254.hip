@@ -142,4 +142,54 @@ int32_t bn254_merkle_build_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leav
     return GL355_OK;
 }
 
+// proof of work with this hasher: same search as pow_grind_dev (smallest passing candidate of the first launch that holds one)
+__global__ void __launch_bounds__(256) bn254_pow_grind_kernel(const uint64_t* state, uint32_t pos, uint32_t bits, uint64_t start,
+                                                             unsigned long long* best) {
+    const uint64_t w = start + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint64_t s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = state[k];
+#pragma unroll
+    for (int k = 0; k < 12; k++) if ((uint32_t)k == pos) s[k] = w;
+    bn254_permute(s);
+    if (bits == 0 || (s[7] >> (64 - bits)) == 0) atomicMin(best, (unsigned long long)w);
+}
+int32_t bn254_pow_grind_dev(Ctx* ctx, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t start, uint64_t* witness_host) {
+    Scratch sc(ctx);
+    GL355_TRY(sc.get(13 * sizeof(uint64_t)));
+    uint64_t* d_state = sc.as<uint64_t>();
+    unsigned long long* d_best = reinterpret_cast<unsigned long long*>(d_state + 12);
+    uint64_t host[13];
+    for (int i = 0; i < 12; i++) host[i] = gl_canon(state[i]);
+    host[12] = ~0ull;
+    GL355_HIP(ctx, hipMemcpyAsync(d_state, host, sizeof host, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t per_launch = 1ull << std::min<uint32_t>(std::max<uint32_t>(bits + 1, 12), 20);
+    uint64_t base = start;
+    for (;;) {
+        ProfScope ps(ctx, "bn254_pow_grind", 0);
+        hipLaunchKernelGGL(bn254_pow_grind_kernel, dim3((uint32_t)(per_launch / 256)), dim3(256), 0, ctx->stream, d_state, pos, bits, base,
+                           d_best);
+        GL355_HIP(ctx, hipGetLastError());
+        unsigned long long best;
+        GL355_HIP(ctx, hipMemcpyAsync(&best, d_best, sizeof best, hipMemcpyDeviceToHost, ctx->stream));
+        GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (best != ~0ull) { *witness_host = best; return GL355_OK; }
+        base += per_launch;
+        if (per_launch < (1ull << 20)) per_launch <<= 1;
+        if (base - start > (1ull << 40)) return ctx->fail(GL355_E_UNSUPPORTED, "pow: no witness found in 2^40 candidates");
+    }
+}
+
+int32_t merkle_build_any(Ctx* ctx, int32_t hasher, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, bool col_major,
+                         uint64_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap) {
+    if (hasher == GL355_HASH_BN254_POSEIDON)
+        return bn254_merkle_build_dev(ctx, leaves, n_leaves, leaf_len, col_major, col_stride, cap_height, digests, cap);
+    return merkle_build_dev(ctx, leaves, n_leaves, leaf_len, col_major, col_stride, cap_height, digests, cap);
+}
+int32_t pow_grind_any(Ctx* ctx, int32_t hasher, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t start,
+                      uint64_t* witness_host) {
+    if (hasher == GL355_HASH_BN254_POSEIDON) return bn254_pow_grind_dev(ctx, state, pos, bits, start, witness_host);
+    return pow_grind_dev(ctx, state, pos, bits, start, witness_host);
+}
+
 }  // namespace gl355

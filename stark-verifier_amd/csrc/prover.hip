@@ -60,7 +60,7 @@ extern "C" int32_t gl355_fri_prove(gl355_ctx* h, const uint64_t* final_coeffs, u
         uint64_t* lv = tree_buf + leaf_off[l];
         uint64_t* dg = tree_buf + dig_off[l];
         GL355_TRY(fri_layer_leaves_dev(ctx, values, len, lv));
-        GL355_TRY(merkle_build_dev(ctx, lv, len / 2, 4, false, 0, cap_height, dg, d_cap));
+        GL355_TRY(merkle_build_any(ctx, ch->hasher, lv, len / 2, 4, false, 0, cap_height, dg, d_cap));
         GL355_HIP(ctx, hipMemcpyAsync(cap_host.data(), d_cap, n_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
         GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
         memcpy(caps_out + (uint64_t)l * n_cap * 4, cap_host.data(), n_cap * 32);
@@ -85,7 +85,7 @@ extern "C" int32_t gl355_fri_prove(gl355_ctx* h, const uint64_t* final_coeffs, u
     uint64_t st[12];
     uint32_t pos;
     if (gl355_challenger_pow_state(ch, st, &pos) != GL355_OK) return ctx->fail(GL355_E_INVALID_ARG, "fri_prove: challenger state");
-    GL355_TRY(pow_grind_dev(ctx, st, pos, pow_bits, 0, pow_witness));
+    GL355_TRY(pow_grind_any(ctx, ch->hasher, st, pos, pow_bits, 0, pow_witness));
     gl355_challenger_observe(ch, pow_witness, 1);
     uint64_t resp;
     gl355_challenger_squeeze(ch, &resp, 1);
@@ -280,8 +280,11 @@ static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, c
     hdr[0] = need; hdr[1] = c.degree_bits; hdr[2] = pd->n_fri_layers; hdr[3] = pd->num_queries; hdr[4] = n_public_inputs;
     hdr[5] = zk; hdr[6] = cap_h; hdr[7] = nch;
 
+    const int32_t hasher = pd->hasher;
+    if (hasher != GL355_HASH_POSEIDON && hasher != GL355_HASH_BN254_POSEIDON) return ctx->fail(GL355_E_INVALID_ARG, "prove: unknown hasher");
+    if (cs->hasher != hasher) return ctx->fail(GL355_E_INVALID_ARG, "prove: constants_sigmas was committed with another hasher");
     gl355_challenger ch;
-    gl355_challenger_init(&ch);
+    gl355_challenger_init_h(&ch, hasher);
     uint64_t pi_hash[4];
     gl355_host_hash_no_pad(public_inputs, n_public_inputs, pi_hash);
     gl355_challenger_observe(&ch, pd->circuit_digest, 4);
@@ -305,7 +308,7 @@ static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, c
     // ---- wires ----------------------------------------------------------------------------------
     OracleGuard g_w, g_z, g_q;
     if (zk) GL355_TRY(fresh_salt(1));
-    GL355_TRY(gl355_commit(h, wires, c.degree_bits, c.num_wires, c.rate_bits, 0, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_w.o));
+    GL355_TRY(gl355_commit_h(h, hasher, wires, c.degree_bits, c.num_wires, c.rate_bits, 0, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_w.o));
     uint64_t* p_wires_cap = out; out += n_cap * 4;
     GL355_TRY(observe_cap(ctx, g_w.o, &ch, p_wires_cap));
     uint64_t betas[4], gammas[4], alphas[4];
@@ -322,7 +325,7 @@ static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, c
                                           betas[k], gammas[k], z, pp));
     }
     if (zk) GL355_TRY(fresh_salt(2));
-    GL355_TRY(gl355_commit(h, zbuf.as<uint64_t>(), c.degree_bits, z_width, c.rate_bits, 0, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_z.o));
+    GL355_TRY(gl355_commit_h(h, hasher, zbuf.as<uint64_t>(), c.degree_bits, z_width, c.rate_bits, 0, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_z.o));
     uint64_t* p_zs_cap = out; out += n_cap * 4;
     GL355_TRY(observe_cap(ctx, g_z.o, &ch, p_zs_cap));
     gl355_challenger_squeeze(&ch, alphas, nch);
@@ -336,7 +339,7 @@ static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, c
     GL355_TRY(quotient_dev(ctx, &c, cs->lde, g_w.o->lde, g_z.o->lde, N, s_k.as<uint64_t>(), betas, gammas, alphas, pi_hash, qv.as<uint64_t>()));
     GL355_TRY(intt_from_bitrev_dev(ctx, qv.as<uint64_t>(), nq, qc.as<uint64_t>(), nq, c.degree_bits + qdb, nch, GL355_COSET_SHIFT));
     if (zk) GL355_TRY(fresh_salt(3));
-    GL355_TRY(gl355_commit(h, qc.as<uint64_t>(), c.degree_bits, nch * qdf, c.rate_bits, 1, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_q.o));
+    GL355_TRY(gl355_commit_h(h, hasher, qc.as<uint64_t>(), c.degree_bits, nch * qdf, c.rate_bits, 1, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_q.o));
     uint64_t* p_q_cap = out; out += n_cap * 4;
     GL355_TRY(observe_cap(ctx, g_q.o, &ch, p_q_cap));
     uint64_t zeta[2], zeta_next[2];

@@ -43,6 +43,7 @@ class CircuitConfig:
         self.num_query_rounds = 28
         self.reduction_arity_bits = 1      # FriReductionStrategy::ConstantArityBits(1, 5)
         self.final_poly_bits = 5
+        self.hasher = 0                    # GenericConfig::Hasher: 0 PoseidonHash, 1 the reference's Bn254PoseidonHash (OuterC)
         self.__dict__.update(kw)
 
     def fri_reduction_arity_bits(self, degree_bits):
@@ -58,10 +59,10 @@ class CircuitConfig:
 class Challenger:
     """plonky2::iop::challenger::Challenger on the host (gl355_challenger_*)."""
 
-    def __init__(self):
+    def __init__(self, hasher=0):
         self.lib = _lib.load()
         self.c = _CChallenger()
-        self.lib.gl355_challenger_init(C.byref(self.c))
+        assert self.lib.gl355_challenger_init_h(C.byref(self.c), hasher) == 0
 
     def observe(self, elems):
         e = _u64(elems).reshape(-1)
@@ -84,11 +85,11 @@ class Challenger:
         return st, pos.value
 
 
-def host_hash_no_pad(x):
+def host_hash_no_pad(x, hasher=0):
     lib = _lib.load()
     x = _u64(x).reshape(-1)
     out = np.empty(4, dtype=np.uint64)
-    lib.gl355_host_hash_no_pad(_ptr(x) if x.size else None, x.size, _ptr(out))
+    assert lib.gl355_host_hash_no_pad_h(hasher, _ptr(x) if x.size else None, x.size, _ptr(out)) == 0
     return out
 
 
@@ -129,7 +130,8 @@ class CircuitBuilder:
         """Pads (blinding rows + noops), computes selectors / sigmas and commits constants_sigmas on the device."""
         data = self.layout(min_degree_bits)
         cs_values = np.concatenate([data.constants, data.sigmas])
-        data.constants_sigmas = PolynomialBatch.from_values(ctx, cs_values, self.config.rate_bits, self.config.cap_height, salt=None)
+        data.constants_sigmas = PolynomialBatch.from_values(ctx, cs_values, self.config.rate_bits, self.config.cap_height, salt=None,
+                                                            hasher=self.config.hasher)
         data.set_digest(data.constants_sigmas.cap)
         return data
 
@@ -270,7 +272,7 @@ class CircuitData:
         shape = [self.degree_bits, len(self.gates), self.num_selectors] + [t * 1000 + p for t, p in self.gates]
         self.constants_sigmas_cap = np.array(constants_sigmas_cap, dtype=np.uint64).reshape(-1, 4)
         self.circuit_digest = host_hash_no_pad(np.concatenate([np.asarray(constants_sigmas_cap, dtype=np.uint64).reshape(-1),
-                                                               np.array(shape, dtype=np.uint64)]))
+                                                               np.array(shape, dtype=np.uint64)]), self.config.hasher)
 
     def prover_data(self, ctx):
         """gl355_prover_data with the sigma values and k_is resident on the device (uploaded once)."""
@@ -292,6 +294,7 @@ class CircuitData:
             cfg = self.config
             pd.cap_height, pd.pow_bits, pd.num_queries = cfg.cap_height, cfg.proof_of_work_bits, cfg.num_query_rounds
             pd.n_fri_layers, pd.zero_knowledge = len(self.fri_arity_bits), int(cfg.zero_knowledge)
+            pd.hasher = cfg.hasher
             cache[key] = pd
         return cache[key]
 
@@ -305,7 +308,7 @@ class CircuitData:
                     num_partial_products=self.num_partial_products, num_gate_constraints=self.num_gate_constraints,
                     k_is=[int(k) for k in self.k_is], rate_bits=cfg.rate_bits, cap_height=cfg.cap_height,
                     pow_bits=cfg.proof_of_work_bits, num_query_rounds=cfg.num_query_rounds,
-                    arity_bits=list(self.fri_arity_bits), hiding=cfg.zero_knowledge,
+                    arity_bits=list(self.fri_arity_bits), hiding=cfg.zero_knowledge, hasher=cfg.hasher,
                     circuit_digest=[int(x) for x in self.circuit_digest],
                     constants_sigmas_cap=self.constants_sigmas_cap.copy())
 

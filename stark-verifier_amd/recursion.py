@@ -15,7 +15,7 @@ import numpy as np
 from ._lib import (GATE_ARITHMETIC, GATE_ARITHMETIC_EXT, GATE_BASE_SUM, GATE_CONSTANT, GATE_NOOP, GATE_POSEIDON,
                    GATE_POSEIDON_MDS, GATE_PUBLIC_INPUT, GATE_RANDOM_ACCESS, GATE_REDUCING, GATE_REDUCING_EXT)
 from .gadgets import CIRC, GadgetBuilder, T
-from .plonk import P, _ptr, _u64, parse_proof_tagged, prove_sparse
+from .plonk import CircuitConfig, P, _ptr, _u64, parse_proof_tagged, prove_sparse
 
 UNUSED_SELECTOR = 0xFFFFFFFF
 _RC = None
@@ -274,6 +274,7 @@ def verify_proof(b, cd, proof, register_pis=True):
     """builder.verify_proof: proof (dict as produced by plonk.parse_proof) becomes virtual targets; the inner
     circuit's verifier data (constants_sigmas cap, circuit digest) are constants.  Returns the inner public-input
     targets."""
+    assert cd.get("hasher", 0) == 0, "the in-circuit verifier hashes with Poseidon-Goldilocks: the inner proof must use PoseidonHash"
     nch = cd["num_challenges"]
     tv = b.add_virtual_target
 
@@ -483,6 +484,19 @@ class RecursiveCircuit:
         assert sh == self.structure, "recursive circuit layout depends on the proof values"
         idx, vals = b.sparse_witness()
         return prove_sparse(self.ctx, self.data, idx, vals, np.array(pi_vals, dtype=np.uint64), seed, flat_only=flat_only)
+
+
+class WrapperCircuit(RecursiveCircuit):
+    """wrapper.rs:20-56: the final wrap.  One inner (Poseidon-Goldilocks) proof is verified in a circuit that is itself proven
+    under OuterC = Bn254PoseidonGoldilocksConfig (access_set.rs:48-49): Merkle trees, transcript and proof-of-work of the
+    OUTER proof use the reference's BN254-Poseidon hasher (bn245_poseidon/plonky2_config.rs:57-104), with
+    `standard_stark_verifier_config()`: cap_height 0, no zero-knowledge blinding, rate 8, 28 queries, 16 PoW bits.  This is
+    the proof the Halo2 verifier circuit consumes (out of scope)."""
+
+    def __init__(self, ctx, inner_common):
+        from .api import HASH_BN254_POSEIDON
+        cfg = CircuitConfig(cap_height=0, zero_knowledge=False, hasher=HASH_BN254_POSEIDON)
+        super().__init__(ctx, inner_common, k=1, config=cfg, public_inputs=wrap_public_inputs)
 
 
 class Aggregator:

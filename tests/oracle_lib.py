@@ -22,7 +22,7 @@ def u64(a):
 
 class Challenger(C.Structure):
     _fields_ = [("state", C.c_uint64 * 12), ("in_buf", C.c_uint64 * 8), ("in_len", C.c_uint32),
-                ("out_buf", C.c_uint64 * 8), ("out_len", C.c_uint32)]
+                ("out_buf", C.c_uint64 * 8), ("out_len", C.c_uint32), ("hasher", C.c_int32)]
 
 
 class Oracle:
@@ -146,10 +146,10 @@ class Oracle:
         self.L.orc_merkle_prove(_p(d), C.c_size_t(n_leaves), C.c_uint32(cap_height), C.c_size_t(index), _p(sib))
         return sib
 
-    def merkle_verify(self, leaf, index, siblings, cap, cap_height):
+    def merkle_verify(self, leaf, index, siblings, cap, cap_height, hasher=0):
         leaf, sib, cap = u64(leaf), u64(siblings), u64(cap)
-        return bool(self.L.orc_merkle_verify(_p(leaf), C.c_uint32(leaf.size), C.c_size_t(index), _p(sib),
-                                             C.c_uint32(sib.size // 4), _p(cap), C.c_uint32(cap_height)))
+        return bool(self.L.orc_merkle_verify_h(C.c_int(hasher), _p(leaf), C.c_uint32(leaf.size), C.c_size_t(index), _p(sib),
+                                               C.c_uint32(sib.size // 4), _p(cap), C.c_uint32(cap_height)))
 
     def commit(self, values, rate_bits, cap_height, salt=None, is_coeffs=False):
         v = u64(values)
@@ -199,9 +199,10 @@ class Oracle:
         s = u64(state)
         return self.L.orc_pow_grind(_p(s), C.c_uint32(pos), C.c_uint32(bits), C.c_uint64(start))
 
-    def challenger(self):
+    def challenger(self, hasher=0):
         c = Challenger()
         self.L.orc_challenger_init(C.byref(c))
+        c.hasher = hasher
         return c
 
     def observe(self, ch, elems):
@@ -252,7 +253,7 @@ class OrcBatch(C.Structure):
 class OrcProverData(C.Structure):
     _fields_ = [("circuit", C.POINTER(OrcCircuit)), ("constants_sigmas", C.POINTER(OrcBatch)), ("sigmas", u64p), ("k_is", u64p),
                 ("circuit_digest", C.c_uint64 * 4), ("cap_height", C.c_uint32), ("pow_bits", C.c_uint32), ("num_queries", C.c_uint32),
-                ("n_fri_layers", C.c_uint32), ("zero_knowledge", C.c_int32)]
+                ("n_fri_layers", C.c_uint32), ("zero_knowledge", C.c_int32), ("hasher", C.c_int32)]
 
 
 class CpuProver:
@@ -260,10 +261,12 @@ class CpuProver:
     copied), constants [num_selectors + num_constants][n], sigmas [routed][n], k_is, circuit_digest and the FRI parameters."""
 
     def __init__(self, orc, shape, constants, sigmas, k_is, circuit_digest, cap_height, pow_bits, num_queries, n_fri_layers,
-                 zero_knowledge, blind_rows=None):
+                 zero_knowledge, blind_rows=None, hasher=0):
         L = self.L = orc.L
         L.orc_batch_commit.restype = C.POINTER(OrcBatch)
         L.orc_batch_commit.argtypes = [u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u64p, C.c_uint32]
+        L.orc_batch_commit_h.restype = C.POINTER(OrcBatch)
+        L.orc_batch_commit_h.argtypes = [C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u64p, C.c_uint32]
         L.orc_batch_free.argtypes = [C.POINTER(OrcBatch)]
         L.orc_proof_words.restype = C.c_uint64
         L.orc_proof_words.argtypes = [C.POINTER(OrcProverData)]
@@ -271,7 +274,7 @@ class CpuProver:
         self.sigmas, self.k_is = u64(sigmas), u64(k_is)
         cs_values = u64(np.concatenate([u64(constants), self.sigmas]))
         c = self.circuit
-        self.cs = L.orc_batch_commit(_p(cs_values), c.degree_bits, cs_values.shape[0], c.rate_bits, 0, None, cap_height)
+        self.cs = L.orc_batch_commit_h(hasher, _p(cs_values), c.degree_bits, cs_values.shape[0], c.rate_bits, 0, None, cap_height)
         pd = self.pd = OrcProverData()
         pd.circuit = C.pointer(self.circuit)
         pd.constants_sigmas = self.cs
@@ -280,6 +283,7 @@ class CpuProver:
             pd.circuit_digest[i] = int(circuit_digest[i]) if circuit_digest is not None else 0
         pd.cap_height, pd.pow_bits, pd.num_queries, pd.n_fri_layers = cap_height, pow_bits, num_queries, n_fri_layers
         pd.zero_knowledge = int(zero_knowledge)
+        pd.hasher = int(hasher)
         self.blind_rows = blind_rows
         self.words = L.orc_proof_words(C.byref(pd))
 
@@ -287,7 +291,8 @@ class CpuProver:
     def from_circuit_data(cls, orc, data):
         cfg = data.config
         return cls(orc, data.c_circuit, data.constants, data.sigmas, data.k_is, data.circuit_digest, cfg.cap_height,
-                   cfg.proof_of_work_bits, cfg.num_query_rounds, len(data.fri_arity_bits), cfg.zero_knowledge, data.blind_rows)
+                   cfg.proof_of_work_bits, cfg.num_query_rounds, len(data.fri_arity_bits), cfg.zero_knowledge, data.blind_rows,
+                   hasher=getattr(cfg, "hasher", 0))
 
     def cap(self):
         n_cap = 1 << self.pd.cap_height

@@ -64,8 +64,8 @@ def ext_pow(a, e):
 
 
 class Transcript:
-    def __init__(self, orc):
-        self.orc, self.ch = orc, orc.challenger()
+    def __init__(self, orc, hasher=0):
+        self.orc, self.ch = orc, orc.challenger(hasher)
 
     def observe(self, elems):
         self.orc.observe(self.ch, np.asarray(elems, dtype=np.uint64).reshape(-1))
@@ -265,7 +265,8 @@ def verify(orc, cd, proof):
     fri = proof["opening_proof"]
     pi_hash = [int(v) for v in orc.hash_no_pad(np.asarray(proof["public_inputs"], dtype=np.uint64))]
     # ---- get_challenges --------------------------------------------------------------------------------
-    tr = Transcript(orc)
+    hasher = cd.get("hasher", 0)          # GenericConfig::Hasher: Merkle trees + transcript (0 Poseidon, 1 the reference's Bn254PoseidonHash)
+    tr = Transcript(orc, hasher)
     tr.observe(cd["circuit_digest"])
     tr.observe(pi_hash)
     tr.observe(proof["wires_cap"])
@@ -320,7 +321,7 @@ def verify(orc, cd, proof):
             raise VerifyError("query index mismatch")
         for o, (leaf, sib) in enumerate(rnd["initial_trees"]):
             want = widths[o] + (4 if (cd["hiding"] and blinding[o]) else 0)
-            if len(leaf) != want or not orc.merkle_verify(leaf, x_index, sib, caps[o], cd["cap_height"]):
+            if len(leaf) != want or not orc.merkle_verify(leaf, x_index, sib, caps[o], cd["cap_height"], hasher):
                 raise VerifyError("initial tree %d opening" % o)
         x = 7 * pow(omega, pm.bitrev(x_index, lde_bits), P) % P
         # batch_initial_polynomials (fri_chip.rs:112-149)
@@ -344,7 +345,7 @@ def verify(orc, cd, proof):
             a1, b1 = evals[0], evals[1]
             numer = mul(sub(fri_betas[i], a0), sub(b1, a1))
             prev = add(a1, mul(numer, pm.ext_inv(sub(b0, a0))))
-            if not orc.merkle_verify(np.asarray(evals_flat, dtype=np.uint64), coset_index, sib, fri["commit_phase_merkle_caps"][i], cd["cap_height"]):
+            if not orc.merkle_verify(np.asarray(evals_flat, dtype=np.uint64), coset_index, sib, fri["commit_phase_merkle_caps"][i], cd["cap_height"], hasher):
                 raise VerifyError("layer %d Merkle opening" % i)
             xx = xx * xx % P
             idx = coset_index

@@ -73,3 +73,36 @@ def test_two_to_one_batch_and_errors(gl, ctx, orc):
     assert np.array_equal(h.two_to_one(l, r), np.stack([b.two_to_one(a, c) for a, c in zip(l, r)]))
     st = np.zeros((1, 12), dtype=np.uint64)
     assert ctx.lib.gl355_permute_h(ctx.h, 7, st.ctypes.data, 1) == -1       # unknown hasher
+
+
+def test_wrap_proof_with_bn254_hasher(gl, ctx, orc):
+    """wrapper.rs:35-56: a Semaphore proof wrapped by a recursive circuit whose OWN proof is made under the
+    Bn254PoseidonGoldilocksConfig (BN254-Poseidon Merkle trees, transcript, PoW; cap_height 0, no blinding).  The GPU proof
+    equals the CPU restatement byte for byte and passes the restated reference verifier run with that hasher."""
+    import plonk_verifier as pv
+    from oracle_lib import CpuProver
+    from test_gpu_prover import make_access_set
+    rec = importlib.import_module("stark-verifier_amd.recursion")
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    aset, sks, rng = make_access_set(gl, ctx, 3, 0x2542)
+    topic = rand_field(rng, 4)
+    sig, data = aset.make_signal_fast(sks[4], topic, 4, 3, flat_only=True)
+    inner = (sig.proof, np.concatenate([aset.tree.cap[0], sig.nullifier[0], sig.topics[0]]))
+    wc = rec.WrapperCircuit(ctx, data.common()).build([inner], rng)
+    cd = wc.data.common()
+    assert cd["hasher"] == 1 and cd["cap_height"] == 0 and not cd["hiding"]
+    flat, pis = wc.prove_flat([inner], seed=17)
+    assert np.array_equal(pis, inner[1])
+    proof = plonk.parse_proof(wc.data, flat)
+    proof["public_inputs"] = pis
+    pv.verify(orc, cd, proof)
+    bad = dict(cd)
+    bad["hasher"] = 0                                     # the same proof checked with the wrong hasher must fail
+    with pytest.raises(pv.VerifyError):
+        pv.verify(orc, bad, proof)
+    cpu = CpuProver.from_circuit_data(orc, wc.data)
+    assert np.array_equal(cpu.cap(), wc.data.constants_sigmas.cap)
+    rows, _ = wc.witness([inner])
+    want = cpu.prove_sparse(wc.row_idx, rows, pis, 17)
+    assert np.array_equal(flat, want)
+    print("wrap circuit: degree 2^%d, proof %d words" % (wc.data.degree_bits, flat.size))

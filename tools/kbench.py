@@ -79,6 +79,27 @@ def bench_poseidon(ctx, log_n, reps=3):
     print("poseidon_permute 2^%-2d         %8.3f ms  %8.1f Mperm/s" % (log_n, ms, n / ms / 1e3))
 
 
+def bench_bn254(ctx, log_n, reps=3):
+    n = 1 << log_n
+    st = dev_rand((n, 12))
+    torch.cuda.synchronize()
+    ms, _ = timed(ctx, lambda: ctx.check(ctx.lib.gl355_permute_h(ctx.h, 1, C.c_void_p(st.data_ptr()), n)), reps)
+    print("bn254_permute 2^%-2d            %8.3f ms  %8.2f Mperm/s" % (log_n, ms, n / ms / 1e3))
+
+
+def bench_merkle_bn254(ctx, log_n, leaf_len, cap, reps=2):
+    n = 1 << log_n
+    leaves = dev_rand((n, leaf_len))
+    dig = torch.empty((2 * (n - (1 << cap)), 4), dtype=torch.int64, device="cuda")
+    capb = torch.empty((1 << cap, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ms, prof = timed(ctx, lambda: ctx.check(ctx.lib.gl355_merkle_build_h(ctx.h, 1, C.c_void_p(leaves.data_ptr()), n, leaf_len, cap,
+                                                                        C.c_void_p(dig.data_ptr()), C.c_void_p(capb.data_ptr()))), reps)
+    perms = n * ((leaf_len + 7) // 8 if leaf_len > 4 else 0) + (n - (1 << cap))
+    print("merkle-bn254 N=2^%-2d L=%-4d cap=%d   %8.3f ms  %8.2f Mperm/s  %s" % (log_n, leaf_len, cap, ms, perms / ms / 1e3,
+                                                                              {k: round(v, 3) for k, v in prof.items()}))
+
+
 def bench_commit(ctx, log_n, batch, rate_bits=3, cap=4, salted=True, reps=3):
     n, N = 1 << log_n, 1 << (log_n + rate_bits)
     vals = dev_rand((batch, n))
@@ -116,6 +137,11 @@ def main():
         bench_merkle(ctx, 20, 4, 0)
         bench_merkle(ctx, 20, 135, 4)
         bench_merkle(ctx, 16, 139, 4)
+    if what in ("bn254", "all"):
+        bench_bn254(ctx, 20)
+        bench_bn254(ctx, 16)
+        bench_merkle_bn254(ctx, 17, 139, 4)
+        bench_merkle_bn254(ctx, 16, 4, 4)
     if what in ("commit", "all"):
         bench_commit(ctx, 13, 135)
         bench_commit(ctx, 13, 85, salted=False)
