@@ -166,31 +166,57 @@ GL_DEV void fr_decode3(fr8 xm, uint64_t out[3]) {
     }
 }
 
-// the Fr permutation (native.rs:45-62), values in Montgomery form and < 2r throughout
+// the Fr permutation (native.rs:45-62), values in Montgomery form and < 2r throughout.  The 8 full rounds follow the
+// definition (constants, x^5 on every element, dense 5x5 MDS: 40 products each).  The 60 partial rounds use the derived
+// sparse form (tools/gen_bn254_tables.py derive_fast, checked there against the definition): one pre-matrix (16 products),
+// then per round x^5 on element 0 and 9 products instead of 25 -- 1 056 products per permutation instead of 2 000.
+GL_DEV void bn254_full_round(fr8 (&s)[5], int rnd) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) s[i] = fr_pow5(fr_add(s[i], fr_const(BN254_RC[5 * rnd + i])));
+    fr8 n[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        fr8 acc = fr_mul(s[0], fr_const(BN254_MDS[5 * i]));
+#pragma unroll
+        for (int j = 1; j < 5; j++) acc = fr_add(acc, fr_mul(s[j], fr_const(BN254_MDS[5 * i + j])));
+        n[i] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) s[i] = n[i];
+}
 GL_DEV void bn254_permute_fr(fr8 (&s)[5]) {
-    int k = 0;
 #pragma unroll 1
-    for (int rnd = 0; rnd < 68; rnd++) {
+    for (int rnd = 0; rnd < 4; rnd++) bn254_full_round(s, rnd);
+    // ---- 60 partial rounds ----
 #pragma unroll
-        for (int i = 0; i < 5; i++) s[i] = fr_add(s[i], fr_const(BN254_RC[k + i]));
-        k += 5;
-        if (rnd < 4 || rnd >= 64) {
-#pragma unroll
-            for (int i = 0; i < 5; i++) s[i] = fr_pow5(s[i]);
-        } else {
-            s[0] = fr_pow5(s[0]);
-        }
+    for (int i = 0; i < 5; i++) s[i] = fr_add(s[i], fr_const(BN254_PART_FIRST[i]));
+    {
         fr8 n[5];
+        n[0] = s[0];
 #pragma unroll
-        for (int i = 0; i < 5; i++) {
-            fr8 acc = fr_mul(s[0], fr_const(BN254_MDS[5 * i]));
+        for (int c = 1; c < 5; c++) {
+            fr8 acc = fr_mul(s[1], fr_const(BN254_PART_INIT[c - 1]));
 #pragma unroll
-            for (int j = 1; j < 5; j++) acc = fr_add(acc, fr_mul(s[j], fr_const(BN254_MDS[5 * i + j])));
-            n[i] = acc;
+            for (int r = 2; r < 5; r++) acc = fr_add(acc, fr_mul(s[r], fr_const(BN254_PART_INIT[(r - 1) * 4 + (c - 1)])));
+            n[c] = acc;
         }
 #pragma unroll
         for (int i = 0; i < 5; i++) s[i] = n[i];
     }
+#pragma unroll 1
+    for (int r = 0; r < 60; r++) {
+        fr8 s0 = fr_pow5(s[0]);
+        if (r < 59) s0 = fr_add(s0, fr_const(BN254_PART_POST[r]));
+        fr8 d = fr_mul(s0, fr_const(BN254_PART_M00[0]));
+#pragma unroll
+        for (int i = 1; i < 5; i++) {
+            d = fr_add(d, fr_mul(s[i], fr_const(BN254_PART_WHAT[4 * r + (i - 1)])));
+            s[i] = fr_add(s[i], fr_mul(s0, fr_const(BN254_PART_VS[4 * r + (i - 1)])));
+        }
+        s[0] = d;
+    }
+#pragma unroll 1
+    for (int rnd = 64; rnd < 68; rnd++) bn254_full_round(s, rnd);
 }
 
 // Bn254PoseidonPermutation::permute on the 12-element sponge state (plonky2_config.rs:38-55)
