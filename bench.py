@@ -350,6 +350,23 @@ def main_recursive(args):
                 line["cpu_baseline"] = cpu_baseline_recursive(pr)
             except Exception as exc:
                 line["cpu_baseline"] = {"error": repr(exc)}
+            try:    # the final wrap (wrapper.rs:35-56): the recursive circuit proven under the BN254-Poseidon hasher, one context
+                rec = importlib.import_module("stark-verifier_amd.recursion")
+                inner = pr.last[0]
+                c0 = pr.sets[0].ctx
+                wc = rec.WrapperCircuit(c0, pr.inner_data.common()).build([inner], np.random.default_rng(3))
+                rows_w, pis_w = wc.witness([inner])
+                pr.plonk.prove_sparse(c0, wc.data, wc.row_idx, rows_w, pis_w, 1, flat_only=True)
+                t_w = time.perf_counter()
+                for k in range(3):
+                    pr.plonk.prove_sparse(c0, wc.data, wc.row_idx, rows_w, pis_w, 2 + k, flat_only=True)
+                line["wrap_proof_bn254"] = {"ms_per_proof": round((time.perf_counter() - t_w) / 3 * 1e3, 2), "degree_bits": wc.data.degree_bits,
+                                            "what": "WrapperCircuit: in-circuit verification of one Semaphore proof, outer proof with "
+                                                    "Bn254PoseidonHash Merkle trees / transcript / PoW, cap_height 0, no blinding; "
+                                                    "single context, latency"}
+                del wc
+            except Exception as exc:
+                line["wrap_proof_bn254"] = {"error": repr(exc)}
             try:
                 del pr
                 line["ntt_lde"] = lde_figure(gl, local_rank)
