@@ -263,12 +263,20 @@ def main_recursive(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    # rehearsal of the N > 1 path on a box with fewer GPUs than ranks: GL355_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # uses gloo for the gather (NCCL refuses two ranks on one device); never set by the driver
+    rehearsal = os.environ.get("GL355_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     gl = importlib.import_module("stark-verifier_amd")
     par = importlib.import_module("stark-verifier_amd.parallel")
     pr = RecursiveProvers(gl, local_rank, args.threads, args.log_members)
