@@ -1,0 +1,106 @@
+"""CPU: the recursive verifier circuit and the witness tape without a GPU.  The circuit tables come from the product's host-only
+builder (`GadgetBuilder` / `CircuitBuilder.layout()`), the proofs from the CPU restatement of prove() (oracle/gl_prover.c), and
+every proof is checked by the restatement of the reference's own verifier (tests/plonk_verifier.py)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+import cpu_semaphore as cs
+import plonk_verifier as pv
+from oracle_lib import CpuProver, rand_field
+
+gad = importlib.import_module("stark-verifier_amd.gadgets")
+plonk = importlib.import_module("stark-verifier_amd.plonk")
+rec = importlib.import_module("stark-verifier_amd.recursion")
+lib = importlib.import_module("stark-verifier_amd._lib").load()
+
+
+def cpu_circuit(orc, builder):
+    """(CircuitData with digest, CpuProver) of a finished GadgetBuilder, no device involved"""
+    data = builder.cb.layout()
+    cpu = CpuProver.from_circuit_data(orc, data)
+    data.set_digest(cpu.cap())
+    for i in range(4):
+        cpu.pd.circuit_digest[i] = int(data.circuit_digest[i])
+    return data, cpu
+
+
+def replay(tape, inputs, n_rows):
+    rows = np.empty((n_rows, 135), dtype=np.uint64)
+    failed = C.c_uint64(0)
+    inputs = np.ascontiguousarray(inputs, dtype=np.uint64)
+    rc = lib.gl355_witness_replay(tape.ctypes.data, tape.shape[0], inputs.ctypes.data, inputs.size, rows.ctypes.data, rows.size, 135,
+                                  C.byref(failed))
+    return rc, rows, failed.value
+
+
+def test_witness_tape_replay_and_malformed_tapes():
+    rng = np.random.default_rng(0x7A9E)
+    b = gad.GadgetBuilder()
+    inputs = rand_field(rng, 40)
+    inputs[8] = 1
+    t = [plonk.Src(v, i) for i, v in enumerate(inputs)]
+    xs = b.add_virtual_targets(t[:8])
+    s = b.add(b.mul(xs[0], xs[1]), xs[2])
+    q = b.ext_div(b.ext_mul((xs[0], xs[1]), (xs[2], xs[3])), (xs[2], xs[3]))
+    h = b.hash_n_to_hash_no_pad(xs + xs[:3])
+    bit = b.add_virtual_target(t[8])
+    b.assert_bool(bit)
+    b.permute_swapped(xs + [b.zero()] * 4, swap=bit)
+    bits = b.split_le_64(xs[5])
+    items = b.add_virtual_targets(t[9:25])
+    b.random_access(b.le_sum(bits[:4]), items)
+    red = b.reduce_with_powers_base(b.add_virtual_targets(t[25:40]), (xs[6], xs[7]))
+    b.mds_ext([(items[2 * i], items[2 * i + 1]) for i in range(6)] * 2)
+    b.register_public_inputs([s, h[0], red[1], q[0]])
+    pi_vals = b.finalize_public_inputs()
+    idx, vals = b.sparse_witness()
+    tape, ridx, pi_pos = b.witness_tape()
+    rc, rows, _ = replay(tape, inputs, idx.size)
+    assert rc == 0 and np.array_equal(rows, vals) and np.array_equal(ridx, idx)
+    assert [int(v) for v in rows.reshape(-1)[pi_pos]] == pi_vals
+    # an input that violates assert_bool is refused at that ASSERT_EQ entry
+    bad = inputs.copy()
+    bad[8] = 3
+    rc, _, failed = replay(tape, bad, idx.size)
+    assert rc == -6 and tape[failed][0] == gad.TAPE_ASSERT_EQ
+    # malformed tapes are rejected with GL355_E_INVALID_ARG, never executed out of bounds
+    for trial in range(200):
+        broken = tape.copy()
+        e = int(rng.integers(0, tape.shape[0]))
+        f = int(rng.integers(0, 5))
+        broken[e, f] = np.uint64(rng.integers(0, 1 << 63)) if trial % 2 else np.uint64(vals.size + int(rng.integers(0, 200)))
+        rc, _, _ = replay(broken, inputs, idx.size)
+        assert rc in (0, -1, -6)
+    assert replay(tape, inputs[:5], idx.size)[0] == -1              # INPUT index past the input vector
+    assert replay(tape, inputs, idx.size - 1)[0] == -1               # rows buffer too small
+
+
+def test_recursive_proof_of_a_cpu_semaphore_proof(orc):
+    """wrapper.rs:35-47 entirely on the CPU side: inner Semaphore proof (CPU prover) -> verify_proof circuit -> outer proof (CPU
+    prover) -> accepted by the restated reference verifier; the tape replay gives the same witness as the gadget pass"""
+    case, topic, (idx, vals, pi), flat = cs.golden_proof(orc)
+    inner_cd = case["data"].common()
+    tagged = plonk.parse_proof_tagged(inner_cd, flat, pi, 0)
+    b = gad.GadgetBuilder()
+    inner_pis = rec.verify_proof(b, inner_cd, tagged, register_pis=False)
+    rec.wrap_public_inputs(b, [inner_pis])
+    pi_vals = b.finalize_public_inputs()
+    assert pi_vals == [int(x) for x in pi]
+    data, cpu = cpu_circuit(orc, b)
+    assert data.degree_bits == 14
+    ridx, rows = b.sparse_witness()
+    tape, tidx, pi_pos = b.witness_tape()
+    rc, trows, _ = replay(tape, np.concatenate([flat, pi]), ridx.size)
+    assert rc == 0 and np.array_equal(trows, rows)
+    outer = cpu.prove_sparse(ridx, rows, np.array(pi_vals, dtype=np.uint64), 31)
+    proof = plonk.parse_proof(data, outer)
+    proof["public_inputs"] = np.array(pi_vals, dtype=np.uint64)
+    pv.verify(orc, data.common(), proof)
+    # a corrupted inner proof (one sibling word) cannot be witnessed
+    bad = flat.copy()
+    bad[-3] ^= np.uint64(1)
+    rc, _, _ = replay(tape, np.concatenate([bad, pi]), ridx.size)
+    assert rc == -6
