@@ -21,22 +21,30 @@
 #define GL_DEV __device__ __forceinline__
 #define GL_HD __host__ __device__ __forceinline__
 
+// data-dependent corrections fire for about half of all random operands: on the host (Challenger, witness tape) ask for
+// conditional moves instead of branches; on the device the compiler predicates anyway
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GL_UNPRED(c) (c)
+#else
+#define GL_UNPRED(c) __builtin_unpredictable(c)
+#endif
+
 GL_HD uint64_t gl_canon(uint64_t a) { return a >= GL_P ? a - GL_P : a; }
 
 GL_HD uint64_t gl_add(uint64_t a, uint64_t b) {
     uint64_t s = a + b;
-    if (s < a) {                 // true sum = s + 2^64 == s + EPS
+    if (GL_UNPRED(s < a)) {      // true sum = s + 2^64 == s + EPS
         s += GL_EPS;
-        if (s < GL_EPS) s += GL_EPS;
+        if (GL_UNPRED(s < GL_EPS)) s += GL_EPS;
     }
     return s;
 }
 
 GL_HD uint64_t gl_sub(uint64_t a, uint64_t b) {
     uint64_t d = a - b;
-    if (a < b) {                 // true diff = d - 2^64 == d - EPS
+    if (GL_UNPRED(a < b)) {      // true diff = d - 2^64 == d - EPS
         uint64_t e = d - GL_EPS;
-        if (d < GL_EPS) e -= GL_EPS;
+        if (GL_UNPRED(d < GL_EPS)) e -= GL_EPS;
         d = e;
     }
     return d;
@@ -48,10 +56,10 @@ GL_HD uint64_t gl_neg(uint64_t a) { return gl_sub(0, a); }
 GL_HD uint64_t gl_reduce128(uint64_t lo, uint64_t hi) {
     uint32_t hi_hi = (uint32_t)(hi >> 32), hi_lo = (uint32_t)hi;
     uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= GL_EPS;
+    if (GL_UNPRED(lo < hi_hi)) t0 -= GL_EPS;
     uint64_t t1 = ((uint64_t)hi_lo << 32) - hi_lo;
     uint64_t r = t0 + t1;
-    if (r < t1) r += GL_EPS;
+    if (GL_UNPRED(r < t1)) r += GL_EPS;
     return r;
 }
 
@@ -82,7 +90,7 @@ GL_HD uint64_t gl_mul_small(uint64_t a, uint32_t c) {
     uint32_t hi = (uint32_t)(u >> 32);           // product = hi*2^64 + lo, hi < 2^32
     uint64_t t1 = ((uint64_t)hi << 32) - hi;
     uint64_t r = lo + t1;
-    if (r < t1) r += GL_EPS;
+    if (GL_UNPRED(r < t1)) r += GL_EPS;
     return r;
 }
 

@@ -18,16 +18,26 @@ static inline uint64_t h_sbox(uint64_t x) {
     uint64_t x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x, x2);
     return gl_mul(x3, x4);
 }
+// MDS layer on the 32-bit halves: 12 x 6-bit constants keep both partial sums below 2^42, so the inner loops are plain
+// 64-bit multiply-adds over a doubled array (no modulo indexing, no 128-bit arithmetic) and vectorise
 static void h_mds(uint64_t s[12]) {
     static const uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    uint64_t t[12];
+    uint32_t lo[24], hi[24];
+    for (int i = 0; i < 12; i++) { lo[i] = lo[i + 12] = (uint32_t)s[i]; hi[i] = hi[i + 12] = (uint32_t)(s[i] >> 32); }
     for (int r = 0; r < 12; r++) {
-        unsigned __int128 acc = 0;
-        for (int i = 0; i < 12; i++) acc += (unsigned __int128)gl_canon(s[(i + r) % 12]) * CIRC[i];
-        if (r == 0) acc += (unsigned __int128)gl_canon(s[0]) * 8;
-        t[r] = gl_reduce128((uint64_t)acc, (uint64_t)(acc >> 64));
+        uint64_t al = 0, ah = 0;
+        for (int i = 0; i < 12; i++) { al += (uint64_t)lo[i + r] * CIRC[i]; ah += (uint64_t)hi[i + r] * CIRC[i]; }
+        if (r == 0) { al += (uint64_t)lo[0] * 8; ah += (uint64_t)hi[0] * 8; }
+        // value = al + ah * 2^32 (< 2^75): ah * 2^32 = (ah >> 32) * 2^64 + (ah << 32)
+        const uint64_t mid = ah << 32;
+        const unsigned __int128 w0 = (unsigned __int128)al + mid;
+        const uint64_t r0 = (uint64_t)w0;
+        const uint64_t top = (ah >> 32) + (uint64_t)(w0 >> 64);
+        const uint64_t t = top * GL_EPS;                  // top < 2^11
+        uint64_t r1 = r0 + t;
+        if (__builtin_unpredictable(r1 < t)) r1 += GL_EPS;
+        s[r] = r1;
     }
-    memcpy(s, t, sizeof t);
 }
 // fast-partial form; sbox_in (optional) receives the 22 partial-round S-box inputs, full_in the
 // S-box inputs of the 8 full rounds (12 each) -- exactly the values PoseidonGate stores as wires
