@@ -40,6 +40,14 @@ GL_HD uint64_t gl_add(uint64_t a, uint64_t b) {
     return s;
 }
 
+// a + c for a CANONICAL c (< p), e.g. a round constant: a + c < 2^64 + p, so after a wrapped sum the single
+// correction s + EPS < p + EPS = 2^64 cannot wrap again -- one correction instead of two
+GL_HD uint64_t gl_add_canonical(uint64_t a, uint64_t c) {
+    uint64_t s = a + c;
+    if (GL_UNPRED(s < a)) s += GL_EPS;
+    return s;
+}
+
 GL_HD uint64_t gl_sub(uint64_t a, uint64_t b) {
     uint64_t d = a - b;
     if (GL_UNPRED(a < b)) {      // true diff = d - 2^64 == d - EPS

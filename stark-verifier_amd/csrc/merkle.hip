@@ -124,7 +124,7 @@ GL_DEV uint64_t psd_permute_lanes(uint64_t s, int li, uint64_t* ring /* 24 u64 o
 #pragma unroll 1
     for (int r = 0; r < 30; r++) {
         const uint64_t rc_next = PSD_ALL_RC[12 * (r < 29 ? r + 1 : 29) + me];
-        const uint64_t t = gl_add(s, rc);
+        const uint64_t t = gl_add_canonical(s, rc);
         rc = rc_next;
         const bool full = r < 4 || r >= 26;
         const uint64_t sb = psd_sbox(t);

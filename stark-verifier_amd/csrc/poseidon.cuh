@@ -54,14 +54,14 @@ GL_DEV void psd_full_rounds(uint64_t (&s)[12]) {
     for (int r = 0; r < 4; r++) {
         const int base = (FIRST_HALF ? 0 : 48) + 12 * r;
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = psd_sbox(gl_add(s[i], PSD_FULL_RC[base + i]));
+        for (int i = 0; i < 12; i++) s[i] = psd_sbox(gl_add_canonical(s[i], PSD_FULL_RC[base + i]));
         psd_mds(s);
     }
 }
 
 GL_DEV void psd_partial_rounds(uint64_t (&s)[12]) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PSD_PART_FIRST[i]);
+    for (int i = 0; i < 12; i++) s[i] = gl_add_canonical(s[i], PSD_PART_FIRST[i]);
     // pre-matrix: out[c] = sum_{r>=1} INIT[r-1][c-1] * s[r]  (lane 0 passes through)
     {
         uint64_t t[12];
@@ -80,7 +80,7 @@ GL_DEV void psd_partial_rounds(uint64_t (&s)[12]) {
 #pragma unroll 1
     for (int r = 0; r < 22; r++) {
         uint64_t s0 = psd_sbox(s[0]);
-        s0 = gl_add(s0, PSD_PART_RC[r]);  // entry 21 is 0
+        s0 = gl_add_canonical(s0, PSD_PART_RC[r]);  // entry 21 is 0
         uint64_t d = gl_mul_small(s0, 25);  // MDS[0][0] = CIRC[0] + DIAG[0]
 #pragma unroll
         for (int i = 1; i < 12; i++) {
@@ -97,7 +97,7 @@ GL_DEV void psd_partial_rounds_dense(uint64_t (&s)[12]) {
 #pragma unroll 1
     for (int r = 0; r < 22; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PSD_ALL_RC[12 * (4 + r) + i]);
+        for (int i = 0; i < 12; i++) s[i] = gl_add_canonical(s[i], PSD_ALL_RC[12 * (4 + r) + i]);
         s[0] = psd_sbox(s[0]);
         psd_mds(s);
     }

@@ -97,7 +97,7 @@ GL_DEV void gate_poseidon(const QuotArgs& a, uint64_t t, GateAcc& g) {
     for (int r = 0; r < 4; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) {
-            s[i] = gl_add(s[i], PSD_FULL_RC[12 * r + i]);
+            s[i] = gl_add_canonical(s[i], PSD_FULL_RC[12 * r + i]);
             if (r != 0) {
                 const uint64_t sin = WIRE(29 + 12 * (r - 1) + i);
                 g.push(gl_sub(s[i], sin));
@@ -113,7 +113,7 @@ GL_DEV void gate_poseidon(const QuotArgs& a, uint64_t t, GateAcc& g) {
 #pragma unroll 1
     for (int r = 0; r < 22; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PSD_ALL_RC[12 * (4 + r) + i]);
+        for (int i = 0; i < 12; i++) s[i] = gl_add_canonical(s[i], PSD_ALL_RC[12 * (4 + r) + i]);
         const uint64_t sin = WIRE(65 + r);
         g.push(gl_sub(s[0], sin));
         s[0] = psd_sbox(sin);
@@ -123,7 +123,7 @@ GL_DEV void gate_poseidon(const QuotArgs& a, uint64_t t, GateAcc& g) {
     for (int r = 0; r < 4; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) {
-            s[i] = gl_add(s[i], PSD_FULL_RC[48 + 12 * r + i]);
+            s[i] = gl_add_canonical(s[i], PSD_FULL_RC[48 + 12 * r + i]);
             const uint64_t sin = WIRE(87 + 12 * r + i);
             g.push(gl_sub(s[i], sin));
             s[i] = psd_sbox(sin);
