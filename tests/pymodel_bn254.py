@@ -2,15 +2,16 @@
 Follows src/plonky2_verifier/bn245_poseidon/native.rs:16-77 (permutation, encode / decode) and
 plonky2_config.rs:38-75 (Bn254PoseidonPermutation::permute, hash_no_pad, two_to_one)."""
 import os
+import sys
 
 R = 21888242871839275222246405745257275088548364400416034343698204186575808495617   # BN254 scalar field
 PG = (1 << 64) - (1 << 32) + 1
 T, RF, RP = 5, 8, 60
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_DATA = os.path.join(os.path.dirname(_HERE), "stark-verifier_amd", "data", "poseidon_bn254_t5.txt")
-_vals = [int(l, 16) for l in open(_DATA).read().split("\n") if l and not l.startswith("#")]
-RC = _vals[:T * (RF + RP)]
-MDS = [_vals[T * (RF + RP) + T * i: T * (RF + RP) + T * (i + 1)] for i in range(T)]
+sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "tools"))
+from poseidon_grain import bn254_t5  # noqa: E402  (Grain-LFSR generation of the published parameters)
+
+RC, MDS = bn254_t5()
 
 
 def permute_fr(state, transposed=False):
