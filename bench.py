@@ -101,35 +101,47 @@ class SemaphoreProvers:
         return leaves
 
 
-class RecursiveProvers(SemaphoreProvers):
-    """The same K contexts; a unit = a Semaphore signal + the recursive proof verifying it (wrapper.rs:35-56 over the
-    Poseidon-Goldilocks config).  The recursive circuit (layout, selectors, sigmas, preprocessed commitment) and its witness
-    tape are built once from the first signal and shared by all contexts; per unit the host thread runs
-    gl355_semaphore_witness -> gl355_prove_sparse (n = 2^13) -> gl355_witness_replay -> gl355_prove_sparse (n = 2^14)."""
+class RecursiveProvers:
+    """K prover contexts (one HIP stream + one host thread each) on one GPU; a unit = a Semaphore signal + the recursive proof
+    verifying it (wrapper.rs:35-56 over the Poseidon-Goldilocks config).  Both circuits are built once, exported as circuit
+    artifacts and loaded into the library (gl355_circuit_load); per unit a host thread makes two native calls:
+    gl355_semaphore_prove (witness + proof, n = 2^13) and gl355_circuit_prove_tape (tape replay + proof, n = 2^14)."""
 
     def __init__(self, gl, device, threads, log_members=20, seed=0x357):
-        super().__init__(gl, device, threads, log_members, seed)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_lib import rand_field  # only the seeded RNG helper, no oracle arithmetic
+        sem = importlib.import_module("stark-verifier_amd.semaphore")
         rec = importlib.import_module("stark-verifier_amd.recursion")
         self.plonk = importlib.import_module("stark-verifier_amd.plonk")
-        a0 = self.sets[0]
-        sig, data = a0.make_signal_fast(self.sks[0], self.topic, 0, 1, flat_only=True)
-        self.inner_data = data
-        first = (sig.proof, np.concatenate([self.root, sig.nullifier[0], self.topic]))
-        self.rc = rec.RecursiveCircuit(a0.ctx, data.common(), k=1).build([first], np.random.default_rng(2))
+        rng = np.random.default_rng(seed)
+        self.sets = [gl.Context(device) for _ in range(threads)]      # one prover context per host thread
+        c0 = self.sets[0]
+        self.sks = rand_field(rng, (1 << log_members, 4))
+        keys = c0.hash_no_pad(np.concatenate([self.sks, np.zeros_like(self.sks)], axis=1))
+        self.topic = rand_field(rng, 4)
+        self.aset = sem.AccessSet(c0, keys)
+        self.root = self.aset.tree.cap[0].copy()
+        self.height = self.aset.tree_height()
+        data, rows = self.aset.build(np.random.default_rng(1))
+        idx, vals, pi = self.aset.witness_rows(rows, self.sks[0], self.topic, 0)
+        self.inner_data, self.inner_rows = data, (idx, vals, pi)
+        self.sem = self.plonk.NativeCircuit(c0, data.export_blob(idx))
+        flat, pis = self.sem.semaphore_prove(c0, self.sks[0], self.topic, 0, self.aset.tree.prove_host(0), 1)
+        self.rc = rec.RecursiveCircuit(c0, data.common(), k=1).build([(flat, pis)], np.random.default_rng(2))
+        self.nat = self.rc.native()
         self.last = None
         self.units_done = [0] * threads
-        for t in range(threads):                              # per-context prover data + warm-up of the 2^14 pipeline
+        for t in range(threads):                              # warm every context's allocator / tables
             self.unit(t, t)
 
     def unit(self, t, i):
-        a = self.sets[t]
-        sig, _ = a.make_signal_fast(self.sks[i], self.topic, i, 0x358 + i, flat_only=True)
-        inner = (sig.proof, np.concatenate([self.root, sig.nullifier[0], self.topic]))
-        rows, pis = self.rc.witness([inner])
-        outer = self.plonk.prove_sparse(a.ctx, self.rc.data, self.rc.row_idx, rows, pis, 0x359 + i, flat_only=True)
-        self.last = (inner, rows, pis, outer)
+        ctx = self.sets[t]
+        flat, pis = self.sem.semaphore_prove(ctx, self.sks[i], self.topic, i, self.aset.tree.prove_host(i), 0x358 + i)
+        inputs = np.concatenate([flat, pis])
+        outer, opis = self.nat.prove_tape(ctx, inputs, 0x359 + i)
+        self.last = ((flat, pis), outer, opis)
         self.units_done[t] += 1
-        return pis[4:12]                                      # nullifier | topic, re-exposed by the recursive proof
+        return opis[4:12]                                     # nullifier | topic, re-exposed by the recursive proof
 
     def prove_batch(self, first, count):
         import threading
@@ -157,16 +169,16 @@ class RecursiveProvers(SemaphoreProvers):
         ~10 % throughput (extra barrier packets between back-to-back kernels); one stream's launches are a 1/12 sample of
         the same timed region."""
         self.prof_ctx = list(range(min(contexts, len(self.sets)))) if on else []
-        for t, a in enumerate(self.sets):
-            a.ctx.profile_enable(on and t in self.prof_ctx)
-            a.ctx.profile_read()
+        for t, c in enumerate(self.sets):
+            c.profile_enable(on and t in self.prof_ctx)
+            c.profile_read()
         self.units_mark = list(self.units_done)
 
     def profile_read(self):
         """({kernel group: (launches, ms, algorithmic bytes)}, units proven by the profiled contexts since profile(True))"""
         agg = {}
         for t in self.prof_ctx:
-            for name, (cnt, ms, nbytes) in self.sets[t].ctx.profile_read().items():
+            for name, (cnt, ms, nbytes) in self.sets[t].profile_read().items():
                 c0, m0, b0 = agg.get(name, (0, 0.0, 0))
                 agg[name] = (c0 + cnt, m0 + ms, b0 + nbytes)
         return agg, sum(self.units_done[t] - self.units_mark[t] for t in self.prof_ctx)
@@ -183,19 +195,18 @@ def cpu_baseline_recursive(pr, units=1):
     cpu_in = CpuProver.from_circuit_data(orc, pr.inner_data)
     cpu_out = CpuProver.from_circuit_data(orc, pr.rc.data)
     t_build = time.perf_counter() - t_build
-    a = pr.sets[0]
-    _, rows = a.build(None)
-    idx, vals, pi = a.witness_rows(rows, pr.sks[5], pr.topic, 5)
-    inner, wrows, wpis, outer = pr.last
+    ctx = pr.sets[0]
+    idx, vals, pi = pr.inner_rows
+    inner = pr.last[0]
+    wrows, wpis = pr.rc.witness([inner])
     t0 = time.perf_counter()
-    same = True
     for u in range(units):
         flat_in = cpu_in.prove_sparse(idx, vals, pi, 7 + u)
         flat_out = cpu_out.prove_sparse(pr.rc.row_idx, wrows, wpis, 9 + u)
     dt = time.perf_counter() - t0
     # bit-exactness of the product against this baseline on the very same inputs (seed of the last unit)
-    g_in = pr.plonk.prove_sparse(a.ctx, pr.inner_data, idx, vals, pi, 7 + units - 1, flat_only=True)
-    g_out = pr.plonk.prove_sparse(a.ctx, pr.rc.data, pr.rc.row_idx, wrows, wpis, 9 + units - 1, flat_only=True)
+    g_in = pr.sem.prove_rows(ctx, vals, pi, 7 + units - 1)
+    g_out, _ = pr.nat.prove_tape(ctx, np.concatenate([inner[0], inner[1]]), 9 + units - 1)
     same = bool(np.array_equal(g_in, flat_in) and np.array_equal(g_out, flat_out))
     return {"value": round(units / dt, 4), "unit": "recursive proofs/s", "cores": int(threads), "kind": "port",
             "byte_identical_to_gpu_proofs": same,
@@ -299,7 +310,7 @@ def main_recursive(args):
         lt = torch.from_numpy(leaves.view(np.int64)).to(dev)
         allv = par.gather_leaves(lt, dist)
         if rank == 0:
-            root = par.aggregation_root(pr.sets[0].ctx, allv.cpu().numpy().view(np.uint64))
+            root = par.aggregation_root(pr.sets[0], allv.cpu().numpy().view(np.uint64))
     barrier()
     elapsed = time.perf_counter() - t0
     prof, local_units = pr.profile_read()
@@ -361,7 +372,7 @@ def main_recursive(args):
             try:    # the final wrap (wrapper.rs:35-56): the recursive circuit proven under the BN254-Poseidon hasher, one context
                 rec = importlib.import_module("stark-verifier_amd.recursion")
                 inner = pr.last[0]
-                c0 = pr.sets[0].ctx
+                c0 = pr.sets[0]
                 wc = rec.WrapperCircuit(c0, pr.inner_data.common()).build([inner], np.random.default_rng(3))
                 rows_w, pis_w = wc.witness([inner])
                 pr.plonk.prove_sparse(c0, wc.data, wc.row_idx, rows_w, pis_w, 1, flat_only=True)

@@ -352,6 +352,35 @@ enum { GL355_TAPE_CONST = 0, GL355_TAPE_INPUT = 1, GL355_TAPE_COPY = 2, GL355_TA
 int32_t gl355_witness_replay(const uint64_t* tape, uint64_t n_ops, const uint64_t* inputs, uint64_t n_inputs,
                              uint64_t* rows, uint64_t n_words, uint32_t num_wires, uint64_t* failed_op);
 
+/* ---- circuit artifacts: the native per-proof path --------------------------------------------------------------
+ * A circuit is BUILT once (plonky2's CircuitBuilder::build at access_set.rs:91, recursion.rs:167, wrapper.rs:41; here the
+ * host-side builder stark-verifier_amd/plonk.py) and serialised with CircuitData.export_blob(): u64 words
+ *   [0] magic "GL355CIR" [1] version 1 [2..11] the gl355_circuit scalars [12..91] 16 gates x {type, param, selector_index,
+ *   group_start, group_end} [92] cap_height [93] pow_bits [94] num_queries [95] n_fri_layers [96] zero_knowledge [97] hasher
+ *   [98] blind_start [99] n_blind [100] z_start [101] n_z_pairs [102] n_rows [103] n_tape_ops [104] n_inputs [105] n_public_inputs
+ *   [106..109] circuit digest, then constants[num_selectors + num_constants][n] | sigmas[routed][n] | k_is[routed] |
+ *   row_idx[n_rows] | public-input positions[n_pi] | tape[n_tape_ops][5] (gl355_witness_replay format).
+ * gl355_circuit_load commits constants_sigmas on `ctx`, re-derives the circuit digest and refuses an artifact whose digest
+ * does not match its tables.  The handle is read-only afterwards: any context of the same device may prove with it, concurrently.
+ *   gl355_semaphore_prove    = fill_semaphore_targets + data.prove (access_set.rs:61-104): witness rows from the member's
+ *                              key / topic / Merkle path, proof, public inputs root | nullifier | topic
+ *   gl355_circuit_prove_tape = set_proof_with_pis_target + data.prove (recursion.rs:72-86,167-168, wrapper.rs:49-55): inputs =
+ *                              each inner proof's flat words followed by its public inputs; GL355_E_WITNESS on an invalid inner proof
+ *   gl355_circuit_prove_rows = data.prove from ready-made sparse rows (in the artifact's row order) */
+typedef struct gl355_circuit_handle gl355_circuit_handle;
+int32_t gl355_circuit_load(gl355_ctx* ctx, const uint64_t* blob, uint64_t words, gl355_circuit_handle** out);
+int32_t gl355_circuit_destroy(gl355_circuit_handle* c);
+int32_t gl355_circuit_info(const gl355_circuit_handle* c, uint64_t* proof_words, uint32_t* n_public_inputs, uint32_t* n_rows,
+                           uint64_t* n_inputs, uint32_t* degree_bits);
+const uint64_t* gl355_circuit_digest(const gl355_circuit_handle* c);
+int32_t gl355_circuit_prove_rows(gl355_ctx* ctx, const gl355_circuit_handle* c, const uint64_t* rows, const uint64_t* public_inputs,
+                                 uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words);
+int32_t gl355_circuit_prove_tape(gl355_ctx* ctx, const gl355_circuit_handle* c, const uint64_t* inputs, uint64_t n_inputs, uint64_t seed,
+                                 uint64_t* proof, uint64_t proof_capacity_words, uint64_t* public_inputs_out);
+int32_t gl355_semaphore_prove(gl355_ctx* ctx, const gl355_circuit_handle* c, const uint64_t private_key[4], const uint64_t topic[4],
+                              uint64_t index, const uint64_t* siblings, uint32_t height, uint64_t seed, uint64_t* proof,
+                              uint64_t proof_capacity_words, uint64_t public_inputs_out[12]);
+
 /* ---- a9: wires_permutation_partial_products_and_zs (vanishing_poly.rs:54-108,183-218) --------- */
 int32_t gl355_zs_partial_products(gl355_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas,
                                   const uint64_t* k_is, uint32_t log_n, uint32_t n_routed,

@@ -103,6 +103,14 @@ SIGNATURES = {
     "gl355_hash_leaves_h": (C.c_int32, [vp, C.c_int32, vp, C.c_uint64, C.c_uint32, vp]),
     "gl355_two_to_one_h": (C.c_int32, [vp, C.c_int32, vp, vp, C.c_uint64, vp]),
     "gl355_merkle_build_h": (C.c_int32, [vp, C.c_int32, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp]),
+    "gl355_circuit_load": (C.c_int32, [vp, vp, C.c_uint64, C.POINTER(vp)]),
+    "gl355_circuit_destroy": (C.c_int32, [vp]),
+    "gl355_circuit_info": (C.c_int32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint32)]),
+    "gl355_circuit_digest": (C.POINTER(C.c_uint64), [vp]),
+    "gl355_circuit_prove_rows": (C.c_int32, [vp, vp, vp, vp, C.c_uint32, C.c_uint64, vp, C.c_uint64]),
+    "gl355_circuit_prove_tape": (C.c_int32, [vp, vp, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp]),
+    "gl355_semaphore_prove": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, vp, C.c_uint32, C.c_uint64, vp, C.c_uint64, vp]),
     "gl355_semaphore_witness": (C.c_int32, [vp, vp, C.c_uint64, vp, C.c_uint32, vp, vp]),
     "gl355_witness_replay": (C.c_int32, [vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
     "gl355_quotient": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),

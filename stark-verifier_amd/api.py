@@ -301,6 +301,22 @@ class MerkleTree:
     def get(self, i):
         return self.leaves[i]
 
+    def prove_host(self, leaf_index):
+        """the same siblings read straight from the host copy of `digests` (plonky2's MerkleTree::prove indexing); no
+        library call, so many threads may use one tree"""
+        n = self.leaves.shape[0]
+        layers = (int(n).bit_length() - 1) - self.cap_height
+        tree_len = 2 * ((n >> self.cap_height) - 1)
+        base = (leaf_index >> layers) * tree_len
+        pair = leaf_index & ((1 << layers) - 1)
+        sib = np.empty((layers, 4), dtype=np.uint64)
+        for i in range(layers):
+            parity = pair & 1
+            pair >>= 1
+            slot = (pair << (i + 1)) + (1 << i) - 1
+            sib[i] = self.digests[base + 2 * slot + (1 - parity)]
+        return sib
+
     def prove(self, leaf_index):
         n = self.leaves.shape[0]
         layers = (int(n).bit_length() - 1) - self.cap_height
@@ -339,7 +355,10 @@ class PolynomialBatch:
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx.lib.gl355_oracle_destroy(self.h)
+            # the oracle's memory belongs to its context's pool: after the context is gone (e.g. an object kept alive by a
+            # reference cycle until interpreter shutdown) there is nothing left to release, and touching it would crash
+            if getattr(self.ctx, "h", None):
+                self.ctx.lib.gl355_oracle_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -1,0 +1,200 @@
+// Circuit artifacts: a built circuit (shape, selector / constant / sigma tables, FRI parameters, blinding rows, the sparse
+// witness-row map and, for the recursive verifier, the witness tape) serialised once by the host-side builder and loaded
+// here, so that the per-proof path is native end to end:
+//   gl355_semaphore_prove      = fill_semaphore_targets + data.prove      (src/plonky2_semaphore/access_set.rs:61-104)
+//   gl355_circuit_prove_tape   = set_proof_with_pis_target + data.prove   (recursion.rs:72-86,167-168; wrapper.rs:49-55)
+// Building a circuit (plonky2's CircuitBuilder::build, access_set.rs:91, recursion.rs:167, wrapper.rs:41) happens once per
+// circuit shape and stays on the host-side builder; proving happens per signal and needs nothing but this file's calls.
+// A loaded circuit is read-only and may be used concurrently by every context of its device.
+#include "gl355_internal.h"
+
+#include <vector>
+
+using namespace gl355;
+
+struct gl355_circuit_handle {
+    Ctx* owner = nullptr;
+    gl355_circuit c;
+    gl355_prover_data pd;
+    gl355_oracle* cs = nullptr;
+    uint64_t* d_sigmas = nullptr;
+    uint64_t* d_kis = nullptr;
+    std::vector<uint32_t> row_idx;
+    std::vector<uint64_t> pi_pos, tape;
+    uint32_t blind_start = 0, n_blind = 0, z_start = 0, n_z_pairs = 0, n_pi = 0;
+    uint64_t n_inputs = 0;
+};
+
+namespace {
+constexpr uint64_t MAGIC = 0x5249433535334c47ull;   // "GL355CIR" little endian
+constexpr uint64_t HDR = 110;
+}
+
+extern "C" {
+
+int32_t gl355_circuit_load(gl355_ctx* h, const uint64_t* blob, uint64_t words, gl355_circuit_handle** out) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+    if (!blob || !out || words < HDR) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: null or truncated artifact");
+    *out = nullptr;
+    if (blob[0] != MAGIC || blob[1] != 1) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: not a version-1 gl355 circuit artifact");
+    gl355_circuit c;
+    memset(&c, 0, sizeof c);
+    c.degree_bits = (uint32_t)blob[2]; c.rate_bits = (uint32_t)blob[3]; c.num_wires = (uint32_t)blob[4];
+    c.num_routed_wires = (uint32_t)blob[5]; c.num_constants = (uint32_t)blob[6]; c.num_selectors = (uint32_t)blob[7];
+    c.num_challenges = (uint32_t)blob[8]; c.max_degree = (uint32_t)blob[9]; c.num_partial_products = (uint32_t)blob[10];
+    c.num_gates = (uint32_t)blob[11];
+    if (c.num_gates > GL355_MAX_GATES || c.degree_bits == 0 || c.degree_bits > 24 || c.num_wires == 0 || c.num_wires > 1024 ||
+        c.num_routed_wires > c.num_wires || c.num_selectors + c.num_constants > 64)
+        return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: implausible circuit shape");
+    for (uint32_t g = 0; g < GL355_MAX_GATES; g++) {
+        const uint64_t* p = blob + 12 + 5 * g;
+        c.gates[g].type = (uint32_t)p[0]; c.gates[g].param = (uint32_t)p[1]; c.gates[g].selector_index = (uint32_t)p[2];
+        c.gates[g].group_start = (uint32_t)p[3]; c.gates[g].group_end = (uint32_t)p[4];
+        if (g < c.num_gates && (c.gates[g].type > GL355_GATE_TYPE_MAX || c.gates[g].selector_index >= c.num_selectors ||
+                                c.gates[g].group_end > c.num_gates || c.gates[g].group_start > c.gates[g].group_end))
+            return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: bad gate table");
+    }
+    const uint64_t n = 1ull << c.degree_bits;
+    const uint64_t n_sc = c.num_selectors + c.num_constants, routed = c.num_routed_wires;
+    const uint64_t n_rows = blob[102], n_ops = blob[103], n_inputs = blob[104], n_pi = blob[105];
+    if (n_rows > n || n_ops > (1ull << 28) || n_pi > (1u << 20)) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: implausible sizes");
+    const uint64_t need = HDR + (n_sc + routed) * n + routed + n_rows + n_pi + 5 * n_ops;
+    if (words != need) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: artifact length does not match its header");
+    const int32_t hasher = (int32_t)blob[97];
+    if (hasher != GL355_HASH_POSEIDON && hasher != GL355_HASH_BN254_POSEIDON) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: unknown hasher");
+
+    gl355_circuit_handle* ch = new (std::nothrow) gl355_circuit_handle();
+    if (!ch) return GL355_E_OOM;
+    ch->owner = ctx;
+    ch->c = c;
+    ch->blind_start = (uint32_t)blob[98]; ch->n_blind = (uint32_t)blob[99]; ch->z_start = (uint32_t)blob[100];
+    ch->n_z_pairs = (uint32_t)blob[101]; ch->n_inputs = n_inputs; ch->n_pi = (uint32_t)n_pi;
+    const uint64_t* p = blob + HDR;
+    const uint64_t* cs_values = p; p += (n_sc + routed) * n;
+    const uint64_t* sigmas = cs_values + n_sc * n;
+    const uint64_t* k_is = p; p += routed;
+    ch->row_idx.resize(n_rows);
+    for (uint64_t i = 0; i < n_rows; i++) {
+        if (p[i] >= n) { delete ch; return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: witness row index out of range"); }
+        ch->row_idx[i] = (uint32_t)p[i];
+    }
+    p += n_rows;
+    ch->pi_pos.assign(p, p + n_pi); p += n_pi;
+    for (uint64_t v : ch->pi_pos)
+        if (v >= n_rows * c.num_wires) { delete ch; return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: public-input position out of range"); }
+    ch->tape.assign(p, p + 5 * n_ops);
+    if ((uint64_t)ch->blind_start + ch->n_blind > n || (uint64_t)ch->z_start + 2ull * ch->n_z_pairs > n) {
+        delete ch; return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: blinding rows out of range");
+    }
+    // device copies of the sigma values / k_is (plain allocations: shared by every context of the device)
+    int32_t rc = GL355_OK;
+    do {
+        if (hipMalloc(&ch->d_sigmas, routed * n * 8) != hipSuccess || hipMalloc(&ch->d_kis, routed * 8 + 8) != hipSuccess) { rc = ctx->fail(GL355_E_OOM, "circuit_load: hipMalloc"); break; }
+        if (hipMemcpyAsync(ch->d_sigmas, sigmas, routed * n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(ch->d_kis, k_is, routed * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = ctx->fail(GL355_E_HIP, "circuit_load: upload"); break; }
+        rc = gl355_commit_h(h, hasher, cs_values, c.degree_bits, (uint32_t)(n_sc + routed), c.rate_bits, 0, nullptr, (uint32_t)blob[92], &ch->cs);
+        if (rc) break;
+        // the digest covers the preprocessed commitment and the shape: recompute it, a stale or foreign artifact is refused
+        const uint64_t n_cap = 1ull << blob[92];
+        std::vector<uint64_t> pre(n_cap * 4 + 3 + c.num_gates);
+        rc = gl355_oracle_cap(ch->cs, pre.data());
+        if (rc) break;
+        uint64_t* s = pre.data() + n_cap * 4;
+        s[0] = c.degree_bits; s[1] = c.num_gates; s[2] = c.num_selectors;
+        for (uint32_t g = 0; g < c.num_gates; g++) s[3 + g] = (uint64_t)c.gates[g].type * 1000 + c.gates[g].param;
+        uint64_t dg[4];
+        gl355_host_hash_no_pad_h(hasher, pre.data(), pre.size(), dg);
+        if (memcmp(dg, blob + 106, 32) != 0) { rc = ctx->fail(GL355_E_INVALID_ARG, "circuit_load: circuit digest of the artifact does not match its tables"); break; }
+    } while (0);
+    if (rc != GL355_OK) {
+        if (ch->cs) gl355_oracle_destroy(ch->cs);
+        if (ch->d_sigmas) (void)hipFree(ch->d_sigmas);
+        if (ch->d_kis) (void)hipFree(ch->d_kis);
+        delete ch;
+        return rc;
+    }
+    memset(&ch->pd, 0, sizeof ch->pd);
+    ch->pd.circuit = &ch->c;
+    ch->pd.constants_sigmas = ch->cs;
+    ch->pd.sigmas = ch->d_sigmas;
+    ch->pd.k_is = ch->d_kis;
+    memcpy(ch->pd.circuit_digest, blob + 106, 32);
+    ch->pd.cap_height = (uint32_t)blob[92]; ch->pd.pow_bits = (uint32_t)blob[93]; ch->pd.num_queries = (uint32_t)blob[94];
+    ch->pd.n_fri_layers = (uint32_t)blob[95]; ch->pd.zero_knowledge = (int32_t)blob[96]; ch->pd.hasher = hasher;
+    *out = ch;
+    return GL355_OK;
+}
+
+int32_t gl355_circuit_destroy(gl355_circuit_handle* ch) {
+    if (!ch) return GL355_OK;
+    if (ch->cs) gl355_oracle_destroy(ch->cs);
+    (void)hipSetDevice(ch->owner->device);
+    if (ch->d_sigmas) (void)hipFree(ch->d_sigmas);
+    if (ch->d_kis) (void)hipFree(ch->d_kis);
+    delete ch;
+    return GL355_OK;
+}
+
+int32_t gl355_circuit_info(const gl355_circuit_handle* ch, uint64_t* proof_words, uint32_t* n_public_inputs, uint32_t* n_rows,
+                           uint64_t* n_inputs, uint32_t* degree_bits) {
+    if (!ch) return GL355_E_INVALID_ARG;
+    if (proof_words) *proof_words = gl355_proof_words(&ch->pd);
+    if (n_public_inputs) *n_public_inputs = ch->n_pi;
+    if (n_rows) *n_rows = (uint32_t)ch->row_idx.size();
+    if (n_inputs) *n_inputs = ch->n_inputs;
+    if (degree_bits) *degree_bits = ch->c.degree_bits;
+    return GL355_OK;
+}
+const uint64_t* gl355_circuit_digest(const gl355_circuit_handle* ch) { return ch ? ch->pd.circuit_digest : nullptr; }
+
+int32_t gl355_circuit_prove_rows(gl355_ctx* h, const gl355_circuit_handle* ch, const uint64_t* rows, const uint64_t* public_inputs,
+                                 uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (!ch || !rows) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_rows: null argument");
+    if (ctx->device != ch->owner->device) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_rows: circuit was loaded on another device");
+    return gl355_prove_sparse(h, &ch->pd, ch->row_idx.data(), rows, (uint32_t)ch->row_idx.size(), ch->blind_start, ch->n_blind, ch->z_start,
+                              ch->n_z_pairs, public_inputs, n_public_inputs, seed, proof, proof_capacity_words);
+}
+
+int32_t gl355_circuit_prove_tape(gl355_ctx* h, const gl355_circuit_handle* ch, const uint64_t* inputs, uint64_t n_inputs, uint64_t seed,
+                                 uint64_t* proof, uint64_t proof_capacity_words, uint64_t* public_inputs_out) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (!ch || !inputs || !proof) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: null argument");
+    if (ch->tape.empty()) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: this artifact carries no witness tape");
+    if (n_inputs != ch->n_inputs) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: wrong number of input words");
+    static thread_local std::vector<uint64_t> rows;      // one prover thread per context: reuse the row buffer
+    const uint64_t n_words = (uint64_t)ch->row_idx.size() * ch->c.num_wires;
+    rows.resize(n_words);
+    uint64_t failed = 0;
+    const int32_t rc = gl355_witness_replay(ch->tape.data(), ch->tape.size() / 5, inputs, n_inputs, rows.data(), n_words, ch->c.num_wires, &failed);
+    if (rc != GL355_OK) {
+        char msg[96];
+        snprintf(msg, sizeof msg, "circuit_prove_tape: witness generation failed at tape entry %llu", (unsigned long long)failed);
+        return ctx->fail(rc, msg);
+    }
+    std::vector<uint64_t> pis(ch->n_pi);
+    for (uint32_t i = 0; i < ch->n_pi; i++) pis[i] = rows[ch->pi_pos[i]];
+    if (public_inputs_out) memcpy(public_inputs_out, pis.data(), (size_t)ch->n_pi * 8);
+    return gl355_circuit_prove_rows(h, ch, rows.data(), pis.data(), ch->n_pi, seed, proof, proof_capacity_words);
+}
+
+int32_t gl355_semaphore_prove(gl355_ctx* h, const gl355_circuit_handle* ch, const uint64_t private_key[4], const uint64_t topic[4],
+                              uint64_t index, const uint64_t* siblings, uint32_t height, uint64_t seed, uint64_t* proof,
+                              uint64_t proof_capacity_words, uint64_t public_inputs_out[12]) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (!ch || !private_key || !topic || !proof || (!siblings && height)) return ctx->fail(GL355_E_INVALID_ARG, "semaphore_prove: null argument");
+    if (ch->row_idx.size() != (size_t)height + 7 || ch->c.num_wires != 135)
+        return ctx->fail(GL355_E_INVALID_ARG, "semaphore_prove: the artifact is not the Semaphore circuit of this tree height");
+    std::vector<uint64_t> rows((size_t)(height + 7) * 135);
+    uint64_t pis[12];
+    GL355_TRY(gl355_semaphore_witness(private_key, topic, index, siblings, height, rows.data(), pis));
+    if (public_inputs_out) memcpy(public_inputs_out, pis, sizeof pis);
+    return gl355_circuit_prove_rows(h, ch, rows.data(), pis, 12, seed, proof, proof_capacity_words);
+}
+
+}  // extern "C"

@@ -298,6 +298,29 @@ class CircuitData:
             cache[key] = pd
         return cache[key]
 
+    def export_blob(self, row_idx, tape=None, pi_pos=None, n_inputs=0):
+        """Serialise the built circuit (+ the sparse witness-row map and optionally a witness tape) as the u64 artifact
+        gl355_circuit_load reads (layout in include/gl355.h)."""
+        cfg = self.config
+        cc = self.c_circuit
+        hdr = np.zeros(110, dtype=np.uint64)
+        hdr[0], hdr[1] = 0x5249433535334c47, 1
+        hdr[2:12] = [cc.degree_bits, cc.rate_bits, cc.num_wires, cc.num_routed_wires, cc.num_constants, cc.num_selectors,
+                     cc.num_challenges, cc.max_degree, cc.num_partial_products, cc.num_gates]
+        for g in range(_lib.MAX_GATES):
+            gt = cc.gates[g]
+            hdr[12 + 5 * g: 17 + 5 * g] = [gt.type, gt.param, gt.selector_index, gt.group_start, gt.group_end]
+        start, n_blind, z_pairs, _ = self.blind_rows
+        tape = np.zeros((0, 5), dtype=np.uint64) if tape is None else _u64(tape)
+        pi_pos = np.zeros(0, dtype=np.uint64) if pi_pos is None else np.asarray(pi_pos, dtype=np.uint64)
+        row_idx = np.asarray(row_idx, dtype=np.uint64)
+        hdr[92:106] = [cfg.cap_height, cfg.proof_of_work_bits, cfg.num_query_rounds, len(self.fri_arity_bits), int(cfg.zero_knowledge),
+                       cfg.hasher, start, n_blind, z_pairs[0][0] if z_pairs else 0, len(z_pairs), row_idx.size, tape.shape[0],
+                       n_inputs, pi_pos.size]
+        hdr[106:110] = self.circuit_digest
+        return np.concatenate([hdr, _u64(self.constants).reshape(-1), _u64(self.sigmas).reshape(-1), _u64(self.k_is), row_idx,
+                               pi_pos, tape.reshape(-1)])
+
     def common(self):
         """Plain-dict common data for the verifier restatement in tests/."""
         cfg = self.config
@@ -409,6 +432,55 @@ def parse_proof(data, flat):
     return dict(wires_cap=wires_cap, plonk_zs_partial_products_cap=zs_cap, quotient_polys_cap=q_cap, openings=openings,
                 opening_proof=dict(commit_phase_merkle_caps=[caps[l] for l in range(n_layers)], query_round_proofs=queries,
                                    final_poly=final_poly, pow_witness=pow_witness))
+
+
+class NativeCircuit:
+    """A circuit artifact loaded into the library (gl355_circuit_load): proving needs no host-side circuit data any more.
+    One instance serves every Context of its device."""
+
+    def __init__(self, ctx, blob):
+        self.ctx = ctx
+        self.blob = np.ascontiguousarray(blob, dtype=np.uint64)
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.gl355_circuit_load(ctx.h, _ptr(self.blob), self.blob.size, C.byref(self.h)))
+        pw, npi, nrows, nin, db = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint32()
+        ctx.lib.gl355_circuit_info(self.h, C.byref(pw), C.byref(npi), C.byref(nrows), C.byref(nin), C.byref(db))
+        self.proof_words, self.n_public_inputs, self.n_rows, self.n_inputs, self.degree_bits = pw.value, npi.value, nrows.value, nin.value, db.value
+
+    def prove_rows(self, ctx, rows, public_inputs, seed):
+        rows, pi = _u64(rows), _u64(public_inputs)
+        flat = np.empty(self.proof_words, dtype=np.uint64)
+        ctx.check(ctx.lib.gl355_circuit_prove_rows(ctx.h, self.h, _ptr(rows), _ptr(pi), pi.size, int(seed) & ((1 << 64) - 1), _ptr(flat), flat.size))
+        return flat
+
+    def prove_tape(self, ctx, inputs, seed):
+        """-> (flat proof, public inputs); raises Gl355Error (GL355_E_WITNESS) when the inputs do not satisfy the circuit"""
+        inputs = _u64(inputs)
+        flat = np.empty(self.proof_words, dtype=np.uint64)
+        pis = np.empty(self.n_public_inputs, dtype=np.uint64)
+        ctx.check(ctx.lib.gl355_circuit_prove_tape(ctx.h, self.h, _ptr(inputs), inputs.size, int(seed) & ((1 << 64) - 1), _ptr(flat), flat.size,
+                                                   _ptr(pis)))
+        return flat, pis
+
+    def semaphore_prove(self, ctx, private_key, topic, index, siblings, seed):
+        sk, tp, sib = _u64(private_key), _u64(topic), _u64(siblings)
+        flat = np.empty(self.proof_words, dtype=np.uint64)
+        pis = np.empty(12, dtype=np.uint64)
+        ctx.check(ctx.lib.gl355_semaphore_prove(ctx.h, self.h, _ptr(sk), _ptr(tp), int(index), _ptr(sib), sib.shape[0], int(seed) & ((1 << 64) - 1),
+                                                _ptr(flat), flat.size, _ptr(pis)))
+        return flat, pis
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.ctx, "h", None):          # see PolynomialBatch.close
+                self.ctx.lib.gl355_circuit_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def prove(ctx, data, wires, public_inputs, seed, flat_only=False):

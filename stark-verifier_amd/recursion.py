@@ -452,6 +452,14 @@ class RecursiveCircuit:
         self.n_inputs = off
         return self
 
+    def native(self):
+        """the circuit + its witness tape as a loaded artifact (plonk.NativeCircuit): per proof one C call,
+        gl355_circuit_prove_tape(inner proofs' flat words | public inputs)"""
+        if getattr(self, "_native", None) is None:
+            from .plonk import NativeCircuit
+            self._native = NativeCircuit(self.ctx, self.data.export_blob(self.row_idx, self.tape, self.pi_pos, self.n_inputs))
+        return self._native
+
     def witness(self, flat_proofs):
         """(rows uint64[n_rows][num_wires], public inputs) by tape replay; raises on an invalid inner proof"""
         inputs = np.concatenate([np.concatenate([_u64(f), _u64(p)]) for f, p in flat_proofs])

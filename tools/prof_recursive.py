@@ -32,15 +32,15 @@ for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1]):
     print("  %-26s launches/unit %6.1f  ms/unit %7.3f  %5.1f %%  alg %8.1f GB/s" % (k, v[0] / 8, v[1] / 8, 100 * v[1] / tot,
                                                                               v[2] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0))
 # host-side split of one unit
-a = sets[0]
-t = time.perf_counter(); sig, _ = a.make_signal_fast(pr.sks[3], pr.topic, 3, 5, flat_only=True); t_in = time.perf_counter() - t
-inner = (sig.proof, np.concatenate([pr.root, sig.nullifier[0], pr.topic]))
-t = time.perf_counter(); rows, pis = pr.rc.witness([inner]); t_rep = time.perf_counter() - t
-t = time.perf_counter(); pr.plonk.prove_sparse(a.ctx, pr.rc.data, pr.rc.row_idx, rows, pis, 1, flat_only=True); t_out = time.perf_counter() - t
-print("latency: signal %.2f ms, tape replay %.2f ms, recursive proof %.2f ms" % (t_in * 1e3, t_rep * 1e3, t_out * 1e3))
+c = sets[0]
+t = time.perf_counter(); flat, pis0 = pr.sem.semaphore_prove(c, pr.sks[3], pr.topic, 3, pr.aset.tree.prove_host(3), 5); t_in = time.perf_counter() - t
+inp = np.concatenate([flat, pis0])
+t = time.perf_counter(); rows, pis = pr.rc.witness([(flat, pis0)]); t_rep = time.perf_counter() - t
+t = time.perf_counter(); pr.nat.prove_tape(c, inp, 1); t_out = time.perf_counter() - t
+print("latency: signal %.2f ms, tape replay %.2f ms (inside the next figure), replay + recursive proof %.2f ms" % (t_in * 1e3, t_rep * 1e3, t_out * 1e3))
 for ll in [int(x) for x in args.lanes_log.split(",")]:
   for a_ in sets:
-    a_.ctx.set_option(1, ll)
+    a_.set_option(1, ll)
   print("MERKLE_LANES_LOG", ll)
   for k in counts:
     pr.sets = sets[:k]
