@@ -105,7 +105,8 @@ class RecursiveProvers:
     """K prover contexts (one HIP stream + one host thread each) on one GPU; a unit = a Semaphore signal + the recursive proof
     verifying it (wrapper.rs:35-56 over the Poseidon-Goldilocks config).  Both circuits are built once, exported as circuit
     artifacts and loaded into the library (gl355_circuit_load); per unit a host thread makes two native calls:
-    gl355_semaphore_prove (witness + proof, n = 2^13) and gl355_circuit_prove_tape (tape replay + proof, n = 2^14)."""
+    gl355_semaphore_prove (witness + proof, n = 2^13) and gl355_circuit_prove_tape (tape replay + proof, n = 2^14); a whole step
+    is one call into the native batch runtime (gl355_semaphore_units), which runs those host threads."""
 
     def __init__(self, gl, device, threads, log_members=20, seed=0x357):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -144,24 +145,14 @@ class RecursiveProvers:
         return opis[4:12]                                     # nullifier | topic, re-exposed by the recursive proof
 
     def prove_batch(self, first, count):
-        import threading
-        k = len(self.sets)
-        leaves = np.zeros((count, 8), dtype=np.uint64)
-        errors = []
-
-        def worker(t):
-            try:
-                for j in range(t, count, k):
-                    leaves[j] = self.unit(t, (first + j) % self.sks.shape[0])
-            except Exception as exc:                          # surface worker failures in the main thread
-                errors.append(exc)
-        ths = [threading.Thread(target=worker, args=(t,)) for t in range(k)]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-        if errors:
-            raise errors[0]
+        """`count` units starting at member `first` through the native batch runtime (gl355_semaphore_units: one host thread
+        per prover context inside the library); returns the (nullifier | topic) leaves [count][8]"""
+        n = self.sks.shape[0]
+        members = (first + np.arange(count, dtype=np.uint64)) % np.uint64(n)
+        leaves, _, per = self.plonk.semaphore_units(self.sets, self.sem, self.nat, self.sks, self.topic, self.aset.tree.digests, members,
+                                                    0x358 + 2 * first)
+        for t, k in enumerate(per):
+            self.units_done[t] += k
         return leaves
 
     def profile(self, on, contexts=1):

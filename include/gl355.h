@@ -381,6 +381,17 @@ int32_t gl355_semaphore_prove(gl355_ctx* ctx, const gl355_circuit_handle* c, con
                               uint64_t index, const uint64_t* siblings, uint32_t height, uint64_t seed, uint64_t* proof,
                               uint64_t proof_capacity_words, uint64_t public_inputs_out[12]);
 
+/* Batch runtime (recursion.rs:300-308 `par_iter` of make_signal, :211-227 of the verification circuits): one host thread per
+ * context, unit j -> context j mod n_ctx.  Per unit: Merkle path of member_indices[j] from tree_digests (the access-set tree over
+ * the public keys, cap height 0, plonky2 digest layout, host memory), gl355_semaphore_prove with seed seed_base + 2j, and if `rec`
+ * is not NULL gl355_circuit_prove_tape(rec, proof | public inputs) with seed seed_base + 2j + 1.  leaves_out[j] = nullifier | topic
+ * (8 words) of unit j; proofs_out (optional) receives the last proof of every unit; units_per_ctx (optional) the units each
+ * context proved.  Returns the first error (the failing context's gl355_last_error tells more). */
+int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx, const gl355_circuit_handle* sem, const gl355_circuit_handle* rec,
+                              const uint64_t* private_keys, uint64_t n_members, const uint64_t topic[4], const uint64_t* tree_digests,
+                              const uint64_t* member_indices, uint32_t count, uint64_t seed_base, uint64_t* leaves_out,
+                              uint64_t* proofs_out, uint32_t* units_per_ctx);
+
 /* ---- a9: wires_permutation_partial_products_and_zs (vanishing_poly.rs:54-108,183-218) --------- */
 int32_t gl355_zs_partial_products(gl355_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas,
                                   const uint64_t* k_is, uint32_t log_n, uint32_t n_routed,

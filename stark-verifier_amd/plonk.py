@@ -483,6 +483,26 @@ class NativeCircuit:
             pass
 
 
+def semaphore_units(ctxs, sem, rec, private_keys, topic, tree_digests, member_indices, seed_base, want_proofs=False):
+    """gl355_semaphore_units: the native batch runtime (recursion.rs:300-308 `par_iter` of make_signal + the verification
+    circuit per signal): one host thread per context inside the library, unit j on context j mod len(ctxs).
+    -> leaves [count][8] (nullifier | topic), proofs [count][words] or None, units proven per context"""
+    lib = ctxs[0].lib
+    hs = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    sk, tp, dg = _u64(private_keys), _u64(topic), _u64(tree_digests)
+    idx = np.ascontiguousarray(member_indices, dtype=np.uint64)
+    leaves = np.zeros((idx.size, 8), dtype=np.uint64)
+    words = (rec or sem).proof_words
+    proofs = np.empty((idx.size, words), dtype=np.uint64) if want_proofs else None
+    per = (C.c_uint32 * len(ctxs))()
+    rc = lib.gl355_semaphore_units(hs, len(ctxs), sem.h, rec.h if rec is not None else None, _ptr(sk), sk.shape[0], _ptr(tp), _ptr(dg),
+                                   _ptr(idx), idx.size, int(seed_base) & ((1 << 64) - 1), _ptr(leaves), _ptr(proofs) if want_proofs else None, per)
+    if rc != 0:
+        msgs = [(c.lib.gl355_last_error(c.h) or b"").decode() for c in ctxs]
+        raise _lib.Gl355Error(rc, "; ".join(m for m in msgs if m))
+    return leaves, proofs, list(per)
+
+
 def prove(ctx, data, wires, public_inputs, seed, flat_only=False):
     """CircuitData::prove through the single resident C entry point gl355_prove (csrc/prover.hip)."""
     lib = ctx.lib

@@ -77,3 +77,40 @@ def test_artifact_validation(gl, ctx):
             b[b.size - 1] = np.uint64(1 << 40)                        # last row index (no pi positions, no tape in this artifact)
         with pytest.raises(gl.Gl355Error):
             plonk.NativeCircuit(ctx, b)
+
+
+def test_native_batch_runtime(gl, ctx, orc):
+    """gl355_semaphore_units: every unit's proofs equal the ones made call by call (same seeds), the leaves are the
+    re-exposed nullifier | topic, bad member indices are refused"""
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    rec = importlib.import_module("stark-verifier_amd.recursion")
+    aset, sks, rng = make_access_set(gl, ctx, 4, 0x903)
+    topic = rand_field(rng, 4)
+    data, rows = aset.build(None)
+    idx, vals, pi = aset.witness_rows(rows, sks[0], topic, 0)
+    sem = plonk.NativeCircuit(ctx, data.export_blob(idx))
+    flat0, pis0 = sem.semaphore_prove(ctx, sks[0], topic, 0, aset.tree.prove_host(0), 1)
+    rc = rec.RecursiveCircuit(ctx, data.common(), k=1).build([(flat0, pis0)], rng)
+    nat = rc.native()
+    ctxs = [gl.Context(0) for _ in range(3)]
+    members = np.array([3, 9, 0, 15, 7], dtype=np.uint64)
+    leaves, proofs, per = plonk.semaphore_units(ctxs, sem, nat, sks, topic, aset.tree.digests, members, 1000, want_proofs=True)
+    assert sum(per) == members.size and per == [2, 2, 1]
+    for j, m in enumerate(members):
+        f, p = sem.semaphore_prove(ctx, sks[m], topic, int(m), aset.tree.prove_host(int(m)), 1000 + 2 * j)
+        o, op = nat.prove_tape(ctx, np.concatenate([f, p]), 1000 + 2 * j + 1)
+        assert np.array_equal(proofs[j], o) and np.array_equal(leaves[j], op[4:12])
+        assert np.array_equal(leaves[j, :4], orc.hash_no_pad(np.concatenate([sks[m], topic]))) and np.array_equal(leaves[j, 4:], topic)
+    # signals only (no verifier circuit)
+    leaves2, proofs2, _ = plonk.semaphore_units(ctxs, sem, None, sks, topic, aset.tree.digests, members[:2], 1000, want_proofs=True)
+    assert np.array_equal(leaves2, leaves[:2]) and proofs2.shape[1] == sem.proof_words
+    # a key that is not in the tree still yields valid proofs -- of ANOTHER root (the verifier compares the public root with the
+    # access set, access_set.rs:33-41); only that unit's leaf changes
+    bad_keys = sks.copy()
+    bad_keys[9] = rand_field(rng, 4)
+    leaves3, _, _ = plonk.semaphore_units(ctxs, sem, nat, bad_keys, topic, aset.tree.digests, members, 1000)
+    assert not np.array_equal(leaves3[1], leaves[1]) and np.array_equal(np.delete(leaves3, 1, 0), np.delete(leaves, 1, 0))
+    with pytest.raises(gl.Gl355Error):
+        plonk.semaphore_units(ctxs, sem, nat, sks, topic, aset.tree.digests, np.array([99], dtype=np.uint64), 1)
+    for c in ctxs:
+        c.close()
