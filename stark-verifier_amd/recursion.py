@@ -530,7 +530,11 @@ class Aggregator:
             rc = self.levels[level]
             nxt = []
             for i in range(0, len(signals), 2):
-                nxt.append(rc.prove_flat(signals[i:i + 2], seed + i, rng))
+                pair = signals[i:i + 2]
+                if rc.data is None:
+                    rc.build(pair, rng)
+                # one native call per node: tape replay + proof (gl355_circuit_prove_tape)
+                nxt.append(rc.native().prove_tape(self.ctx, np.concatenate([np.concatenate([_u64(f), _u64(p)]) for f, p in pair]), seed + i))
             if level + 1 == len(self.commons):
                 self.commons.append(rc.data.common())
             signals = nxt
