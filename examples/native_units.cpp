@@ -1,0 +1,90 @@
+// Host program without any scripting layer: proves Semaphore signals and their recursive proofs through the C ABI only
+// (include/gl355.h), the way a Rust binary of the reference would after INTEGRATION.md section 3b.
+//
+//   tools/export_artifacts.py <dir> [log_members]      writes <dir>/semaphore.gl355 and <dir>/recursive.gl355 (once per shape)
+//   examples/native_units <dir> [log_members] [contexts] [units]
+//
+// It builds the access set like the reference does (signal.rs:31-40: public key = Poseidon(sk | 0^4), MerkleTree::new over the
+// keys), loads the two circuit artifacts, runs the native batch runtime (recursion.rs:300-308) and folds the returned
+// (nullifier | topic) leaves into the aggregation root.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "gl355.h"
+
+static std::vector<uint64_t> read_words(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); exit(2); }
+    fseek(f, 0, SEEK_END);
+    const long bytes = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint64_t> v(bytes / 8);
+    if (fread(v.data(), 8, v.size(), f) != v.size()) { fprintf(stderr, "short read on %s\n", path.c_str()); exit(2); }
+    fclose(f);
+    return v;
+}
+static uint64_t splitmix(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+#define CHECK(ctx, expr)                                                                            \
+    do {                                                                                            \
+        const int32_t rc_ = (expr);                                                                 \
+        if (rc_ != GL355_OK) { fprintf(stderr, "%s -> %d: %s\n", #expr, rc_, gl355_last_error(ctx)); return 1; } \
+    } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s <artifact dir> [log_members=20] [contexts=12] [units=96]\n", argv[0]); return 2; }
+    const std::string dir = argv[1];
+    const uint32_t log_members = argc > 2 ? atoi(argv[2]) : 20, n_ctx = argc > 3 ? atoi(argv[3]) : 12, units = argc > 4 ? atoi(argv[4]) : 96;
+    const uint64_t n = 1ull << log_members;
+    std::vector<gl355_ctx*> ctxs(n_ctx);
+    for (auto& c : ctxs)
+        if (gl355_ctx_create(0, &c) != GL355_OK) { fprintf(stderr, "no MI355X context\n"); return 1; }
+    gl355_ctx* c0 = ctxs[0];
+    // access set: secret keys from a seeded stream (values < 2^63 are canonical), public keys, Merkle tree (cap height 0)
+    uint64_t seed = 0x357;
+    std::vector<uint64_t> sks(4 * n), pre(8 * n, 0), keys(4 * n), digests(8 * (n - 1)), root(4), topic(4);
+    for (auto& v : sks) v = splitmix(seed) >> 1;
+    for (auto& v : topic) v = splitmix(seed) >> 1;
+    for (uint64_t i = 0; i < n; i++)
+        for (int k = 0; k < 4; k++) pre[8 * i + k] = sks[4 * i + k];
+    CHECK(c0, gl355_hash_no_pad(c0, pre.data(), n, 8, keys.data()));
+    CHECK(c0, gl355_merkle_build(c0, keys.data(), n, 4, 0, digests.data(), root.data()));
+    // circuits
+    const std::vector<uint64_t> sem_blob = read_words(dir + "/semaphore.gl355"), rec_blob = read_words(dir + "/recursive.gl355");
+    gl355_circuit_handle *sem = nullptr, *rec = nullptr;
+    CHECK(c0, gl355_circuit_load(c0, sem_blob.data(), sem_blob.size(), &sem));
+    CHECK(c0, gl355_circuit_load(c0, rec_blob.data(), rec_blob.size(), &rec));
+    uint64_t words = 0;
+    uint32_t degree = 0;
+    gl355_circuit_info(rec, &words, nullptr, nullptr, nullptr, &degree);
+    std::vector<uint64_t> members(units), leaves(8ull * units), proofs(words * units);
+    for (uint32_t j = 0; j < units; j++) members[j] = (12 + j) % n;                 // signal.rs:42 starts at index 12
+    // warm-up, then the timed batch
+    CHECK(c0, gl355_semaphore_units(ctxs.data(), n_ctx, sem, rec, sks.data(), n, topic.data(), digests.data(), members.data(), n_ctx, 1, leaves.data(),
+                                    nullptr, nullptr));
+    const auto t0 = std::chrono::steady_clock::now();
+    CHECK(c0, gl355_semaphore_units(ctxs.data(), n_ctx, sem, rec, sks.data(), n, topic.data(), digests.data(), members.data(), units, 1000,
+                                    leaves.data(), proofs.data(), nullptr));
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // aggregation root over the (nullifier | topic) leaves, zero-padded to a power of two
+    uint64_t m = 1;
+    while (m < units) m <<= 1;
+    leaves.resize(8 * m, 0);
+    std::vector<uint64_t> adig(8 * (m - 1) + 8), aroot(4);
+    CHECK(c0, gl355_merkle_build(c0, leaves.data(), m, 8, 0, adig.data(), aroot.data()));
+    printf("group 2^%u, %u units (signal + recursive proof, n = 2^%u) on %u contexts: %.1f units/s; %llu-word proofs\n", log_members, units, degree,
+           n_ctx, units / dt, (unsigned long long)words);
+    printf("access-set root %016llx..., aggregation root %016llx %016llx %016llx %016llx\n", (unsigned long long)root[0], (unsigned long long)aroot[0],
+           (unsigned long long)aroot[1], (unsigned long long)aroot[2], (unsigned long long)aroot[3]);
+    gl355_circuit_destroy(rec);
+    gl355_circuit_destroy(sem);
+    for (auto c : ctxs) gl355_ctx_destroy(c);
+    return 0;
+}

@@ -114,3 +114,24 @@ def test_native_batch_runtime(gl, ctx, orc):
         plonk.semaphore_units(ctxs, sem, nat, sks, topic, aset.tree.digests, np.array([99], dtype=np.uint64), 1)
     for c in ctxs:
         c.close()
+
+
+def test_cpp_host_program(tmp_path):
+    """examples/native_units.cpp: a plain C++ host (g++, no scripting layer) that loads exported circuit artifacts and proves
+    signals + recursive proofs through the C ABI alone"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    art = str(tmp_path / "art")
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "export_artifacts.py"), art, "3"], stdout=subprocess.DEVNULL,
+                          stderr=subprocess.DEVNULL)
+    assert os.path.getsize(os.path.join(art, "recursive.gl355")) > 1 << 20
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.DEVNULL)
+    out = subprocess.check_output([os.path.join(root, "examples", "native_units"), art, "3", "2", "6"], text=True)
+    assert "6 units" in out and "aggregation root" in out, out
+    # a truncated artifact is refused
+    blob = np.fromfile(os.path.join(art, "semaphore.gl355"), dtype=np.uint64)
+    blob[:-5].tofile(os.path.join(art, "semaphore.gl355"))
+    assert subprocess.call([os.path.join(root, "examples", "native_units"), art, "3", "2", "6"], stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL) != 0
