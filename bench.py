@@ -38,6 +38,7 @@ def cpu_baseline(seconds=4.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle, rand_field
     orc = Oracle()
+    orc.L.orc_set_num_threads(os.cpu_count() or 1)
     threads = orc.L.orc_num_threads()
     rng = np.random.default_rng(0x355)
     n, N = 1 << LOG_N, 1 << (LOG_N + RATE_BITS)
@@ -181,6 +182,7 @@ def cpu_baseline_recursive(pr, units=1):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import CpuProver, Oracle
     orc = Oracle()
+    orc.L.orc_set_num_threads(os.cpu_count() or 1)      # torchrun exports OMP_NUM_THREADS=1; the baseline uses every host core
     threads = orc.L.orc_num_threads()
     t_build = time.perf_counter()
     cpu_in = CpuProver.from_circuit_data(orc, pr.inner_data)

@@ -202,6 +202,7 @@ int orc_prove_sparse(const orc_prover_data *pd, const uint32_t *row_idx, const u
                      uint64_t seed, uint64_t *proof);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n);   /* launchers such as torchrun export OMP_NUM_THREADS=1 */
 
 #ifdef __cplusplus
 }
