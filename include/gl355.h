@@ -55,7 +55,9 @@ int32_t gl355_ctx_sync(gl355_ctx* ctx);
 /* tuning knobs (results never depend on them).  MERKLE_LANES_LOG: Merkle levels with at most 2^value nodes run the
  * 16-lanes-per-node kernel (lowest latency, ~3x the instructions of the one-lane-per-node kernel); default 14 suits a
  * single proof stream, 11..12 gives more proofs/s when many contexts share the GPU. */
-enum { GL355_OPT_MERKLE_LANES_LOG = 1 };
+enum { GL355_OPT_MERKLE_LANES_LOG = 1,
+       GL355_OPT_BLOCKING_SYNC = 2 };   /* != 0: wait for the device with a blocking event instead of a spinning
+                                           hipStreamSynchronize -- for more prover threads than host cores */
 int32_t gl355_ctx_set_option(gl355_ctx* ctx, int32_t option, int64_t value);
 const char* gl355_last_error(gl355_ctx* ctx);
 const char* gl355_version(void);

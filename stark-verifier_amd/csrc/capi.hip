@@ -101,7 +101,7 @@ int32_t oracle_open_batch_on(Ctx* ctx, const gl355_oracle* o, const uint64_t* in
     GL355_TRY(open_batch_dev(ctx, o->lde, N, o->leaf_len, o->digests, bits, o->cap_height, d_idx, n_idx, d_leaf, d_sib));
     GL355_HIP(ctx, hipMemcpyAsync(leaves, d_leaf, n_leaf * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (n_sib) GL355_HIP(ctx, hipMemcpyAsync(siblings, d_sib, n_sib * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GL355_HIP(ctx, ctx->wait());
     return GL355_OK;
 }
 
@@ -292,7 +292,7 @@ static int32_t prove_from(Ctx* ctx, const uint64_t* digests_dev, uint64_t n_leav
         const uint64_t slot = (pair_index << (i + 1)) + (1ull << i) - 1;
         GL355_HIP(ctx, hipMemcpyAsync(siblings_host + 4 * i, tree + (2 * slot + (1 - parity)) * 4, 32, hipMemcpyDeviceToHost, ctx->stream));
     }
-    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GL355_HIP(ctx, ctx->wait());
     return GL355_OK;
 }
 int32_t gl355_merkle_prove(gl355_ctx* h, const uint64_t* digests, uint64_t n_leaves, uint32_t cap_height, uint64_t leaf_index,
@@ -371,7 +371,7 @@ int32_t gl355_commit_h(gl355_ctx* h, int32_t hasher, const uint64_t* values, uin
         }
         rc = merkle_build_any(ctx, hasher, o->lde, N, leaf_len, true, N, cap_height, o->digests, o->cap);
         if (rc) break;
-        e = hipStreamSynchronize(ctx->stream);
+        e = ctx->wait();
         if (e != hipSuccess) { rc = ctx->fail_hip(e, "hipStreamSynchronize(commit)", __FILE__, __LINE__); break; }
     } while (0);
     if (rc != GL355_OK) { ctx->release(base); delete o; return rc; }
@@ -381,7 +381,7 @@ int32_t gl355_commit_h(gl355_ctx* h, int32_t hasher, const uint64_t* values, uin
 int32_t gl355_oracle_destroy(gl355_oracle* o) {
     if (!o) return GL355_OK;
     (void)hipSetDevice(o->ctx->device);
-    (void)hipStreamSynchronize(o->ctx->stream);
+    (void)o->ctx->wait();
     o->ctx->release(o->coeffs);
     delete o;
     return GL355_OK;
@@ -400,7 +400,7 @@ static int32_t oracle_copy_out(const gl355_oracle* o, void* dst, const void* src
     Ctx* ctx = o->ctx;
     hipMemcpyKind kind = ptr_is_device(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     GL355_HIP(ctx, hipMemcpyAsync(dst, src_dev, bytes, kind, ctx->stream));
-    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GL355_HIP(ctx, ctx->wait());
     return GL355_OK;
 }
 int32_t gl355_oracle_cap(const gl355_oracle* o, uint64_t* cap) {

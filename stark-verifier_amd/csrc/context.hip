@@ -13,6 +13,17 @@ int32_t Ctx::fail_hip(hipError_t e, const char* expr, const char* file, int line
     return GL355_E_HIP;
 }
 
+hipError_t Ctx::wait() {
+    if (!blocking_sync) return hipStreamSynchronize(stream);
+    if (!sync_ev) {
+        hipError_t e = hipEventCreateWithFlags(&sync_ev, hipEventBlockingSync | hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipEventRecord(sync_ev, stream);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(sync_ev);
+}
+
 hipEvent_t Ctx::prof_event() {
     if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -73,7 +84,7 @@ int32_t Ctx::pow_tables_multi(const std::vector<uint64_t>& bases, const uint64_t
     uint64_t* d = nullptr;
     GL355_HIP(this, hipMalloc((void**)&d, h.size() * 8));
     GL355_HIP(this, hipMemcpyAsync(d, h.data(), h.size() * 8, hipMemcpyHostToDevice, stream));
-    GL355_HIP(this, hipStreamSynchronize(stream));
+    GL355_HIP(this, wait());
     PowTab t{d, d + nb * 4096};
     pow_cache[bases] = t;
     *lo = t.lo; *hi = t.hi;
@@ -103,7 +114,7 @@ int32_t Staged::finish() {
     if (is_host && copy_back) {
         GL355_HIP(ctx, hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (is_host) GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (is_host) GL355_HIP(ctx, ctx->wait());
     return GL355_OK;
 }
 
@@ -123,7 +134,7 @@ static int32_t ctx_init(Ctx* c) {
     GL355_HIP(c, hipMalloc((void**)&c->tw_fwd, h.size() * 8));
     c->tw_inv = c->tw_fwd + 16384;
     GL355_HIP(c, hipMemcpyAsync(c->tw_fwd, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream));
-    GL355_HIP(c, hipStreamSynchronize(c->stream));
+    GL355_HIP(c, c->wait());
     return ntt_init_constants(c);
 }
 
@@ -180,6 +191,7 @@ int32_t gl355_ctx_destroy(gl355_ctx* ctx) {
     for (auto& kv : c.pow_cache) (void)hipFree(kv.second.lo);
     for (auto& kv : c.full_cache) (void)hipFree(kv.second);
     if (c.tw_fwd) (void)hipFree(c.tw_fwd);
+    if (c.sync_ev) (void)hipEventDestroy(c.sync_ev);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     for (auto& r : c.prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -191,6 +203,9 @@ int32_t gl355_ctx_destroy(gl355_ctx* ctx) {
 int32_t gl355_ctx_set_option(gl355_ctx* ctx, int32_t option, int64_t value) {
     if (!ctx) return GL355_E_INVALID_ARG;
     switch (option) {
+    case GL355_OPT_BLOCKING_SYNC:
+        ctx->c.blocking_sync = value != 0;
+        return GL355_OK;
     case GL355_OPT_MERKLE_LANES_LOG:
         if (value < 0 || value > 30) return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: MERKLE_LANES_LOG must be in 0..30");
         ctx->c.merkle_lanes_log = (uint32_t)value;
@@ -201,7 +216,7 @@ int32_t gl355_ctx_set_option(gl355_ctx* ctx, int32_t option, int64_t value) {
 }
 int32_t gl355_ctx_sync(gl355_ctx* ctx) {
     if (!ctx) return GL355_E_INVALID_ARG;
-    GL355_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    GL355_HIP(&ctx->c, ctx->c.wait());
     return GL355_OK;
 }
 const char* gl355_last_error(gl355_ctx* ctx) { return ctx ? ctx->c.err.c_str() : g_create_error.c_str(); }
@@ -215,19 +230,19 @@ int32_t gl355_malloc(gl355_ctx* ctx, size_t bytes, void** dptr) {
 }
 int32_t gl355_free(gl355_ctx* ctx, void* dptr) {
     if (!ctx) return GL355_E_INVALID_ARG;
-    if (dptr) { GL355_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream)); GL355_HIP(&ctx->c, hipFree(dptr)); }
+    if (dptr) { GL355_HIP(&ctx->c, ctx->c.wait()); GL355_HIP(&ctx->c, hipFree(dptr)); }
     return GL355_OK;
 }
 int32_t gl355_memcpy_h2d(gl355_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return GL355_E_INVALID_ARG;
     GL355_HIP(&ctx->c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->c.stream));
-    GL355_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    GL355_HIP(&ctx->c, ctx->c.wait());
     return GL355_OK;
 }
 int32_t gl355_memcpy_d2h(gl355_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return GL355_E_INVALID_ARG;
     GL355_HIP(&ctx->c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->c.stream));
-    GL355_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    GL355_HIP(&ctx->c, ctx->c.wait());
     return GL355_OK;
 }
 int32_t gl355_timer_start(gl355_ctx* ctx) {
@@ -252,7 +267,7 @@ int32_t gl355_profile_enable(gl355_ctx* ctx, int32_t on) {
 int32_t gl355_profile_read(gl355_ctx* ctx, char* buf, size_t buf_len) {
     if (!ctx || !buf || buf_len == 0) return GL355_E_INVALID_ARG;
     Ctx& c = ctx->c;
-    GL355_HIP(&c, hipStreamSynchronize(c.stream));
+    GL355_HIP(&c, c.wait());
     struct Agg { uint64_t n = 0; double ms = 0; uint64_t bytes = 0; };
     std::map<std::string, Agg> agg;
     for (auto& r : c.prof) {

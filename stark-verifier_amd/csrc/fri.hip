@@ -142,7 +142,7 @@ int32_t deep_batch_dev(Ctx* ctx, const uint64_t* const* poly_ptrs_host, uint32_t
     GL355_HIP(ctx, hipMemcpyAsync(d_tab, host.data(), tab_u64 * 8, hipMemcpyHostToDevice, ctx->stream));
     GL355_HIP(ctx, hipMemcpyAsync(d_ptrs, poly_ptrs_host, ptr_bytes, hipMemcpyHostToDevice, ctx->stream));
     // the host vectors must outlive the async copies
-    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GL355_HIP(ctx, ctx->wait());
     const uint64_t* d_alpha = d_tab;
     const uint64_t* d_shift = d_tab + 2 * n_polys;
     const uint64_t* d_zpow2 = d_tab + 2 * (n_polys + 1);
@@ -201,7 +201,7 @@ int32_t eval_polys_ext_dev(Ctx* ctx, const uint64_t* const* poly_ptrs_host, uint
     uint64_t zc[2] = {gl_canon(z[0]), gl_canon(z[1])};
     GL355_HIP(ctx, hipMemcpyAsync(d_z, zc, 16, hipMemcpyHostToDevice, ctx->stream));
     GL355_HIP(ctx, hipMemcpyAsync(d_ptrs, poly_ptrs_host, sizeof(uint64_t*) * n_polys, hipMemcpyHostToDevice, ctx->stream));
-    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GL355_HIP(ctx, ctx->wait());
     ProfScope ps(ctx, "eval_polys", ((uint64_t)n_polys << log_n) * 8);
     hipLaunchKernelGGL(eval_polys_kernel, dim3(n_polys), dim3(256), 0, ctx->stream, d_ptrs, 1ull << log_n, d_z, out_dev);
     GL355_HIP(ctx, hipGetLastError());

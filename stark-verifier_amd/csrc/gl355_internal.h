@@ -66,6 +66,11 @@ struct Ctx {
 
     // optional per-kernel timing (gl355_profile_enable): HIP events around every launch group
     struct ProfRec { const char* name; hipEvent_t e0, e1; uint64_t bytes; };
+    // host wait for the stream: spinning hipStreamSynchronize (lowest latency) or, with GL355_OPT_BLOCKING_SYNC, a blocking
+    // event wait that leaves the CPU to other prover threads (more host threads than cores)
+    bool blocking_sync = false;
+    hipEvent_t sync_ev = nullptr;
+    hipError_t wait();
     uint32_t merkle_lanes_log = 14;   // Merkle levels with <= 2^this nodes use the 16-lanes-per-node kernel (GL355_OPT_MERKLE_LANES_LOG)
     bool prof_on = false;
     std::vector<ProfRec> prof;

@@ -605,7 +605,7 @@ int32_t ntt_init_constants(Ctx* ctx) {
     uint64_t x = 1, y = 1;
     for (int j = 0; j < 8; j++) { w16[0][j] = gl_canon(x); w16[1][j] = gl_canon(y); x = gl_mul(x, w); y = gl_mul(y, wi); }
     GL355_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_w16), w16, sizeof w16, 0, hipMemcpyHostToDevice, ctx->stream));
-    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GL355_HIP(ctx, ctx->wait());
     return GL355_OK;
 }
 

@@ -62,7 +62,7 @@ extern "C" int32_t gl355_fri_prove(gl355_ctx* h, const uint64_t* final_coeffs, u
         GL355_TRY(fri_layer_leaves_dev(ctx, values, len, lv));
         GL355_TRY(merkle_build_any(ctx, ch->hasher, lv, len / 2, 4, false, 0, cap_height, dg, d_cap));
         GL355_HIP(ctx, hipMemcpyAsync(cap_host.data(), d_cap, n_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
-        GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        GL355_HIP(ctx, ctx->wait());
         memcpy(caps_out + (uint64_t)l * n_cap * 4, cap_host.data(), n_cap * 32);
         gl355_challenger_observe(ch, cap_host.data(), n_cap * 4);
         uint64_t beta[2];
@@ -79,7 +79,7 @@ extern "C" int32_t gl355_fri_prove(gl355_ctx* h, const uint64_t* final_coeffs, u
     // final polynomial: the upper (1 - 2^-rate_bits) of the coefficients is zero by construction
     const uint64_t final_len = len >> rate_bits;
     GL355_HIP(ctx, hipMemcpyAsync(final_poly_out, coeffs, final_len * 16, hipMemcpyDeviceToHost, ctx->stream));
-    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GL355_HIP(ctx, ctx->wait());
     gl355_challenger_observe(ch, final_poly_out, final_len * 2);
     // proof of work
     uint64_t st[12];
@@ -108,7 +108,7 @@ extern "C" int32_t gl355_fri_prove(gl355_ctx* h, const uint64_t* final_coeffs, u
     }
     GL355_HIP(ctx, hipMemcpyAsync(step_evals, d_ev, (uint64_t)num_queries * n_layers * 32, hipMemcpyDeviceToHost, ctx->stream));
     if (sib_total) GL355_HIP(ctx, hipMemcpyAsync(step_siblings, d_sib, (uint64_t)num_queries * sib_total * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GL355_HIP(ctx, ctx->wait());
     return GL355_OK;
 }
 
@@ -141,7 +141,7 @@ struct OracleGuard {
 static int32_t observe_cap(Ctx* ctx, const gl355_oracle* o, gl355_challenger* ch, uint64_t* dst) {
     const uint64_t words = 4ull << o->cap_height;
     GL355_HIP(ctx, hipMemcpyAsync(dst, o->cap, words * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GL355_HIP(ctx, ctx->wait());
     gl355_challenger_observe(ch, dst, words);
     return GL355_OK;
 }
@@ -254,7 +254,7 @@ extern "C" int32_t gl355_prove_sparse(gl355_ctx* h, const gl355_prover_data* pd,
                            blind_start, n_blind, z_start, n_z_pairs, seed * 0xA24BAED4963EE407ull + 0x9FB21C651E98DF25ull);
         GL355_HIP(ctx, hipGetLastError());
     }
-    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host row buffers may be reused by the caller
+    GL355_HIP(ctx, ctx->wait());  // host row buffers may be reused by the caller
     return prove_core(h, ctx, pd, w.as<uint64_t>(), public_inputs, n_public_inputs, seed, proof, proof_capacity_words);
 }
 
@@ -359,7 +359,7 @@ static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, c
     GL355_TRY(eval_polys_ext_dev(ctx, z_ptrs.data(), nch, c.degree_bits, zeta_next, evb.as<uint64_t>() + 2 * n_open));
     uint64_t* p_open = out; out += 2 * (n_open + nch);
     GL355_HIP(ctx, hipMemcpyAsync(p_open, evb.as<uint64_t>(), (n_open + nch) * 16, hipMemcpyDeviceToHost, ctx->stream));
-    GL355_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GL355_HIP(ctx, ctx->wait());
     gl355_challenger_observe(&ch, p_open, 2 * (n_open + nch));
     uint64_t fri_alpha[2];
     gl355_challenger_squeeze(&ch, fri_alpha, 2);
