@@ -56,7 +56,8 @@ int32_t gl355_ctx_sync(gl355_ctx* ctx);
  * 16-lanes-per-node kernel (lowest latency, ~3x the instructions of the one-lane-per-node kernel); default 14 suits a
  * single proof stream, 11..12 gives more proofs/s when many contexts share the GPU. */
 enum { GL355_OPT_MERKLE_LANES_LOG = 1,
-       GL355_OPT_BLOCKING_SYNC = 2 };   /* != 0: wait for the device with a blocking event instead of a spinning
+       GL355_OPT_BLOCKING_SYNC = 2,
+       GL355_OPT_REPLAY_THREADS = 3 };  /* host threads gl355_circuit_prove_tape uses for a segmented tape (default 1) */   /* != 0: wait for the device with a blocking event instead of a spinning
                                            hipStreamSynchronize -- for more prover threads than host cores */
 int32_t gl355_ctx_set_option(gl355_ctx* ctx, int32_t option, int64_t value);
 const char* gl355_last_error(gl355_ctx* ctx);
@@ -353,15 +354,21 @@ enum { GL355_TAPE_CONST = 0, GL355_TAPE_INPUT = 1, GL355_TAPE_COPY = 2, GL355_TA
        GL355_TAPE_EXT_INV = 13 };
 int32_t gl355_witness_replay(const uint64_t* tape, uint64_t n_ops, const uint64_t* inputs, uint64_t n_inputs,
                              uint64_t* rows, uint64_t n_words, uint32_t num_wires, uint64_t* failed_op);
+/* A segmented tape = [n_seq sequential entries | segment 0 | segment 1 | ...] where the builder has checked that a segment reads
+ * only the sequential part and itself (the FRI query rounds of a verifier circuit): the segments run on `threads` host threads.
+ * Same rows and same error reporting (smallest failing entry) as the sequential replay of the same tape. */
+int32_t gl355_witness_replay_segmented(const uint64_t* tape, uint64_t n_ops, uint64_t n_seq, const uint64_t* seg_lens, uint32_t n_segs,
+                                       uint32_t threads, const uint64_t* inputs, uint64_t n_inputs, uint64_t* rows, uint64_t n_words,
+                                       uint32_t num_wires, uint64_t* failed_op);
 
 /* ---- circuit artifacts: the native per-proof path --------------------------------------------------------------
  * A circuit is BUILT once (plonky2's CircuitBuilder::build at access_set.rs:91, recursion.rs:167, wrapper.rs:41; here the
  * host-side builder stark-verifier_amd/plonk.py) and serialised with CircuitData.export_blob(): u64 words
- *   [0] magic "GL355CIR" [1] version 1 [2..11] the gl355_circuit scalars [12..91] 16 gates x {type, param, selector_index,
+ *   [0] magic "GL355CIR" [1] version 2 [2..11] the gl355_circuit scalars [12..91] 16 gates x {type, param, selector_index,
  *   group_start, group_end} [92] cap_height [93] pow_bits [94] num_queries [95] n_fri_layers [96] zero_knowledge [97] hasher
  *   [98] blind_start [99] n_blind [100] z_start [101] n_z_pairs [102] n_rows [103] n_tape_ops [104] n_inputs [105] n_public_inputs
- *   [106..109] circuit digest, then constants[num_selectors + num_constants][n] | sigmas[routed][n] | k_is[routed] |
- *   row_idx[n_rows] | public-input positions[n_pi] | tape[n_tape_ops][5] (gl355_witness_replay format).
+ *   [106..109] circuit digest [110] sequential tape entries [111] independent tape segments, then constants[num_selectors + num_constants][n] | sigmas[routed][n] | k_is[routed] |
+ *   row_idx[n_rows] | public-input positions[n_pi] | tape[n_tape_ops][5] (gl355_witness_replay format) | segment lengths.
  * gl355_circuit_load commits constants_sigmas on `ctx`, re-derives the circuit digest and refuses an artifact whose digest
  * does not match its tables.  The handle is read-only afterwards: any context of the same device may prove with it, concurrently.
  *   gl355_semaphore_prove    = fill_semaphore_targets + data.prove (access_set.rs:61-104): witness rows from the member's

@@ -113,6 +113,8 @@ SIGNATURES = {
     "gl355_semaphore_prove": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, vp, C.c_uint32, C.c_uint64, vp, C.c_uint64, vp]),
     "gl355_semaphore_units": (C.c_int32, [vp, C.c_uint32, vp, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint32, C.c_uint64, vp, vp, vp]),
     "gl355_semaphore_witness": (C.c_int32, [vp, vp, C.c_uint64, vp, C.c_uint32, vp, vp]),
+    "gl355_witness_replay_segmented": (C.c_int32, [vp, C.c_uint64, C.c_uint64, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, C.c_uint32,
+                                                   C.POINTER(C.c_uint64)]),
     "gl355_witness_replay": (C.c_int32, [vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
     "gl355_quotient": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gl355_quotient_values": (C.c_int32, [vp, C.POINTER(Circuit), vp, vp, vp, vp, vp, vp, vp, vp, vp]),

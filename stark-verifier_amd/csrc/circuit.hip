@@ -20,14 +20,15 @@ struct gl355_circuit_handle {
     uint64_t* d_sigmas = nullptr;
     uint64_t* d_kis = nullptr;
     std::vector<uint32_t> row_idx;
-    std::vector<uint64_t> pi_pos, tape;
+    std::vector<uint64_t> pi_pos, tape, seg_lens;
+    uint64_t n_seq = 0;
     uint32_t blind_start = 0, n_blind = 0, z_start = 0, n_z_pairs = 0, n_pi = 0;
     uint64_t n_inputs = 0;
 };
 
 namespace {
 constexpr uint64_t MAGIC = 0x5249433535334c47ull;   // "GL355CIR" little endian
-constexpr uint64_t HDR = 110;
+constexpr uint64_t HDR = 112;
 }
 
 extern "C" {
@@ -38,7 +39,7 @@ int32_t gl355_circuit_load(gl355_ctx* h, const uint64_t* blob, uint64_t words, g
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
     if (!blob || !out || words < HDR) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: null or truncated artifact");
     *out = nullptr;
-    if (blob[0] != MAGIC || blob[1] != 1) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: not a version-1 gl355 circuit artifact");
+    if (blob[0] != MAGIC || blob[1] != 2) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: not a version-2 gl355 circuit artifact");
     gl355_circuit c;
     memset(&c, 0, sizeof c);
     c.degree_bits = (uint32_t)blob[2]; c.rate_bits = (uint32_t)blob[3]; c.num_wires = (uint32_t)blob[4];
@@ -60,7 +61,9 @@ int32_t gl355_circuit_load(gl355_ctx* h, const uint64_t* blob, uint64_t words, g
     const uint64_t n_sc = c.num_selectors + c.num_constants, routed = c.num_routed_wires;
     const uint64_t n_rows = blob[102], n_ops = blob[103], n_inputs = blob[104], n_pi = blob[105];
     if (n_rows > n || n_ops > (1ull << 28) || n_pi > (1u << 20)) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: implausible sizes");
-    const uint64_t need = HDR + (n_sc + routed) * n + routed + n_rows + n_pi + 5 * n_ops;
+    const uint64_t n_seq = blob[110], n_segs = blob[111];
+    if (n_seq > n_ops || n_segs > n_ops) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: implausible tape segmentation");
+    const uint64_t need = HDR + (n_sc + routed) * n + routed + n_rows + n_pi + 5 * n_ops + n_segs;
     if (words != need) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: artifact length does not match its header");
     const int32_t hasher = (int32_t)blob[97];
     if (hasher != GL355_HASH_POSEIDON && hasher != GL355_HASH_BN254_POSEIDON) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: unknown hasher");
@@ -84,7 +87,14 @@ int32_t gl355_circuit_load(gl355_ctx* h, const uint64_t* blob, uint64_t words, g
     ch->pi_pos.assign(p, p + n_pi); p += n_pi;
     for (uint64_t v : ch->pi_pos)
         if (v >= n_rows * c.num_wires) { delete ch; return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: public-input position out of range"); }
-    ch->tape.assign(p, p + 5 * n_ops);
+    ch->tape.assign(p, p + 5 * n_ops); p += 5 * n_ops;
+    ch->seg_lens.assign(p, p + n_segs);
+    ch->n_seq = n_seq;
+    {
+        uint64_t tot = n_seq;
+        for (uint64_t v : ch->seg_lens) tot += v;
+        if (tot != n_ops) { delete ch; return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: tape segments do not add up"); }
+    }
     if ((uint64_t)ch->blind_start + ch->n_blind > n || (uint64_t)ch->z_start + 2ull * ch->n_z_pairs > n) {
         delete ch; return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: blinding rows out of range");
     }
@@ -170,7 +180,8 @@ int32_t gl355_circuit_prove_tape(gl355_ctx* h, const gl355_circuit_handle* ch, c
     const uint64_t n_words = (uint64_t)ch->row_idx.size() * ch->c.num_wires;
     rows.resize(n_words);
     uint64_t failed = 0;
-    const int32_t rc = gl355_witness_replay(ch->tape.data(), ch->tape.size() / 5, inputs, n_inputs, rows.data(), n_words, ch->c.num_wires, &failed);
+    const int32_t rc = gl355_witness_replay_segmented(ch->tape.data(), ch->tape.size() / 5, ch->n_seq, ch->seg_lens.data(), (uint32_t)ch->seg_lens.size(),
+                                                      ctx->replay_threads, inputs, n_inputs, rows.data(), n_words, ch->c.num_wires, &failed);
     if (rc != GL355_OK) {
         char msg[96];
         snprintf(msg, sizeof msg, "circuit_prove_tape: witness generation failed at tape entry %llu", (unsigned long long)failed);

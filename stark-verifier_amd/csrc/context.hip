@@ -203,6 +203,10 @@ int32_t gl355_ctx_destroy(gl355_ctx* ctx) {
 int32_t gl355_ctx_set_option(gl355_ctx* ctx, int32_t option, int64_t value) {
     if (!ctx) return GL355_E_INVALID_ARG;
     switch (option) {
+    case GL355_OPT_REPLAY_THREADS:
+        if (value < 1 || value > 64) return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: REPLAY_THREADS must be in 1..64");
+        ctx->c.replay_threads = (uint32_t)value;
+        return GL355_OK;
     case GL355_OPT_BLOCKING_SYNC:
         ctx->c.blocking_sync = value != 0;
         return GL355_OK;

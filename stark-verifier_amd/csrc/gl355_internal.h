@@ -68,6 +68,7 @@ struct Ctx {
     struct ProfRec { const char* name; hipEvent_t e0, e1; uint64_t bytes; };
     // host wait for the stream: spinning hipStreamSynchronize (lowest latency) or, with GL355_OPT_BLOCKING_SYNC, a blocking
     // event wait that leaves the CPU to other prover threads (more host threads than cores)
+    uint32_t replay_threads = 1;      // GL355_OPT_REPLAY_THREADS
     bool blocking_sync = false;
     hipEvent_t sync_ev = nullptr;
     hipError_t wait();

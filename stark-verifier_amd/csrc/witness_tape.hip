@@ -12,18 +12,21 @@
 // reducing.rs, reducing_extension.rs).
 #include "gl355_internal.h"
 
+#include <atomic>
+#include <thread>
+#include <vector>
+
 using namespace gl355;
 
 namespace {
 constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
 }
 
-extern "C" int32_t gl355_witness_replay(const uint64_t* tape, uint64_t n_ops, const uint64_t* inputs, uint64_t n_inputs,
-                                        uint64_t* rows, uint64_t n_words, uint32_t num_wires, uint64_t* failed_op) {
-    if (!tape || !rows || (!inputs && n_inputs) || num_wires < 135) return GL355_E_INVALID_ARG;
-    if (failed_op) *failed_op = ~0ull;
-    memset(rows, 0, n_words * 8);
+// entries [begin, end) of the tape on the (already initialised) rows
+static int32_t run_entries(const uint64_t* tape, uint64_t begin, uint64_t end, const uint64_t* inputs, uint64_t n_inputs, uint64_t* rows,
+                           uint64_t n_words, uint32_t num_wires, uint64_t* failed_op) {
     uint64_t* W = rows;
+    const uint64_t n_ops = end;
 #define CHK(i, span)                                                        \
     if ((uint64_t)(i) + (span) > n_words) {                                   \
         if (failed_op) *failed_op = t;                                        \
@@ -35,7 +38,7 @@ extern "C" int32_t gl355_witness_replay(const uint64_t* tape, uint64_t n_ops, co
         if (failed_op) *failed_op = t;                                        \
         return GL355_E_INVALID_ARG;                                           \
     }
-    for (uint64_t t = 0; t < n_ops; t++) {
+    for (uint64_t t = begin; t < n_ops; t++) {
         const uint64_t* e = tape + 5 * t;
         const uint64_t a = e[1], b = e[2], c = e[3], d = e[4];
         switch (e[0]) {
@@ -140,4 +143,54 @@ extern "C" int32_t gl355_witness_replay(const uint64_t* tape, uint64_t n_ops, co
 #undef CHK
 #undef ROWCHK
     return GL355_OK;
+}
+
+extern "C" int32_t gl355_witness_replay(const uint64_t* tape, uint64_t n_ops, const uint64_t* inputs, uint64_t n_inputs,
+                                        uint64_t* rows, uint64_t n_words, uint32_t num_wires, uint64_t* failed_op) {
+    if (!tape || !rows || (!inputs && n_inputs) || num_wires < 135) return GL355_E_INVALID_ARG;
+    if (failed_op) *failed_op = ~0ull;
+    memset(rows, 0, n_words * 8);
+    return run_entries(tape, 0, n_ops, inputs, n_inputs, rows, n_words, num_wires, failed_op);
+}
+
+// The same with the independent segments of a segmented tape (gadgets.py begin_segment / end_segment, e.g. the FRI query
+// rounds of a verifier circuit) spread over `threads` host threads: entries [0, n_seq) run first on the calling thread, then
+// segment k = the next seg_lens[k] entries.  The builder has checked that a segment reads only the sequential part and
+// itself, so the rows are the same as those of the sequential replay; the reported failing entry is the smallest one.
+extern "C" int32_t gl355_witness_replay_segmented(const uint64_t* tape, uint64_t n_ops, uint64_t n_seq, const uint64_t* seg_lens, uint32_t n_segs,
+                                                  uint32_t threads, const uint64_t* inputs, uint64_t n_inputs, uint64_t* rows, uint64_t n_words,
+                                                  uint32_t num_wires, uint64_t* failed_op) {
+    if (!tape || !rows || (!inputs && n_inputs) || num_wires < 135 || (!seg_lens && n_segs) || n_seq > n_ops) return GL355_E_INVALID_ARG;
+    uint64_t total = n_seq;
+    for (uint32_t k = 0; k < n_segs; k++) total += seg_lens[k];
+    if (total != n_ops) return GL355_E_INVALID_ARG;
+    if (failed_op) *failed_op = ~0ull;
+    memset(rows, 0, n_words * 8);
+    int32_t rc = run_entries(tape, 0, n_seq, inputs, n_inputs, rows, n_words, num_wires, failed_op);
+    if (rc != GL355_OK || n_segs == 0) return rc;
+    if (threads <= 1) return run_entries(tape, n_seq, n_ops, inputs, n_inputs, rows, n_words, num_wires, failed_op);
+    std::vector<uint64_t> start(n_segs + 1, n_seq);
+    for (uint32_t k = 0; k < n_segs; k++) start[k + 1] = start[k] + seg_lens[k];
+    const uint32_t nt = threads < n_segs ? threads : n_segs;
+    std::vector<int32_t> rcs(nt, GL355_OK);
+    std::vector<uint64_t> fails(nt, ~0ull);
+    std::atomic<uint32_t> next{0};
+    auto worker = [&](uint32_t t) {
+        for (;;) {
+            const uint32_t k = next.fetch_add(1);
+            if (k >= n_segs) return;
+            uint64_t f = ~0ull;
+            const int32_t r = run_entries(tape, start[k], start[k + 1], inputs, n_inputs, rows, n_words, num_wires, &f);
+            if (r != GL355_OK && f < fails[t]) { rcs[t] = r; fails[t] = f; }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < nt; t++) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& th : pool) th.join();
+    uint64_t best = ~0ull;
+    for (uint32_t t = 0; t < nt; t++)
+        if (rcs[t] != GL355_OK && fails[t] < best) { best = fails[t]; rc = rcs[t]; }
+    if (failed_op && best != ~0ull) *failed_op = best;
+    return rc;
 }

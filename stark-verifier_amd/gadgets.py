@@ -66,12 +66,24 @@ class GadgetBuilder:
         self.trace = hashlib.sha256()
         self._free = None         # (row, next col) of the current Noop storage row
         self.tape = []            # (op, a, b, c, d) with wire operands as row * num_wires + col
+        self.tape_seg = []        # segment of each tape entry: 0 = sequential part, k >= 1 = independent segment k
+        self.segment, self._n_segments = 0, 0
 
     def _w(self, row, col):
         return row * self.nw + col
 
     def _rec(self, op, a=0, b=0, c=0, d=0):
         self.tape.append((op, a, b, c, d))
+        self.tape_seg.append(self.segment)
+
+    def begin_segment(self):
+        """ops recorded until end_segment() form one independent unit of witness generation (e.g. one FRI query round): they
+        may read what the unsegmented ops and they themselves produced, nothing else -- checked in witness_tape()"""
+        self._n_segments += 1
+        self.segment = self._n_segments
+
+    def end_segment(self):
+        self.segment = 0
 
     # ---- low level ------------------------------------------------------------------------------------
     def _new_row(self, gtype, param=0, constants=()):
@@ -472,4 +484,64 @@ class GadgetBuilder:
             col[is_wire] = (r * self.nw + w % self.nw).astype(np.uint64)
             out[:, 1 + f] = col
         pi_pos = np.array([rank[t.row] * self.nw + t.col for t in self.public_inputs], dtype=np.int64)
+        self.tape_layout = self._segment_layout(out)
+        if self.tape_layout is not None:
+            order, n_seq, seg_lens = self.tape_layout
+            out = out[order]
+            self.tape_layout = (n_seq, seg_lens)
         return out, np.array(idx, dtype=np.uint32), pi_pos
+
+    def _segment_layout(self, tape):
+        """(permutation, number of sequential entries, lengths of the independent segments) for a tape reordered as
+        [CONST entries | unsegmented entries in recording order | segment 1 | segment 2 | ...], or None when some segment reads
+        another segment's wires (then the tape stays in recording order and is replayed sequentially)."""
+        seg = np.array(self.tape_seg, dtype=np.int64)
+        if seg.max(initial=0) == 0:
+            return None
+        ops = tape[:, 0].astype(np.int64)
+        seg = np.where(ops == TAPE_CONST, 0, seg)
+        writer = {}
+
+        def reads_writes(e):
+            op, a, b, c, d = (int(x) for x in e)
+            if op in (TAPE_CONST, TAPE_INPUT):
+                return (), (a,)
+            if op in (TAPE_COPY, TAPE_LO32, TAPE_HI32):
+                return (b,), (a,)
+            if op == TAPE_ASSERT_EQ:
+                return (a, b), ()
+            if op == TAPE_ARITH:
+                return (a, a + 1, a + 2), (a + 3,)
+            if op == TAPE_ARITH_EXT:
+                return tuple(range(a, a + 6)), (a + 6, a + 7)
+            if op == TAPE_POSEIDON:
+                return tuple(range(a, a + 12)) + (a + 24,), tuple(range(a, a + self.nw))
+            if op == TAPE_MDS_EXT:
+                return tuple(range(a, a + 24)), tuple(range(a + 24, a + 48))
+            if op == TAPE_BASE_SUM:
+                return (a,), tuple(range(a + 1, a + 1 + b))
+            if op == TAPE_RANDOM_ACCESS:
+                return (a + 18 * b,) + tuple(range(a + 18 * b + 2, a + 18 * b + 18)), (a + 18 * b + 1,) + tuple(range(a + 74 + 4 * b, a + 78 + 4 * b))
+            if op == TAPE_REDUCING:
+                n_c = b * (2 if c else 1)
+                return tuple(range(a + 2, a + 6 + n_c)), (a, a + 1) + tuple(range(a + 6 + n_c, a + 6 + n_c + 2 * (b - 1)))
+            if op == TAPE_EXT_INV:
+                return (c, d), (a, b)
+            raise ValueError(op)
+        for k in range(tape.shape[0]):
+            sk = int(seg[k])
+            rd, wr = reads_writes(tape[k])
+            for w in rd:
+                ws = writer.get(w, 0)
+                if ws != 0 and ws != sk:
+                    return None
+            for w in wr:
+                ws = writer.setdefault(w, sk)
+                if ws != sk:
+                    return None
+        is_const = ops == TAPE_CONST
+        order = np.concatenate([np.nonzero(is_const)[0], np.nonzero((seg == 0) & ~is_const)[0]] +
+                               [np.nonzero(seg == s)[0] for s in range(1, int(seg.max()) + 1)])
+        n_seq = int((seg == 0).sum())
+        seg_lens = [int((seg == s).sum()) for s in range(1, int(seg.max()) + 1)]
+        return order, n_seq, seg_lens

@@ -298,13 +298,13 @@ class CircuitData:
             cache[key] = pd
         return cache[key]
 
-    def export_blob(self, row_idx, tape=None, pi_pos=None, n_inputs=0):
+    def export_blob(self, row_idx, tape=None, pi_pos=None, n_inputs=0, tape_layout=None):
         """Serialise the built circuit (+ the sparse witness-row map and optionally a witness tape) as the u64 artifact
         gl355_circuit_load reads (layout in include/gl355.h)."""
         cfg = self.config
         cc = self.c_circuit
-        hdr = np.zeros(110, dtype=np.uint64)
-        hdr[0], hdr[1] = 0x5249433535334c47, 1
+        hdr = np.zeros(112, dtype=np.uint64)
+        hdr[0], hdr[1] = 0x5249433535334c47, 2
         hdr[2:12] = [cc.degree_bits, cc.rate_bits, cc.num_wires, cc.num_routed_wires, cc.num_constants, cc.num_selectors,
                      cc.num_challenges, cc.max_degree, cc.num_partial_products, cc.num_gates]
         for g in range(_lib.MAX_GATES):
@@ -318,8 +318,10 @@ class CircuitData:
                        cfg.hasher, start, n_blind, z_pairs[0][0] if z_pairs else 0, len(z_pairs), row_idx.size, tape.shape[0],
                        n_inputs, pi_pos.size]
         hdr[106:110] = self.circuit_digest
+        n_seq, seg_lens = tape_layout if tape_layout is not None else (tape.shape[0], [])
+        hdr[110], hdr[111] = n_seq, len(seg_lens)
         return np.concatenate([hdr, _u64(self.constants).reshape(-1), _u64(self.sigmas).reshape(-1), _u64(self.k_is), row_idx,
-                               pi_pos, tape.reshape(-1)])
+                               pi_pos, tape.reshape(-1), np.asarray(seg_lens, dtype=np.uint64)])
 
     def common(self):
         """Plain-dict common data for the verifier restatement in tests/."""

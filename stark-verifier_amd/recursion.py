@@ -346,6 +346,7 @@ def verify_proof(b, cd, proof, register_pis=True):
     omega = pow(7, (P - 1) >> lde_bits, P)
     one, zero = b.one(), b.zero()
     for q, rnd in zip(query_challenges, fri["query_round_proofs"]):
+        b.begin_segment()             # a query round reads the transcript / openings above and its own wires only
         bits = b.split_le_64(q)[:lde_bits]
         cap_index = b.le_sum(bits[lde_bits - cap_h:]) if cap_h else zero
         leaves = [[tv(v) for v in leaf] for leaf, _ in rnd["initial_trees"]]
@@ -389,6 +390,7 @@ def verify_proof(b, cd, proof, register_pis=True):
             idx_bits = coset_bits
         fin = b.reduce_with_powers_ext(final_poly, b.ext_from_base(x))
         b.connect_ext(fin, prev)
+        b.end_segment()
     return pis
 
 
@@ -448,6 +450,7 @@ class RecursiveCircuit:
         assert getattr(b, "untagged_inputs", 0) == 0
         self.structure = b.structure_hash()
         self.tape, self.row_idx, self.pi_pos = b.witness_tape()
+        self.tape_layout = b.tape_layout
         self.data = b.cb.build(self.ctx, rng)
         self.n_inputs = off
         return self
@@ -457,7 +460,7 @@ class RecursiveCircuit:
         gl355_circuit_prove_tape(inner proofs' flat words | public inputs)"""
         if getattr(self, "_native", None) is None:
             from .plonk import NativeCircuit
-            self._native = NativeCircuit(self.ctx, self.data.export_blob(self.row_idx, self.tape, self.pi_pos, self.n_inputs))
+            self._native = NativeCircuit(self.ctx, self.data.export_blob(self.row_idx, self.tape, self.pi_pos, self.n_inputs, self.tape_layout))
         return self._native
 
     def witness(self, flat_proofs):

@@ -95,6 +95,18 @@ def test_recursive_proof_of_a_cpu_semaphore_proof(orc):
     tape, tidx, pi_pos = b.witness_tape()
     rc, trows, _ = replay(tape, np.concatenate([flat, pi]), ridx.size)
     assert rc == 0 and np.array_equal(trows, rows)
+    # the tape is segmented (28 independent FRI query rounds after a sequential part): the multi-threaded replay gives the same
+    # rows and reports the same failing entry as the sequential one
+    n_seq, seg_lens = b.tape_layout
+    assert len(seg_lens) == inner_cd["num_query_rounds"] and n_seq + sum(seg_lens) == tape.shape[0]
+    seg = np.array(seg_lens, dtype=np.uint64)
+    inp = np.concatenate([flat, pi])
+    for threads in (1, 3, 8):
+        prow = np.empty_like(rows)
+        failed = C.c_uint64(0)
+        rc = lib.gl355_witness_replay_segmented(tape.ctypes.data, tape.shape[0], n_seq, seg.ctypes.data, seg.size, threads, inp.ctypes.data,
+                                                inp.size, prow.ctypes.data, prow.size, 135, C.byref(failed))
+        assert rc == 0 and np.array_equal(prow, rows)
     outer = cpu.prove_sparse(ridx, rows, np.array(pi_vals, dtype=np.uint64), 31)
     proof = plonk.parse_proof(data, outer)
     proof["public_inputs"] = np.array(pi_vals, dtype=np.uint64)
@@ -102,5 +114,13 @@ def test_recursive_proof_of_a_cpu_semaphore_proof(orc):
     # a corrupted inner proof (one sibling word) cannot be witnessed
     bad = flat.copy()
     bad[-3] ^= np.uint64(1)
-    rc, _, _ = replay(tape, np.concatenate([bad, pi]), ridx.size)
+    rc, _, where = replay(tape, np.concatenate([bad, pi]), ridx.size)
     assert rc == -6
+    badin = np.concatenate([bad, pi])
+    failed = C.c_uint64(0)
+    prow = np.empty_like(rows)
+    rc = lib.gl355_witness_replay_segmented(tape.ctypes.data, tape.shape[0], n_seq, seg.ctypes.data, seg.size, 4, badin.ctypes.data, badin.size,
+                                            prow.ctypes.data, prow.size, 135, C.byref(failed))
+    assert rc == -6 and failed.value == where
+    assert lib.gl355_witness_replay_segmented(tape.ctypes.data, tape.shape[0], n_seq + 1, seg.ctypes.data, seg.size, 4, badin.ctypes.data,
+                                              badin.size, prow.ctypes.data, prow.size, 135, None) == -1

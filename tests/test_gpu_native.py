@@ -36,6 +36,10 @@ def test_native_semaphore_and_recursive_proofs(gl, ctx, orc):
     proof = plonk.parse_proof(rc.data, flat_nat)
     proof["public_inputs"] = pis_nat
     pv.verify(orc, rc.data.common(), proof)
+    ctx.set_option(3, 4)                                  # GL355_OPT_REPLAY_THREADS: the query rounds of the tape on 4 host threads
+    flat_mt, pis_mt = nat.prove_tape(ctx, np.concatenate([inner[0], inner[1]]), 44)
+    ctx.set_option(3, 1)
+    assert np.array_equal(flat_mt, flat_py) and np.array_equal(pis_mt, pis_py)
     # an invalid inner proof is refused with GL355_E_WITNESS
     bad = inner[0].copy()
     bad[50] ^= np.uint64(1)
@@ -70,7 +74,7 @@ def test_artifact_validation(gl, ctx):
         elif mutate == "truncate":
             b = b[:-1]
         elif mutate == "table":
-            b[110 + 12345] ^= np.uint64(1)            # a selector / constant value: the digest no longer matches
+            b[112 + 12345] ^= np.uint64(1)            # a selector / constant value: the digest no longer matches
         elif mutate == "digest":
             b[107] ^= np.uint64(1)
         elif mutate == "rowidx":

@@ -26,7 +26,7 @@ blob = data.export_blob(idx)
 blob.tofile(os.path.join(out, "semaphore.gl355"))
 sig, _ = aset.make_signal_fast(sks[0], topic, 0, 1, flat_only=True)
 rc = rec.RecursiveCircuit(ctx, data.common(), k=1).build([(sig.proof, pi)], rng)
-rblob = rc.data.export_blob(rc.row_idx, rc.tape, rc.pi_pos, rc.n_inputs)
+rblob = rc.data.export_blob(rc.row_idx, rc.tape, rc.pi_pos, rc.n_inputs, rc.tape_layout)
 rblob.tofile(os.path.join(out, "recursive.gl355"))
 print("semaphore.gl355: %.1f MB (degree 2^%d), recursive.gl355: %.1f MB (degree 2^%d, %d tape entries)" % (
     blob.nbytes / 1e6, data.degree_bits, rblob.nbytes / 1e6, rc.data.degree_bits, rc.tape.shape[0]))

@@ -37,6 +37,10 @@ t = time.perf_counter(); flat, pis0 = pr.sem.semaphore_prove(c, pr.sks[3], pr.to
 inp = np.concatenate([flat, pis0])
 t = time.perf_counter(); rows, pis = pr.rc.witness([(flat, pis0)]); t_rep = time.perf_counter() - t
 t = time.perf_counter(); pr.nat.prove_tape(c, inp, 1); t_out = time.perf_counter() - t
+c.set_option(3, 4)
+t = time.perf_counter(); pr.nat.prove_tape(c, inp, 1); t_out4 = time.perf_counter() - t
+c.set_option(3, 1)
+print("with 4 replay threads: replay + recursive proof %.2f ms" % (t_out4 * 1e3))
 print("latency: signal %.2f ms, tape replay %.2f ms (inside the next figure), replay + recursive proof %.2f ms" % (t_in * 1e3, t_rep * 1e3, t_out * 1e3))
 for ll in [int(x) for x in args.lanes_log.split(",")]:
   for a_ in sets:
