@@ -173,6 +173,41 @@ __global__ void __launch_bounds__(64) merkle_level_lanes_kernel(uint64_t* digest
     }
 }
 
+// The top of every cap subtree in ONE launch: one block per subtree takes its 2^TOP_LOG nodes of layer `layer0` and climbs to
+// the cap entry (2^TOP_LOG, ..., 2, 1 nodes), the digests of a level staying in LDS for the next one (and going to the plonky2
+// layout in HBM).  Each of those levels is a single lane-parallel permutation deep; as separate launches they cost ~20 us
+// apiece, mostly launch latency.  Waves whose groups have no node on a level skip its permutation.
+#define MERKLE_TOP_LOG 5
+__global__ void __launch_bounds__(512) merkle_top_kernel(uint64_t* digests, uint64_t* cap, uint32_t sub_bits, uint32_t layer0) {
+    __shared__ uint64_t rings[32][24];
+    __shared__ uint64_t lvl[2][(1 << MERKLE_TOP_LOG) * 4];
+    const int li = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int wave_first_grp = (threadIdx.x >> 6) << 2;
+    const uint64_t sub_leaves = 1ull << sub_bits;
+    const uint64_t t = blockIdx.x;
+    uint64_t* tree = digests + t * 2 * (sub_leaves - 1) * 4;
+    int cur = 0;
+    for (uint32_t l = 0; l <= MERKLE_TOP_LOG; l++) {
+        const uint32_t layer = layer0 + l;
+        const int cnt = 1 << (MERKLE_TOP_LOG - l);
+        if (wave_first_grp < cnt) {                       // wave-uniform: this wave owns at least one node of the level
+            const bool valid = grp < cnt;
+            const int j = valid ? grp : 0;
+            uint64_t s = 0;
+            if (li < 8) s = (l == 0) ? tree[digest_slot(layer - 1, 2 * (uint64_t)j) * 4 + li] : lvl[cur][(2 * j) * 4 + li];
+            s = psd_permute_lanes(s, li, rings[grp]);
+            if (valid && li < 4) {
+                const uint64_t v = gl_canon(s);
+                lvl[cur ^ 1][j * 4 + li] = v;
+                uint64_t* dst = (layer == sub_bits) ? cap + t * 4 : tree + digest_slot(layer, (uint64_t)j) * 4;
+                dst[li] = v;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 __global__ void __launch_bounds__(256) two_to_one_kernel(const uint64_t* l, const uint64_t* r, uint64_t n, uint64_t* out) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -293,8 +328,17 @@ int32_t merkle_build_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, ui
     a.out = digests; a.cap = cap; a.sub_bits = sub_bits;
     { ProfScope ps(ctx, "hash_leaves_kernel", n_leaves * ((uint64_t)leaf_len * 8 + 32)); GL355_TRY(launch_leaves(ctx, a)); }
     const uint64_t lanes_max = 1ull << ctx->merkle_lanes_log;
+    // the last MERKLE_TOP_LOG + 1 levels of every cap subtree go to merkle_top_kernel (when they are lane-parallel levels anyway)
+    uint32_t top_from = sub_bits + 1;
+    if (sub_bits > MERKLE_TOP_LOG && ((n_leaves >> (sub_bits - MERKLE_TOP_LOG)) <= lanes_max)) top_from = sub_bits - MERKLE_TOP_LOG;
     for (uint32_t layer = 1; layer <= sub_bits; layer++) {
         const uint64_t n_nodes = n_leaves >> layer;
+        if (layer == top_from) {
+            ProfScope ps(ctx, "merkle_top_kernel", (2 * n_nodes - (n_leaves >> sub_bits)) * 96);
+            hipLaunchKernelGGL(merkle_top_kernel, dim3((uint32_t)(n_leaves >> sub_bits)), dim3(512), 0, ctx->stream, digests, cap, sub_bits, layer);
+            GL355_HIP(ctx, hipGetLastError());
+            break;
+        }
         // one scope per level (= per launch): 2 child digests in, 1 out per node
         ProfScope ps(ctx, n_nodes <= lanes_max ? "merkle_level_lanes_kernel" : "merkle_level_kernel", n_nodes * 96);
         if (n_nodes <= lanes_max) {
