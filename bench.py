@@ -414,14 +414,15 @@ def main_recursive(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["recursive", "lde", "semaphore"], default="recursive",
                     help="recursive = Semaphore d=20 signal + recursive proof per unit (default; BASELINE configs[3]/[4]); "
                          "lde = configs[1]; semaphore = the signals alone")
-    ap.add_argument("--proofs-per-step", type=int, default=24, help="units (recursive) / proofs (semaphore) per GPU per step")
-    ap.add_argument("--threads", type=int, default=12, help="concurrent prover contexts per GPU")
+    ap.add_argument("--proofs-per-step", type=int, default=128,
+                    help="units (recursive) / proofs (semaphore) per GPU per step; 128 = BASELINE configs[4] (1024 proofs over 8 GPUs)")
+    ap.add_argument("--threads", type=int, default=16, help="concurrent prover contexts per GPU (one HIP stream + one host thread each)")
     ap.add_argument("--log-members", type=int, default=20, help="log2 of the access-set size (tree depth)")
     args = ap.parse_args()
     if args.workload == "semaphore":

@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_r01b
 mkdir -p $O
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps 3 --warmup 1 --proofs-per-step 12 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps 3 --warmup 1 --proofs-per-step 12 --threads 12 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --steps 1 --warmup 0 --proofs-per-step 12 --threads 1 --no-cpu-baseline > /dev/null 2> $O/pmc_$c.err
 done
