@@ -299,11 +299,12 @@ def main_recursive(args):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     gl = importlib.import_module("stark-verifier_amd")
     par = importlib.import_module("stark-verifier_amd.parallel")
-    # the prover threads spin in hipStreamSynchronize by default (lowest latency); when this rank has fewer usable host
-    # cores than prover threads they wait on blocking events instead (measured with 24 threads on 16 cores: 101 -> 109 units/s; hipDeviceScheduleBlockingSync for the whole device gives 135)
+    # one prover context = one host thread that spins in hipStreamSynchronize (lowest latency): never more of them than this rank
+    # has usable host cores (cgroup quota / ranks); with a single core left, wait on blocking events instead
     cores_per_rank = max(1, host_cores() // max(1, world))
-    blocking = cores_per_rank < args.threads
-    pr = RecursiveProvers(gl, local_rank, args.threads, args.log_members, blocking_sync=blocking)
+    n_threads = max(2, min(args.threads, cores_per_rank))
+    blocking = cores_per_rank < 2
+    pr = RecursiveProvers(gl, local_rank, n_threads, args.log_members, blocking_sync=blocking)
     per = args.proofs_per_step
     total = per * world
     lo, hi = par.shard_range(total, rank, world)
@@ -361,7 +362,7 @@ def main_recursive(args):
             "config": {"workload": "recursive: per unit one Semaphore signal (group 2^%d, n=2^13, blowup 8, 28 FRI queries, 16 PoW bits, "
                                    "zk) + the recursive proof verifying it (n=2^%d, same FRI parameters); %d units per GPU per step, %d "
                                    "prover contexts per GPU; all_gather of (nullifier|topic) + Poseidon aggregation root per step"
-                                   % (args.log_members, pr.rc.data.degree_bits, per, args.threads),
+                                   % (args.log_members, pr.rc.data.degree_bits, per, n_threads),
                        "parallelism": "independent proofs sharded over ranks, no data-path collective",
                        "host": "%d usable host cores per rank, %s device waits" % (cores_per_rank, "blocking" if blocking else "spinning")},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -374,7 +375,7 @@ def main_recursive(args):
                          "gpu_ms_per_unit_all_kernels": round(sum(v[1] for v in iso.values()) / max(1, iso_units), 3),
                          "kernel_groups": groups(iso, iso_units, 10),
                          "timed_region_events": {"what": "the same scopes on 1 of the %d concurrent streams during the timed region "
-                                                         "(includes queueing behind the other streams)" % args.threads,
+                                                         "(includes queueing behind the other streams)" % n_threads,
                                                  "units": local_units, "kernel_groups": groups(prof, local_units, 6)}},
             "aggregation_root": ["%016x" % int(x) for x in root[0]],
         }
