@@ -520,24 +520,43 @@ class Aggregator:
         self.levels = []            # RecursiveCircuit per level
         self.commons = [signal_common]
 
-    def aggregate(self, signals, seed=1, rng=None):
+    def aggregate(self, signals, seed=1, rng=None, ctxs=None):
         """signals: list of (flat proof, public inputs), power-of-two many, all of the level-0 circuit and the
-        same Merkle root.  Returns (flat proof, public inputs, common data of the final circuit)."""
+        same Merkle root.  Returns (flat proof, public inputs, common data of the final circuit).
+        ctxs: prover contexts of the same device; the nodes of a level are independent and are proven on them in parallel
+        (the reference's `par_chunks_exact(2)`, recursion.rs:211-227), one host thread per context."""
+        import threading
         n = len(signals)
         assert n >= 2 and n & (n - 1) == 0
+        ctxs = list(ctxs) if ctxs else [self.ctx]
         level = 0
         while len(signals) > 1:
             if level == len(self.levels):
                 self.levels.append(RecursiveCircuit(self.ctx, self.commons[level], k=2, config=self.config,
                                                     public_inputs=aggregate_public_inputs))
             rc = self.levels[level]
-            nxt = []
-            for i in range(0, len(signals), 2):
-                pair = signals[i:i + 2]
-                if rc.data is None:
-                    rc.build(pair, rng)
-                # one native call per node: tape replay + proof (gl355_circuit_prove_tape)
-                nxt.append(rc.native().prove_tape(self.ctx, np.concatenate([np.concatenate([_u64(f), _u64(p)]) for f, p in pair]), seed + i))
+            if rc.data is None:
+                rc.build(signals[0:2], rng)
+            nat = rc.native()
+            n_nodes = len(signals) // 2
+            nxt, errors = [None] * n_nodes, []
+            cur = signals
+
+            def worker(t, cur=cur, nxt=nxt, nat=nat, n_nodes=n_nodes):
+                try:
+                    for j in range(t, n_nodes, len(ctxs)):
+                        pair = cur[2 * j:2 * j + 2]
+                        # one native call per node: tape replay + proof (gl355_circuit_prove_tape)
+                        nxt[j] = nat.prove_tape(ctxs[t], np.concatenate([np.concatenate([_u64(f), _u64(p)]) for f, p in pair]), seed + 2 * j)
+                except Exception as exc:
+                    errors.append(exc)
+            ths = [threading.Thread(target=worker, args=(t,)) for t in range(min(len(ctxs), n_nodes))]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            if errors:
+                raise errors[0]
             if level + 1 == len(self.commons):
                 self.commons.append(rc.data.common())
             signals = nxt

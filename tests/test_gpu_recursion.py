@@ -180,6 +180,10 @@ def test_aggregate_four_signals(gl, ctx, orc):
         sigs.append(s)
     agg = rec.Aggregator(ctx, data.common())
     proof, pis, cd = agg.aggregate(sigs, seed=100, rng=rng)
+    ctx2 = gl.Context(0)                                   # the nodes of a level in parallel on two prover contexts: same proofs
+    proof_p, pis_p, _ = agg.aggregate(sigs, seed=100, ctxs=[ctx, ctx2])
+    assert np.array_equal(proof_p, proof) and np.array_equal(pis_p, pis)
+    ctx2.close()
     outer = plonk.parse_proof(cd, proof)
     outer["public_inputs"] = pis
     pv.verify(orc, cd, outer)
