@@ -53,3 +53,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "gl_oracle" not in src and "oracle_lib" not in src and "libgl_oracle" not in src, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: include/gl355.h must compile as C99 on its own (what a cgo / Rust bindgen / ctypes user sees)"""
+    import subprocess
+    src = tmp_path / "hc.c"
+    src.write_text('#include "gl355.h"\nint main(void) { return (int)sizeof(gl355_prover_data) * 0; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-fsyntax-only", str(src)])
