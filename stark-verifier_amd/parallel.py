@@ -42,3 +42,28 @@ def aggregation_root(ctx, leaves, cap_height=0):
     from .api import MerkleTree
     lv = pad_pow2(np.ascontiguousarray(leaves, dtype=np.uint64))
     return MerkleTree(ctx, lv, cap_height).cap
+
+
+def aggregate_distributed(aggregator, local_signals, dist=None, device=None, ctxs=None, seed=1, rng=None):
+    """recursion.rs:187-247 across GPUs: every rank aggregates its own block of signals into one proof (the lower
+    log2(len(local_signals)) levels of the tree, no communication), the per-rank proofs -- flat words | public inputs, the wire
+    format of SURVEY N3 -- are exchanged with ONE all_gather (about 0.2 MB per rank over RCCL / xGMI), and rank 0 aggregates them
+    through the upper log2(world) levels.  Every rank builds the same level circuits (deterministic builder), so a proof made on
+    one GPU is an input of a circuit loaded on another.  Returns (proof, public inputs, common data) on rank 0, None elsewhere."""
+    import torch
+    proof, pis, cd = aggregator.aggregate(local_signals, seed=seed, rng=rng, ctxs=ctxs)
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    if world == 1:
+        return proof, pis, cd
+    assert world & (world - 1) == 0, "the aggregation tree is binary: a power-of-two number of ranks"
+    local_levels = len(local_signals).bit_length() - 1
+    packed = np.concatenate([np.ascontiguousarray(proof, dtype=np.uint64), np.ascontiguousarray(pis, dtype=np.uint64)])
+    t = torch.from_numpy(packed.view(np.int64)).reshape(1, -1)
+    if device is not None:
+        t = t.to(device)
+    allp = gather_leaves(t, dist).cpu().numpy().view(np.uint64)
+    if dist.get_rank() != 0:
+        return None
+    n_words = proof.size
+    signals = [(allp[r, :n_words].copy(), allp[r, n_words:].copy()) for r in range(world)]
+    return aggregator.aggregate(signals, seed=seed + 1000003, rng=rng, ctxs=ctxs, start_level=local_levels)

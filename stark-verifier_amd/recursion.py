@@ -520,16 +520,19 @@ class Aggregator:
         self.levels = []            # RecursiveCircuit per level
         self.commons = [signal_common]
 
-    def aggregate(self, signals, seed=1, rng=None, ctxs=None):
+    def aggregate(self, signals, seed=1, rng=None, ctxs=None, start_level=0):
         """signals: list of (flat proof, public inputs), power-of-two many, all of the level-0 circuit and the
         same Merkle root.  Returns (flat proof, public inputs, common data of the final circuit).
         ctxs: prover contexts of the same device; the nodes of a level are independent and are proven on them in parallel
-        (the reference's `par_chunks_exact(2)`, recursion.rs:211-227), one host thread per context."""
+        (the reference's `par_chunks_exact(2)`, recursion.rs:211-227), one host thread per context.
+        start_level: the signals are proofs of tree level `start_level` already (continuing a tree whose lower part was aggregated
+        elsewhere, e.g. on other GPUs: parallel.aggregate_distributed)."""
         import threading
         n = len(signals)
         assert n >= 2 and n & (n - 1) == 0
         ctxs = list(ctxs) if ctxs else [self.ctx]
-        level = 0
+        level = start_level
+        assert level < len(self.commons), "the circuit of the incoming proofs is not known yet"
         while len(signals) > 1:
             if level == len(self.levels):
                 self.levels.append(RecursiveCircuit(self.ctx, self.commons[level], k=2, config=self.config,
