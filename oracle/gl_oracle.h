@@ -15,7 +15,14 @@
  *   pinned   : Poseidon permutation / sponge -- reproduces the upstream plonky2 Poseidon-Goldilocks
  *              known-answer vectors (tests/golden/poseidon_kat.json) from the reference's constants
  *              (chip/plonk/gates/poseidon.rs:26-322).
- *   pinned by definition: NTT / LDE / Merkle / DEEP / fold -- the reference holds NO golden vectors
+ *   pinned   : BN254-Poseidon hasher (bn254_oracle.c) -- with the reference's parameters (bn245_poseidon/constants.rs,
+ *              regenerated here by the Poseidon paper's Grain-LFSR procedure) it reproduces the published circomlib known
+ *              answer poseidon([1,2,3,4]) (tests/golden/poseidon_bn254_kat.json).
+ *   pinned   : the whole prove() (gl_prover.c) -- its proofs are accepted by tests/plonk_verifier.py, a restatement of the
+ *              REFERENCE'S OWN in-tree verifier (src/plonky2_verifier/chip/**), tampered proofs are rejected, and one proof's
+ *              SHA-256 is committed (tests/golden/semaphore_proof.json).  This pins the composition of everything below
+ *              (NTT / LDE / Merkle / quotient / DEEP / FRI / PoW / transcript) up to what a verifier can observe.
+ *   pinned by definition: NTT / LDE / Merkle / DEEP / fold in isolation -- the reference holds NO golden vectors
  *              for them (every reference test draws random inputs).  They are
  *              pinned against an independent big-integer model of the mathematical definition the
  *              reference's verifier fixes (omega_N = 7^((p-1)/N), coset 7, bit-reversed leaves,
