@@ -9,11 +9,11 @@ import psutil
 import bench
 gl = importlib.import_module("stark-verifier_amd")
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120
-pr = bench.RecursiveProvers(gl, 0, 12)
+pr = bench.RecursiveProvers(gl, 0, 16)
 proc = psutil.Process()
 t0 = time.time(); units = 0; k = 0
 while time.time() - t0 < seconds:
-    pr.prove_batch(1000 + units, 48); units += 48; k += 1
+    pr.prove_batch(1000 + units, 128); units += 128; k += 1
     if k % 10 == 0:
         free, total = torch.cuda.mem_get_info()
         print("t=%5.0fs units=%6d  %.1f units/s  device used %.2f GB  host RSS %.2f GB" % (
