@@ -60,8 +60,78 @@ GL_HD uint64_t gl_sub(uint64_t a, uint64_t b) {
 
 GL_HD uint64_t gl_neg(uint64_t a) { return gl_sub(0, a); }
 
+// ---- device multiplication / 128-bit reduction ----
+// The compiler cannot be made to use the carry-out of v_mad_u64_u32 (it re-derives carries with 64-bit compares and
+// selects every correction with two v_cndmask: 26 VALU instructions per product).  Two device formulations:
+//   GL_MUL_VARIANT 1: the carry-out / borrow steps in inline asm: 15 VALU instructions, but gfx950 needs two wait states
+//     between a VALU write of an SGPR/VCC and a VALU read of it, the hazard recogniser does not look inside inline asm, and
+//     an asm block cannot be interleaved with its neighbours: 8 s_nop per product.  Best where many waves hide them (Poseidon).
+//   GL_MUL_VARIANT 2: overflow builtins the compiler schedules itself: 19 VALU instructions, no forced s_nop (latency-bound
+//     kernels with many independent products in flight: the NTT butterflies).
+// A translation unit picks with -DGL_MUL_VARIANT / #define before this header; the host always uses the 128-bit C product.
+#ifndef GL_MUL_VARIANT
+#define GL_MUL_VARIANT 1
+#endif
+// two wait states between a VALU write of an SGPR / VCC and the VALU instruction that reads it (carry-in, select mask)
+#ifdef GL_EXPERIMENT_NO_HAZARD_NOP   // timing experiments only: results are undefined without the wait states
+#define GL_HAZARD_NOP ""
+#else
+#define GL_HAZARD_NOP "s_nop 1\n\t"
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#if GL_MUL_VARIANT == 1
+// x = lo - sub32: a borrow is repaid with -EPS (the wrapped x is >= p then, so no second borrow)
+GL_DEV uint64_t gl_dev_sub32(uint32_t lo0, uint32_t lo1, uint32_t sub32) {
+    uint32_t x0, x1, m;
+    asm("v_sub_co_u32_e32 %0, vcc, %3, %5\n\t" GL_HAZARD_NOP ""
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %4, vcc\n\t" GL_HAZARD_NOP ""
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
+        "v_sub_co_u32_e32 %0, vcc, %0, %2\n\t" GL_HAZARD_NOP ""
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
+        : "=&v"(x0), "=&v"(x1), "=&v"(m) : "v"(lo0), "v"(lo1), "v"(sub32) : "vcc");
+    return ((uint64_t)x1 << 32) | x0;
+}
+// x + k * EPS for k < 2^32: one multiply-add, its carry-out repaid with +EPS (the wrapped sum is < (2^32-1)^2, no second carry)
+GL_DEV uint64_t gl_dev_add_mul_eps(uint64_t x, uint32_t k) {
+    uint64_t r, carry;
+    uint32_t m;
+    asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\t" GL_HAZARD_NOP "v_cndmask_b32_e64 %2, 0, -1, %1"
+        : "=v"(r), "=s"(carry), "=v"(m) : "v"(k), "v"(x));
+    return r + (uint64_t)m;
+}
+// (a1*b0 + u) >> 32 as a 33-bit value: the sum can overflow 64 bits once, its carry-out becomes bit 32
+GL_DEV uint64_t gl_dev_mid(uint32_t a1, uint32_t b0, uint64_t u, uint32_t* v0) {
+    uint64_t v, carry;
+    uint32_t ch;
+    asm("v_mad_u64_u32 %0, %1, %3, %4, %5\n\t" GL_HAZARD_NOP "v_cndmask_b32_e64 %2, 0, 1, %1"
+        : "=v"(v), "=s"(carry), "=v"(ch) : "v"(a1), "v"(b0), "v"(u));
+    *v0 = (uint32_t)v;
+    return ((uint64_t)ch << 32) | (v >> 32);
+}
+#else
+GL_DEV uint64_t gl_dev_sub32(uint32_t lo0, uint32_t lo1, uint32_t sub32) {
+    unsigned long x, y;
+    const bool b = __builtin_usubl_overflow(((unsigned long)lo1 << 32) | lo0, (unsigned long)sub32, &x);
+    __builtin_usubl_overflow(x, (unsigned long)(b ? 0xFFFFFFFFu : 0u), &y);
+    return y;
+}
+GL_DEV uint64_t gl_dev_add_mul_eps(uint64_t x, uint32_t k) {
+    const uint64_t r = (uint64_t)k * 0xFFFFFFFFu + x;
+    return r + (r < x ? 0xFFFFFFFFu : 0u);
+}
+GL_DEV uint64_t gl_dev_mid(uint32_t a1, uint32_t b0, uint64_t u, uint32_t* v0) {
+    const uint64_t v = (uint64_t)a1 * b0 + u;
+    *v0 = (uint32_t)v;
+    return ((uint64_t)(v < u ? 1u : 0u) << 32) | (v >> 32);
+}
+#endif
+#endif
+
 // (lo, hi) = hi*2^64 + lo  ->  lo - hi_hi + hi_lo*(2^32 - 1)      [2^64 = 2^32-1, 2^96 = -1 mod p]
 GL_HD uint64_t gl_reduce128(uint64_t lo, uint64_t hi) {
+#if defined(__HIP_DEVICE_COMPILE__) && GL_MUL_VARIANT != 0
+    return gl_dev_add_mul_eps(gl_dev_sub32((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)(hi >> 32)), (uint32_t)hi);
+#else
     uint32_t hi_hi = (uint32_t)(hi >> 32), hi_lo = (uint32_t)hi;
     uint64_t t0 = lo - hi_hi;
     if (GL_UNPRED(lo < hi_hi)) t0 -= GL_EPS;
@@ -69,11 +139,20 @@ GL_HD uint64_t gl_reduce128(uint64_t lo, uint64_t hi) {
     uint64_t r = t0 + t1;
     if (GL_UNPRED(r < t1)) r += GL_EPS;
     return r;
+#endif
 }
 
 GL_HD uint64_t gl_mul(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // four chained 32x32+64 multiply-adds (v_mad_u64_u32); no intermediate can overflow 64 bits
+#if defined(__HIP_DEVICE_COMPILE__) && GL_MUL_VARIANT != 0
+    // four 32x32+64 multiply-adds (v_mad_u64_u32): t and u cannot overflow, the third sum is taken with its carry
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t t = (uint64_t)a0 * b0;
+    const uint64_t u = (uint64_t)a0 * b1 + (t >> 32);
+    uint32_t v0;
+    const uint64_t mid = gl_dev_mid(a1, b0, u, &v0);
+    const uint64_t w = (uint64_t)a1 * b1 + mid;
+    return gl_dev_add_mul_eps(gl_dev_sub32((uint32_t)t, v0, (uint32_t)(w >> 32)), (uint32_t)w);
+#elif defined(__HIP_DEVICE_COMPILE__)
     uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
     uint64_t t = (uint64_t)a0 * b0;
     uint64_t u = (uint64_t)a0 * b1 + (t >> 32);
@@ -96,6 +175,9 @@ GL_HD uint64_t gl_mul_small(uint64_t a, uint32_t c) {
     uint64_t u = (uint64_t)a1 * c + (t >> 32);   // < 2^64
     uint64_t lo = (u << 32) | (uint32_t)t;
     uint32_t hi = (uint32_t)(u >> 32);           // product = hi*2^64 + lo, hi < 2^32
+#if defined(__HIP_DEVICE_COMPILE__) && GL_MUL_VARIANT != 0
+    return gl_dev_add_mul_eps(lo, hi);
+#endif
     uint64_t t1 = ((uint64_t)hi << 32) - hi;
     uint64_t r = lo + t1;
     if (GL_UNPRED(r < t1)) r += GL_EPS;
@@ -112,6 +194,9 @@ GL_HD uint64_t gl_mul_2exp(uint64_t x) {
     } else if constexpr (S <= 32) {
         const uint32_t hi = (uint32_t)(x >> (64 - S));       // < 2^S <= 2^32
         const uint64_t lo = x << S;
+#if defined(__HIP_DEVICE_COMPILE__) && GL_MUL_VARIANT != 0
+        return gl_dev_add_mul_eps(lo, hi);
+#endif
         const uint64_t t = (uint64_t)hi * 0xFFFFFFFFu;        // hi * 2^64 == hi * EPS
         uint64_t r = lo + t;
         if (r < t) r += GL_EPS;

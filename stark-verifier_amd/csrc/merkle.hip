@@ -120,18 +120,15 @@ GL_DEV uint64_t psd_permute_lanes(uint64_t s, int li, uint64_t* ring /* 24 u64 o
     const int me = active ? li : 0;
     // the constant index depends on the lane, so this is a vector load: fetch round r+1's constant while round r
     // computes (a load issued and awaited inside the round costs an L2 round trip per round, ~40 % of the latency)
-    uint64_t rc = PSD_ALL_RC[me];
+    s = gl_add_canonical(s, PSD_ALL_RC[me]);
 #pragma unroll 1
     for (int r = 0; r < 30; r++) {
-        const uint64_t rc_next = PSD_ALL_RC[12 * (r < 29 ? r + 1 : 29) + me];
-        const uint64_t t = gl_add_canonical(s, rc);
-        rc = rc_next;
+        const uint64_t rc_next = PSD_ALL_RC[12 * (r + 1) + me];     // row 30 is zero; consumed by this round's MDS accumulators
         const bool full = r < 4 || r >= 26;
-        const uint64_t sb = psd_sbox(t);
-        s = (full || li == 0) ? sb : t;
+        if (full || li == 0) s = psd_sbox(s);
         if (active) { ring[me] = s; ring[me + 12] = s; }
         GL_WAVE_LDS_SYNC();
-        uint64_t al = 0, ah = 0;
+        uint64_t al = (uint32_t)rc_next, ah = rc_next >> 32;
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const uint64_t x = ring[me + j];
@@ -140,14 +137,7 @@ GL_DEV uint64_t psd_permute_lanes(uint64_t s, int li, uint64_t* ring /* 24 u64 o
             ah += (uint64_t)(uint32_t)(x >> 32) * c;
         }
         GL_WAVE_LDS_SYNC();
-        const uint64_t mid = ah << 32;
-        const uint32_t top = (uint32_t)(ah >> 32);
-        uint64_t r0 = al + mid;
-        const uint64_t carry = r0 < mid ? 1u : 0u;
-        const uint64_t tt = (uint64_t)(top + carry) * GL_EPS;
-        uint64_t r1 = r0 + tt;
-        if (r1 < tt) r1 += GL_EPS;
-        s = r1;
+        s = psd_recombine(al, ah);
     }
     return s;
 }

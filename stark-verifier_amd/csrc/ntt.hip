@@ -23,6 +23,10 @@
 //     layers of the zero-padded size-N transform are trivial); coset c's output is the contiguous
 //     block bitrev(c) of the bit-reversed result, and workgroup id % n_cosets selects the coset so
 //     that with 8 cosets each XCD's L2 keeps exactly one coset's power table.
+// Field products: the compiler-scheduled formulation (gl_field.cuh, GL_MUL_VARIANT 2).  These kernels run 2-4 waves per SIMD
+// between LDS exchanges, so what matters is that the 16 independent butterflies of a thread interleave freely; the
+// inline-asm formulation has fewer instructions but serialises each product (measured: 4-7 % slower single-pass tiles).
+#define GL_MUL_VARIANT 2
 #include "gl355_internal.h"
 
 namespace gl355 {
@@ -192,7 +196,7 @@ struct PassArgs {
 
 // Row pass: each row = 2^LOG_T contiguous elements; a tile packs 2^(LT-LOG_T) rows.
 template <int LT, int LOG_T, bool INV>
-__global__ void __launch_bounds__(1 << (LT - 4)) ntt_rows_kernel(PassArgs a) {
+__global__ void __launch_bounds__(1 << (LT - 4)) __attribute__((amdgpu_waves_per_eu(LT == 12 ? 3 : 1))) ntt_rows_kernel(PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     constexpr int NT = 1 << (LT - 4);
     constexpr int RPT = 1 << (LT - LOG_T);  // rows per tile
@@ -243,7 +247,7 @@ __global__ void __launch_bounds__(1 << (LT - 4)) ntt_rows_kernel(PassArgs a) {
 // Column pass: transform over the row index of an [2^LOG_T][N2] matrix (N2 = 2^log_rows... here
 // a.log_rows holds log2(N2)); a tile is all 2^LOG_T rows x TC = 2^(12-LOG_T) adjacent columns.
 template <int LOG_T, bool INV>
-__global__ void __launch_bounds__(256) ntt_cols_kernel(PassArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) ntt_cols_kernel(PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     constexpr int LT = 12, NT = 256;
     constexpr int LOG_TC = LT - LOG_T, TC = 1 << LOG_TC;

@@ -93,11 +93,14 @@ GL_DEV void gate_poseidon(const QuotArgs& a, uint64_t t, GateAcc& g) {
     }
 #pragma unroll
     for (int i = 8; i < 12; i++) s[i] = WIRE(i);
+    // every MDS layer also adds the NEXT round's constants (psd_mds; row 30 of the table is zero), so s is "state + constants",
+    // the quantity the S-box-input wires are constrained to, whenever a round starts
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add_canonical(s[i], PSD_ALL_RC[i]);
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) {
-            s[i] = gl_add_canonical(s[i], PSD_FULL_RC[12 * r + i]);
             if (r != 0) {
                 const uint64_t sin = WIRE(29 + 12 * (r - 1) + i);
                 g.push(gl_sub(s[i], sin));
@@ -105,30 +108,27 @@ GL_DEV void gate_poseidon(const QuotArgs& a, uint64_t t, GateAcc& g) {
             }
             s[i] = psd_sbox(s[i]);
         }
-        psd_mds(s);
+        psd_mds(s, &PSD_ALL_RC[12 * (r + 1)]);
     }
     // partial rounds in the dense form: the S-box input of round r is s[0] + RC[4+r][0] in either form, so the
     // 22 constraints (and the state handed to the closing full rounds) are the same polynomials in the wires
-    // as in the reference's sparse formulation (gates/poseidon.rs:652-673), at ~15 % fewer VALU cycles
+    // as in the reference's sparse formulation (gates/poseidon.rs:652-673), at fewer VALU cycles
 #pragma unroll 1
     for (int r = 0; r < 22; r++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl_add_canonical(s[i], PSD_ALL_RC[12 * (4 + r) + i]);
         const uint64_t sin = WIRE(65 + r);
         g.push(gl_sub(s[0], sin));
         s[0] = psd_sbox(sin);
-        psd_mds(s);
+        psd_mds(s, &PSD_ALL_RC[12 * (5 + r)]);
     }
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) {
-            s[i] = gl_add_canonical(s[i], PSD_FULL_RC[48 + 12 * r + i]);
             const uint64_t sin = WIRE(87 + 12 * r + i);
             g.push(gl_sub(s[i], sin));
             s[i] = psd_sbox(sin);
         }
-        psd_mds(s);
+        psd_mds(s, &PSD_ALL_RC[12 * (27 + r)]);
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) g.push(gl_sub(s[i], WIRE(12 + i)));

@@ -165,13 +165,13 @@ def emit(rc, tb):
     with open(os.path.join(ROOT, "oracle", "poseidon_rc.h"), "w") as f:
         f.write(oracle)
     full = [x for r in list(range(HALF_F)) + list(range(HALF_F + R_P, 2 * HALF_F + R_P)) for x in rc[r]]
-    prod = hdr + ("// Layout: PSD_ALL_RC[30][12] (all rounds, naive form), PSD_FULL_RC[8][12] (first 4 = opening full rounds, last 4 = closing),\n"
+    prod = hdr + ("// Layout: PSD_ALL_RC[31][12] (all rounds, naive form, then a zero row), PSD_FULL_RC[8][12] (first 4 = opening full rounds, last 4 = closing),\n"
                   "// PSD_PART_FIRST[12], PSD_PART_INIT[11][11] (row r-1, col c-1: out[c] += M*in[r]),\n"
                   "// PSD_PART_RC[22] (entry 21 unused = 0), PSD_PART_VS[22][11], PSD_PART_WHAT[22][11].\n"
                   "#pragma once\n#include <stdint.h>\n#ifndef PSD_TABLE_QUAL\n#define PSD_TABLE_QUAL static const\n#endif\n")
     q = "PSD_TABLE_QUAL"
     prod += c_array("PSD_FULL_RC", full, qual=q) + "\n"
-    prod += c_array("PSD_ALL_RC", flat_rc, qual=q) + "\n"
+    prod += c_array("PSD_ALL_RC", flat_rc + [0] * 12, qual=q) + "\n"       # row 30 = zeros: "the constants of the round after the last"
     prod += c_array("PSD_PART_FIRST", tb["first"], qual=q) + "\n"
     prod += c_array("PSD_PART_INIT", [x for row in tb["init"] for x in row], qual=q) + "\n"
     prod += c_array("PSD_PART_RC", tb["post"], qual=q) + "\n"
