@@ -24,6 +24,11 @@ import os
 import sys
 import time
 
+# 16 prover contexts = 16 HIP streams: give each its own hardware queue (the HIP runtime's default is 4, streams then share
+# queues and a latency-bound Merkle-top kernel on one stream holds up the other streams behind it; measured 164 -> 172 proofs/s).
+# Must be set before the HIP runtime initialises, i.e. before torch / libgl355 are loaded.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -133,6 +138,9 @@ class RecursiveProvers:
         if blocking_sync:
             for c in self.sets:
                 c.set_option(2, 1)                                   # GL355_OPT_BLOCKING_SYNC
+        if os.environ.get("GL355_BENCH_LANES_LOG"):                  # experiments: GL355_OPT_MERKLE_LANES_LOG
+            for c in self.sets:
+                c.set_option(1, int(os.environ["GL355_BENCH_LANES_LOG"]))
         c0 = self.sets[0]
         self.sks = rand_field(rng, (1 << log_members, 4))
         keys = c0.hash_no_pad(np.concatenate([self.sks, np.zeros_like(self.sks)], axis=1))
@@ -261,7 +269,7 @@ def lde_figure(gl, device, steps=8):
         step()
     ctx.sync()
     dt = time.perf_counter() - t0
-    prof = ctx.profile_read()
+    prof = {k: v for k, v in ctx.profile_read().items() if not k.startswith("host:")}
     ctx.profile_enable(False)
     alg = 8.0 * BATCH * (n + N)
     kern_ms = sum(v[1] / max(1, v[0]) for k, v in prof.items() if k.startswith("ntt_"))
@@ -304,6 +312,9 @@ def main_recursive(args):
     cores_per_rank = max(1, host_cores() // max(1, world))
     n_threads = max(2, min(args.threads, cores_per_rank))
     blocking = cores_per_rank < 2
+    if os.environ.get("GL355_BENCH_CONTEXTS"):        # experiments: more contexts than cores, optionally on blocking waits
+        n_threads = int(os.environ["GL355_BENCH_CONTEXTS"])
+        blocking = os.environ.get("GL355_BENCH_BLOCKING", "0") == "1"
     pr = RecursiveProvers(gl, local_rank, n_threads, args.log_members, blocking_sync=blocking)
     per = args.proofs_per_step
     total = per * world
@@ -317,6 +328,8 @@ def main_recursive(args):
         torch.cuda.synchronize()
     pr.profile(True)
     barrier()
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     root = None
     for step in range(args.steps):
@@ -327,6 +340,8 @@ def main_recursive(args):
             root = par.aggregation_root(pr.sets[0], allv.cpu().numpy().view(np.uint64))
     barrier()
     elapsed = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)   # rank 0's process, spinning waits included
     prof, local_units = pr.profile_read()
     pr.profile(False)
     if dist is not None:
@@ -343,9 +358,22 @@ def main_recursive(args):
         pr.sets = all_sets[:1]
         pr.profile(True)
         pr.prove_batch(9000, 8)
+        t_iso = time.perf_counter()
+        pr.prove_batch(9100, 8)
+        t_iso = time.perf_counter() - t_iso
         iso, iso_units = pr.profile_read()
+        iso_units //= 2
+        iso = {k: (v[0] // 2, v[1] / 2, v[2] // 2) for k, v in iso.items()}      # two 8-unit batches, the second one timed on the host
         pr.profile(False)
         pr.sets = all_sets
+        # host/device split of one context: wall time in Ctx::wait() ("host:stream_wait" pseudo-scope) against the wall time per unit
+        iso_wait = iso.pop("host:stream_wait", (0, 0.0, 0))
+        tr_wait = prof.pop("host:stream_wait", (0, 0.0, 0))
+        host_split = {"what": "wall ms per unit of one prover context's host thread: waiting for its stream (Ctx::wait) vs everything else "
+                              "(witness generation, tape replay, transcript, copies, launches)",
+                      "isolated_one_context": {"wall": round(1e3 * t_iso / 8, 2), "waiting": round(iso_wait[1] / 8, 2)},
+                      "timed_region_%d_contexts" % n_threads: {"wall": round(1e3 * elapsed * 1 / max(1, local_units), 2) if local_units else None,
+                                                                "waiting": round(tr_wait[1] / max(1, local_units), 2)}}
         dname, (dcnt, dms, dbytes) = max(iso.items(), key=lambda kv: kv[1][1]) if iso else ("none", (1, 0.0, 0))
         ach = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
 
@@ -364,7 +392,9 @@ def main_recursive(args):
                                    "prover contexts per GPU; all_gather of (nullifier|topic) + Poseidon aggregation root per step"
                                    % (args.log_members, pr.rc.data.degree_bits, per, n_threads),
                        "parallelism": "independent proofs sharded over ranks, no data-path collective",
-                       "host": "%d usable host cores per rank, %s device waits" % (cores_per_rank, "blocking" if blocking else "spinning")},
+                       "host": "%d usable host cores per rank, %s device waits" % (cores_per_rank, "blocking" if blocking else "spinning"),
+                       "host_cpu_ms_per_unit": round(1e3 * host_cpu_s / max(1, (hi - lo) * args.steps), 2),
+                       "host_split": host_split},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": dname, "launches_per_unit": round(dcnt / max(1, iso_units), 1),
                          "avg_launch_ms": round(dms / max(1, dcnt), 4), "algorithmic_bytes_per_launch": round(dbytes / max(1, dcnt)),
@@ -505,7 +535,7 @@ def main_lde(args):
             root = [int(x) & ((1 << 64) - 1) for x in capbuf.cpu().tolist()]
     barrier()
     t1 = time.perf_counter()
-    prof = ctx.profile_read()
+    prof = {k: v for k, v in ctx.profile_read().items() if not k.startswith("host:")}
     ctx.profile_enable(False)
 
     elapsed = t1 - t0
@@ -586,6 +616,8 @@ def main_semaphore(args):
             dist.barrier()
         torch.cuda.synchronize()
     barrier()
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     root = None
     for step in range(args.steps):

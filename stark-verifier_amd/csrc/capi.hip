@@ -99,8 +99,8 @@ int32_t oracle_open_batch_on(Ctx* ctx, const gl355_oracle* o, const uint64_t* in
     uint64_t* d_sib = d_leaf + n_leaf;
     GL355_HIP(ctx, hipMemcpyAsync(d_idx, indices, (uint64_t)n_idx * 8, hipMemcpyHostToDevice, ctx->stream));
     GL355_TRY(open_batch_dev(ctx, o->lde, N, o->leaf_len, o->digests, bits, o->cap_height, d_idx, n_idx, d_leaf, d_sib));
-    GL355_HIP(ctx, hipMemcpyAsync(leaves, d_leaf, n_leaf * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (n_sib) GL355_HIP(ctx, hipMemcpyAsync(siblings, d_sib, n_sib * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GL355_HIP(ctx, ctx->d2h(leaves, d_leaf, n_leaf * 8));
+    if (n_sib) GL355_HIP(ctx, ctx->d2h(siblings, d_sib, n_sib * 8));
     GL355_HIP(ctx, ctx->wait());
     return GL355_OK;
 }
@@ -290,7 +290,7 @@ static int32_t prove_from(Ctx* ctx, const uint64_t* digests_dev, uint64_t n_leav
         const uint64_t parity = pair_index & 1;
         pair_index >>= 1;
         const uint64_t slot = (pair_index << (i + 1)) + (1ull << i) - 1;
-        GL355_HIP(ctx, hipMemcpyAsync(siblings_host + 4 * i, tree + (2 * slot + (1 - parity)) * 4, 32, hipMemcpyDeviceToHost, ctx->stream));
+        GL355_HIP(ctx, ctx->d2h(siblings_host + 4 * i, tree + (2 * slot + (1 - parity)) * 4, 32));
     }
     GL355_HIP(ctx, ctx->wait());
     return GL355_OK;

@@ -1,5 +1,6 @@
 // Context, stream, scratch allocator, host/device buffer staging and cached tables of libgl355.
 #include "gl355_internal.h"
+#include <chrono>
 
 namespace gl355 {
 
@@ -14,6 +15,23 @@ int32_t Ctx::fail_hip(hipError_t e, const char* expr, const char* file, int line
 }
 
 hipError_t Ctx::wait() {
+    if (prof_on) {      // host-side accounting: wall time this context's thread spends waiting for its stream
+        const auto t0 = std::chrono::steady_clock::now();
+        const hipError_t e = wait_impl();
+        wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        wait_calls++;
+        return e;
+    }
+    return wait_impl();
+}
+hipError_t Ctx::d2h(void* dst, const void* src, size_t bytes) {
+    if (!prof_on) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+    wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    return e;
+}
+hipError_t Ctx::wait_impl() {
     if (!blocking_sync) return hipStreamSynchronize(stream);
     if (!sync_ev) {
         hipError_t e = hipEventCreateWithFlags(&sync_ev, hipEventBlockingSync | hipEventDisableTiming);
@@ -112,7 +130,7 @@ int32_t Staged::open(const void* ptr, size_t nbytes, int dir) {
 }
 int32_t Staged::finish() {
     if (is_host && copy_back) {
-        GL355_HIP(ctx, hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        GL355_HIP(ctx, ctx->d2h(user, dev, bytes));
     }
     if (is_host) GL355_HIP(ctx, ctx->wait());
     return GL355_OK;
@@ -245,7 +263,7 @@ int32_t gl355_memcpy_h2d(gl355_ctx* ctx, void* dst, const void* src, size_t byte
 }
 int32_t gl355_memcpy_d2h(gl355_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return GL355_E_INVALID_ARG;
-    GL355_HIP(&ctx->c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->c.stream));
+    GL355_HIP(&ctx->c, ctx->c.d2h(dst, src, bytes));
     GL355_HIP(&ctx->c, ctx->c.wait());
     return GL355_OK;
 }
@@ -283,6 +301,10 @@ int32_t gl355_profile_read(gl355_ctx* ctx, char* buf, size_t buf_len) {
     }
     c.prof.clear();
     std::string out;
+    if (c.wait_calls) {     // pseudo-entry: calls and total wall milliseconds of Ctx::wait() while profiling was on
+        out += "host:stream_wait " + std::to_string(c.wait_calls) + " " + std::to_string(c.wait_ns * 1e-6) + " 0\n";
+        c.wait_calls = 0; c.wait_ns = 0;
+    }
     for (auto& kv : agg) out += kv.first + " " + std::to_string(kv.second.n) + " " + std::to_string(kv.second.ms) + " " + std::to_string(kv.second.bytes) + "\n";
     if (out.size() + 1 > buf_len) out.resize(buf_len - 1);
     memcpy(buf, out.c_str(), out.size() + 1);

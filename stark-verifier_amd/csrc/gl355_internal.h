@@ -72,6 +72,10 @@ struct Ctx {
     bool blocking_sync = false;
     hipEvent_t sync_ev = nullptr;
     hipError_t wait();
+    hipError_t wait_impl();
+    // device -> host copy on the stream; into pageable memory the call itself waits for the stream, so it is accounted like wait()
+    hipError_t d2h(void* dst, const void* src, size_t bytes);
+    uint64_t wait_ns = 0, wait_calls = 0;   // accumulated by wait() while prof_on
     uint32_t merkle_lanes_log = 14;   // Merkle levels with <= 2^this nodes use the 16-lanes-per-node kernel (GL355_OPT_MERKLE_LANES_LOG)
     bool prof_on = false;
     std::vector<ProfRec> prof;

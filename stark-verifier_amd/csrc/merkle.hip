@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256) poseidon_permute_kernel(uint64_t* states,
 
 
 // one lane = one leaf: overwrite-mode sponge over ceil(len/8) chunks
-__global__ void __launch_bounds__(256) hash_leaves_kernel(LeafArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) hash_leaves_kernel(LeafArgs a) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= a.n_leaves) return;
     uint64_t s[12];
@@ -367,7 +367,7 @@ int32_t pow_grind_dev(Ctx* ctx, const uint64_t state[12], uint32_t pos, uint32_t
                            bits, base, d_best);
         GL355_HIP(ctx, hipGetLastError());
         unsigned long long best;
-        GL355_HIP(ctx, hipMemcpyAsync(&best, d_best, sizeof best, hipMemcpyDeviceToHost, ctx->stream));
+        GL355_HIP(ctx, ctx->d2h(&best, d_best, sizeof best));
         GL355_HIP(ctx, ctx->wait());
         if (best != ~0ull) { *witness_host = best; return GL355_OK; }
         base += per_launch;

@@ -255,7 +255,7 @@ int32_t bn254_pow_grind_dev(Ctx* ctx, const uint64_t state[12], uint32_t pos, ui
                            d_best);
         GL355_HIP(ctx, hipGetLastError());
         unsigned long long best;
-        GL355_HIP(ctx, hipMemcpyAsync(&best, d_best, sizeof best, hipMemcpyDeviceToHost, ctx->stream));
+        GL355_HIP(ctx, ctx->d2h(&best, d_best, sizeof best));
         GL355_HIP(ctx, ctx->wait());
         if (best != ~0ull) { *witness_host = best; return GL355_OK; }
         base += per_launch;

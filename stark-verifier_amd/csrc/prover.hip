@@ -61,7 +61,7 @@ extern "C" int32_t gl355_fri_prove(gl355_ctx* h, const uint64_t* final_coeffs, u
         uint64_t* dg = tree_buf + dig_off[l];
         GL355_TRY(fri_layer_leaves_dev(ctx, values, len, lv));
         GL355_TRY(merkle_build_any(ctx, ch->hasher, lv, len / 2, 4, false, 0, cap_height, dg, d_cap));
-        GL355_HIP(ctx, hipMemcpyAsync(cap_host.data(), d_cap, n_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
+        GL355_HIP(ctx, ctx->d2h(cap_host.data(), d_cap, n_cap * 32));
         GL355_HIP(ctx, ctx->wait());
         memcpy(caps_out + (uint64_t)l * n_cap * 4, cap_host.data(), n_cap * 32);
         gl355_challenger_observe(ch, cap_host.data(), n_cap * 4);
@@ -78,7 +78,7 @@ extern "C" int32_t gl355_fri_prove(gl355_ctx* h, const uint64_t* final_coeffs, u
     }
     // final polynomial: the upper (1 - 2^-rate_bits) of the coefficients is zero by construction
     const uint64_t final_len = len >> rate_bits;
-    GL355_HIP(ctx, hipMemcpyAsync(final_poly_out, coeffs, final_len * 16, hipMemcpyDeviceToHost, ctx->stream));
+    GL355_HIP(ctx, ctx->d2h(final_poly_out, coeffs, final_len * 16));
     GL355_HIP(ctx, ctx->wait());
     gl355_challenger_observe(ch, final_poly_out, final_len * 2);
     // proof of work
@@ -106,8 +106,8 @@ extern "C" int32_t gl355_fri_prove(gl355_ctx* h, const uint64_t* final_coeffs, u
         GL355_TRY(open_batch_ex_dev(ctx, tree_buf + leaf_off[l], 0, 4, tree_buf + dig_off[l], lde_bits - 1 - l, cap_height, d_idx,
                                     l + 1, num_queries, d_ev + (uint64_t)l * 4, (uint64_t)n_layers * 4, d_sib + sib_off[l], sib_total));
     }
-    GL355_HIP(ctx, hipMemcpyAsync(step_evals, d_ev, (uint64_t)num_queries * n_layers * 32, hipMemcpyDeviceToHost, ctx->stream));
-    if (sib_total) GL355_HIP(ctx, hipMemcpyAsync(step_siblings, d_sib, (uint64_t)num_queries * sib_total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GL355_HIP(ctx, ctx->d2h(step_evals, d_ev, (uint64_t)num_queries * n_layers * 32));
+    if (sib_total) GL355_HIP(ctx, ctx->d2h(step_siblings, d_sib, (uint64_t)num_queries * sib_total * 8));
     GL355_HIP(ctx, ctx->wait());
     return GL355_OK;
 }
@@ -140,7 +140,7 @@ struct OracleGuard {
 
 static int32_t observe_cap(Ctx* ctx, const gl355_oracle* o, gl355_challenger* ch, uint64_t* dst) {
     const uint64_t words = 4ull << o->cap_height;
-    GL355_HIP(ctx, hipMemcpyAsync(dst, o->cap, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GL355_HIP(ctx, ctx->d2h(dst, o->cap, words * 8));
     GL355_HIP(ctx, ctx->wait());
     gl355_challenger_observe(ch, dst, words);
     return GL355_OK;
@@ -358,7 +358,7 @@ static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, c
     GL355_TRY(eval_polys_ext_dev(ctx, all_ptrs.data(), (uint32_t)n_open, c.degree_bits, zeta, evb.as<uint64_t>()));
     GL355_TRY(eval_polys_ext_dev(ctx, z_ptrs.data(), nch, c.degree_bits, zeta_next, evb.as<uint64_t>() + 2 * n_open));
     uint64_t* p_open = out; out += 2 * (n_open + nch);
-    GL355_HIP(ctx, hipMemcpyAsync(p_open, evb.as<uint64_t>(), (n_open + nch) * 16, hipMemcpyDeviceToHost, ctx->stream));
+    GL355_HIP(ctx, ctx->d2h(p_open, evb.as<uint64_t>(), (n_open + nch) * 16));
     GL355_HIP(ctx, ctx->wait());
     gl355_challenger_observe(&ch, p_open, 2 * (n_open + nch));
     uint64_t fri_alpha[2];

@@ -30,7 +30,7 @@ def timed(ctx, fn, reps=5, warm=1):
     for _ in range(reps):
         fn()
     ms = ctx.timer_stop() / reps
-    prof = {k: v[1] / reps for k, v in ctx.profile_read().items()}
+    prof = {k: v[1] / reps for k, v in ctx.profile_read().items() if not k.startswith("host:")}
     ctx.profile_enable(False)
     return ms, prof
 

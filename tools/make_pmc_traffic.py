@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""profiles/<round>_pmc_traffic.json from the per-kernel summaries tools/prof_round1c.sh leaves in gpurun_out/<dir>/:
+HBM-side bytes per launch (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as reported; both in KB)
+and cycles per VALU instruction per SIMD (SQ_INSTS_VALU / 1024 SIMDs against SQ_BUSY_CYCLES / 32 shader engines).
+usage: make_pmc_traffic.py gpurun_out/prof_r01c profiles/r01_pmc_traffic.json"""
+import json
+import re
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+
+
+def read(name):
+    out = {}
+    for line in open("%s/%s_summary.txt" % (src, name)):
+        kern, rest = line.rsplit(": ", 1)
+        vals = {m.group(1): (float(m.group(2)), int(m.group(3))) for m in re.finditer(r"(\w+)=([\d.e+]+) \(n=(\d+)\)", rest)}
+        out[kern] = vals
+    return out
+
+
+def short(kern):
+    k = re.sub(r"^void ", "", kern)
+    k = re.sub(r"^gl355::", "", k)
+    return re.sub(r"\(.*$", "", k)
+
+
+fetch, write, sq = read("pmc_FETCH_SIZE"), read("pmc_WRITE_SIZE"), read("pmc_sq")
+kernels = {}
+for kern, v in fetch.items():
+    f, n = v["FETCH_SIZE"]
+    w = write.get(kern, {}).get("WRITE_SIZE", (0.0, 0))[0]
+    e = {"fetch_kb_reported": f, "write_kb_reported": w, "launches": n, "bytes_per_launch_corrected": int((2 * f + w) * 1024)}
+    s = sq.get(kern)
+    if s and "SQ_INSTS_VALU" in s and s["SQ_BUSY_CYCLES"][0] > 0:
+        e["valu_insts_per_launch"] = s["SQ_INSTS_VALU"][0]
+        e["busy_cycles_per_se"] = s["SQ_BUSY_CYCLES"][0] / 32
+        e["clk_per_valu_inst_per_simd"] = round((s["SQ_BUSY_CYCLES"][0] / 32) / (s["SQ_INSTS_VALU"][0] / 1024), 2) if s["SQ_INSTS_VALU"][0] else None
+    kernels[short(kern)] = e
+doc = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over `python bench.py --steps 1 --warmup 0 --proofs-per-step 12 "
+                  "--threads 1 --no-cpu-baseline` (tools/prof_round1c.sh, tools/make_pmc_traffic.py), per-dispatch averages in KB; FETCH_SIZE doubled "
+                  "per the gfx950 note of MI355X_MICROARCH.md (HBM section); WRITE_SIZE taken as reported",
+       "_valu_note": "SQ_INSTS_VALU (wave instructions, whole chip) / 1024 SIMDs vs SQ_BUSY_CYCLES / 32 shader engines, same rocprofv3 --pmc run: "
+                     "cycles per VALU instruction per SIMD; the issue floor measured by tools/ubench is ~4.2-4.4",
+       "kernels": kernels}
+json.dump(doc, open(dst, "w"), indent=1)
+print("wrote", dst, len(kernels), "kernels")
