@@ -236,10 +236,10 @@ def cpu_baseline_recursive(pr, units=1):
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (bench.py cannot collect PMC counters
     itself); None when no pass covers the kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
     try:
         d = json.load(open(path))
-        return d["kernels"][kernel]["bytes_per_launch_corrected"], "profiles/r01_pmc_traffic.json: " + d["_source"]
+        return d["kernels"][kernel]["bytes_per_launch_corrected"], "profiles/r01c_pmc_traffic.json: " + d["_source"]
     except Exception:
         return None, None
 
@@ -294,6 +294,14 @@ def main_recursive(args):
     # rehearsal of the N > 1 path on a box with fewer GPUs than ranks: GL355_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # uses gloo for the gather (NCCL refuses two ranks on one device); never set by the driver
     rehearsal = os.environ.get("GL355_BENCH_ONE_DEVICE") == "1"
+    sleeping_waits = os.environ.get("GL355_BENCH_SLEEP_WAITS", "0") == "1"
+    if sleeping_waits:
+        # hipDeviceScheduleBlockingSync: every device wait of this process (stream/event synchronise, pageable copies) sleeps on
+        # the completion interrupt instead of spinning; has to be set before the device's HIP context exists
+        hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        dev_index = 0 if rehearsal else local_rank
+        if hip.hipSetDevice(dev_index) != 0 or hip.hipSetDeviceFlags(0x4) != 0:
+            raise SystemExit("hipSetDeviceFlags(hipDeviceScheduleBlockingSync) failed")
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)

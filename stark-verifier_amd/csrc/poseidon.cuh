@@ -91,11 +91,14 @@ GL_DEV void psd_permute(uint64_t (&s)[12]) {
     for (int i = 0; i < 12; i++) s[i] = gl_add_canonical(s[i], PSD_ALL_RC[i]);
     // two rounds per iteration (4 + 22 + 4: a pair is never mixed), so the state ping-pongs between two register sets
     // instead of being copied back at the loop edge
+#ifndef PSD_ROUNDS_PER_ITER
+#define PSD_ROUNDS_PER_ITER 2
+#endif
 #pragma unroll 1
-    for (int r = 0; r < 30; r += 2) {
+    for (int r = 0; r < 30; r += PSD_ROUNDS_PER_ITER) {
         const bool full = r < 4 || r >= 26;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < PSD_ROUNDS_PER_ITER; h++) {
             if (full) {
 #pragma unroll
                 for (int i = 0; i < 12; i++) s[i] = psd_sbox(s[i]);
