@@ -294,7 +294,12 @@ def main_recursive(args):
     # rehearsal of the N > 1 path on a box with fewer GPUs than ranks: GL355_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # uses gloo for the gather (NCCL refuses two ranks on one device); never set by the driver
     rehearsal = os.environ.get("GL355_BENCH_ONE_DEVICE") == "1"
-    sleeping_waits = os.environ.get("GL355_BENCH_SLEEP_WAITS", "0") == "1"
+    # one prover context = one HIP stream + one host thread.  With a core per context the threads spin in hipStreamSynchronize
+    # (lowest latency); with fewer usable cores per rank (cgroup quota / ranks) than contexts every device wait sleeps instead,
+    # so the contexts still keep the GPU fed (host work is ~10-12 ms of ~90 ms per unit and context)
+    cores_per_rank = max(1, host_cores() // max(1, world))
+    n_threads = max(1, int(os.environ.get("GL355_BENCH_CONTEXTS", args.threads)))
+    sleeping_waits = os.environ.get("GL355_BENCH_SLEEP_WAITS", "1" if cores_per_rank < n_threads else "0") == "1"
     if sleeping_waits:
         # hipDeviceScheduleBlockingSync: every device wait of this process (stream/event synchronise, pageable copies) sleeps on
         # the completion interrupt instead of spinning; has to be set before the device's HIP context exists
@@ -315,15 +320,8 @@ def main_recursive(args):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     gl = importlib.import_module("stark-verifier_amd")
     par = importlib.import_module("stark-verifier_amd.parallel")
-    # one prover context = one host thread that spins in hipStreamSynchronize (lowest latency): never more of them than this rank
-    # has usable host cores (cgroup quota / ranks); with a single core left, wait on blocking events instead
-    cores_per_rank = max(1, host_cores() // max(1, world))
-    n_threads = max(2, min(args.threads, cores_per_rank))
-    blocking = cores_per_rank < 2
-    if os.environ.get("GL355_BENCH_CONTEXTS"):        # experiments: more contexts than cores, optionally on blocking waits
-        n_threads = int(os.environ["GL355_BENCH_CONTEXTS"])
-        blocking = os.environ.get("GL355_BENCH_BLOCKING", "0") == "1"
-    pr = RecursiveProvers(gl, local_rank, n_threads, args.log_members, blocking_sync=blocking)
+    blocking = sleeping_waits
+    pr = RecursiveProvers(gl, local_rank, n_threads, args.log_members)
     per = args.proofs_per_step
     total = per * world
     lo, hi = par.shard_range(total, rank, world)
@@ -400,7 +398,7 @@ def main_recursive(args):
                                    "prover contexts per GPU; all_gather of (nullifier|topic) + Poseidon aggregation root per step"
                                    % (args.log_members, pr.rc.data.degree_bits, per, n_threads),
                        "parallelism": "independent proofs sharded over ranks, no data-path collective",
-                       "host": "%d usable host cores per rank, %s device waits" % (cores_per_rank, "blocking" if blocking else "spinning"),
+                       "host": "%d usable host cores per rank, %s device waits" % (cores_per_rank, "sleeping (hipDeviceScheduleBlockingSync)" if blocking else "spinning"),
                        "host_cpu_ms_per_unit": round(1e3 * host_cpu_s / max(1, (hi - lo) * args.steps), 2),
                        "host_split": host_split},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
