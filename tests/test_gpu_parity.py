@@ -45,6 +45,23 @@ def test_field_ops(ctx, orc):
     eq(got, want)
 
 
+def test_field_mul_structured_operands(ctx):
+    """The device product takes its carries from the hardware (v_mad_u64_u32 carry-out, v_sub_co borrow; gl_field.cuh): the
+    borrow of `lo - hi_hi` needs a 128-bit product whose low 64 bits are < 2^32 and fires for ~2^-32 of random operands, so
+    it is driven here by structured ones -- all pairs of 2^k, 2^k - 1, 2^k + 1 and the edges -- against Python integers."""
+    vals = {0, 1, P - 1, P, P + 1, (1 << 64) - 1, 0xFFFFFFFF00000000, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFE00000001}
+    for k in range(64):
+        vals.update({(1 << k) % (1 << 64), ((1 << k) - 1) % (1 << 64), ((1 << k) + 1) % (1 << 64), ((1 << 64) - (1 << k)) % (1 << 64)})
+    vals = np.array(sorted(vals), dtype=np.uint64)
+    a, b = np.repeat(vals, len(vals)), np.tile(vals, len(vals))
+    borrow_cases = sum(1 for x, y in zip(a.tolist(), b.tolist()) if ((x * y) & ((1 << 64) - 1)) < ((x * y) >> 96))
+    assert borrow_cases > 1000          # the rare path is exercised
+    for op, f in ((2, lambda x, y: x * y % P), (0, lambda x, y: (x + y) % P), (1, lambda x, y: (x - y) % P)):
+        got = ctx.field_batch(op, a, b)
+        want = np.array([f(x, y) for x, y in zip(a.tolist(), b.tolist())], dtype=np.uint64)
+        eq(got, want)
+
+
 # ---- a2 ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("log_n", list(range(0, 15)) + [15, 16, 17, 18, 20])
 def test_ntt_forward_inverse(ctx, orc, log_n):
