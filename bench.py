@@ -24,11 +24,6 @@ import os
 import sys
 import time
 
-# 16 prover contexts = 16 HIP streams: give each its own hardware queue (the HIP runtime's default is 4, streams then share
-# queues and a latency-bound Merkle-top kernel on one stream holds up the other streams behind it; measured 164 -> 172 proofs/s).
-# Must be set before the HIP runtime initialises, i.e. before torch / libgl355 are loaded.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -300,13 +295,11 @@ def main_recursive(args):
     cores_per_rank = max(1, host_cores() // max(1, world))
     n_threads = max(1, int(os.environ.get("GL355_BENCH_CONTEXTS", args.threads)))
     sleeping_waits = os.environ.get("GL355_BENCH_SLEEP_WAITS", "1" if cores_per_rank < n_threads else "0") == "1"
-    if sleeping_waits:
-        # hipDeviceScheduleBlockingSync: every device wait of this process (stream/event synchronise, pageable copies) sleeps on
-        # the completion interrupt instead of spinning; has to be set before the device's HIP context exists
-        hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
-        dev_index = 0 if rehearsal else local_rank
-        if hip.hipSetDevice(dev_index) != 0 or hip.hipSetDeviceFlags(0x4) != 0:
-            raise SystemExit("hipSetDeviceFlags(hipDeviceScheduleBlockingSync) failed")
+    # gl355_runtime_config: hardware queues per context (unless GPU_MAX_HW_QUEUES is already set) and, if asked, sleeping waits
+    # (hipDeviceScheduleBlockingSync); it has to run before the device's HIP context exists, i.e. before torch touches the GPU
+    lib = importlib.import_module("stark-verifier_amd._lib").load(init_torch=False)
+    if lib.gl355_runtime_config(0 if rehearsal else local_rank, n_threads, 1 if sleeping_waits else 0) != 0:
+        raise SystemExit("gl355_runtime_config failed (HIP runtime already initialised?)")
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -459,9 +452,15 @@ def main():
                          "lde = configs[1]; semaphore = the signals alone")
     ap.add_argument("--proofs-per-step", type=int, default=128,
                     help="units (recursive) / proofs (semaphore) per GPU per step; 128 = BASELINE configs[4] (1024 proofs over 8 GPUs)")
-    ap.add_argument("--threads", type=int, default=16, help="concurrent prover contexts per GPU (one HIP stream + one host thread each)")
+    ap.add_argument("--threads", type=int, default=22,
+                    help="concurrent prover contexts per GPU (one HIP stream + one host thread each).  22: measured best with sleeping "
+                         "waits (16: 170/s, 20: 174-178, 22: 178-182, 24: 162-168 -- past the device's hardware queues)")
     ap.add_argument("--log-members", type=int, default=20, help="log2 of the access-set size (tree depth)")
     args = ap.parse_args()
+    # one hardware queue per prover context: the HIP runtime's default is 4, streams then share queues and a latency-bound
+    # Merkle-top kernel on one stream holds up the streams behind it (measured 164 -> 172 proofs/s at 16 contexts).  Read when
+    # the HIP runtime initialises, i.e. before torch / libgl355 touch the device (they are imported by the main_* functions).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, int(os.environ.get("GL355_BENCH_CONTEXTS", args.threads)))))
     if args.workload == "semaphore":
         return main_semaphore(args)
     if args.workload == "recursive":

@@ -39,11 +39,12 @@ static uint64_t splitmix(uint64_t& s) {
     } while (0)
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s <artifact dir> [log_members=20] [contexts=16] [units=128]\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s <artifact dir> [log_members=20] [contexts=22] [units=128]\n", argv[0]); return 2; }
     const std::string dir = argv[1];
-    const uint32_t log_members = argc > 2 ? atoi(argv[2]) : 20, n_ctx = argc > 3 ? atoi(argv[3]) : 16, units = argc > 4 ? atoi(argv[4]) : 128;
+    const uint32_t log_members = argc > 2 ? atoi(argv[2]) : 20, n_ctx = argc > 3 ? atoi(argv[3]) : 22, units = argc > 4 ? atoi(argv[4]) : 128;
     const uint64_t n = 1ull << log_members;
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);      // one hardware queue per prover context; read when the HIP runtime initialises
+    // one hardware queue per prover context, and sleeping device waits (more contexts than cores is the normal case)
+    if (gl355_runtime_config(0, n_ctx, 1) != GL355_OK) { fprintf(stderr, "gl355_runtime_config failed\n"); return 1; }
     std::vector<gl355_ctx*> ctxs(n_ctx);
     for (auto& c : ctxs)
         if (gl355_ctx_create(0, &c) != GL355_OK) { fprintf(stderr, "no MI355X context\n"); return 1; }

@@ -47,6 +47,13 @@ typedef struct gl355_ctx gl355_ctx;
 typedef struct gl355_oracle gl355_oracle; /* a committed polynomial batch resident in HBM */
 
 /* ---- context ------------------------------------------------------------------------------ */
+/* Process-level runtime settings for the many-provers-per-GPU regime of the reference's rayon loop (recursion.rs:214-227,
+ * 300-308); call ONCE PER DEVICE BEFORE anything initialises the HIP runtime for it (first gl355_ctx_create, torch, ...):
+ *   contexts > 0      one hardware queue per prover context (GPU_MAX_HW_QUEUES, unless the variable is already set);
+ *   sleeping_waits    hipDeviceScheduleBlockingSync: every device wait of the process sleeps on the completion interrupt
+ *                     instead of spinning -- needed when there are more contexts than usable cores.
+ * GL355_E_HIP if the runtime refuses (typically: the device was already initialised). */
+int32_t gl355_runtime_config(int32_t device, uint32_t contexts, int32_t sleeping_waits);
 int32_t gl355_ctx_create(int32_t device, gl355_ctx** out);
 /* use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
 int32_t gl355_ctx_create_on_stream(int32_t device, void* hip_stream, gl355_ctx** out);

@@ -51,6 +51,7 @@ class Circuit(C.Structure):
 # name -> (restype, argtypes).  Data pointers are void* so numpy arrays, torch data_ptr() ints and
 # raw device pointers all pass through the same signature.
 SIGNATURES = {
+    "gl355_runtime_config": (C.c_int32, [C.c_int32, C.c_uint32, C.c_int32]),
     "gl355_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(vp)]),
     "gl355_ctx_create_on_stream": (C.c_int32, [C.c_int32, vp, C.POINTER(vp)]),
     "gl355_ctx_destroy": (C.c_int32, [vp]),
@@ -143,8 +144,10 @@ SIGNATURES = {
 _lib = None
 
 
-def load():
-    """Load libgl355.so and attach signatures.  Raises if the library has not been built."""
+def load(init_torch=True):
+    """Load libgl355.so and attach signatures.  Raises if the library has not been built.
+    init_torch=False: do not initialise torch's CUDA state first -- for callers that must run gl355_runtime_config before the
+    HIP runtime starts (torch has to be imported already, so that its libamdhip64 is the one in the process)."""
     global _lib
     if _lib is not None:
         return _lib
@@ -155,7 +158,7 @@ def load():
     # If torch is in this process it must own the HIP runtime initialisation (it ships its own ROCm
     # libraries; loading the system libamdhip64 first makes torch report "No HIP GPUs are available").
     import sys
-    if "torch" in sys.modules:
+    if init_torch and "torch" in sys.modules:
         try:
             t = sys.modules["torch"]
             t.cuda.is_available() and t.cuda.init()

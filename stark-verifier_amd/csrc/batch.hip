@@ -34,10 +34,11 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
         if (member_indices[j] >= n_members) return ctx_of(ctxs[0])->fail(GL355_E_INVALID_ARG, "semaphore_units: member index out of range");
     const uint64_t out_words = rec ? rec_words : sem_words;
     std::atomic<int32_t> first_error{GL355_OK};
+    std::atomic<uint32_t> next_unit{0};     // units are handed out one at a time: a context that finishes early takes the next one
     auto worker = [&](uint32_t t) {
         std::vector<uint64_t> sib((size_t)height * 4 + 4), flat(sem_words + 12), outer(rec ? rec_words : 0);
         uint32_t done = 0;
-        for (uint32_t j = t; j < count && first_error.load() == GL355_OK; j += n_ctx) {
+        for (uint32_t j; (j = next_unit.fetch_add(1)) < count && first_error.load() == GL355_OK;) {
             const uint64_t idx = member_indices[j];
             // MerkleTree::prove on the plonky2 digest layout (cap height 0: one tree)
             uint64_t pair = idx;

@@ -1,6 +1,7 @@
 // Context, stream, scratch allocator, host/device buffer staging and cached tables of libgl355.
 #include "gl355_internal.h"
 #include <chrono>
+#include <cstdlib>
 
 namespace gl355 {
 
@@ -193,6 +194,19 @@ static int32_t create_common(int32_t device, void* stream, bool external, gl355_
     int32_t rc = ctx_init(&h->c);
     if (rc != GL355_OK) { g_create_error = h->c.err; delete h; return rc; }
     *out = h;
+    return GL355_OK;
+}
+int32_t gl355_runtime_config(int32_t device, uint32_t contexts, int32_t sleeping_waits) {
+    if (device < 0) return GL355_E_INVALID_ARG;
+    if (contexts) {
+        char buf[16];
+        snprintf(buf, sizeof buf, "%u", contexts < 4 ? 4u : contexts);
+        setenv("GPU_MAX_HW_QUEUES", buf, 0);      // read by the HIP runtime when it initialises
+    }
+    if (sleeping_waits) {
+        if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return GL355_E_HIP; }
+        if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) { (void)hipGetLastError(); return GL355_E_HIP; }
+    }
     return GL355_OK;
 }
 int32_t gl355_ctx_create(int32_t device, gl355_ctx** out) { return create_common(device, nullptr, false, out); }
