@@ -239,6 +239,24 @@ def pmc_traffic(kernel):
         return None, None
 
 
+def pmc_valu(kernel, avg_launch_ms):
+    """The bound that actually applies to the dominant kernel: wave-level VALU instructions per launch (SQ_INSTS_VALU of the same
+    committed --pmc pass) over the launch duration measured here, against the chip's issue rate (1 024 SIMDs, one instruction per
+    ~4.2 clk for this instruction mix (tools/ubench), ~2.05 GHz sustained under this load)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")))
+        insts = d["kernels"][kernel]["valu_insts_per_launch"]
+    except Exception:
+        return None
+    peak = 1024 * 2.05e9 / 4.2 / 1e9
+    ach = insts / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    return {"unit": "G wave-instructions/s", "insts_per_launch": insts, "achieved": round(ach, 1), "peak": round(peak, 1),
+            "frac": round(ach / peak, 3),
+            "note": "one prover context alone: a launch of 2^16-2^17 leaves is 1-2 waves per SIMD, so part of the issue rate is "
+                    "dependent-issue latency; under the multi-context load the SIMDs are shared (DESIGN.md section 5: the whole "
+                    "job runs at ~95 % of the VALU issue rate)"}
+
+
 def lde_figure(gl, device, steps=8):
     """BASELINE configs[1] on this GPU, a few steps: the metric's 'NTT HBM GB/s' half (full treatment: --workload lde)."""
     import torch
@@ -401,6 +419,7 @@ def main_recursive(args):
                                 "kernel = the scope group with the largest summed duration" % iso_units,
                          "note": "not an HBM-bound kernel: Poseidon is ~1.1k Goldilocks modmuls per permutation on the integer VALU "
                                  "(no MFMA form, DESIGN.md section 5); its own ceiling is permutations/s, reported per kernel in DESIGN.md",
+                         "valu_issue": pmc_valu(dname, dms / max(1, dcnt)),
                          "gpu_ms_per_unit_all_kernels": round(sum(v[1] for v in iso.values()) / max(1, iso_units), 3),
                          "kernel_groups": groups(iso, iso_units, 10),
                          "timed_region_events": {"what": "the same scopes on 1 of the %d concurrent streams during the timed region "
