@@ -66,7 +66,7 @@ GL_HD uint64_t gl_neg(uint64_t a) { return gl_sub(0, a); }
 //   GL_MUL_VARIANT 1: the carry-out / borrow steps in inline asm: 15 VALU instructions, but gfx950 needs two wait states
 //     between a VALU write of an SGPR/VCC and a VALU read of it, the hazard recogniser does not look inside inline asm, and
 //     an asm block cannot be interleaved with its neighbours: 8 s_nop per product.  Best where many waves hide them (Poseidon).
-//   GL_MUL_VARIANT 2: overflow builtins the compiler schedules itself: 19 VALU instructions, no forced s_nop (latency-bound
+//   GL_MUL_VARIANT 2: carries re-derived in C the way the compiler digests best: 22 VALU instructions, no forced s_nop (latency-bound
 //     kernels with many independent products in flight: the NTT butterflies).
 // A translation unit picks with -DGL_MUL_VARIANT / #define before this header; the host always uses the 128-bit C product.
 #ifndef GL_MUL_VARIANT
