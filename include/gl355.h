@@ -398,7 +398,8 @@ int32_t gl355_semaphore_prove(gl355_ctx* ctx, const gl355_circuit_handle* c, con
                               uint64_t proof_capacity_words, uint64_t public_inputs_out[12]);
 
 /* Batch runtime (recursion.rs:300-308 `par_iter` of make_signal, :211-227 of the verification circuits): one host thread per
- * context, unit j -> context j mod n_ctx.  Per unit: Merkle path of member_indices[j] from tree_digests (the access-set tree over
+ * context, units handed to the contexts one at a time (results are placed by j, so they do not depend on which context proved
+ * which unit).  Per unit: Merkle path of member_indices[j] from tree_digests (the access-set tree over
  * the public keys, cap height 0, plonky2 digest layout, host memory), gl355_semaphore_prove with seed seed_base + 2j, and if `rec`
  * is not NULL gl355_circuit_prove_tape(rec, proof | public inputs) with seed seed_base + 2j + 1.  leaves_out[j] = nullifier | topic
  * (8 words) of unit j; proofs_out (optional) receives the last proof of every unit; units_per_ctx (optional) the units each

@@ -37,43 +37,43 @@ struct QuotArgs {
     uint64_t pi_hash[4];
     uint64_t n_inv;           // 1/n
     uint64_t* out;            // [num_challenges][Nq], storage (bit-reversed) order
+    const uint64_t* alpha_pw; // alpha_c^k at [c * pw_stride + k], k < pw_stride (alpha_table_kernel)
+    uint32_t pw_stride;
 };
 
-// running alpha-power accumulation of the constraint stream; NCH (the number of challenges) is a template
-// parameter so that acc / pw stay in registers (a run-time bound puts the arrays in scratch memory and every
-// push() becomes scratch loads + stores)
+// alpha-power accumulation of the constraint stream: term k of the stream is weighted alpha_c^k.  The powers are the same for
+// every lane, so they come from a table built once per launch (alpha_table_kernel) and read through the scalar cache
+// (constant address space, wave-uniform index) instead of being multiplied along per lane -- one product per push and
+// challenge instead of two.  NCH (the number of challenges) is a template parameter so that acc stays in registers (a
+// run-time bound puts the array in scratch memory and every push() becomes scratch loads + stores).
+typedef const __attribute__((address_space(4))) uint64_t* PwTable;
 template <int NCH>
 struct AlphaAcc {
-    uint64_t acc[NCH], pw[NCH], alpha[NCH];
-    GL_DEV void init(const QuotArgs& a) {
+    uint64_t acc[NCH];
+    PwTable tab;
+    uint32_t stride, idx;
+    GL_DEV void init(const QuotArgs& a, uint32_t first = 0) {
 #pragma unroll
-        for (int c = 0; c < NCH; c++) { acc[c] = 0; pw[c] = 1; alpha[c] = a.alphas[c]; }
+        for (int c = 0; c < NCH; c++) acc[c] = 0;
+        tab = (PwTable)a.alpha_pw; stride = a.pw_stride; idx = first;
     }
     GL_DEV void push(uint64_t term) {
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            acc[c] = gl_add(acc[c], gl_mul(term, pw[c]));
-            pw[c] = gl_mul(pw[c], alpha[c]);
-        }
+        for (int c = 0; c < NCH; c++) acc[c] = gl_add(acc[c], gl_mul(term, tab[c * stride + idx]));
+        idx++;
     }
 };
-
 // per-gate accumulation: sum_k alpha^(base+k) * c_k, later multiplied by the gate's filter
 template <int NCH>
-struct GateAccT {
-    uint64_t acc[NCH], pw[NCH], alpha[NCH];
-    GL_DEV void init(const uint64_t* alphas, const uint64_t* base_pw) {
-#pragma unroll
-        for (int c = 0; c < NCH; c++) { acc[c] = 0; pw[c] = base_pw[c]; alpha[c] = alphas[c]; }
-    }
-    GL_DEV void push(uint64_t term) {
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            acc[c] = gl_add(acc[c], gl_mul(term, pw[c]));
-            pw[c] = gl_mul(pw[c], alpha[c]);
-        }
-    }
-};
+using GateAccT = AlphaAcc<NCH>;
+
+// alpha_c^k for k < stride, one thread per entry (square-and-multiply over the bits of k)
+__global__ void alpha_table_kernel(uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3, uint32_t nch, uint32_t stride, uint64_t* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= stride) return;
+    const uint64_t al[4] = {a0, a1, a2, a3};
+    for (uint32_t c = 0; c < nch; c++) out[c * stride + k] = gl_canon(gl_pow(al[c], k));
+}
 
 #define WIRE(j) (a.wires[(uint64_t)(j) * a.lde_stride + t])
 #define CONST(j) (a.cs[(uint64_t)(j) * a.lde_stride + t])
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         const gl355_gate gt = a.c.gates[gi];
         if (gt.type == GL355_GATE_NOOP) continue;
         GateAccT<NCH> g;
-        g.init(a.alphas, total.pw);
+        g.init(a, total.idx);
         switch (gt.type) {
             case GL355_GATE_POSEIDON: gate_poseidon(a, t, g); break;
             case GL355_GATE_BASE_SUM: gate_base_sum(a, t, g, gt.param); break;
@@ -365,6 +365,33 @@ int32_t quotient_dev(Ctx* ctx, const gl355_circuit* c, const uint64_t* cs_lde, c
     for (int i = 0; i < 4; i++) a.pi_hash[i] = gl_canon(pi_hash[i]);
     a.n_inv = gl_canon(gl_inv((1ull << c->degree_bits) % GL_P));
     a.out = out_values;
+    // length of the constraint stream = the permutation-argument prefix + the longest gate (constraint counts as in
+    // gates/*.rs num_constraints; the gate evaluators below push exactly that many terms)
+    uint32_t longest = 0;
+    for (uint32_t g = 0; g < c->num_gates; g++) {
+        const uint32_t p = c->gates[g].param;
+        uint32_t k = 0;
+        switch (c->gates[g].type) {
+            case GL355_GATE_CONSTANT: k = p; break;
+            case GL355_GATE_PUBLIC_INPUT: k = 4; break;
+            case GL355_GATE_BASE_SUM: k = 1 + p; break;
+            case GL355_GATE_POSEIDON: k = 123; break;
+            case GL355_GATE_ARITHMETIC: k = p; break;
+            case GL355_GATE_ARITHMETIC_EXT: case GL355_GATE_MUL_EXT: case GL355_GATE_REDUCING: case GL355_GATE_REDUCING_EXT: k = 2 * p; break;
+            case GL355_GATE_POSEIDON_MDS: k = 24; break;
+            case GL355_GATE_RANDOM_ACCESS: k = ((p >> 8) & 0xFF) * ((p & 0xFF) + 2) + ((p >> 16) & 0xFF); break;
+            default: break;
+        }
+        longest = k > longest ? k : longest;
+    }
+    const uint32_t n_chunks = (c->num_routed_wires + c->max_degree - 1) / c->max_degree;
+    a.pw_stride = ((c->num_challenges * (1 + n_chunks) + longest + 1) + 63) & ~63u;
+    Scratch pw(ctx);
+    GL355_TRY(pw.get((size_t)c->num_challenges * a.pw_stride * 8));
+    a.alpha_pw = pw.as<uint64_t>();
+    hipLaunchKernelGGL(alpha_table_kernel, dim3((a.pw_stride + 255) / 256), dim3(256), 0, ctx->stream, a.alphas[0], a.alphas[1], a.alphas[2],
+                       a.alphas[3], c->num_challenges, a.pw_stride, pw.as<uint64_t>());
+    GL355_HIP(ctx, hipGetLastError());
     const uint64_t nq = 1ull << a.qbits;
     // every column of the three oracles once per point of the quotient coset + the result
     ProfScope ps(ctx, "quotient_kernel", nq * 8 * ((uint64_t)c->num_selectors + c->num_constants + c->num_routed_wires + c->num_wires +
