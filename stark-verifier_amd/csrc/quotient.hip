@@ -253,7 +253,7 @@ GL_DEV void gate_reducing(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t n)
 }
 
 template <int NCH>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) quotient_kernel(QuotArgs a) {
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) quotient_kernel(QuotArgs a) {
     const uint64_t nq = 1ull << a.qbits;
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= nq) return;
