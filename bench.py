@@ -133,6 +133,9 @@ class RecursiveProvers:
         if blocking_sync:
             for c in self.sets:
                 c.set_option(2, 1)                                   # GL355_OPT_BLOCKING_SYNC
+        if os.environ.get("GL355_BENCH_NTT_SINGLE_MAX"):             # experiments: GL355_OPT_NTT_SINGLE_PASS_MAX_LOG
+            for c in self.sets:
+                c.set_option(4, int(os.environ["GL355_BENCH_NTT_SINGLE_MAX"]))
         if os.environ.get("GL355_BENCH_LANES_LOG"):                  # experiments: GL355_OPT_MERKLE_LANES_LOG
             for c in self.sets:
                 c.set_option(1, int(os.environ["GL355_BENCH_LANES_LOG"]))

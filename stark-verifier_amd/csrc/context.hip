@@ -242,6 +242,10 @@ int32_t gl355_ctx_set_option(gl355_ctx* ctx, int32_t option, int64_t value) {
     case GL355_OPT_BLOCKING_SYNC:
         ctx->c.blocking_sync = value != 0;
         return GL355_OK;
+    case GL355_OPT_NTT_SINGLE_PASS_MAX_LOG:
+        if (value < 12 || value > 14) return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: NTT_SINGLE_PASS_MAX_LOG must be in 12..14");
+        ctx->c.ntt_single_pass_max_log = (uint32_t)value;
+        return GL355_OK;
     case GL355_OPT_MERKLE_LANES_LOG:
         if (value < 0 || value > 30) return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: MERKLE_LANES_LOG must be in 0..30");
         ctx->c.merkle_lanes_log = (uint32_t)value;

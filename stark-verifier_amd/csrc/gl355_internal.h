@@ -69,6 +69,7 @@ struct Ctx {
     // host wait for the stream: spinning hipStreamSynchronize (lowest latency) or, with GL355_OPT_BLOCKING_SYNC, a blocking
     // event wait that leaves the CPU to other prover threads (more host threads than cores)
     uint32_t replay_threads = 1;      // GL355_OPT_REPLAY_THREADS
+    uint32_t ntt_single_pass_max_log = 14;   // GL355_OPT_NTT_SINGLE_PASS_MAX_LOG (12..14)
     bool blocking_sync = false;
     hipEvent_t sync_ev = nullptr;
     hipError_t wait();

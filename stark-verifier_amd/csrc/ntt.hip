@@ -455,7 +455,11 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
     a.tw = inv ? ctx->tw_inv : ctx->tw_fwd;
     a.scale = 1;
 
-    if (p.log_n <= 14) {
+    // n = 2^13, 2^14 in one pass need a 64 / 128-KB LDS tile and every VGPR of the CU: nothing else can share the CU with such
+    // a block.  GL355_OPT_NTT_SINGLE_PASS_MAX_LOG < 14 sends the commit-path shape (natural in, bit-reversed out, no
+    // post-multiplier, contiguous coset blocks) of those sizes through the two-pass path with 4096-point tiles instead.
+    const bool two_pass_ok = !p.in_bitrev && p.out_bitrev && !p.post_lo && (p.n_cosets == 1 || p.coset_out_stride == (1ull << p.log_n));
+    if (p.log_n <= 12 || (p.log_n <= 14 && !(two_pass_ok && p.log_n > ctx->ntt_single_pass_max_log))) {
         // single pass over HBM
         a.in = p.in; a.out = p.out;
         a.in_col_stride = p.in_col_stride; a.out_col_stride = p.out_col_stride;

@@ -117,6 +117,24 @@ def test_lde(ctx, orc, log_n, rate_bits):
     eq(ctx.lde(c, rate_bits, bitrev=True), orc.reverse_index_bits(want.T.copy()).T)
 
 
+@pytest.mark.parametrize("log_n", [13, 14])
+def test_lde_small_sizes_in_two_passes(gl, orc, log_n):
+    """GL355_OPT_NTT_SINGLE_PASS_MAX_LOG = 12: the commit-path shape (natural coefficients in, bit-reversed cosets out) of
+    2^13 / 2^14 points runs as two passes of 4096-point tiles instead of one CU-filling pass; same values, and the proofs that
+    use it stay byte-identical (checked on a whole Semaphore proof below)"""
+    c2 = gl.Context(0)
+    c2.set_option(4, 12)
+    rng = np.random.default_rng(0x386 + log_n)
+    c = rand_field(rng, (5, 1 << log_n))
+    for rate_bits in (1, 3):
+        want = orc.lde(c, rate_bits)
+        eq(c2.lde(c, rate_bits, bitrev=True), orc.reverse_index_bits(want.T.copy()).T)
+        eq(c2.lde(c, rate_bits), want)
+    with pytest.raises(gl.Gl355Error):
+        c2.set_option(4, 15)
+    c2.close()
+
+
 # ---- a5 ------------------------------------------------------------------------------------------
 def test_transpose_and_bitrev(ctx, orc):
     rng = np.random.default_rng(0x395)
