@@ -139,3 +139,37 @@ def test_cpp_host_program(tmp_path):
     blob[:-5].tofile(os.path.join(art, "semaphore.gl355"))
     assert subprocess.call([os.path.join(root, "examples", "native_units"), art, "3", "2", "6"], stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL) != 0
+
+
+def test_runtime_config_sleeping_waits():
+    """gl355_runtime_config has to run before the HIP runtime initialises, so it is exercised in a fresh process: after it, a
+    device wait costs (almost) no CPU time, and the results are the usual ones"""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, importlib, os, sys, time
+sys.path.insert(0, %r)
+import numpy as np
+import torch                                   # imported (its libamdhip64 is the process's HIP runtime) but not initialised
+lib = importlib.import_module("stark-verifier_amd._lib").load(init_torch=False)
+assert lib.gl355_runtime_config(0, 8, 1) == 0
+getenv = C.CDLL(None).getenv; getenv.restype = C.c_char_p
+assert getenv(b"GPU_MAX_HW_QUEUES") == b"8"       # set in the C environment (os.environ is Python's own copy)
+gl = importlib.import_module("stark-verifier_amd")
+ctx = gl.Context(0)
+x = torch.arange(12 << 22, dtype=torch.int64, device="cuda").reshape(-1, 12)
+ref = ctx.poseidon_permute(np.arange(24, dtype=np.uint64).reshape(2, 12))
+for rep in range(2):
+    w0, c0 = time.perf_counter(), time.process_time()
+    for _ in range(4):
+        ctx.check(lib.gl355_poseidon_permute(ctx.h, C.c_void_p(x.data_ptr()), x.shape[0]))
+    ctx.sync()
+    wall, cpu = time.perf_counter() - w0, time.process_time() - c0
+print("RESULT", wall, cpu, int(ref[1, 0]))
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code % root], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    wall, cpu, v = out.stdout.split("RESULT")[1].split()
+    assert float(cpu) < 0.5 * float(wall), (wall, cpu)          # a spinning wait would make them equal
