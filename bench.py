@@ -79,8 +79,7 @@ class SemaphoreProvers:
     (make_signal, access_set.rs:61-104), without the recursive proof."""
 
     def __init__(self, gl, device, threads, log_members=20, seed=0x357):
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from oracle_lib import rand_field  # only the seeded RNG helper, no oracle arithmetic
+        rand_field = gl.api.rand_field
         sem = importlib.import_module("stark-verifier_amd.semaphore")
         rng = np.random.default_rng(seed)
         ctx0 = gl.Context(device)
@@ -123,8 +122,7 @@ class RecursiveProvers:
     is one call into the native batch runtime (gl355_semaphore_units), which runs those host threads."""
 
     def __init__(self, gl, device, threads, log_members=20, seed=0x357, blocking_sync=False, replay_threads=1):
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from oracle_lib import rand_field  # only the seeded RNG helper, no oracle arithmetic
+        rand_field = gl.api.rand_field
         sem = importlib.import_module("stark-verifier_amd.semaphore")
         rec = importlib.import_module("stark-verifier_amd.recursion")
         self.plonk = importlib.import_module("stark-verifier_amd.plonk")
@@ -175,8 +173,9 @@ class RecursiveProvers:
         per prover context inside the library); returns the (nullifier | topic) leaves [count][8]"""
         n = self.sks.shape[0]
         members = (first + np.arange(count, dtype=np.uint64)) % np.uint64(n)
+        # blinding key None = the production setting: every proof draws a fresh 256-bit key from the OS CSPRNG inside the library
         leaves, _, per = self.plonk.semaphore_units(self.sets, self.sem, self.nat, self.sks, self.topic, self.aset.tree.digests, members,
-                                                    0x358 + 2 * first)
+                                                    None)
         for t, k in enumerate(per):
             self.units_done[t] += k
         return leaves

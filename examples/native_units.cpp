@@ -69,10 +69,10 @@ int main(int argc, char** argv) {
     std::vector<uint64_t> members(units), leaves(8ull * units), proofs(words * units);
     for (uint32_t j = 0; j < units; j++) members[j] = (12 + j) % n;                 // signal.rs:42 starts at index 12
     // warm-up, then the timed batch
-    CHECK(c0, gl355_semaphore_units(ctxs.data(), n_ctx, sem, rec, sks.data(), n, topic.data(), digests.data(), members.data(), n_ctx, 1, leaves.data(),
+    CHECK(c0, gl355_semaphore_units(ctxs.data(), n_ctx, sem, rec, sks.data(), n, topic.data(), digests.data(), members.data(), n_ctx, nullptr, leaves.data(),
                                     nullptr, nullptr));
     const auto t0 = std::chrono::steady_clock::now();
-    CHECK(c0, gl355_semaphore_units(ctxs.data(), n_ctx, sem, rec, sks.data(), n, topic.data(), digests.data(), members.data(), units, 1000,
+    CHECK(c0, gl355_semaphore_units(ctxs.data(), n_ctx, sem, rec, sks.data(), n, topic.data(), digests.data(), members.data(), units, nullptr /* blinding keys from the OS CSPRNG */,
                                     leaves.data(), proofs.data(), nullptr));
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     // aggregation root over the (nullifier | topic) leaves, zero-padded to a power of two

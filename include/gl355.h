@@ -315,8 +315,22 @@ typedef struct {
 } gl355_prover_data;
 /* u64 words of the flat proof gl355_prove writes */
 uint64_t gl355_proof_words(const gl355_prover_data* pd);
-/* wires: the full witness [num_wires][n] (host or device), including the blinding rows.  seed drives the
- * salt columns (counter-based PRNG on the device), so a (witness, seed) pair gives a reproducible proof.
+/* Zero-knowledge blinding (zero_knowledge: true at access_set.rs:69, recursion.rs:33; SALT_SIZE types/assigned.rs:67-71).
+ * Every proving entry point takes `blinding_key`: 32 bytes, or NULL.
+ *   NULL      the library draws a fresh 256-bit key from the OS CSPRNG (getrandom) for this proof -- the production setting,
+ *             the counterpart of plonky2's OsRng;
+ *   non-NULL  the caller's SECRET key: a (witness, key) pair then gives a reproducible proof (tests, the byte-for-byte parity
+ *             with the CPU restatement, deterministic provers that derive the key from their own secret).  A key must never be
+ *             reused for a different witness and must be as secret as the witness: it determines every blinding value.
+ * Salt columns and blinding rows are ChaCha20 key streams (RFC 8439 block function, counter = block index, nonce = (stream, 0, 0);
+ * streams 1/2/3 = salt of the wires / Z / quotient oracle, 4 = witness blinding rows); stream element k = key-stream bytes
+ * [16k, 16k+16) as a little-endian 128-bit number reduced mod p.  The published salt therefore reveals nothing about the key or
+ * about the wire blinding. */
+int32_t gl355_derive_key(const uint8_t base_key[32], uint64_t index, uint8_t out[32]);  /* per-unit key of a batch: ChaCha20(base, nonce ("key", index)) */
+/* the first `count` elements of a blinding stream, from the device kernel the prover uses (parity surface) */
+int32_t gl355_blinding_elements(gl355_ctx* ctx, const uint8_t key[32], uint32_t stream, uint64_t count, uint64_t* out);
+
+/* wires: the full witness [num_wires][n] (host or device), including the blinding rows; blinding_key drives the salt columns.
  * Flat proof layout (all u64; E = extension element = 2 words, H = digest = 4 words, C = 2^cap_height):
  *   header[8] = {total_words, degree_bits, n_fri_layers, num_queries, n_public_inputs, zero_knowledge, cap_height, num_challenges}
  *   wires_cap[C]H  zs_partial_products_cap[C]H  quotient_polys_cap[C]H
@@ -325,15 +339,15 @@ uint64_t gl355_proof_words(const gl355_prover_data* pd);
  *   per query: x_index; for oracle 0..3: leaf[leaf_len], siblings[log2 N - cap_height]H;
  *              for layer l: evals[2]E, siblings[log2 N - 1 - l - cap_height]H */
 int32_t gl355_prove(gl355_ctx* ctx, const gl355_prover_data* pd, const uint64_t* wires, const uint64_t* public_inputs,
-                    uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words);
+                    uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof, uint64_t proof_capacity_words);
 
 /* the same proof from a SPARSE witness: only the n_rows non-trivial circuit rows are given (rows[r] = all
  * num_wires values of circuit row row_idx[r]; all other rows are zero Noop rows), and the zero-knowledge
- * blinding rows are filled on the device from `seed`: rows [blind_start, blind_start + n_blind) random on
+ * blinding rows are filled on the device from stream 4 of `blinding_key`: rows [blind_start, blind_start + n_blind) random on
  * every wire, n_z_pairs consecutive row pairs from z_start sharing one random value on wire 0. */
 int32_t gl355_prove_sparse(gl355_ctx* ctx, const gl355_prover_data* pd, const uint32_t* row_idx, const uint64_t* rows,
                            uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
-                           const uint64_t* public_inputs, uint32_t n_public_inputs, uint64_t seed, uint64_t* proof,
+                           const uint64_t* public_inputs, uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof,
                            uint64_t proof_capacity_words);
 /* host-side witness rows of the Semaphore circuit (circuit.rs:67-99): (height + 7) rows x 135 wires in the
  * order PublicInput | pi-hash 1 | pi-hash 2 | BaseSum{height} | leaf hash | height Merkle levels | nullifier |
@@ -392,23 +406,24 @@ int32_t gl355_circuit_info(const gl355_circuit_handle* c, uint64_t* proof_words,
                            uint64_t* n_inputs, uint32_t* degree_bits);
 const uint64_t* gl355_circuit_digest(const gl355_circuit_handle* c);
 int32_t gl355_circuit_prove_rows(gl355_ctx* ctx, const gl355_circuit_handle* c, const uint64_t* rows, const uint64_t* public_inputs,
-                                 uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words);
-int32_t gl355_circuit_prove_tape(gl355_ctx* ctx, const gl355_circuit_handle* c, const uint64_t* inputs, uint64_t n_inputs, uint64_t seed,
+                                 uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof, uint64_t proof_capacity_words);
+int32_t gl355_circuit_prove_tape(gl355_ctx* ctx, const gl355_circuit_handle* c, const uint64_t* inputs, uint64_t n_inputs, const uint8_t* blinding_key,
                                  uint64_t* proof, uint64_t proof_capacity_words, uint64_t* public_inputs_out);
 int32_t gl355_semaphore_prove(gl355_ctx* ctx, const gl355_circuit_handle* c, const uint64_t private_key[4], const uint64_t topic[4],
-                              uint64_t index, const uint64_t* siblings, uint32_t height, uint64_t seed, uint64_t* proof,
+                              uint64_t index, const uint64_t* siblings, uint32_t height, const uint8_t* blinding_key, uint64_t* proof,
                               uint64_t proof_capacity_words, uint64_t public_inputs_out[12]);
 
 /* Batch runtime (recursion.rs:300-308 `par_iter` of make_signal, :211-227 of the verification circuits): one host thread per
  * context, units handed to the contexts one at a time (results are placed by j, so they do not depend on which context proved
  * which unit).  Per unit: Merkle path of member_indices[j] from tree_digests (the access-set tree over
- * the public keys, cap height 0, plonky2 digest layout, host memory), gl355_semaphore_prove with seed seed_base + 2j, and if `rec`
- * is not NULL gl355_circuit_prove_tape(rec, proof | public inputs) with seed seed_base + 2j + 1.  leaves_out[j] = nullifier | topic
+ * the public keys, cap height 0, plonky2 digest layout, host memory), gl355_semaphore_prove with key gl355_derive_key(key_base, 2j), and
+ * if `rec` is not NULL gl355_circuit_prove_tape(rec, proof | public inputs) with key gl355_derive_key(key_base, 2j + 1); key_base NULL =
+ * a fresh OS-random key per proof.  leaves_out[j] = nullifier | topic
  * (8 words) of unit j; proofs_out (optional) receives the last proof of every unit; units_per_ctx (optional) the units each
  * context proved.  Returns the first error (the failing context's gl355_last_error tells more). */
 int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx, const gl355_circuit_handle* sem, const gl355_circuit_handle* rec,
                               const uint64_t* private_keys, uint64_t n_members, const uint64_t topic[4], const uint64_t* tree_digests,
-                              const uint64_t* member_indices, uint32_t count, uint64_t seed_base, uint64_t* leaves_out,
+                              const uint64_t* member_indices, uint32_t count, const uint8_t* key_base, uint64_t* leaves_out,
                               uint64_t* proofs_out, uint32_t* units_per_ctx);
 
 /* ---- a9: wires_permutation_partial_products_and_zs (vanishing_poly.rs:54-108,183-218) --------- */

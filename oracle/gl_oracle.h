@@ -202,11 +202,15 @@ void orc_vanishing_values(const orc_circuit *c, const orc_batch *cs, const orc_b
                           const uint64_t pi_hash[4], uint64_t *out);
 uint64_t orc_proof_words(const orc_prover_data *pd);
 /* flat proof in the layout of include/gl355.h; 0 on success */
-int orc_prove(const orc_prover_data *pd, const uint64_t *wires, const uint64_t *public_inputs, uint32_t n_pi, uint64_t seed,
+/* blinding: ChaCha20 key streams under the proof's 256-bit key (convention in gl_prover.c / include/gl355.h) */
+void orc_chacha20_block(const uint8_t key[32], uint32_t counter, const uint32_t nonce[3], uint8_t out[64]);
+void orc_blinding_elements(const uint8_t key[32], uint32_t stream, uint64_t count, uint64_t *out);
+void orc_derive_key(const uint8_t base[32], uint64_t index, uint8_t out[32]);
+int orc_prove(const orc_prover_data *pd, const uint64_t *wires, const uint64_t *public_inputs, uint32_t n_pi, const uint8_t key[32],
               uint64_t *proof);
 int orc_prove_sparse(const orc_prover_data *pd, const uint32_t *row_idx, const uint64_t *rows, uint32_t n_rows, uint32_t blind_start,
                      uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs, const uint64_t *public_inputs, uint32_t n_pi,
-                     uint64_t seed, uint64_t *proof);
+                     const uint8_t key[32], uint64_t *proof);
 
 int orc_num_threads(void);
 void orc_set_num_threads(int n);   /* launchers such as torchrun export OMP_NUM_THREADS=1 */

@@ -15,8 +15,11 @@
  * Written independently of the HIP implementation: per point of the quotient coset it materialises plonky2's
  * `vanishing_terms` vector [L0 (Z - 1)] ++ [partial-product checks] ++ [sum_g filter_g constraint_g,k] and then
  * reduces it with powers of alpha, where the HIP kernel streams the terms through running accumulators.
- * The blinding / salt values are a counter-based SplitMix64 of the proof seed (the product's documented
- * convention, include/gl355.h), so (witness, seed) fixes the proof on both sides.
+ * The blinding / salt values follow the product's documented key -> stream convention (include/gl355.h): ChaCha20
+ * (RFC 8439 2.3 block function, restated below and pinned by the RFC's own test vector, tests/test_oracle_golden.py)
+ * under the proof's 256-bit key, block counter = block index, nonce = (stream, 0, 0); streams 1/2/3 = salt of the
+ * wires / Z / quotient oracle, 4 = witness blinding rows; element k = key-stream bytes [16k, 16k+16) as a little-endian
+ * 128-bit number mod p.  So (witness, key) fixes the proof on both sides.
  */
 #include "gl_oracle.h"
 #include "gl_inline.h"
@@ -39,11 +42,48 @@ static inline e2 e2_mul(e2 a, e2 b) {
 }
 static inline e2 e2_scale(e2 a, uint64_t s) { return e2_mk(f_mul(a.c0, s), f_mul(a.c1, s)); }
 
-static inline uint64_t mix64(uint64_t seed, uint64_t i) {
-    uint64_t z = seed + (i + 1) * UINT64_C(0x9E3779B97F4A7C15);
-    z = (z ^ (z >> 30)) * UINT64_C(0xBF58476D1CE4E5B9);
-    z = (z ^ (z >> 27)) * UINT64_C(0x94D049BB133111EB);
-    return canon(z ^ (z >> 31));
+/* ---- ChaCha20 block function, RFC 8439 section 2.3 (written from the RFC text) -------------------------------- */
+static inline uint32_t rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+static void quarter_round(uint32_t *st, int a, int b, int c, int d) {
+    st[a] += st[b]; st[d] ^= st[a]; st[d] = rotl32(st[d], 16);
+    st[c] += st[d]; st[b] ^= st[c]; st[b] = rotl32(st[b], 12);
+    st[a] += st[b]; st[d] ^= st[a]; st[d] = rotl32(st[d], 8);
+    st[c] += st[d]; st[b] ^= st[c]; st[b] = rotl32(st[b], 7);
+}
+static uint32_t le32(const uint8_t *b) { return (uint32_t)b[0] | (uint32_t)b[1] << 8 | (uint32_t)b[2] << 16 | (uint32_t)b[3] << 24; }
+/* key 32 bytes, nonce 3 words, -> 64 key-stream bytes (serialised little-endian, RFC 8439 2.3) */
+void orc_chacha20_block(const uint8_t key[32], uint32_t counter, const uint32_t nonce[3], uint8_t out[64]) {
+    uint32_t init[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u}, w[16];
+    for (int i = 0; i < 8; i++) init[4 + i] = le32(key + 4 * i);
+    init[12] = counter; init[13] = nonce[0]; init[14] = nonce[1]; init[15] = nonce[2];
+    memcpy(w, init, sizeof w);
+    for (int r = 0; r < 10; r++) {
+        quarter_round(w, 0, 4, 8, 12); quarter_round(w, 1, 5, 9, 13); quarter_round(w, 2, 6, 10, 14); quarter_round(w, 3, 7, 11, 15);
+        quarter_round(w, 0, 5, 10, 15); quarter_round(w, 1, 6, 11, 12); quarter_round(w, 2, 7, 8, 13); quarter_round(w, 3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; i++) {
+        const uint32_t v = w[i] + init[i];
+        out[4 * i] = (uint8_t)v; out[4 * i + 1] = (uint8_t)(v >> 8); out[4 * i + 2] = (uint8_t)(v >> 16); out[4 * i + 3] = (uint8_t)(v >> 24);
+    }
+}
+/* elements [0, count) of blinding stream `stream` under `key` (the convention of include/gl355.h) */
+void orc_blinding_elements(const uint8_t key[32], uint32_t stream, uint64_t count, uint64_t *out) {
+    const uint32_t nonce[3] = {stream, 0, 0};
+    uint8_t blk[64];
+    for (uint64_t k = 0; k < count; k++) {
+        if ((k & 3) == 0) orc_chacha20_block(key, (uint32_t)(k >> 2), nonce, blk);
+        const uint8_t *b = blk + 16 * (k & 3);
+        unsigned __int128 v = 0;
+        for (int i = 15; i >= 0; i--) v = (v << 8) | b[i];
+        out[k] = (uint64_t)(v % (unsigned __int128)P);
+    }
+}
+/* per-unit key of a batch: first 32 bytes of block 0 under the batch key with nonce ("key", index_lo, index_hi) */
+void orc_derive_key(const uint8_t base[32], uint64_t index, uint8_t out[32]) {
+    const uint32_t nonce[3] = {0x0079656bu, (uint32_t)index, (uint32_t)(index >> 32)};
+    uint8_t blk[64];
+    orc_chacha20_block(base, 0, nonce, blk);
+    memcpy(out, blk, 32);
 }
 
 /* ---- committed batch (PolynomialBatch) ------------------------------------------------------------------ */
@@ -366,7 +406,7 @@ static uint64_t grind(const orc_challenger *ch, uint32_t bits) {
 }
 
 /* wires: the full witness [num_wires][n] (including blinding rows).  proof: orc_proof_words(pd) words. */
-int orc_prove(const orc_prover_data *pd, const uint64_t *wires, const uint64_t *public_inputs, uint32_t n_pi, uint64_t seed,
+int orc_prove(const orc_prover_data *pd, const uint64_t *wires, const uint64_t *public_inputs, uint32_t n_pi, const uint8_t key[32],
               uint64_t *proof) {
     const orc_circuit *c = pd->circuit;
     const orc_batch *cs = pd->constants_sigmas;
@@ -389,11 +429,8 @@ int orc_prove(const orc_prover_data *pd, const uint64_t *wires, const uint64_t *
     orc_challenger_observe(&ch, pi_hash, 4);
 
     uint64_t *salt = zk ? (uint64_t *)malloc((size_t)SALT * N * 8) : NULL;
-#define FRESH_SALT(id)                                                                                        \
-    if (zk) {                                                                                                 \
-        const uint64_t s_ = seed * UINT64_C(0x100000001B3) + (uint64_t)(id) * UINT64_C(0xD6E8FEB86659FD93);    \
-        for (size_t i_ = 0; i_ < (size_t)SALT * N; i_++) salt[i_] = mix64(s_, i_);                            \
-    }
+#define FRESH_SALT(id) \
+    if (zk) orc_blinding_elements(key, (uint32_t)(id), (uint64_t)SALT * N, salt);
     /* ---- wires ---- */
     FRESH_SALT(1)
     orc_batch *b_w = orc_batch_commit_h(hs, wires, c->degree_bits, c->num_wires, c->rate_bits, 0, salt, cap_h);
@@ -497,21 +534,23 @@ int orc_prove(const orc_prover_data *pd, const uint64_t *wires, const uint64_t *
     return (uint64_t)(out - proof) == need ? 0 : -1;
 }
 
-/* the sparse-witness entry: scatter the given rows, fill the blinding rows from the seed exactly as the
+/* the sparse-witness entry: scatter the given rows, fill the blinding rows from the key exactly as the
  * product documents (include/gl355.h gl355_prove_sparse), then prove */
 int orc_prove_sparse(const orc_prover_data *pd, const uint32_t *row_idx, const uint64_t *rows, uint32_t n_rows, uint32_t blind_start,
                      uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs, const uint64_t *public_inputs, uint32_t n_pi,
-                     uint64_t seed, uint64_t *proof) {
+                     const uint8_t key[32], uint64_t *proof) {
     const uint32_t nw = pd->circuit->num_wires;
     const size_t n = (size_t)1 << pd->circuit->degree_bits;
     uint64_t *wires = (uint64_t *)calloc((size_t)nw * n, 8);
     for (uint32_t r = 0; r < n_rows; r++)
         for (uint32_t cidx = 0; cidx < nw; cidx++) wires[(size_t)cidx * n + row_idx[r]] = canon(rows[(size_t)r * nw + cidx]);
-    const uint64_t s2 = seed * UINT64_C(0xA24BAED4963EE407) + UINT64_C(0x9FB21C651E98DF25);
     const size_t n_a = (size_t)n_blind * nw;
-    for (size_t gidx = 0; gidx < n_a; gidx++) wires[(gidx / n_blind) * n + blind_start + gidx % n_blind] = mix64(s2, gidx);
-    for (size_t k = 0; k < n_z_pairs; k++) wires[z_start + 2 * k] = wires[z_start + 2 * k + 1] = mix64(s2, n_a + k);
-    int rc = orc_prove(pd, wires, public_inputs, n_pi, seed, proof);
+    uint64_t *bl = (uint64_t *)malloc((n_a + n_z_pairs + 1) * 8);
+    orc_blinding_elements(key, 4, n_a + n_z_pairs, bl);
+    for (size_t gidx = 0; gidx < n_a; gidx++) wires[(gidx / n_blind) * n + blind_start + gidx % n_blind] = bl[gidx];
+    for (size_t k = 0; k < n_z_pairs; k++) wires[z_start + 2 * k] = wires[z_start + 2 * k + 1] = bl[n_a + k];
+    free(bl);
+    int rc = orc_prove(pd, wires, public_inputs, n_pi, key, proof);
     free(wires);
     return rc;
 }

@@ -438,3 +438,13 @@ def eval_polys(ctx, polys, z):
     zz = _u64(z)
     ctx.check(ctx.lib.gl355_eval_polys(ctx.h, _poly_refs(polys), len(polys), _ptr(zz), _ptr(out)))
     return out
+
+
+def rand_field(rng, shape):
+    """synthetic field elements, uniform in [0, p) by rejection (numpy Generator `rng`)"""
+    a = rng.integers(0, 1 << 64, size=shape, dtype=np.uint64, endpoint=False)
+    bad = a >= np.uint64(P)
+    while bad.any():
+        a[bad] = rng.integers(0, 1 << 64, size=int(bad.sum()), dtype=np.uint64, endpoint=False)
+        bad = a >= np.uint64(P)
+    return a

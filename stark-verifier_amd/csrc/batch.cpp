@@ -13,7 +13,7 @@ using namespace gl355;
 
 extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx, const gl355_circuit_handle* sem, const gl355_circuit_handle* rec,
                                          const uint64_t* private_keys, uint64_t n_members, const uint64_t topic[4], const uint64_t* tree_digests,
-                                         const uint64_t* member_indices, uint32_t count, uint64_t seed_base, uint64_t* leaves_out,
+                                         const uint64_t* member_indices, uint32_t count, const uint8_t* key_base, uint64_t* leaves_out,
                                          uint64_t* proofs_out, uint32_t* units_per_ctx) {
     if (!ctxs || n_ctx == 0 || !sem || !private_keys || !topic || (!tree_digests && n_members > 1) || (!member_indices && count) || !leaves_out)
         return GL355_E_INVALID_ARG;
@@ -49,12 +49,15 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
                 memcpy(&sib[4 * i], tree_digests + (2 * slot + (1 - parity)) * 4, 32);
             }
             uint64_t* pis = flat.data() + sem_words;
-            int32_t rc = gl355_semaphore_prove(ctxs[t], sem, private_keys + 4 * idx, topic, idx, sib.data(), height, seed_base + 2ull * j,
+            // per-proof blinding keys: derived from the batch key (reproducible batches), or NULL = fresh OS randomness per proof
+            uint8_t k_sem[32], k_rec[32];
+            if (key_base) { gl355_derive_key(key_base, 2ull * j, k_sem); gl355_derive_key(key_base, 2ull * j + 1, k_rec); }
+            int32_t rc = gl355_semaphore_prove(ctxs[t], sem, private_keys + 4 * idx, topic, idx, sib.data(), height, key_base ? k_sem : nullptr,
                                                flat.data(), sem_words, pis);
             uint64_t opis[12];
             const uint64_t* result = flat.data();
             if (rc == GL355_OK && rec) {
-                rc = gl355_circuit_prove_tape(ctxs[t], rec, flat.data(), sem_words + 12, seed_base + 2ull * j + 1, outer.data(), rec_words, opis);
+                rc = gl355_circuit_prove_tape(ctxs[t], rec, flat.data(), sem_words + 12, key_base ? k_rec : nullptr, outer.data(), rec_words, opis);
                 result = outer.data();
             } else if (rc == GL355_OK) {
                 memcpy(opis, pis, sizeof opis);

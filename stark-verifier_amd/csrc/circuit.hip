@@ -113,7 +113,7 @@ int32_t gl355_circuit_load(gl355_ctx* h, const uint64_t* blob, uint64_t words, g
         if (rc) break;
         uint64_t* s = pre.data() + n_cap * 4;
         s[0] = c.degree_bits; s[1] = c.num_gates; s[2] = c.num_selectors;
-        for (uint32_t g = 0; g < c.num_gates; g++) s[3 + g] = (uint64_t)c.gates[g].type * 1000 + c.gates[g].param;
+        for (uint32_t g = 0; g < c.num_gates; g++) s[3 + g] = ((uint64_t)c.gates[g].type << 32) | c.gates[g].param;   // no aliasing between (type, param) pairs
         uint64_t dg[4];
         gl355_host_hash_no_pad_h(hasher, pre.data(), pre.size(), dg);
         if (memcmp(dg, blob + 106, 32) != 0) { rc = ctx->fail(GL355_E_INVALID_ARG, "circuit_load: circuit digest of the artifact does not match its tables"); break; }
@@ -160,16 +160,16 @@ int32_t gl355_circuit_info(const gl355_circuit_handle* ch, uint64_t* proof_words
 const uint64_t* gl355_circuit_digest(const gl355_circuit_handle* ch) { return ch ? ch->pd.circuit_digest : nullptr; }
 
 int32_t gl355_circuit_prove_rows(gl355_ctx* h, const gl355_circuit_handle* ch, const uint64_t* rows, const uint64_t* public_inputs,
-                                 uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words) {
+                                 uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof, uint64_t proof_capacity_words) {
     Ctx* ctx = ctx_of(h);
     if (!ctx) return GL355_E_INVALID_ARG;
     if (!ch || !rows) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_rows: null argument");
     if (ctx->device != ch->owner->device) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_rows: circuit was loaded on another device");
     return gl355_prove_sparse(h, &ch->pd, ch->row_idx.data(), rows, (uint32_t)ch->row_idx.size(), ch->blind_start, ch->n_blind, ch->z_start,
-                              ch->n_z_pairs, public_inputs, n_public_inputs, seed, proof, proof_capacity_words);
+                              ch->n_z_pairs, public_inputs, n_public_inputs, blinding_key, proof, proof_capacity_words);
 }
 
-int32_t gl355_circuit_prove_tape(gl355_ctx* h, const gl355_circuit_handle* ch, const uint64_t* inputs, uint64_t n_inputs, uint64_t seed,
+int32_t gl355_circuit_prove_tape(gl355_ctx* h, const gl355_circuit_handle* ch, const uint64_t* inputs, uint64_t n_inputs, const uint8_t* blinding_key,
                                  uint64_t* proof, uint64_t proof_capacity_words, uint64_t* public_inputs_out) {
     Ctx* ctx = ctx_of(h);
     if (!ctx) return GL355_E_INVALID_ARG;
@@ -190,11 +190,11 @@ int32_t gl355_circuit_prove_tape(gl355_ctx* h, const gl355_circuit_handle* ch, c
     std::vector<uint64_t> pis(ch->n_pi);
     for (uint32_t i = 0; i < ch->n_pi; i++) pis[i] = rows[ch->pi_pos[i]];
     if (public_inputs_out) memcpy(public_inputs_out, pis.data(), (size_t)ch->n_pi * 8);
-    return gl355_circuit_prove_rows(h, ch, rows.data(), pis.data(), ch->n_pi, seed, proof, proof_capacity_words);
+    return gl355_circuit_prove_rows(h, ch, rows.data(), pis.data(), ch->n_pi, blinding_key, proof, proof_capacity_words);
 }
 
 int32_t gl355_semaphore_prove(gl355_ctx* h, const gl355_circuit_handle* ch, const uint64_t private_key[4], const uint64_t topic[4],
-                              uint64_t index, const uint64_t* siblings, uint32_t height, uint64_t seed, uint64_t* proof,
+                              uint64_t index, const uint64_t* siblings, uint32_t height, const uint8_t* blinding_key, uint64_t* proof,
                               uint64_t proof_capacity_words, uint64_t public_inputs_out[12]) {
     Ctx* ctx = ctx_of(h);
     if (!ctx) return GL355_E_INVALID_ARG;
@@ -205,7 +205,7 @@ int32_t gl355_semaphore_prove(gl355_ctx* h, const gl355_circuit_handle* ch, cons
     uint64_t pis[12];
     GL355_TRY(gl355_semaphore_witness(private_key, topic, index, siblings, height, rows.data(), pis));
     if (public_inputs_out) memcpy(public_inputs_out, pis, sizeof pis);
-    return gl355_circuit_prove_rows(h, ch, rows.data(), pis, 12, seed, proof, proof_capacity_words);
+    return gl355_circuit_prove_rows(h, ch, rows.data(), pis, 12, blinding_key, proof, proof_capacity_words);
 }
 
 }  // extern "C"

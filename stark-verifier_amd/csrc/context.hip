@@ -165,13 +165,15 @@ struct gl355_ctx {
     Ctx c;
 };
 
-static std::string g_create_error;
+// text of the last failed gl355_ctx_create on this thread (contexts are created from many threads at once)
+static thread_local std::string g_create_error;
 
 extern "C" {
 
 const char* gl355_version(void) { return "gl355 0.1 (gfx950)"; }
 
 int32_t gl355_device_count(int32_t* out) {
+    if (!out) return GL355_E_INVALID_ARG;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { (void)hipGetLastError(); *out = 0; return GL355_E_NO_DEVICE; }

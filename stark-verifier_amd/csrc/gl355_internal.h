@@ -187,7 +187,7 @@ int32_t open_batch_dev(Ctx* ctx, const uint64_t* lde, uint64_t stride, uint32_t 
 int32_t open_batch_ex_dev(Ctx* ctx, const uint64_t* leaves, uint64_t stride, uint32_t leaf_len, const uint64_t* digests,
                           uint32_t log_n, uint32_t cap_height, const uint64_t* idx_dev, uint32_t idx_shift, uint32_t n_idx,
                           uint64_t* leaves_out, uint64_t leaf_out_stride, uint64_t* sib_out, uint64_t sib_out_stride);
-// second hash back-end (merkle_bn254.hip, host_bn254.hip)
+// second hash back-end (merkle_bn254.hip, host_bn254.cpp)
 void host_bn254_permute(uint64_t state[12]);
 // Merkle tree / PoW with the hasher chosen at run time
 int32_t merkle_build_any(Ctx* ctx, int32_t hasher, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, bool col_major,

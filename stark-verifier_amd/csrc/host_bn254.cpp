@@ -1,7 +1,7 @@
 // Host-side (CPU, sequential) BN254-Poseidon permutation of the 12-element sponge state: what the Fiat-Shamir
 // Challenger and the circuit digest need when the proof's hasher is the reference's Bn254PoseidonHash
 // (src/plonky2_verifier/bn245_poseidon/plonky2_config.rs:38-75, native.rs:16-77).  About 50 permutations per proof, so it
-// runs on the calling thread like the Poseidon-Goldilocks one in host_transcript.hip; the data-parallel work is in
+// runs on the calling thread like the Poseidon-Goldilocks one in host_transcript.cpp; the data-parallel work is in
 // merkle_bn254.hip.  4 x 64-bit limbs with unsigned __int128, Montgomery form (tables: bn254_tables.h, 32-bit limbs).
 #include "gl355_internal.h"
 

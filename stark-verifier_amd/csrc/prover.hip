@@ -8,6 +8,10 @@
 // (src/plonky2_verifier/chip/fri_chip.rs:168-226,275-316; transcript order
 // chip/plonk/plonk_verifier_chip.rs:120-140).  Only the cap (<= 16 digests) crosses PCIe per layer.
 #include "gl355_internal.h"
+#include "blinding.cuh"
+
+#include <errno.h>
+#include <sys/random.h>
 
 using namespace gl355;
 
@@ -122,15 +126,31 @@ extern "C" int32_t gl355_fri_prove(gl355_ctx* h, const uint64_t* final_coeffs, u
 // ================================================================================================
 namespace gl355 {
 
-// counter-based blinding salt: SplitMix64(seed, index) folded into [0, p)
-__global__ void salt_kernel(uint64_t* out, uint64_t n, uint64_t seed) {
-    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    out[i] = gl_canon(z);
+// salt columns of a blinded oracle: thread b writes the four elements of ChaCha20 block b of `stream` (blinding.cuh)
+__global__ void salt_kernel(uint64_t* out, uint64_t n, BlindKey key, uint32_t stream) {
+    const uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (4 * b >= n) return;
+    uint64_t e[4];
+    blind_block_elements(key, stream, (uint32_t)b, e);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (4 * b + j < n) out[4 * b + j] = e[j];
+}
+
+// key == NULL: a fresh 256-bit key from the OS CSPRNG for this proof (what plonky2's OsRng does); else the caller's key
+int32_t resolve_blinding_key(Ctx* ctx, const uint8_t* key, BlindKey* out) {
+    uint8_t buf[32];
+    if (!key) {
+        size_t got = 0;
+        while (got < sizeof buf) {
+            const ssize_t r = getrandom(buf + got, sizeof buf - got, 0);
+            if (r < 0) { if (errno == EINTR) continue; return ctx->fail(GL355_E_UNSUPPORTED, "getrandom failed: no blinding key"); }
+            got += (size_t)r;
+        }
+        key = buf;
+    }
+    *out = blind_key_from_bytes(key);
+    return GL355_OK;
 }
 
 struct OracleGuard {
@@ -182,37 +202,43 @@ __global__ void witness_rows_kernel(uint64_t* wires, uint64_t n, uint32_t num_wi
     const uint32_t r = g / num_wires, c = g % num_wires;
     wires[(uint64_t)c * n + row_idx[r]] = gl_canon(row_vals[g]);
 }
+// element g of the witness-blinding stream: g < n_blind * num_wires fills wire g / n_blind of blinding row g % n_blind,
+// the next n_z_pairs elements are the shared routed value of the Z-blinding row pairs
 __global__ void witness_blind_kernel(uint64_t* wires, uint64_t n, uint32_t num_wires, uint32_t blind_start, uint32_t n_blind,
-                                     uint32_t z_start, uint32_t n_z_pairs, uint64_t seed) {
-    const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+                                     uint32_t z_start, uint32_t n_z_pairs, BlindKey key) {
+    const uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const uint64_t n_a = (uint64_t)n_blind * num_wires;
-    if (g >= n_a + n_z_pairs) return;
-    uint64_t z = seed + (g + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = gl_canon(z ^ (z >> 31));
-    if (g < n_a) {
-        const uint32_t c = g / n_blind, r = g % n_blind;          // every wire of the wire-blinding rows
-        wires[(uint64_t)c * n + blind_start + r] = z;
-    } else {
-        const uint64_t k = g - n_a;                                 // one shared routed value per Z-blinding pair
-        wires[z_start + 2 * k] = z;
-        wires[z_start + 2 * k + 1] = z;
+    if (4 * b >= n_a + n_z_pairs) return;
+    uint64_t e[4];
+    blind_block_elements(key, GL355_BLIND_STREAM_WITNESS, (uint32_t)b, e);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint64_t g = 4 * b + j;
+        if (g < n_a) {
+            const uint32_t c = g / n_blind, r = g % n_blind;          // every wire of the wire-blinding rows
+            wires[(uint64_t)c * n + blind_start + r] = e[j];
+        } else if (g < n_a + n_z_pairs) {
+            const uint64_t k = g - n_a;                                 // one shared routed value per Z-blinding pair
+            wires[z_start + 2 * k] = e[j];
+            wires[z_start + 2 * k + 1] = e[j];
+        }
     }
 }
 
 static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, const uint64_t* d_wires, const uint64_t* public_inputs,
-                          uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words);
+                          uint32_t n_public_inputs, const BlindKey& key, uint64_t* proof, uint64_t proof_capacity_words);
 
 extern "C" int32_t gl355_prove(gl355_ctx* h, const gl355_prover_data* pd, const uint64_t* wires, const uint64_t* public_inputs,
-                               uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words) {
+                               uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof, uint64_t proof_capacity_words) {
     Ctx* ctx = ctx_of(h);
     if (!ctx) return GL355_E_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
     if (!pd || !pd->circuit || !wires) return ctx->fail(GL355_E_INVALID_ARG, "prove: null argument");
     Staged s_wires(ctx);
     GL355_TRY(s_wires.open(wires, ((uint64_t)pd->circuit->num_wires << pd->circuit->degree_bits) * 8, 1));
-    return prove_core(h, ctx, pd, s_wires.as<uint64_t>(), public_inputs, n_public_inputs, seed, proof, proof_capacity_words);
+    BlindKey key;
+    GL355_TRY(resolve_blinding_key(ctx, blinding_key, &key));
+    return prove_core(h, ctx, pd, s_wires.as<uint64_t>(), public_inputs, n_public_inputs, key, proof, proof_capacity_words);
 }
 
 // Witness given as its non-zero rows only (the rest of the 2^degree_bits rows are Noop rows): rows[r] lists
@@ -221,7 +247,7 @@ extern "C" int32_t gl355_prove(gl355_ctx* h, const gl355_prover_data* pd, const 
 // pairs starting at z_start share one random value on routed wire 0 (the builder copy-constrains them).
 extern "C" int32_t gl355_prove_sparse(gl355_ctx* h, const gl355_prover_data* pd, const uint32_t* row_idx, const uint64_t* rows,
                                       uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
-                                      const uint64_t* public_inputs, uint32_t n_public_inputs, uint64_t seed, uint64_t* proof,
+                                      const uint64_t* public_inputs, uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof,
                                       uint64_t proof_capacity_words) {
     Ctx* ctx = ctx_of(h);
     if (!ctx) return GL355_E_INVALID_ARG;
@@ -232,6 +258,8 @@ extern "C" int32_t gl355_prove_sparse(gl355_ctx* h, const gl355_prover_data* pd,
     if ((uint64_t)blind_start + n_blind > n || (uint64_t)z_start + 2ull * n_z_pairs > n) return ctx->fail(GL355_E_INVALID_ARG, "prove_sparse: blinding rows out of range");
     for (uint32_t r = 0; r < n_rows; r++)
         if (row_idx[r] >= n) return ctx->fail(GL355_E_INVALID_ARG, "prove_sparse: row index out of range");
+    BlindKey key;
+    GL355_TRY(resolve_blinding_key(ctx, blinding_key, &key));
     Scratch w(ctx), rbuf(ctx);
     GL355_TRY(w.get((uint64_t)nw * n * 8));
     GL355_HIP(ctx, hipMemsetAsync(w.p, 0, (uint64_t)nw * n * 8, ctx->stream));
@@ -250,16 +278,16 @@ extern "C" int32_t gl355_prove_sparse(gl355_ctx* h, const gl355_prover_data* pd,
     const uint64_t cnt_b = (uint64_t)n_blind * nw + n_z_pairs;
     if (cnt_b) {
         ProfScope ps(ctx, "witness_blind", cnt_b * 8);
-        hipLaunchKernelGGL(witness_blind_kernel, dim3((uint32_t)((cnt_b + 255) / 256)), dim3(256), 0, ctx->stream, w.as<uint64_t>(), n, nw,
-                           blind_start, n_blind, z_start, n_z_pairs, seed * 0xA24BAED4963EE407ull + 0x9FB21C651E98DF25ull);
+        hipLaunchKernelGGL(witness_blind_kernel, dim3((uint32_t)((cnt_b / 4 + 256) / 256)), dim3(256), 0, ctx->stream, w.as<uint64_t>(), n, nw,
+                           blind_start, n_blind, z_start, n_z_pairs, key);
         GL355_HIP(ctx, hipGetLastError());
     }
     GL355_HIP(ctx, ctx->wait());  // host row buffers may be reused by the caller
-    return prove_core(h, ctx, pd, w.as<uint64_t>(), public_inputs, n_public_inputs, seed, proof, proof_capacity_words);
+    return prove_core(h, ctx, pd, w.as<uint64_t>(), public_inputs, n_public_inputs, key, proof, proof_capacity_words);
 }
 
 static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, const uint64_t* d_wires, const uint64_t* public_inputs,
-                          uint32_t n_public_inputs, uint64_t seed, uint64_t* proof, uint64_t proof_capacity_words) {
+                          uint32_t n_public_inputs, const BlindKey& key, uint64_t* proof, uint64_t proof_capacity_words) {
     const uint64_t* wires = d_wires;
     if (!pd || !pd->circuit || !pd->constants_sigmas || !pd->sigmas || !pd->k_is || !wires || !proof || (!public_inputs && n_public_inputs))
         return ctx->fail(GL355_E_INVALID_ARG, "prove: null argument");
@@ -296,18 +324,17 @@ static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, c
     GL355_TRY(s_k.open(pd->k_is, (uint64_t)routed * 8, 1));
     Scratch salt(ctx);
     if (zk) GL355_TRY(salt.get((uint64_t)GL355_SALT_SIZE * N * 8));
-    auto fresh_salt = [&](uint64_t stream_id) -> int32_t {
+    auto fresh_salt = [&](uint32_t stream_id) -> int32_t {
         const uint64_t cnt = (uint64_t)GL355_SALT_SIZE * N;
         ProfScope ps(ctx, "salt", cnt * 8);
-        hipLaunchKernelGGL(salt_kernel, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, salt.as<uint64_t>(), cnt,
-                           seed * 0x100000001B3ull + stream_id * 0xD6E8FEB86659FD93ull);
+        hipLaunchKernelGGL(salt_kernel, dim3((uint32_t)((cnt / 4 + 255) / 256)), dim3(256), 0, ctx->stream, salt.as<uint64_t>(), cnt, key, stream_id);
         GL355_HIP(ctx, hipGetLastError());
         return GL355_OK;
     };
 
     // ---- wires ----------------------------------------------------------------------------------
     OracleGuard g_w, g_z, g_q;
-    if (zk) GL355_TRY(fresh_salt(1));
+    if (zk) GL355_TRY(fresh_salt(GL355_BLIND_STREAM_WIRES_SALT));
     GL355_TRY(gl355_commit_h(h, hasher, wires, c.degree_bits, c.num_wires, c.rate_bits, 0, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_w.o));
     uint64_t* p_wires_cap = out; out += n_cap * 4;
     GL355_TRY(observe_cap(ctx, g_w.o, &ch, p_wires_cap));
@@ -324,7 +351,7 @@ static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, c
         GL355_TRY(zs_partial_products_dev(ctx, wires, s_sig.as<uint64_t>(), s_k.as<uint64_t>(), c.degree_bits, routed, qdf,
                                           betas[k], gammas[k], z, pp));
     }
-    if (zk) GL355_TRY(fresh_salt(2));
+    if (zk) GL355_TRY(fresh_salt(GL355_BLIND_STREAM_ZS_SALT));
     GL355_TRY(gl355_commit_h(h, hasher, zbuf.as<uint64_t>(), c.degree_bits, z_width, c.rate_bits, 0, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_z.o));
     uint64_t* p_zs_cap = out; out += n_cap * 4;
     GL355_TRY(observe_cap(ctx, g_z.o, &ch, p_zs_cap));
@@ -338,7 +365,7 @@ static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, c
     GL355_TRY(qc.get((uint64_t)nch * nq * 8));
     GL355_TRY(quotient_dev(ctx, &c, cs->lde, g_w.o->lde, g_z.o->lde, N, s_k.as<uint64_t>(), betas, gammas, alphas, pi_hash, qv.as<uint64_t>()));
     GL355_TRY(intt_from_bitrev_dev(ctx, qv.as<uint64_t>(), nq, qc.as<uint64_t>(), nq, c.degree_bits + qdb, nch, GL355_COSET_SHIFT));
-    if (zk) GL355_TRY(fresh_salt(3));
+    if (zk) GL355_TRY(fresh_salt(GL355_BLIND_STREAM_QUOTIENT_SALT));
     GL355_TRY(gl355_commit_h(h, hasher, qc.as<uint64_t>(), c.degree_bits, nch * qdf, c.rate_bits, 1, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_q.o));
     uint64_t* p_q_cap = out; out += n_cap * 4;
     GL355_TRY(observe_cap(ctx, g_q.o, &ch, p_q_cap));
@@ -405,4 +432,30 @@ static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, c
     }
     if ((uint64_t)(out - proof) != need) return ctx->fail(GL355_E_HIP, "prove: internal proof-size mismatch");
     return GL355_OK;
+}
+
+// ---- blinding-stream surface (blinding.cuh) ----------------------------------------------------------------------------
+// per-unit key of a batch: first 32 bytes of ChaCha20 block 0 under the batch key with nonce ("key", index_lo, index_hi)
+extern "C" int32_t gl355_derive_key(const uint8_t base_key[32], uint64_t index, uint8_t out[32]) {
+    if (!base_key || !out) return GL355_E_INVALID_ARG;
+    uint32_t o[16];
+    chacha20_block(blind_key_from_bytes(base_key), 0, GL355_BLIND_NONCE_KEY, (uint32_t)index, (uint32_t)(index >> 32), o);
+    for (int i = 0; i < 8; i++)
+        for (int b = 0; b < 4; b++) out[4 * i + b] = (uint8_t)(o[i] >> (8 * b));
+    return GL355_OK;
+}
+// the first `count` field elements of blinding stream `stream` under `key`, produced by the device kernel the prover uses
+extern "C" int32_t gl355_blinding_elements(gl355_ctx* h, const uint8_t key[32], uint32_t stream, uint64_t count, uint64_t* out) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+    if (!key || (!out && count)) return ctx->fail(GL355_E_INVALID_ARG, "blinding_elements: null argument");
+    if (count == 0) return GL355_OK;
+    if (count > (1ull << 34)) return ctx->fail(GL355_E_UNSUPPORTED, "blinding_elements: a stream holds 2^34 elements");
+    Staged so(ctx);
+    GL355_TRY(so.open(out, count * 8, 2));
+    hipLaunchKernelGGL(salt_kernel, dim3((uint32_t)((count / 4 + 256) / 256)), dim3(256), 0, ctx->stream, so.as<uint64_t>(), count,
+                       blind_key_from_bytes(key), stream);
+    GL355_HIP(ctx, hipGetLastError());
+    return so.finish();
 }

@@ -28,7 +28,7 @@ static int32_t run_entries(const uint64_t* tape, uint64_t begin, uint64_t end, c
     uint64_t* W = rows;
     const uint64_t n_ops = end;
 #define CHK(i, span)                                                        \
-    if ((uint64_t)(i) + (span) > n_words) {                                   \
+    if ((uint64_t)(i) >= n_words || (uint64_t)(span) > n_words - (uint64_t)(i)) { /* no wrap for offsets near 2^64 */ \
         if (failed_op) *failed_op = t;                                        \
         return GL355_E_INVALID_ARG;                                           \
     }

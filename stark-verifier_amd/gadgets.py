@@ -25,7 +25,7 @@ from .plonk import CircuitBuilder, CircuitConfig, P, host_hash_no_pad, poseidon_
 RA_PARAM = 4 | 4 << 8 | 2 << 16
 CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
 
-# witness-tape opcodes (include/gl355.h GL355_TAPE_*, interpreter: csrc/witness_tape.hip).  Every builder
+# witness-tape opcodes (include/gl355.h GL355_TAPE_*, interpreter: csrc/witness_tape.cpp).  Every builder
 # primitive appends the entries that recompute its wires from earlier wires, so a circuit built once can be
 # re-witnessed for new inputs by gl355_witness_replay without running the Python gadgets again.
 (TAPE_CONST, TAPE_INPUT, TAPE_COPY, TAPE_ASSERT_EQ, TAPE_ARITH, TAPE_ARITH_EXT, TAPE_POSEIDON, TAPE_MDS_EXT,

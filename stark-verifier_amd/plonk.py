@@ -263,13 +263,39 @@ _GATE_CONSTRAINTS = {
 }
 
 
+def key_bytes(seed):
+    """the 32-byte blinding key of an integer test seed: its little-endian encoding (tests, tools, reproducible benches).
+    Production callers pass None (the library draws the key from the OS CSPRNG) or their own secret 32 bytes."""
+    if isinstance(seed, (bytes, bytearray)):
+        if len(seed) != 32:
+            raise ValueError("a blinding key is 32 bytes")
+        return bytes(seed)
+    return (int(seed) % (1 << 256)).to_bytes(32, "little")
+
+
+def blinding_key(seed):
+    """seed -> the `const uint8_t* blinding_key` argument of the C ABI: None stays NULL (fresh OS randomness per proof)"""
+    if seed is None:
+        return None
+    return C.cast(C.create_string_buffer(key_bytes(seed), 32), C.c_void_p)
+
+
+def derive_key(base, index):
+    """gl355_derive_key: the per-unit key the batch runtime uses for proof `index` of a batch keyed with `base`"""
+    out = C.create_string_buffer(32)
+    rc = _lib.load().gl355_derive_key(key_bytes(base), C.c_uint64(int(index)), out)
+    if rc != 0:
+        raise _lib.Gl355Error(rc, "gl355_derive_key")
+    return out.raw
+
+
 class CircuitData:
     """The prover/verifier data of one built circuit (plonky2 CircuitData / CommonCircuitData)."""
 
     def set_digest(self, constants_sigmas_cap):
         """circuit digest: hash of the preprocessed commitment and the shape (this framework's own definition;
         plonky2's digest additionally covers its builder's domain separator)"""
-        shape = [self.degree_bits, len(self.gates), self.num_selectors] + [t * 1000 + p for t, p in self.gates]
+        shape = [self.degree_bits, len(self.gates), self.num_selectors] + [(t << 32) | p for t, p in self.gates]
         self.constants_sigmas_cap = np.array(constants_sigmas_cap, dtype=np.uint64).reshape(-1, 4)
         self.circuit_digest = host_hash_no_pad(np.concatenate([np.asarray(constants_sigmas_cap, dtype=np.uint64).reshape(-1),
                                                                np.array(shape, dtype=np.uint64)]), self.config.hasher)
@@ -452,7 +478,7 @@ class NativeCircuit:
     def prove_rows(self, ctx, rows, public_inputs, seed):
         rows, pi = _u64(rows), _u64(public_inputs)
         flat = np.empty(self.proof_words, dtype=np.uint64)
-        ctx.check(ctx.lib.gl355_circuit_prove_rows(ctx.h, self.h, _ptr(rows), _ptr(pi), pi.size, int(seed) & ((1 << 64) - 1), _ptr(flat), flat.size))
+        ctx.check(ctx.lib.gl355_circuit_prove_rows(ctx.h, self.h, _ptr(rows), _ptr(pi), pi.size, blinding_key(seed), _ptr(flat), flat.size))
         return flat
 
     def prove_tape(self, ctx, inputs, seed):
@@ -460,7 +486,7 @@ class NativeCircuit:
         inputs = _u64(inputs)
         flat = np.empty(self.proof_words, dtype=np.uint64)
         pis = np.empty(self.n_public_inputs, dtype=np.uint64)
-        ctx.check(ctx.lib.gl355_circuit_prove_tape(ctx.h, self.h, _ptr(inputs), inputs.size, int(seed) & ((1 << 64) - 1), _ptr(flat), flat.size,
+        ctx.check(ctx.lib.gl355_circuit_prove_tape(ctx.h, self.h, _ptr(inputs), inputs.size, blinding_key(seed), _ptr(flat), flat.size,
                                                    _ptr(pis)))
         return flat, pis
 
@@ -468,7 +494,7 @@ class NativeCircuit:
         sk, tp, sib = _u64(private_key), _u64(topic), _u64(siblings)
         flat = np.empty(self.proof_words, dtype=np.uint64)
         pis = np.empty(12, dtype=np.uint64)
-        ctx.check(ctx.lib.gl355_semaphore_prove(ctx.h, self.h, _ptr(sk), _ptr(tp), int(index), _ptr(sib), sib.shape[0], int(seed) & ((1 << 64) - 1),
+        ctx.check(ctx.lib.gl355_semaphore_prove(ctx.h, self.h, _ptr(sk), _ptr(tp), int(index), _ptr(sib), sib.shape[0], blinding_key(seed),
                                                 _ptr(flat), flat.size, _ptr(pis)))
         return flat, pis
 
@@ -498,7 +524,7 @@ def semaphore_units(ctxs, sem, rec, private_keys, topic, tree_digests, member_in
     proofs = np.empty((idx.size, words), dtype=np.uint64) if want_proofs else None
     per = (C.c_uint32 * len(ctxs))()
     rc = lib.gl355_semaphore_units(hs, len(ctxs), sem.h, rec.h if rec is not None else None, _ptr(sk), sk.shape[0], _ptr(tp), _ptr(dg),
-                                   _ptr(idx), idx.size, int(seed_base) & ((1 << 64) - 1), _ptr(leaves), _ptr(proofs) if want_proofs else None, per)
+                                   _ptr(idx), idx.size, blinding_key(seed_base), _ptr(leaves), _ptr(proofs) if want_proofs else None, per)
     if rc != 0:
         msgs = [(c.lib.gl355_last_error(c.h) or b"").decode() for c in ctxs]
         raise _lib.Gl355Error(rc, "; ".join(m for m in msgs if m))
@@ -514,7 +540,7 @@ def prove(ctx, data, wires, public_inputs, seed, flat_only=False):
     words = lib.gl355_proof_words(C.byref(pd))
     flat = np.empty(words, dtype=np.uint64)
     w = wires if hasattr(wires, "data_ptr") else np.ascontiguousarray(wires, dtype=np.uint64)
-    ctx.check(lib.gl355_prove(ctx.h, C.byref(pd), _ptr(w), _ptr(pi), pi.size, int(seed) & ((1 << 64) - 1), _ptr(flat), words))
+    ctx.check(lib.gl355_prove(ctx.h, C.byref(pd), _ptr(w), _ptr(pi), pi.size, blinding_key(seed), _ptr(flat), words))
     if flat_only:
         return flat
     proof = parse_proof(data, flat)
@@ -534,7 +560,7 @@ def prove_sparse(ctx, data, row_idx, rows, public_inputs, seed, flat_only=False)
     start, n_blind, z_pairs, _ = data.blind_rows
     z_start = z_pairs[0][0] if z_pairs else 0
     ctx.check(lib.gl355_prove_sparse(ctx.h, C.byref(pd), idx.ctypes.data_as(C.c_void_p), _ptr(rows), idx.size, start, n_blind,
-                                     z_start, len(z_pairs), _ptr(pi), pi.size, int(seed) & ((1 << 64) - 1), _ptr(flat), words))
+                                     z_start, len(z_pairs), _ptr(pi), pi.size, blinding_key(seed), _ptr(flat), words))
     if flat_only:
         return flat
     proof = parse_proof(data, flat)

@@ -6,6 +6,9 @@ import pytest
 
 # torch bundles its own ROCm runtime: let it initialise HIP BEFORE libgl355.so pulls in the system
 # libamdhip64, otherwise torch later reports "No HIP GPUs are available" in the same process.
+# one hardware queue per prover context for the many-contexts tests (read by the HIP runtime when it starts; the product's own
+# way to set it is gl355_runtime_config, which must run before HIP is initialised -- here torch initialises it first)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 try:
     import torch
     torch.cuda.is_available() and torch.cuda.init()

@@ -17,7 +17,8 @@ def build_case(orc, log_members, seed, config=None):
     sem = importlib.import_module("stark-verifier_amd.semaphore")
     rng = np.random.default_rng(seed)
     sks = rand_field(rng, (1 << log_members, 4))
-    keys = np.stack([orc.hash_no_pad(np.concatenate([sk, np.zeros(4, np.uint64)])) for sk in sks])    # signal.rs:32-39
+    # public keys = hash_no_pad(sk | 0^4) (signal.rs:32-39): the all-cap "tree" over the 8-element leaves is exactly that batch of hashes
+    keys = orc.merkle_build(np.concatenate([sks, np.zeros_like(sks)], axis=1), log_members)[1]
     digests, cap = orc.merkle_build(keys, 0)
     builder = plonk.CircuitBuilder(config or plonk.CircuitConfig())
     rows = sem.semaphore_circuit(builder, log_members)

@@ -10,6 +10,7 @@
   semaphore_proof.json  SHA-256 of the flat proof of one depth-2 Semaphore signal (tests/cpu_semaphore.py GOLDEN_CASE),
                       minted by the CPU restatement of prove() AFTER the restated reference verifier accepted it; the
                       CPU suite re-derives it, the GPU suite requires the product's proof to hash to the same value.
+  unit_depth20.json   SHA-256 of the two proofs of one depth-20 unit (tests/cpu_unit.py UNIT_CASE), same rule.
 Run: python tests/golden/make_golden.py
 """
 import json
@@ -52,6 +53,26 @@ def mint_semaphore_proof():
                "public_inputs": ["%016x" % int(x) for x in pi]}, open(os.path.join(HERE, "semaphore_proof.json"), "w"), indent=1)
 
 
+def mint_unit_depth20():
+    """unit_depth20.json: BASELINE configs[3] at its stated size -- one depth-20 Semaphore signal (2^20 members, signer 12) and the
+    recursive proof verifying it, both from the CPU restatement of prove(), minted only after the restated reference verifier
+    accepted both.  The GPU suite must reproduce both proofs byte for byte (tests/test_gpu_large.py)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import cpu_semaphore as cs
+    import cpu_unit as cu
+    import plonk_verifier as pv
+    from oracle_lib import Oracle
+    orc = Oracle()
+    case, topic, flat, pi, rc, outer, opis = cu.cpu_unit(orc)
+    for data, f, p in ((case["data"], flat, pi), (rc["data"], outer, opis)):
+        proof = case["plonk"].parse_proof(data, f)
+        proof["public_inputs"] = p
+        pv.verify(orc, data.common(), proof)
+    json.dump({"case": cu.UNIT_CASE, "semaphore_words": int(flat.size), "semaphore_sha256": cs.digest_of(flat),
+               "recursive_words": int(outer.size), "recursive_sha256": cs.digest_of(outer), "recursive_degree_bits": int(rc["data"].degree_bits),
+               "public_inputs": ["%016x" % int(x) for x in opis]}, open(os.path.join(HERE, "unit_depth20.json"), "w"), indent=1)
+
+
 def mint_bn254_kat():
     """poseidon_bn254_kat.json: (1) the published circomlib known answer poseidon([1,2,3,4]) for t = 5 -- the script refuses to
     write unless the big-integer model with the reference's parameters reproduces it; (2) permutation / hash vectors of the
@@ -76,6 +97,7 @@ def mint_bn254_kat():
 
 def main():
     mint_semaphore_proof()
+    mint_unit_depth20()
     mint_bn254_kat()
     kat = {"permute": []}
     for name, (inp, want) in UPSTREAM.items():

@@ -223,6 +223,14 @@ class Oracle:
         return z, pp
 
 
+def key_bytes(seed):
+    """32-byte blinding key of an integer test seed (little-endian), the same convention as stark-verifier_amd.plonk.key_bytes"""
+    if isinstance(seed, (bytes, bytearray)):
+        assert len(seed) == 32
+        return bytes(seed)
+    return (int(seed) % (1 << 256)).to_bytes(32, "little")
+
+
 def rand_field(rng, shape):
     """uniform in [0, p) by rejection (SplitMix-style seeds, values < p)."""
     a = rng.integers(0, 1 << 64, size=shape, dtype=np.uint64, endpoint=False)
@@ -301,7 +309,7 @@ class CpuProver:
     def prove(self, wires, public_inputs, seed):
         wires, pi = u64(wires), u64(public_inputs)
         flat = np.zeros(self.words, dtype=np.uint64)
-        rc = self.L.orc_prove(C.byref(self.pd), _p(wires), _p(pi), C.c_uint32(pi.size), C.c_uint64(seed & ((1 << 64) - 1)), _p(flat))
+        rc = self.L.orc_prove(C.byref(self.pd), _p(wires), _p(pi), C.c_uint32(pi.size), key_bytes(seed), _p(flat))
         assert rc == 0
         return flat
 
@@ -313,7 +321,7 @@ class CpuProver:
         flat = np.zeros(self.words, dtype=np.uint64)
         rc = self.L.orc_prove_sparse(C.byref(self.pd), idx.ctypes.data_as(C.POINTER(C.c_uint32)), _p(rows), C.c_uint32(idx.size),
                                      C.c_uint32(start), C.c_uint32(n_blind), C.c_uint32(z_start), C.c_uint32(len(z_pairs)), _p(pi),
-                                     C.c_uint32(pi.size), C.c_uint64(seed & ((1 << 64) - 1)), _p(flat))
+                                     C.c_uint32(pi.size), key_bytes(seed), _p(flat))
         assert rc == 0
         return flat
 

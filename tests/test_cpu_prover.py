@@ -22,7 +22,7 @@ def test_cpu_semaphore_proof_verifies_and_matches_golden(orc):
     assert np.array_equal(pi[:4], case["root"]) and np.array_equal(pi[8:], topic)
     assert np.array_equal(pi[4:8], orc.hash_no_pad(np.concatenate([case["sks"][member], topic])))
     assert np.array_equal(data.circuit_digest, orc.hash_no_pad(np.concatenate([
-        case["cpu"].cap().reshape(-1), np.array([data.degree_bits, len(data.gates), data.num_selectors] + [t * 1000 + p for t, p in data.gates], dtype=np.uint64)])))
+        case["cpu"].cap().reshape(-1), np.array([data.degree_bits, len(data.gates), data.num_selectors] + [(t << 32) | p for t, p in data.gates], dtype=np.uint64)])))
     proof = plonk.parse_proof(data, flat)
     proof["public_inputs"] = pi
     ch = pv.verify(orc, data.common(), proof)

@@ -124,3 +124,16 @@ def test_recursive_proof_of_a_cpu_semaphore_proof(orc):
     assert rc == -6 and failed.value == where
     assert lib.gl355_witness_replay_segmented(tape.ctypes.data, tape.shape[0], n_seq + 1, seg.ctypes.data, seg.size, 4, badin.ctypes.data,
                                               badin.size, prow.ctypes.data, prow.size, 135, None) == -1
+
+
+def test_depth20_unit_matches_golden(orc):
+    """BASELINE configs[3] at its stated size on the CPU side: 2^20-member access set, signer 12 (signal.rs:42), Semaphore proof
+    + recursive proof by the CPU restatement of prove() hash to tests/golden/unit_depth20.json (the GPU suite requires the
+    product's proofs of the same unit to hash to the same values)"""
+    import json, os
+    import cpu_unit as cu
+    case, topic, flat, pi, rc, outer, opis = cu.cpu_unit(orc)
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "unit_depth20.json")))
+    assert golden["case"] == cu.UNIT_CASE and rc["data"].degree_bits == golden["recursive_degree_bits"] == 14
+    assert cs.digest_of(flat) == golden["semaphore_sha256"] and cs.digest_of(outer) == golden["recursive_sha256"]
+    assert np.array_equal(opis[:4], case["root"]) and np.array_equal(opis[8:], topic)      # root | nullifier | topic re-exposed

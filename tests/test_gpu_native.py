@@ -84,7 +84,7 @@ def test_artifact_validation(gl, ctx):
 
 
 def test_native_batch_runtime(gl, ctx, orc):
-    """gl355_semaphore_units: every unit's proofs equal the ones made call by call (same seeds), the leaves are the
+    """gl355_semaphore_units: every unit's proofs equal the ones made call by call (per-unit keys = gl355_derive_key of the batch key), the leaves are the
     re-exposed nullifier | topic, bad member indices are refused"""
     plonk = importlib.import_module("stark-verifier_amd.plonk")
     rec = importlib.import_module("stark-verifier_amd.recursion")
@@ -101,8 +101,8 @@ def test_native_batch_runtime(gl, ctx, orc):
     leaves, proofs, per = plonk.semaphore_units(ctxs, sem, nat, sks, topic, aset.tree.digests, members, 1000, want_proofs=True)
     assert sum(per) == members.size and all(0 <= k <= members.size for k in per)      # units are handed out one at a time
     for j, m in enumerate(members):
-        f, p = sem.semaphore_prove(ctx, sks[m], topic, int(m), aset.tree.prove_host(int(m)), 1000 + 2 * j)
-        o, op = nat.prove_tape(ctx, np.concatenate([f, p]), 1000 + 2 * j + 1)
+        f, p = sem.semaphore_prove(ctx, sks[m], topic, int(m), aset.tree.prove_host(int(m)), plonk.derive_key(1000, 2 * j))
+        o, op = nat.prove_tape(ctx, np.concatenate([f, p]), plonk.derive_key(1000, 2 * j + 1))
         assert np.array_equal(proofs[j], o) and np.array_equal(leaves[j], op[4:12])
         assert np.array_equal(leaves[j, :4], orc.hash_no_pad(np.concatenate([sks[m], topic]))) and np.array_equal(leaves[j, 4:], topic)
     # signals only (no verifier circuit)
