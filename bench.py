@@ -300,6 +300,72 @@ def lde_figure(gl, device, steps=8):
                          "kernels_ms_per_launch": {k: round(v[1] / max(1, v[0]), 4) for k, v in prof.items()}}}
 
 
+class _TorchComm:
+    """stand-in with the Comm interface over torch.distributed -- used ONLY if some rank cannot bind librccl for the gl355
+    communicator (reported in the JSON line as config.exchange); the product's exchange is gl355_gather_digests"""
+
+    def __init__(self, dist, dev):
+        self.dist, self.dev, self.backend_name = dist, dev, "torch.distributed (gl355 RCCL communicator unavailable on some rank)"
+
+    def gather(self, local):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.uint64).view(np.int64)).to(self.dev)
+        parts = [torch.empty_like(t) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(parts, t)
+        return torch.cat(parts, dim=0).cpu().numpy().view(np.uint64)
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max(self, v):
+        import torch
+        t = torch.tensor([v], dtype=torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+def open_comm(lib, par, ctx, rank, world, rehearsal, dev=None):
+    """The exchange of the N > 1 job through the C ABI (gl355_comm_*): RCCL over xGMI, or TCP between the host processes in the
+    one-device rehearsal.  The 128-byte communicator id travels through the launcher's key-value store (torchrun's TCPStore,
+    MASTER_ADDR / MASTER_PORT) -- plumbing a Rust host would do with its own launcher; no torch collective is involved."""
+    if world == 1:
+        return None
+    from datetime import timedelta
+    from torch.distributed import PrefixStore, TCPStore
+    addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"])
+    agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    store = TCPStore(addr, port, world, (rank == 0 and not agent_store), timedelta(seconds=300), multi_tenant=True)
+    store = PrefixStore("gl355_bench/%s" % os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), store)
+    backend = par.COMM_HOST if rehearsal else par.COMM_RCCL
+    # phase 1: can every rank bind its communicator library?  (a rank that cannot must not leave the others inside ncclCommInitRank)
+    ok, cid, why = True, b"", ""
+    try:
+        if backend == par.COMM_HOST:
+            import socket
+            if rank == 0:
+                s = socket.socket(); s.bind((addr if addr[0].isdigit() else "127.0.0.1", 0)); hp = s.getsockname()[1]; s.close()
+                cid = par.Comm.unique_id(lib, backend, addr if addr[0].isdigit() else "127.0.0.1", hp)
+        else:
+            cid = par.Comm.unique_id(lib, backend)          # every rank: proves librccl binds here; rank 0's id is the one used
+    except Exception as exc:
+        ok, why = False, repr(exc)
+    store.set("ok/%d" % rank, b"1" if ok else why.encode()[:200] or b"0")
+    if rank == 0 and ok:
+        store.set("id", cid)
+    flags = [bytes(store.get("ok/%d" % r)) for r in range(world)]
+    if all(f == b"1" for f in flags):
+        comm = par.Comm(ctx, backend, bytes(store.get("id")), rank, world, lib=lib)
+        comm.backend_name = "gl355_gather_digests over RCCL (ncclAllGather)" if backend == par.COMM_RCCL else "gl355_gather_digests over TCP (one-device rehearsal)"
+        return comm
+    sys.stderr.write("[bench] rank %d: gl355 communicator unavailable (%s); using torch.distributed for the exchange\n" % (rank, [f for f in flags if f != b"1"][:1]))
+    import torch.distributed as dist
+    dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world, **({} if rehearsal else {"device_id": dev}))
+    return _TorchComm(dist, dev)
+
+
 def main_recursive(args):
     """units sharded over ranks (recursion.rs:300-308: one block of members per GPU), no collective on the data path; one RCCL
     all_gather of the (nullifier | topic) leaves per step and the aggregation root on rank 0."""
@@ -327,13 +393,6 @@ def main_recursive(args):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     gl = importlib.import_module("stark-verifier_amd")
     par = importlib.import_module("stark-verifier_amd.parallel")
     blocking = sleeping_waits
@@ -341,15 +400,18 @@ def main_recursive(args):
     # meanwhile); its FRI-query segments replay on 2 threads when the waits sleep and cores are to spare (191 -> 195 proofs/s)
     replay_threads = int(os.environ.get("GL355_BENCH_REPLAY_THREADS", 2 if (sleeping_waits and cores_per_rank >= 8) else 1))
     pr = RecursiveProvers(gl, local_rank, n_threads, args.log_members, replay_threads=replay_threads)
+    comm = open_comm(lib, par, pr.sets[0], rank, world, rehearsal, dev)
     per = args.proofs_per_step
     total = per * world
     lo, hi = par.shard_range(total, rank, world)
     for w in range(args.warmup):
         pr.prove_batch(1000 + w * total + lo, hi - lo)
+        if comm is not None:
+            comm.gather(np.zeros((hi - lo, 8), dtype=np.uint64))       # warm the communicator's first-use set-up as well
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
         torch.cuda.synchronize()
     pr.profile(True)
     barrier()
@@ -359,20 +421,17 @@ def main_recursive(args):
     root = None
     for step in range(args.steps):
         leaves = pr.prove_batch(5000 + step * total + lo, hi - lo)
-        lt = torch.from_numpy(leaves.view(np.int64)).to(dev)
-        allv = par.gather_leaves(lt, dist)
+        allv = comm.gather(leaves) if comm is not None else leaves          # gl355_gather_digests: 64 B per unit, rank order
         if rank == 0:
-            root = par.aggregation_root(pr.sets[0], allv.cpu().numpy().view(np.uint64))
+            root = par.aggregation_root(pr.sets[0], allv)                   # gl355_aggregation_root
     barrier()
     elapsed = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)   # rank 0's process, spinning waits included
     prof, local_units = pr.profile_read()
     pr.profile(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = comm.max(elapsed)                                         # gl355_comm_max_f64
     if rank == 0:
         units = total * args.steps
         # ---- roofline pass: the same units on ONE prover context right after the timed region.  With 12 streams sharing the
@@ -417,6 +476,7 @@ def main_recursive(args):
                                    "prover contexts per GPU; all_gather of (nullifier|topic) + Poseidon aggregation root per step"
                                    % (args.log_members, pr.rc.data.degree_bits, per, n_threads),
                        "parallelism": "independent proofs sharded over ranks, no data-path collective",
+                       "exchange": getattr(comm, "backend_name", "none (one rank): gl355_aggregation_root over the local leaves"),
                        "host": "%d usable host cores per rank, %s device waits, %d tape-replay thread(s) per context" % (
                            cores_per_rank, "sleeping (hipDeviceScheduleBlockingSync)" if blocking else "spinning", replay_threads),
                        "host_cpu_ms_per_unit": round(1e3 * host_cpu_s / max(1, (hi - lo) * args.steps), 2),
@@ -464,9 +524,9 @@ def main_recursive(args):
             except Exception as exc:
                 line["ntt_lde"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 def main():
@@ -506,14 +566,11 @@ def main_lde(args):
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
     gl = importlib.import_module("stark-verifier_amd")
+    par = importlib.import_module("stark-verifier_amd.parallel")
     ctx = gl.Context(local_rank)
     lib = ctx.lib
+    comm = open_comm(lib, par, ctx, rank, world, False, dev)
     n, N = 1 << LOG_N, 1 << (LOG_N + RATE_BITS)
 
     # synthetic coefficients, uniform in [0, p) up to the negligible rejection tail (seeded per rank)
@@ -532,8 +589,8 @@ def main_lde(args):
     ctx.sync()
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
         torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides ----------------------
@@ -549,33 +606,18 @@ def main_lde(args):
     ctx.check(lib.gl355_hash_no_pad(ctx.h, C.c_void_p(out.data_ptr()), 1, 8, C.c_void_p(digest.data_ptr())))
     ctx.sync()
     root = None
-    if dist is not None:
-        gathered = [torch.empty_like(digest) for _ in range(world)]
-        dist.all_gather(gathered, digest)
+    if comm is not None:
+        allv = comm.gather(digest.cpu().numpy().view(np.uint64).reshape(1, 4))          # gl355_gather_digests: one digest per rank
         if rank == 0:
-            leaves = torch.stack(gathered).contiguous()
-            pad = 1
-            while pad < world:
-                pad *= 2
-            if pad != world:
-                leaves = torch.cat([leaves, torch.zeros((pad - world, 4), dtype=torch.int64, device=dev)])
-            capbuf = torch.empty(4, dtype=torch.int64, device=dev)
-            digs = torch.empty((max(1, 2 * (pad - 1)), 4), dtype=torch.int64, device=dev)
-            torch.cuda.synchronize()
-            ctx.check(lib.gl355_merkle_build(ctx.h, C.c_void_p(leaves.data_ptr()), pad, 4, 0, C.c_void_p(digs.data_ptr()),
-                                             C.c_void_p(capbuf.data_ptr())))
-            ctx.sync()
-            root = [int(x) & ((1 << 64) - 1) for x in capbuf.cpu().tolist()]
+            root = [int(x) for x in par.aggregation_root(ctx, allv)[0]]
     barrier()
     t1 = time.perf_counter()
     prof = {k: v for k, v in ctx.profile_read().items() if not k.startswith("host:")}
     ctx.profile_enable(False)
 
     elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = comm.max(elapsed)
 
     if rank == 0:
         alg_bytes_step = 8.0 * BATCH * (n + N)
@@ -617,9 +659,9 @@ def main_lde(args):
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 def main_semaphore(args):
@@ -631,13 +673,10 @@ def main_semaphore(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     gl = importlib.import_module("stark-verifier_amd")
     par = importlib.import_module("stark-verifier_amd.parallel")
     pr = SemaphoreProvers(gl, local_rank, args.threads)
+    comm = open_comm(pr.sets[0].ctx.lib, par, pr.sets[0].ctx, rank, world, False, dev)
     per = args.proofs_per_step
     total = per * world
     lo, hi = par.shard_range(total, rank, world)
@@ -645,8 +684,8 @@ def main_semaphore(args):
         pr.prove_batch(1000 + lo, hi - lo)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
         torch.cuda.synchronize()
     barrier()
     import resource
@@ -655,16 +694,13 @@ def main_semaphore(args):
     root = None
     for step in range(args.steps):
         leaves = pr.prove_batch(2000 + step * total + lo, hi - lo)
-        lt = torch.from_numpy(leaves.view(np.int64)).to(dev)
-        allv = par.gather_leaves(lt, dist)
+        allv = comm.gather(leaves) if comm is not None else leaves
         if rank == 0:
-            root = par.aggregation_root(pr.sets[0].ctx, allv.cpu().numpy().view(np.uint64))
+            root = par.aggregation_root(pr.sets[0].ctx, allv)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = comm.max(elapsed)
     if rank == 0:
         line = {"metric": "plonky2 proofs/sec (Semaphore d=20, no recursive wrap)", "value": round(total * args.steps / elapsed, 2),
                 "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -674,9 +710,9 @@ def main_semaphore(args):
                                        "all_gather of (nullifier|topic) leaves + Poseidon aggregation root per step" % (per, args.threads)},
                 "aggregation_root": ["%016x" % int(x) for x in root[0]]}
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -3,6 +3,11 @@
 //
 //   tools/export_artifacts.py <dir> [log_members]      writes <dir>/semaphore.gl355 and <dir>/recursive.gl355 (once per shape)
 //   examples/native_units <dir> [log_members] [contexts] [units]
+//   examples/native_units <dir> <log_members> <contexts> <units> --ranks <world> <rank> <id file> [--host-comm <port>]
+//       one process per GPU (rank r proves on device r and takes block r of the units); the only exchange is
+//       gl355_gather_digests of the (nullifier | topic) leaves, then rank 0 folds them with gl355_aggregation_root.  Rank 0 mints
+//       the communicator id and writes it to <id file>, the other ranks read it from there (the "caller's own means" of
+//       include/gl355.h).  --host-comm: TCP between the host processes instead of RCCL (ranks sharing one GPU, hosts without RCCL).
 //
 // It builds the access set like the reference does (signal.rs:31-40: public key = Poseidon(sk | 0^4), MerkleTree::new over the
 // keys), loads the two circuit artifacts, runs the native batch runtime (recursion.rs:300-308) and folds the returned
@@ -10,7 +15,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gl355.h"
@@ -41,13 +48,23 @@ static uint64_t splitmix(uint64_t& s) {
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: %s <artifact dir> [log_members=20] [contexts=22] [units=128]\n", argv[0]); return 2; }
     const std::string dir = argv[1];
-    const uint32_t log_members = argc > 2 ? atoi(argv[2]) : 20, n_ctx = argc > 3 ? atoi(argv[3]) : 22, units = argc > 4 ? atoi(argv[4]) : 128;
+    const uint32_t log_members = argc > 2 ? atoi(argv[2]) : 20, n_ctx = argc > 3 ? atoi(argv[3]) : 22;
+    uint32_t units = argc > 4 ? atoi(argv[4]) : 128;
     const uint64_t n = 1ull << log_members;
+    int world = 1, rank = 0, host_port = 0;
+    std::string id_file;
+    for (int a = 5; a < argc; a++) {
+        if (!strcmp(argv[a], "--ranks") && a + 3 < argc) { world = atoi(argv[a + 1]); rank = atoi(argv[a + 2]); id_file = argv[a + 3]; a += 3; }
+        else if (!strcmp(argv[a], "--host-comm") && a + 1 < argc) { host_port = atoi(argv[a + 1]); a += 1; }
+    }
+    int32_t n_dev = 0;
+    gl355_device_count(&n_dev);
+    const int device = n_dev > 0 ? rank % n_dev : 0;
     // one hardware queue per prover context, and sleeping device waits (more contexts than cores is the normal case)
-    if (gl355_runtime_config(0, n_ctx, 1) != GL355_OK) { fprintf(stderr, "gl355_runtime_config failed\n"); return 1; }
+    if (gl355_runtime_config(device, n_ctx, 1) != GL355_OK) { fprintf(stderr, "gl355_runtime_config failed\n"); return 1; }
     std::vector<gl355_ctx*> ctxs(n_ctx);
     for (auto& c : ctxs)
-        if (gl355_ctx_create(0, &c) != GL355_OK) { fprintf(stderr, "no MI355X context\n"); return 1; }
+        if (gl355_ctx_create(device, &c) != GL355_OK) { fprintf(stderr, "no MI355X context\n"); return 1; }
     gl355_ctx* c0 = ctxs[0];
     // access set: secret keys from a seeded stream (values < 2^63 are canonical), public keys, Merkle tree (cap height 0)
     uint64_t seed = 0x357;
@@ -66,21 +83,52 @@ int main(int argc, char** argv) {
     uint64_t words = 0;
     uint32_t degree = 0;
     gl355_circuit_info(rec, &words, nullptr, nullptr, nullptr, &degree);
+    // the communicator of the N > 1 job: id minted by rank 0, handed over through a file
+    gl355_comm* comm = nullptr;
+    if (world > 1) {
+        uint8_t id[GL355_COMM_ID_BYTES];
+        const int backend = host_port ? GL355_COMM_HOST : GL355_COMM_RCCL;
+        if (rank == 0) {
+            const int32_t rc = host_port ? gl355_comm_host_id("127.0.0.1", (uint16_t)host_port, id) : gl355_comm_unique_id(GL355_COMM_RCCL, id);
+            if (rc != GL355_OK) { fprintf(stderr, "communicator id: %s\n", gl355_comm_last_error(nullptr)); return 1; }
+            const std::string tmp = id_file + ".tmp";
+            FILE* f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
+            fclose(f);
+            rename(tmp.c_str(), id_file.c_str());
+        } else {
+            FILE* f = nullptr;
+            for (int k = 0; k < 3000 && !(f = fopen(id_file.c_str(), "rb")); k++) std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            if (!f || fread(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "cannot read %s\n", id_file.c_str()); return 1; }
+            fclose(f);
+        }
+        if (gl355_comm_create(c0, backend, id, rank, world, &comm) != GL355_OK) { fprintf(stderr, "gl355_comm_create: %s\n", gl355_comm_last_error(nullptr)); return 1; }
+    }
+    const uint32_t all_units = units * (uint32_t)world;        // weak scaling: `units` per rank; rank r takes block r
     std::vector<uint64_t> members(units), leaves(8ull * units), proofs(words * units);
-    for (uint32_t j = 0; j < units; j++) members[j] = (12 + j) % n;                 // signal.rs:42 starts at index 12
+    for (uint32_t j = 0; j < units; j++) members[j] = (12 + (uint64_t)rank * units + j) % n;      // signal.rs:42 starts at index 12
     // warm-up, then the timed batch
     CHECK(c0, gl355_semaphore_units(ctxs.data(), n_ctx, sem, rec, sks.data(), n, topic.data(), digests.data(), members.data(), n_ctx, nullptr, leaves.data(),
                                     nullptr, nullptr));
     const auto t0 = std::chrono::steady_clock::now();
     CHECK(c0, gl355_semaphore_units(ctxs.data(), n_ctx, sem, rec, sks.data(), n, topic.data(), digests.data(), members.data(), units, nullptr /* blinding keys from the OS CSPRNG */,
                                     leaves.data(), proofs.data(), nullptr));
+    // the only exchange: all-gather of the leaves in rank (= unit) order, then the aggregation root on rank 0
+    std::vector<uint64_t> all_leaves(8ull * all_units), aroot(4);
+    if (comm) {
+        if (gl355_gather_digests(comm, leaves.data(), 8ull * units, all_leaves.data()) != GL355_OK) { fprintf(stderr, "gather: %s\n", gl355_comm_last_error(comm)); return 1; }
+        double dmax = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        gl355_comm_max_f64(comm, &dmax);
+    } else all_leaves = leaves;
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    // aggregation root over the (nullifier | topic) leaves, zero-padded to a power of two
-    uint64_t m = 1;
-    while (m < units) m <<= 1;
-    leaves.resize(8 * m, 0);
-    std::vector<uint64_t> adig(8 * (m - 1) + 8), aroot(4);
-    CHECK(c0, gl355_merkle_build(c0, leaves.data(), m, 8, 0, adig.data(), aroot.data()));
+    if (rank == 0) CHECK(c0, gl355_aggregation_root(c0, all_leaves.data(), all_units, 8, aroot.data()));
+    if (comm) { gl355_comm_barrier(comm); gl355_comm_destroy(comm); }
+    if (rank != 0) {
+        gl355_circuit_destroy(rec); gl355_circuit_destroy(sem);
+        for (auto c : ctxs) gl355_ctx_destroy(c);
+        return 0;
+    }
+    units = all_units;
     printf("group 2^%u, %u units (signal + recursive proof, n = 2^%u) on %u contexts: %.1f units/s; %llu-word proofs\n", log_members, units, degree,
            n_ctx, units / dt, (unsigned long long)words);
     printf("access-set root %016llx..., aggregation root %016llx %016llx %016llx %016llx\n", (unsigned long long)root[0], (unsigned long long)aroot[0],

@@ -426,6 +426,34 @@ int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx, const gl35
                               const uint64_t* member_indices, uint32_t count, const uint8_t* key_base, uint64_t* leaves_out,
                               uint64_t* proofs_out, uint32_t* units_per_ctx);
 
+/* ---- multi-GPU exchange: the counterpart of the reference's collection of its parallel proofs into one Vec
+ * (recursion.rs:189-227 `Mutex<Vec<..>>` behind par_chunks_exact, :300-308 par_iter().collect()).  One process per GPU; the units
+ * of a batch are block-partitioned over the ranks with no data-path collective; the only exchange is this all-gather of one small
+ * leaf per unit (nullifier | topic, recursion.rs:110-165) or of one proof per rank, then rank 0 builds the aggregation root.
+ *   GL355_COMM_RCCL  ncclAllGather / ncclAllReduce over xGMI on the context's stream; librccl is bound on first use.  The
+ *                    communicator is created from a unique id the caller distributes: rank 0 calls gl355_comm_unique_id and
+ *                    hands the 128 bytes to the other ranks by the host's own means (launcher, file, socket).
+ *   GL355_COMM_HOST  the same calls over TCP between the host processes, rank 0 listening on the address named by
+ *                    gl355_comm_host_id (hosts without RCCL; CPU tests).  Selected explicitly, never a fallback.
+ * gl355_gather_digests: every rank contributes words_per_rank u64 (host or device memory); `all` receives world * words_per_rank
+ * words in rank order on every rank.  gl355_comm_barrier / gl355_comm_max_f64: what a benchmark or a driver needs around it. */
+#define GL355_COMM_ID_BYTES 128
+enum { GL355_COMM_RCCL = 0, GL355_COMM_HOST = 1 };
+typedef struct gl355_comm gl355_comm;
+int32_t gl355_comm_unique_id(int32_t backend, uint8_t id[GL355_COMM_ID_BYTES]);
+int32_t gl355_comm_host_id(const char* ipv4, uint16_t port, uint8_t id[GL355_COMM_ID_BYTES]);
+int32_t gl355_comm_create(gl355_ctx* ctx /* may be NULL for GL355_COMM_HOST */, int32_t backend, const uint8_t id[GL355_COMM_ID_BYTES],
+                          int32_t rank, int32_t world, gl355_comm** out);
+int32_t gl355_comm_destroy(gl355_comm* comm);
+int32_t gl355_comm_info(const gl355_comm* comm, int32_t* rank, int32_t* world, int32_t* backend);
+const char* gl355_comm_last_error(gl355_comm* comm);   /* comm == NULL: the last failed create / id call of this thread */
+int32_t gl355_gather_digests(gl355_comm* comm, const uint64_t* local, uint64_t words_per_rank, uint64_t* all);
+int32_t gl355_comm_barrier(gl355_comm* comm);
+int32_t gl355_comm_max_f64(gl355_comm* comm, double* inout);
+/* Poseidon-Goldilocks Merkle root (cap height 0) over n_leaves leaves of leaf_len words, zero-padded to a power of two:
+ * MerkleTree::new(leaves, 0).cap[0], the "aggregation root" over the gathered (nullifier | topic) leaves */
+int32_t gl355_aggregation_root(gl355_ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, uint64_t root[4]);
+
 /* ---- a9: wires_permutation_partial_products_and_zs (vanishing_poly.rs:54-108,183-218) --------- */
 int32_t gl355_zs_partial_products(gl355_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas,
                                   const uint64_t* k_is, uint32_t log_n, uint32_t n_routed,

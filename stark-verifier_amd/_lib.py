@@ -139,6 +139,16 @@ SIGNATURES = {
     "gl355_fri_layer_commit": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
     "gl355_pow_grind_h": (C.c_int32, [vp, C.c_int32, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]),
     "gl355_pow_grind": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "gl355_comm_unique_id": (C.c_int32, [C.c_int32, C.c_char_p]),
+    "gl355_comm_host_id": (C.c_int32, [C.c_char_p, C.c_uint16, C.c_char_p]),
+    "gl355_comm_create": (C.c_int32, [vp, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp)]),
+    "gl355_comm_destroy": (C.c_int32, [vp]),
+    "gl355_comm_info": (C.c_int32, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gl355_comm_last_error": (C.c_char_p, [vp]),
+    "gl355_gather_digests": (C.c_int32, [vp, vp, C.c_uint64, vp]),
+    "gl355_comm_barrier": (C.c_int32, [vp]),
+    "gl355_comm_max_f64": (C.c_int32, [vp, C.POINTER(C.c_double)]),
+    "gl355_aggregation_root": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
     "gl355_zs_partial_products": (C.c_int32, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                               C.c_uint64, vp, vp]),
 }

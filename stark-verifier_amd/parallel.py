@@ -6,7 +6,66 @@ over ranks with NO data-path collective.  The only exchange is the gather of one
 (nullifier || topic = 8 u64, recursion.rs:110-165, or a 4-u64 digest) for the aggregation root --
 latency-bound, so a single all_gather over RCCL (backend "nccl") on GPUs, gloo in the CPU tests.
 """
+import ctypes as C
+
 import numpy as np
+
+COMM_RCCL, COMM_HOST, COMM_ID_BYTES = 0, 1, 128
+
+
+class Comm:
+    """gl355_comm (include/gl355.h): the multi-GPU exchange behind the C ABI -- all-gather of per-unit leaves / per-rank proofs,
+    barrier, max -- over RCCL (xGMI) or, explicitly chosen, over TCP between the host processes.  The id travels by the caller's
+    own means: `exchange_id(store)` uses any key-value object with set/get (torch.distributed.TCPStore under torchrun)."""
+
+    def __init__(self, ctx, backend, comm_id, rank, world, lib=None):
+        from . import _lib
+        self.lib = lib or (ctx.lib if ctx is not None else _lib.load())
+        self.ctx, self.rank, self.world, self.backend = ctx, rank, world, backend
+        self.h = C.c_void_p()
+        rc = self.lib.gl355_comm_create(ctx.h if ctx is not None else None, backend, comm_id, rank, world, C.byref(self.h))
+        if rc != 0:
+            raise _lib.Gl355Error(rc, (self.lib.gl355_comm_last_error(None) or b"").decode())
+
+    @staticmethod
+    def unique_id(lib, backend=COMM_RCCL, addr="127.0.0.1", port=0):
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        rc = lib.gl355_comm_host_id(addr.encode(), port, buf) if backend == COMM_HOST else lib.gl355_comm_unique_id(backend, buf)
+        if rc != 0:
+            from . import _lib
+            raise _lib.Gl355Error(rc, (lib.gl355_comm_last_error(None) or b"").decode())
+        return buf.raw
+
+    def _check(self, rc):
+        if rc != 0:
+            from . import _lib
+            raise _lib.Gl355Error(rc, (self.lib.gl355_comm_last_error(self.h) or b"").decode())
+
+    def gather(self, local):
+        """all-gather of equally shaped uint64 arrays [k, w] -> [world * k, w] in rank order (gl355_gather_digests)"""
+        loc = np.ascontiguousarray(local, dtype=np.uint64)
+        out = np.empty((self.world,) + loc.shape, dtype=np.uint64)
+        self._check(self.lib.gl355_gather_digests(self.h, loc.ctypes.data, loc.size, out.ctypes.data))
+        return out.reshape((self.world * loc.shape[0],) + loc.shape[1:]) if loc.ndim else out
+
+    def barrier(self):
+        self._check(self.lib.gl355_comm_barrier(self.h))
+
+    def max(self, value):
+        v = C.c_double(float(value))
+        self._check(self.lib.gl355_comm_max_f64(self.h, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gl355_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_range(total, rank, world):
@@ -38,10 +97,15 @@ def pad_pow2(leaves):
 
 
 def aggregation_root(ctx, leaves, cap_height=0):
-    """Poseidon-Goldilocks Merkle cap over the gathered leaves, on the GPU (rank 0)."""
+    """Poseidon-Goldilocks Merkle cap over the gathered leaves, on the GPU (rank 0): gl355_aggregation_root for the root
+    (cap height 0), the general MerkleTree for a wider cap."""
+    lv = np.ascontiguousarray(leaves, dtype=np.uint64)
+    if cap_height == 0:
+        root = np.empty((1, 4), dtype=np.uint64)
+        ctx.check(ctx.lib.gl355_aggregation_root(ctx.h, lv.ctypes.data, lv.shape[0], lv.shape[1], root.ctypes.data))
+        return root
     from .api import MerkleTree
-    lv = pad_pow2(np.ascontiguousarray(leaves, dtype=np.uint64))
-    return MerkleTree(ctx, lv, cap_height).cap
+    return MerkleTree(ctx, pad_pow2(lv), cap_height).cap
 
 
 def aggregate_distributed(aggregator, local_signals, dist=None, device=None, ctxs=None, seed=1, rng=None):
