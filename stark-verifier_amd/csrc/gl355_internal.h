@@ -12,6 +12,7 @@
 
 #include "../../include/gl355.h"
 #include "gl_field.cuh"
+#include "merkle_common.cuh"
 
 namespace gl355 { struct Ctx; }
 
@@ -179,6 +180,9 @@ int32_t hash_leaves_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, uin
                         uint64_t col_stride, uint64_t* digests /* n_leaves * 4, linear order */);
 int32_t merkle_build_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, bool col_major,
                          uint64_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap);
+int32_t merkle_build_args(Ctx* ctx, LeafArgs a, uint32_t sub_bits, uint64_t* digests, uint64_t* cap);
+int32_t bn254_merkle_build_args(Ctx* ctx, LeafArgs a, uint32_t sub_bits, uint64_t* digests, uint64_t* cap);
+int32_t merkle_build_args_any(Ctx* ctx, int32_t hasher, const LeafArgs& a, uint32_t sub_bits, uint64_t* digests, uint64_t* cap);
 int32_t hash_no_pad_dev(Ctx* ctx, const uint64_t* inputs, uint64_t n, uint32_t len, uint64_t* digests);
 int32_t two_to_one_dev(Ctx* ctx, const uint64_t* l, const uint64_t* r, uint64_t n, uint64_t* out);
 int32_t open_batch_dev(Ctx* ctx, const uint64_t* lde, uint64_t stride, uint32_t leaf_len, const uint64_t* digests,

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) h
     if (len <= 4 && !a.always_hash) {
         for (uint32_t k = 0; k < 4; k++) {
             uint64_t v = 0;
-            if (k < len) v = a.col_major ? a.leaves[(uint64_t)k * a.stride + i] : a.leaves[i * a.stride + k];
+            if (k < len) v = leaf_elem(a, i, k);
             d[k] = gl_canon(v);
         }
     } else {
@@ -55,8 +55,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) h
             const uint32_t m = min(8u, len - off);
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++) {
-                if (k < m) s[k] = a.col_major ? a.leaves[(uint64_t)(off + k) * a.stride + i]
-                                              : a.leaves[i * a.stride + off + k];
+                if (k < m) s[k] = leaf_elem(a, i, off + k);
             }
             psd_permute(s);
         }
@@ -310,13 +309,20 @@ int32_t merkle_build_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, ui
     const uint32_t log_n = log2_u64(n_leaves);
     if ((1ull << log_n) != n_leaves) return ctx->fail(GL355_E_INVALID_ARG, "merkle: n_leaves must be a power of two");
     if (cap_height > log_n) return ctx->fail(GL355_E_INVALID_ARG, "merkle: cap_height > log2(n_leaves)");
-    const uint32_t sub_bits = log_n - cap_height;
     LeafArgs a;
     memset(&a, 0, sizeof a);
     a.leaves = leaves; a.n_leaves = n_leaves; a.leaf_len = leaf_len; a.col_major = col_major;
     a.stride = col_major ? col_stride : leaf_len;
-    a.out = digests; a.cap = cap; a.sub_bits = sub_bits;
-    { ProfScope ps(ctx, "hash_leaves_kernel", n_leaves * ((uint64_t)leaf_len * 8 + 32)); GL355_TRY(launch_leaves(ctx, a)); }
+    return merkle_build_args(ctx, a, log_n - cap_height, digests, cap);
+}
+
+// a.n_leaves leaves (any multiple of 2^sub_bits: the cap subtrees of one tree, or of several units' trees laid out one after
+// the other) -> per-subtree digests in plonky2's layout + one cap entry per subtree.  `a` describes where the leaves are.
+int32_t merkle_build_args(Ctx* ctx, LeafArgs a, uint32_t sub_bits, uint64_t* digests, uint64_t* cap) {
+    const uint64_t n_leaves = a.n_leaves;
+    if (n_leaves == 0 || (n_leaves & ((1ull << sub_bits) - 1))) return ctx->fail(GL355_E_INVALID_ARG, "merkle: leaves do not fill whole cap subtrees");
+    a.out = digests; a.cap = cap; a.sub_bits = sub_bits; a.linear = 0;
+    { ProfScope ps(ctx, "hash_leaves_kernel", n_leaves * ((uint64_t)a.leaf_len * 8 + 32)); GL355_TRY(launch_leaves(ctx, a)); }
     const uint64_t lanes_max = 1ull << ctx->merkle_lanes_log;
     // the last MERKLE_TOP_LOG + 1 levels of every cap subtree go to merkle_top_kernel (when they are lane-parallel levels anyway)
     uint32_t top_from = sub_bits + 1;

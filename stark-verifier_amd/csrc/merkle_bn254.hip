@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) bn254_hash_leaves_kernel(LeafArgs a) {
     if (len <= 4 && !a.always_hash) {
         for (uint32_t k = 0; k < 4; k++) {
             uint64_t v = 0;
-            if (k < len) v = a.col_major ? a.leaves[(uint64_t)k * a.stride + i] : a.leaves[i * a.stride + k];
+            if (k < len) v = leaf_elem(a, i, k);
             d[k] = gl_canon(v);
         }
     } else {
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) bn254_hash_leaves_kernel(LeafArgs a) {
             const uint32_t m = min(8u, len - off);
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++) {
-                if (k < m) s[k] = a.col_major ? a.leaves[(uint64_t)(off + k) * a.stride + i] : a.leaves[i * a.stride + off + k];
+                if (k < m) s[k] = leaf_elem(a, i, off + k);
             }
             bn254_permute(s);
         }
@@ -204,12 +204,16 @@ int32_t bn254_merkle_build_dev(Ctx* ctx, const uint64_t* leaves, uint64_t n_leav
     const uint32_t log_n = log2_u64(n_leaves);
     if ((1ull << log_n) != n_leaves) return ctx->fail(GL355_E_INVALID_ARG, "merkle: n_leaves must be a power of two");
     if (cap_height > log_n) return ctx->fail(GL355_E_INVALID_ARG, "merkle: cap_height > log2(n_leaves)");
-    const uint32_t sub_bits = log_n - cap_height;
     LeafArgs a;
     memset(&a, 0, sizeof a);
     a.leaves = leaves; a.n_leaves = n_leaves; a.leaf_len = leaf_len; a.col_major = col_major;
     a.stride = col_major ? col_stride : leaf_len;
-    a.out = digests; a.cap = cap; a.sub_bits = sub_bits;
+    return bn254_merkle_build_args(ctx, a, log_n - cap_height, digests, cap);
+}
+int32_t bn254_merkle_build_args(Ctx* ctx, LeafArgs a, uint32_t sub_bits, uint64_t* digests, uint64_t* cap) {
+    const uint64_t n_leaves = a.n_leaves;
+    if (n_leaves == 0 || (n_leaves & ((1ull << sub_bits) - 1))) return ctx->fail(GL355_E_INVALID_ARG, "merkle: leaves do not fill whole cap subtrees");
+    a.out = digests; a.cap = cap; a.sub_bits = sub_bits; a.linear = 0;
     GL355_TRY(launch_leaves(ctx, a));
     for (uint32_t layer = 1; layer <= sub_bits; layer++) {
         const uint64_t n_nodes = n_leaves >> layer;
@@ -269,6 +273,10 @@ int32_t merkle_build_any(Ctx* ctx, int32_t hasher, const uint64_t* leaves, uint6
     if (hasher == GL355_HASH_BN254_POSEIDON)
         return bn254_merkle_build_dev(ctx, leaves, n_leaves, leaf_len, col_major, col_stride, cap_height, digests, cap);
     return merkle_build_dev(ctx, leaves, n_leaves, leaf_len, col_major, col_stride, cap_height, digests, cap);
+}
+int32_t merkle_build_args_any(Ctx* ctx, int32_t hasher, const LeafArgs& a, uint32_t sub_bits, uint64_t* digests, uint64_t* cap) {
+    if (hasher == GL355_HASH_BN254_POSEIDON) return bn254_merkle_build_args(ctx, a, sub_bits, digests, cap);
+    return merkle_build_args(ctx, a, sub_bits, digests, cap);
 }
 int32_t pow_grind_any(Ctx* ctx, int32_t hasher, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t start,
                       uint64_t* witness_host) {

@@ -14,7 +14,7 @@ __host__ __device__ __forceinline__ uint64_t digest_slot(uint32_t layer, uint64_
 
 struct LeafArgs {
     const uint64_t* leaves;
-    uint64_t n_leaves;
+    uint64_t n_leaves;      // all units together
     uint32_t leaf_len;
     uint32_t col_major;
     uint64_t stride;        // col-major: elements between columns; row-major: elements between rows
@@ -23,6 +23,25 @@ struct LeafArgs {
     uint32_t linear;        // 1: out[i*4..] (no layout)
     uint32_t always_hash;   // hash_no_pad semantics (no <=4 shortcut)
     uint64_t* cap;          // used when sub_bits == 0 (tree is all cap)
+    // several units (independent trees of 2^unit_log leaves each, the lock-step proofs of one prover context) in one launch:
+    // leaf g belongs to unit g >> unit_log; its columns [0, n_main) come from `leaves + unit * unit_stride`, the remaining ones
+    // (the salt columns of a blinded oracle) from `salt + unit * salt_unit_stride`.  unit_log == 0 means one unit, no salt segment.
+    uint32_t unit_log;
+    uint32_t n_main;
+    uint64_t unit_stride;
+    const uint64_t* salt;
+    uint64_t salt_unit_stride;
 };
+
+// element k of leaf g
+__device__ __forceinline__ uint64_t leaf_elem(const LeafArgs& a, uint64_t g, uint32_t k) {
+    if (a.unit_log == 0) return a.col_major ? a.leaves[(uint64_t)k * a.stride + g] : a.leaves[g * a.stride + k];
+    const uint64_t u = g >> a.unit_log, i = g & ((1ull << a.unit_log) - 1);
+    if (k < a.n_main) {
+        const uint64_t* base = a.leaves + u * a.unit_stride;
+        return a.col_major ? base[(uint64_t)k * a.stride + i] : base[i * a.stride + k];
+    }
+    return a.salt[u * a.salt_unit_stride + (uint64_t)(k - a.n_main) * a.stride + i];     // salt columns are always column-major
+}
 
 }  // namespace gl355
