@@ -42,6 +42,7 @@ extern "C" {
 #define GL355_P UINT64_C(0xFFFFFFFF00000001) /* chip/native_chip/arithmetic_chip.rs:19 */
 #define GL355_COSET_SHIFT UINT64_C(7)        /* chip/plonk/plonk_verifier_chip.rs:225-227 */
 #define GL355_SALT_SIZE 4                    /* types/assigned.rs:67-71 */
+#define GL355_MAX_UNITS 16                   /* independent proofs of one circuit a prover context proves in lock-step (gl355_*_units) */
 
 typedef struct gl355_ctx gl355_ctx;
 typedef struct gl355_oracle gl355_oracle; /* a committed polynomial batch resident in HBM */
@@ -66,8 +67,9 @@ enum { GL355_OPT_MERKLE_LANES_LOG = 1,
        GL355_OPT_BLOCKING_SYNC = 2,     /* != 0: wait for the device with a blocking event instead of a spinning hipStreamSynchronize
                                            (gl355_runtime_config(.., sleeping_waits) is the effective way on this runtime) */
        GL355_OPT_REPLAY_THREADS = 3,    /* host threads gl355_circuit_prove_tape uses for a segmented tape (default 1) */
-       GL355_OPT_NTT_SINGLE_PASS_MAX_LOG = 4 }; /* 12..14 (default 14): commit-path transforms of 2^13 / 2^14 points above this size run
+       GL355_OPT_NTT_SINGLE_PASS_MAX_LOG = 4, /* 12..14 (default 14): commit-path transforms of 2^13 / 2^14 points above this size run
                                            in two passes of 4096-point tiles instead of one pass that owns a whole CU */
+       GL355_OPT_BATCH_UNITS = 5 };     /* 1..GL355_MAX_UNITS (default 8): units gl355_semaphore_units proves in lock-step per context */
 int32_t gl355_ctx_set_option(gl355_ctx* ctx, int32_t option, int64_t value);
 const char* gl355_last_error(gl355_ctx* ctx);
 const char* gl355_version(void);
@@ -349,6 +351,15 @@ int32_t gl355_prove_sparse(gl355_ctx* ctx, const gl355_prover_data* pd, const ui
                            uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
                            const uint64_t* public_inputs, uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof,
                            uint64_t proof_capacity_words);
+/* n_units (<= GL355_MAX_UNITS) independent witnesses of ONE circuit proven in lock-step on this context -- the reference's
+ * rayon par_iter over proofs (recursion.rs:214-227,300-308) as a unit dimension of every kernel, which is what fills the GPU with
+ * circuits of n = 2^13..2^15: rows = [n_units][n_rows][num_wires], public_inputs = [n_units][n_public_inputs], proofs =
+ * [n_units][proof_capacity_words], blinding_keys = [n_units][32] or NULL (a fresh OS-random key for every unit).  Every unit's
+ * proof is byte for byte the proof gl355_prove_sparse makes of that unit alone with the same key. */
+int32_t gl355_prove_sparse_units(gl355_ctx* ctx, const gl355_prover_data* pd, uint32_t n_units, const uint32_t* row_idx, const uint64_t* rows,
+                                 uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
+                                 const uint64_t* public_inputs, uint32_t n_public_inputs, const uint8_t* blinding_keys,
+                                 uint64_t* proofs, uint64_t proof_capacity_words);
 /* host-side witness rows of the Semaphore circuit (circuit.rs:67-99): (height + 7) rows x 135 wires in the
  * order PublicInput | pi-hash 1 | pi-hash 2 | BaseSum{height} | leaf hash | height Merkle levels | nullifier |
  * Constant; public_inputs = merkle_root | nullifier | topic (circuit.rs:27-32). */
@@ -413,9 +424,21 @@ int32_t gl355_semaphore_prove(gl355_ctx* ctx, const gl355_circuit_handle* c, con
                               uint64_t index, const uint64_t* siblings, uint32_t height, const uint8_t* blinding_key, uint64_t* proof,
                               uint64_t proof_capacity_words, uint64_t public_inputs_out[12]);
 
+/* the same three calls for n_units (<= GL355_MAX_UNITS) units in lock-step (gl355_prove_sparse_units): rows [n_units][n_rows][num_wires],
+ * public_inputs [n_units][n_public_inputs], inputs [n_units][n_inputs], private_keys [n_units][4], topics [n_units][4], indices [n_units],
+ * siblings [n_units][height][4], blinding_keys [n_units][32] or NULL, proofs [n_units][proof_words], public_inputs_out [n_units][n_public_inputs].
+ * gl355_circuit_prove_tape_units replays the units' tapes on GL355_OPT_REPLAY_THREADS host threads. */
+int32_t gl355_circuit_prove_rows_units(gl355_ctx* ctx, const gl355_circuit_handle* c, uint32_t n_units, const uint64_t* rows, const uint64_t* public_inputs,
+                                       uint32_t n_public_inputs, const uint8_t* blinding_keys, uint64_t* proofs);
+int32_t gl355_circuit_prove_tape_units(gl355_ctx* ctx, const gl355_circuit_handle* c, uint32_t n_units, const uint64_t* inputs, uint64_t n_inputs,
+                                       const uint8_t* blinding_keys, uint64_t* proofs, uint64_t* public_inputs_out);
+int32_t gl355_semaphore_prove_units(gl355_ctx* ctx, const gl355_circuit_handle* c, uint32_t n_units, const uint64_t* private_keys, const uint64_t* topics,
+                                    const uint64_t* indices, const uint64_t* siblings, uint32_t height, const uint8_t* blinding_keys, uint64_t* proofs,
+                                    uint64_t* public_inputs_out);
+
 /* Batch runtime (recursion.rs:300-308 `par_iter` of make_signal, :211-227 of the verification circuits): one host thread per
- * context, units handed to the contexts one at a time (results are placed by j, so they do not depend on which context proved
- * which unit).  Per unit: Merkle path of member_indices[j] from tree_digests (the access-set tree over
+ * context; a context takes the next GL355_OPT_BATCH_UNITS units at a time and proves them in lock-step (results are placed by j and
+ * every unit has its own key, so they do not depend on which context proved which unit, nor on the batch size).  Per unit: Merkle path of member_indices[j] from tree_digests (the access-set tree over
  * the public keys, cap height 0, plonky2 digest layout, host memory), gl355_semaphore_prove with key gl355_derive_key(key_base, 2j), and
  * if `rec` is not NULL gl355_circuit_prove_tape(rec, proof | public inputs) with key gl355_derive_key(key_base, 2j + 1); key_base NULL =
  * a fresh OS-random key per proof.  leaves_out[j] = nullifier | topic

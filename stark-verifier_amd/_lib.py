@@ -101,6 +101,8 @@ SIGNATURES = {
     "gl355_blinding_elements": (C.c_int32, [vp, C.c_char_p, C.c_uint32, C.c_uint64, vp]),
     "gl355_prove_sparse": (C.c_int32, [vp, C.POINTER(ProverData), vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        vp, C.c_uint32, vp, vp, C.c_uint64]),
+    "gl355_prove_sparse_units": (C.c_int32, [vp, C.POINTER(ProverData), C.c_uint32, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             vp, C.c_uint32, vp, vp, C.c_uint64]),
     "gl355_permute_h": (C.c_int32, [vp, C.c_int32, vp, C.c_uint64]),
     "gl355_hash_no_pad_h": (C.c_int32, [vp, C.c_int32, vp, C.c_uint64, C.c_uint32, vp]),
     "gl355_hash_leaves_h": (C.c_int32, [vp, C.c_int32, vp, C.c_uint64, C.c_uint32, vp]),
@@ -114,6 +116,9 @@ SIGNATURES = {
     "gl355_circuit_prove_rows": (C.c_int32, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64]),
     "gl355_circuit_prove_tape": (C.c_int32, [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp]),
     "gl355_semaphore_prove": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, vp, C.c_uint32, vp, vp, C.c_uint64, vp]),
+    "gl355_circuit_prove_rows_units": (C.c_int32, [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp]),
+    "gl355_circuit_prove_tape_units": (C.c_int32, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp]),
+    "gl355_semaphore_prove_units": (C.c_int32, [vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, vp, vp, vp]),
     "gl355_semaphore_units": (C.c_int32, [vp, C.c_uint32, vp, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint32, vp, vp, vp, vp]),
     "gl355_semaphore_witness": (C.c_int32, [vp, vp, C.c_uint64, vp, C.c_uint32, vp, vp]),
     "gl355_witness_replay_segmented": (C.c_int32, [vp, C.c_uint64, C.c_uint64, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, C.c_uint32,

@@ -1,6 +1,6 @@
 // Native batch runtime: the reference proves its signals from a rayon `par_iter` (src/plonky2_semaphore/recursion.rs:300-308:
 // one `make_signal` per member) and verifies / aggregates them from `par_chunks_exact` (recursion.rs:211-227).  Here one host
-// thread per prover context takes every n_ctx-th unit: Merkle path of the member from the access-set tree, gl355_semaphore_prove,
+// thread per prover context takes the next GL355_OPT_BATCH_UNITS units and proves them in lock-step: Merkle path of the member from the access-set tree, gl355_semaphore_prove,
 // and -- when a verifier circuit is given -- gl355_circuit_prove_tape on (proof | public inputs).  No host-language code runs
 // between the units; the caller gets the (nullifier | topic) leaf of every unit for the aggregation root.
 #include "gl355_internal.h"
@@ -34,42 +34,58 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
         if (member_indices[j] >= n_members) return ctx_of(ctxs[0])->fail(GL355_E_INVALID_ARG, "semaphore_units: member index out of range");
     const uint64_t out_words = rec ? rec_words : sem_words;
     std::atomic<int32_t> first_error{GL355_OK};
-    std::atomic<uint32_t> next_unit{0};     // units are handed out one at a time: a context that finishes early takes the next one
+    std::atomic<uint32_t> next_unit{0};     // units are handed out a batch at a time: a context that finishes early takes the next batch
     auto worker = [&](uint32_t t) {
-        std::vector<uint64_t> sib((size_t)height * 4 + 4), flat(sem_words + 12), outer(rec ? rec_words : 0);
+        const uint32_t B = std::max<uint32_t>(1, std::min<uint32_t>(ctx_of(ctxs[t])->batch_units, GL355_MAX_UNITS));
+        std::vector<uint64_t> sib((size_t)B * height * 4 + 4), flat((size_t)B * sem_words), pis((size_t)B * 12), inputs(rec ? (size_t)B * (sem_words + 12) : 0),
+            outer(rec ? (size_t)B * rec_words : 0), opis((size_t)B * 12), sks((size_t)B * 4), topics((size_t)B * 4), idxs(B);
+        std::vector<uint8_t> k_sem((size_t)B * 32), k_rec((size_t)B * 32);
         uint32_t done = 0;
-        for (uint32_t j; (j = next_unit.fetch_add(1)) < count && first_error.load() == GL355_OK;) {
-            const uint64_t idx = member_indices[j];
-            // MerkleTree::prove on the plonky2 digest layout (cap height 0: one tree)
-            uint64_t pair = idx;
-            for (uint32_t i = 0; i < height; i++) {
-                const uint64_t parity = pair & 1;
-                pair >>= 1;
-                const uint64_t slot = (pair << (i + 1)) + (1ull << i) - 1;
-                memcpy(&sib[4 * i], tree_digests + (2 * slot + (1 - parity)) * 4, 32);
+        for (;;) {
+            if (first_error.load() != GL355_OK) break;
+            const uint32_t j0 = next_unit.fetch_add(B);
+            if (j0 >= count) break;
+            const uint32_t nb = std::min<uint32_t>(B, count - j0);
+            for (uint32_t b = 0; b < nb; b++) {
+                const uint32_t j = j0 + b;
+                const uint64_t idx = member_indices[j];
+                idxs[b] = idx;
+                memcpy(&sks[4 * b], private_keys + 4 * idx, 32);
+                memcpy(&topics[4 * b], topic, 32);
+                // MerkleTree::prove on the plonky2 digest layout (cap height 0: one tree)
+                uint64_t pair = idx;
+                for (uint32_t i = 0; i < height; i++) {
+                    const uint64_t parity = pair & 1;
+                    pair >>= 1;
+                    const uint64_t slot = (pair << (i + 1)) + (1ull << i) - 1;
+                    memcpy(&sib[((size_t)b * height + i) * 4], tree_digests + (2 * slot + (1 - parity)) * 4, 32);
+                }
+                // per-proof blinding keys: derived from the batch key (reproducible batches), or NULL = fresh OS randomness per proof
+                if (key_base) { gl355_derive_key(key_base, 2ull * j, &k_sem[32 * b]); gl355_derive_key(key_base, 2ull * j + 1, &k_rec[32 * b]); }
             }
-            uint64_t* pis = flat.data() + sem_words;
-            // per-proof blinding keys: derived from the batch key (reproducible batches), or NULL = fresh OS randomness per proof
-            uint8_t k_sem[32], k_rec[32];
-            if (key_base) { gl355_derive_key(key_base, 2ull * j, k_sem); gl355_derive_key(key_base, 2ull * j + 1, k_rec); }
-            int32_t rc = gl355_semaphore_prove(ctxs[t], sem, private_keys + 4 * idx, topic, idx, sib.data(), height, key_base ? k_sem : nullptr,
-                                               flat.data(), sem_words, pis);
-            uint64_t opis[12];
+            int32_t rc = gl355_semaphore_prove_units(ctxs[t], sem, nb, sks.data(), topics.data(), idxs.data(), sib.data(), height,
+                                                     key_base ? k_sem.data() : nullptr, flat.data(), pis.data());
             const uint64_t* result = flat.data();
             if (rc == GL355_OK && rec) {
-                rc = gl355_circuit_prove_tape(ctxs[t], rec, flat.data(), sem_words + 12, key_base ? k_rec : nullptr, outer.data(), rec_words, opis);
+                for (uint32_t b = 0; b < nb; b++) {
+                    memcpy(&inputs[(size_t)b * (sem_words + 12)], &flat[(size_t)b * sem_words], sem_words * 8);
+                    memcpy(&inputs[(size_t)b * (sem_words + 12) + sem_words], &pis[(size_t)b * 12], 96);
+                }
+                rc = gl355_circuit_prove_tape_units(ctxs[t], rec, nb, inputs.data(), sem_words + 12, key_base ? k_rec.data() : nullptr, outer.data(), opis.data());
                 result = outer.data();
             } else if (rc == GL355_OK) {
-                memcpy(opis, pis, sizeof opis);
+                memcpy(opis.data(), pis.data(), (size_t)nb * 96);
             }
             if (rc != GL355_OK) {
                 int32_t expected = GL355_OK;
                 first_error.compare_exchange_strong(expected, rc);
                 break;
             }
-            memcpy(leaves_out + 8ull * j, opis + 4, 64);            // nullifier | topic
-            if (proofs_out) memcpy(proofs_out + (uint64_t)j * out_words, result, out_words * 8);
-            done++;
+            for (uint32_t b = 0; b < nb; b++) {
+                memcpy(leaves_out + 8ull * (j0 + b), &opis[(size_t)b * 12 + 4], 64);            // nullifier | topic
+                if (proofs_out) memcpy(proofs_out + (uint64_t)(j0 + b) * out_words, result + (uint64_t)b * out_words, out_words * 8);
+            }
+            done += nb;
         }
         if (units_per_ctx) units_per_ctx[t] = done;
     };

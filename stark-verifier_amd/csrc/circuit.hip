@@ -8,6 +8,8 @@
 // A loaded circuit is read-only and may be used concurrently by every context of its device.
 #include "gl355_internal.h"
 
+#include <atomic>
+#include <thread>
 #include <vector>
 
 using namespace gl355;
@@ -168,44 +170,108 @@ int32_t gl355_circuit_prove_rows(gl355_ctx* h, const gl355_circuit_handle* ch, c
     return gl355_prove_sparse(h, &ch->pd, ch->row_idx.data(), rows, (uint32_t)ch->row_idx.size(), ch->blind_start, ch->n_blind, ch->z_start,
                               ch->n_z_pairs, public_inputs, n_public_inputs, blinding_key, proof, proof_capacity_words);
 }
+int32_t gl355_circuit_prove_rows_units(gl355_ctx* h, const gl355_circuit_handle* ch, uint32_t n_units, const uint64_t* rows, const uint64_t* public_inputs,
+                                       uint32_t n_public_inputs, const uint8_t* blinding_keys, uint64_t* proofs) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (!ch || !rows || !proofs) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_rows_units: null argument");
+    if (ctx->device != ch->owner->device) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_rows_units: circuit was loaded on another device");
+    return gl355_prove_sparse_units(h, &ch->pd, n_units, ch->row_idx.data(), rows, (uint32_t)ch->row_idx.size(), ch->blind_start, ch->n_blind, ch->z_start,
+                                    ch->n_z_pairs, public_inputs, n_public_inputs, blinding_keys, proofs, gl355_proof_words(&ch->pd));
+}
 
+// witness generation of n_units units: tape replays spread over the context's replay threads (one unit per thread at a time;
+// a single unit still uses its segments in parallel)
+static int32_t replay_units(Ctx* ctx, const gl355_circuit_handle* ch, uint32_t n_units, const uint64_t* inputs, uint64_t* rows, uint64_t n_words,
+                            uint64_t* failed_unit, uint64_t* failed_op) {
+    const uint32_t nt = std::max<uint32_t>(1, std::min<uint32_t>(ctx->replay_threads, n_units));
+    if (n_units == 1 || nt == 1) {
+        for (uint32_t u = 0; u < n_units; u++) {
+            uint64_t f = 0;
+            const int32_t rc = gl355_witness_replay_segmented(ch->tape.data(), ch->tape.size() / 5, ch->n_seq, ch->seg_lens.data(), (uint32_t)ch->seg_lens.size(),
+                                                              n_units == 1 ? ctx->replay_threads : 1, inputs + (uint64_t)u * ch->n_inputs, ch->n_inputs,
+                                                              rows + (uint64_t)u * n_words, n_words, ch->c.num_wires, &f);
+            if (rc != GL355_OK) { *failed_unit = u; *failed_op = f; return rc; }
+        }
+        return GL355_OK;
+    }
+    std::atomic<uint32_t> next{0};
+    std::vector<int32_t> rcs(n_units, GL355_OK);
+    std::vector<uint64_t> fails(n_units, 0);
+    auto worker = [&]() {
+        for (uint32_t u; (u = next.fetch_add(1)) < n_units;)
+            rcs[u] = gl355_witness_replay_segmented(ch->tape.data(), ch->tape.size() / 5, ch->n_seq, ch->seg_lens.data(), (uint32_t)ch->seg_lens.size(), 1,
+                                                    inputs + (uint64_t)u * ch->n_inputs, ch->n_inputs, rows + (uint64_t)u * n_words, n_words, ch->c.num_wires,
+                                                    &fails[u]);
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < nt; t++) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+    for (uint32_t u = 0; u < n_units; u++)
+        if (rcs[u] != GL355_OK) { *failed_unit = u; *failed_op = fails[u]; return rcs[u]; }
+    return GL355_OK;
+}
+
+int32_t gl355_circuit_prove_tape_units(gl355_ctx* h, const gl355_circuit_handle* ch, uint32_t n_units, const uint64_t* inputs, uint64_t n_inputs,
+                                       const uint8_t* blinding_keys, uint64_t* proofs, uint64_t* public_inputs_out) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (!ch || !inputs || !proofs) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: null argument");
+    if (ch->tape.empty()) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: this artifact carries no witness tape");
+    if (n_inputs != ch->n_inputs) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: wrong number of input words");
+    if (n_units == 0 || n_units > GL355_MAX_UNITS) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: 1..GL355_MAX_UNITS units per call");
+    static thread_local std::vector<uint64_t> rows;      // one prover thread per context: reuse the row buffer
+    const uint64_t n_words = (uint64_t)ch->row_idx.size() * ch->c.num_wires;
+    rows.resize(n_words * n_units);
+    uint64_t failed_unit = 0, failed_op = 0;
+    const int32_t rc = replay_units(ctx, ch, n_units, inputs, rows.data(), n_words, &failed_unit, &failed_op);
+    if (rc != GL355_OK) {
+        char msg[128];
+        snprintf(msg, sizeof msg, "circuit_prove_tape: witness generation of unit %llu failed at tape entry %llu", (unsigned long long)failed_unit,
+                 (unsigned long long)failed_op);
+        return ctx->fail(rc, msg);
+    }
+    std::vector<uint64_t> pis((size_t)ch->n_pi * n_units);
+    for (uint32_t u = 0; u < n_units; u++)
+        for (uint32_t i = 0; i < ch->n_pi; i++) pis[(size_t)u * ch->n_pi + i] = rows[(uint64_t)u * n_words + ch->pi_pos[i]];
+    if (public_inputs_out) memcpy(public_inputs_out, pis.data(), pis.size() * 8);
+    return gl355_circuit_prove_rows_units(h, ch, n_units, rows.data(), pis.data(), ch->n_pi, blinding_keys, proofs);
+}
 int32_t gl355_circuit_prove_tape(gl355_ctx* h, const gl355_circuit_handle* ch, const uint64_t* inputs, uint64_t n_inputs, const uint8_t* blinding_key,
                                  uint64_t* proof, uint64_t proof_capacity_words, uint64_t* public_inputs_out) {
     Ctx* ctx = ctx_of(h);
     if (!ctx) return GL355_E_INVALID_ARG;
-    if (!ch || !inputs || !proof) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: null argument");
-    if (ch->tape.empty()) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: this artifact carries no witness tape");
-    if (n_inputs != ch->n_inputs) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: wrong number of input words");
-    static thread_local std::vector<uint64_t> rows;      // one prover thread per context: reuse the row buffer
-    const uint64_t n_words = (uint64_t)ch->row_idx.size() * ch->c.num_wires;
-    rows.resize(n_words);
-    uint64_t failed = 0;
-    const int32_t rc = gl355_witness_replay_segmented(ch->tape.data(), ch->tape.size() / 5, ch->n_seq, ch->seg_lens.data(), (uint32_t)ch->seg_lens.size(),
-                                                      ctx->replay_threads, inputs, n_inputs, rows.data(), n_words, ch->c.num_wires, &failed);
-    if (rc != GL355_OK) {
-        char msg[96];
-        snprintf(msg, sizeof msg, "circuit_prove_tape: witness generation failed at tape entry %llu", (unsigned long long)failed);
-        return ctx->fail(rc, msg);
-    }
-    std::vector<uint64_t> pis(ch->n_pi);
-    for (uint32_t i = 0; i < ch->n_pi; i++) pis[i] = rows[ch->pi_pos[i]];
-    if (public_inputs_out) memcpy(public_inputs_out, pis.data(), (size_t)ch->n_pi * 8);
-    return gl355_circuit_prove_rows(h, ch, rows.data(), pis.data(), ch->n_pi, blinding_key, proof, proof_capacity_words);
+    if (!ch || !proof) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: null argument");
+    if (proof_capacity_words < gl355_proof_words(&ch->pd)) return ctx->fail(GL355_E_INVALID_ARG, "prove: proof buffer too small (see gl355_proof_words)");
+    return gl355_circuit_prove_tape_units(h, ch, 1, inputs, n_inputs, blinding_key, proof, public_inputs_out);
 }
 
+int32_t gl355_semaphore_prove_units(gl355_ctx* h, const gl355_circuit_handle* ch, uint32_t n_units, const uint64_t* private_keys, const uint64_t* topics,
+                                    const uint64_t* indices, const uint64_t* siblings, uint32_t height, const uint8_t* blinding_keys, uint64_t* proofs,
+                                    uint64_t* public_inputs_out) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (!ch || !private_keys || !topics || !indices || !proofs || (!siblings && height)) return ctx->fail(GL355_E_INVALID_ARG, "semaphore_prove: null argument");
+    if (ch->row_idx.size() != (size_t)height + 7 || ch->c.num_wires != 135)
+        return ctx->fail(GL355_E_INVALID_ARG, "semaphore_prove: the artifact is not the Semaphore circuit of this tree height");
+    if (n_units == 0 || n_units > GL355_MAX_UNITS) return ctx->fail(GL355_E_INVALID_ARG, "semaphore_prove: 1..GL355_MAX_UNITS units per call");
+    const size_t per = (size_t)(height + 7) * 135;
+    std::vector<uint64_t> rows(per * n_units), pis(12 * (size_t)n_units);
+    for (uint32_t u = 0; u < n_units; u++)
+        GL355_TRY(gl355_semaphore_witness(private_keys + 4 * u, topics + 4 * u, indices[u], siblings + (size_t)u * height * 4, height, rows.data() + u * per,
+                                          pis.data() + 12 * u));
+    if (public_inputs_out) memcpy(public_inputs_out, pis.data(), pis.size() * 8);
+    return gl355_circuit_prove_rows_units(h, ch, n_units, rows.data(), pis.data(), 12, blinding_keys, proofs);
+}
 int32_t gl355_semaphore_prove(gl355_ctx* h, const gl355_circuit_handle* ch, const uint64_t private_key[4], const uint64_t topic[4],
                               uint64_t index, const uint64_t* siblings, uint32_t height, const uint8_t* blinding_key, uint64_t* proof,
                               uint64_t proof_capacity_words, uint64_t public_inputs_out[12]) {
     Ctx* ctx = ctx_of(h);
     if (!ctx) return GL355_E_INVALID_ARG;
-    if (!ch || !private_key || !topic || !proof || (!siblings && height)) return ctx->fail(GL355_E_INVALID_ARG, "semaphore_prove: null argument");
-    if (ch->row_idx.size() != (size_t)height + 7 || ch->c.num_wires != 135)
-        return ctx->fail(GL355_E_INVALID_ARG, "semaphore_prove: the artifact is not the Semaphore circuit of this tree height");
-    std::vector<uint64_t> rows((size_t)(height + 7) * 135);
-    uint64_t pis[12];
-    GL355_TRY(gl355_semaphore_witness(private_key, topic, index, siblings, height, rows.data(), pis));
-    if (public_inputs_out) memcpy(public_inputs_out, pis, sizeof pis);
-    return gl355_circuit_prove_rows(h, ch, rows.data(), pis, 12, blinding_key, proof, proof_capacity_words);
+    if (!ch || !proof) return ctx->fail(GL355_E_INVALID_ARG, "semaphore_prove: null argument");
+    if (proof_capacity_words < gl355_proof_words(&ch->pd)) return ctx->fail(GL355_E_INVALID_ARG, "prove: proof buffer too small (see gl355_proof_words)");
+    return gl355_semaphore_prove_units(h, ch, 1, private_key, topic, &index, siblings, height, blinding_key, proof, public_inputs_out);
 }
 
 }  // extern "C"

@@ -80,6 +80,17 @@ void Ctx::release(void* p) {
     for (auto& b : blocks)
         if (b.p == p) { b.used = false; return; }
 }
+int32_t Ctx::pinned(size_t bytes, void** out) {
+    if (bytes > pinned_size) {
+        if (pinned_buf) { (void)wait_impl(); (void)hipHostFree(pinned_buf); pinned_buf = nullptr; pinned_size = 0; }
+        const size_t want = (bytes + (1 << 20)) & ~size_t((1 << 20) - 1);
+        hipError_t e = hipHostMalloc(&pinned_buf, want, hipHostMallocDefault);
+        if (e != hipSuccess) { (void)hipGetLastError(); pinned_buf = nullptr; return fail_hip(e, "hipHostMalloc(staging)", __FILE__, __LINE__); }
+        pinned_size = want;
+    }
+    *out = pinned_buf;
+    return GL355_OK;
+}
 void Ctx::release_all() {
     for (auto& b : blocks) (void)hipFree(b.p);
     blocks.clear();
@@ -225,6 +236,7 @@ int32_t gl355_ctx_destroy(gl355_ctx* ctx) {
     for (auto& kv : c.pow_cache) (void)hipFree(kv.second.lo);
     for (auto& kv : c.full_cache) (void)hipFree(kv.second);
     if (c.tw_fwd) (void)hipFree(c.tw_fwd);
+    if (c.pinned_buf) (void)hipHostFree(c.pinned_buf);
     if (c.sync_ev) (void)hipEventDestroy(c.sync_ev);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
@@ -240,6 +252,10 @@ int32_t gl355_ctx_set_option(gl355_ctx* ctx, int32_t option, int64_t value) {
     case GL355_OPT_REPLAY_THREADS:
         if (value < 1 || value > 64) return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: REPLAY_THREADS must be in 1..64");
         ctx->c.replay_threads = (uint32_t)value;
+        return GL355_OK;
+    case GL355_OPT_BATCH_UNITS:
+        if (value < 1 || value > GL355_MAX_UNITS) return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: BATCH_UNITS must be in 1..GL355_MAX_UNITS");
+        ctx->c.batch_units = (uint32_t)value;
         return GL355_OK;
     case GL355_OPT_BLOCKING_SYNC:
         ctx->c.blocking_sync = value != 0;

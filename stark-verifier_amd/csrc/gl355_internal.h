@@ -70,6 +70,7 @@ struct Ctx {
     // host wait for the stream: spinning hipStreamSynchronize (lowest latency) or, with GL355_OPT_BLOCKING_SYNC, a blocking
     // event wait that leaves the CPU to other prover threads (more host threads than cores)
     uint32_t replay_threads = 1;      // GL355_OPT_REPLAY_THREADS
+    uint32_t batch_units = 8;         // GL355_OPT_BATCH_UNITS
     uint32_t ntt_single_pass_max_log = 14;   // GL355_OPT_NTT_SINGLE_PASS_MAX_LOG (12..14)
     bool blocking_sync = false;
     hipEvent_t sync_ev = nullptr;
@@ -88,6 +89,10 @@ struct Ctx {
     int32_t fail_hip(hipError_t e, const char* expr, const char* file, int line);
     int32_t alloc(size_t bytes, void** out);
     void release(void* p);
+    // pinned host staging area of the context (grow-only): device -> host copies into it are truly asynchronous
+    void* pinned_buf = nullptr;
+    size_t pinned_size = 0;
+    int32_t pinned(size_t bytes, void** out);
     void release_all();
     // lo[c*4096 + j] = bases[c]^j, hi[c*4096 + j] = bases[c]^(4096 j)
     int32_t pow_tables_multi(const std::vector<uint64_t>& bases, const uint64_t** lo, const uint64_t** hi);
@@ -118,6 +123,7 @@ struct Scratch {
     explicit Scratch(Ctx* c) : ctx(c) {}
     ~Scratch() { if (p) ctx->release(p); }
     int32_t get(size_t bytes) { return ctx->alloc(bytes, &p); }
+    void reset() { if (p) ctx->release(p); p = nullptr; }      // give the block back early (reuse is stream-ordered)
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
     Scratch(const Scratch&) = delete;
     Scratch& operator=(const Scratch&) = delete;
@@ -230,6 +236,23 @@ int32_t quotient_dev(Ctx* ctx, const gl355_circuit* c, const uint64_t* cs_lde, c
                      const uint64_t* zs_lde, uint64_t lde_stride, const uint64_t* k_is_dev, const uint64_t* betas,
                      const uint64_t* gammas, const uint64_t* alphas, const uint64_t pi_hash[4], uint64_t* out_values);
 Ctx* ctx_of(gl355_ctx* h);
+
+// ---- prover_batch.hip: CircuitData::prove for B lock-step units of one circuit ---------------------------------------------
+struct BlindKey;
+struct ProveUnit {
+    const uint64_t* public_inputs; uint32_t n_public_inputs;
+    uint32_t key[8];                       // the unit's blinding key (blinding.cuh BlindKey words)
+    uint64_t* proof; uint64_t proof_capacity_words;
+};
+// dense witness: d_wires_dense = [B][num_wires][n] on the device; sparse: rows_host = [B][n_rows][num_wires] (host) of circuit rows
+// row_idx[r], blinding rows generated on the device from each unit's key
+int32_t prove_units(Ctx* ctx, const gl355_prover_data* pd, uint32_t B, const uint64_t* d_wires_dense, const uint32_t* row_idx,
+                    const uint64_t* rows_host, uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
+                    const ProveUnit* io);
+int32_t resolve_blinding_key_words(Ctx* ctx, const uint8_t* key, uint32_t out[8]);
+int32_t quotient_units_dev(Ctx* ctx, const gl355_circuit* c, uint32_t B, const uint64_t* cs_lde, const uint64_t* wires_lde, uint64_t wires_us,
+                           const uint64_t* zs_lde, uint64_t zs_us, uint64_t lde_stride, const uint64_t* k_is_dev, const uint64_t* betas /* [B][4] */,
+                           const uint64_t* gammas, const uint64_t* alphas, const uint64_t* pi_hashes /* [B][4] */, uint64_t* out_values /* [B][nch][nq] */);
 
 static inline uint32_t log2_u64(uint64_t n) { uint32_t l = 0; while ((1ull << l) < n) l++; return l; }
 static inline uint32_t host_brev(uint32_t x, uint32_t bits) {

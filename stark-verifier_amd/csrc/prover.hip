@@ -153,16 +153,10 @@ int32_t resolve_blinding_key(Ctx* ctx, const uint8_t* key, BlindKey* out) {
     return GL355_OK;
 }
 
-struct OracleGuard {
-    gl355_oracle* o = nullptr;
-    ~OracleGuard() { if (o) gl355_oracle_destroy(o); }
-};
-
-static int32_t observe_cap(Ctx* ctx, const gl355_oracle* o, gl355_challenger* ch, uint64_t* dst) {
-    const uint64_t words = 4ull << o->cap_height;
-    GL355_HIP(ctx, ctx->d2h(dst, o->cap, words * 8));
-    GL355_HIP(ctx, ctx->wait());
-    gl355_challenger_observe(ch, dst, words);
+int32_t resolve_blinding_key_words(Ctx* ctx, const uint8_t* key, uint32_t out[8]) {
+    BlindKey k;
+    GL355_TRY(resolve_blinding_key(ctx, key, &k));
+    memcpy(out, k.w, 32);
     return GL355_OK;
 }
 
@@ -194,40 +188,7 @@ extern "C" uint64_t gl355_proof_words(const gl355_prover_data* pd) {
     return w;
 }
 
-// scatter the sparse witness rows into the column-major wire matrix and fill the blinding rows on the device
-__global__ void witness_rows_kernel(uint64_t* wires, uint64_t n, uint32_t num_wires, const uint32_t* row_idx,
-                                    const uint64_t* row_vals, uint32_t n_rows) {
-    const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (g >= (uint64_t)n_rows * num_wires) return;
-    const uint32_t r = g / num_wires, c = g % num_wires;
-    wires[(uint64_t)c * n + row_idx[r]] = gl_canon(row_vals[g]);
-}
-// element g of the witness-blinding stream: g < n_blind * num_wires fills wire g / n_blind of blinding row g % n_blind,
-// the next n_z_pairs elements are the shared routed value of the Z-blinding row pairs
-__global__ void witness_blind_kernel(uint64_t* wires, uint64_t n, uint32_t num_wires, uint32_t blind_start, uint32_t n_blind,
-                                     uint32_t z_start, uint32_t n_z_pairs, BlindKey key) {
-    const uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    const uint64_t n_a = (uint64_t)n_blind * num_wires;
-    if (4 * b >= n_a + n_z_pairs) return;
-    uint64_t e[4];
-    blind_block_elements(key, GL355_BLIND_STREAM_WITNESS, (uint32_t)b, e);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint64_t g = 4 * b + j;
-        if (g < n_a) {
-            const uint32_t c = g / n_blind, r = g % n_blind;          // every wire of the wire-blinding rows
-            wires[(uint64_t)c * n + blind_start + r] = e[j];
-        } else if (g < n_a + n_z_pairs) {
-            const uint64_t k = g - n_a;                                 // one shared routed value per Z-blinding pair
-            wires[z_start + 2 * k] = e[j];
-            wires[z_start + 2 * k + 1] = e[j];
-        }
-    }
-}
-
-static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, const uint64_t* d_wires, const uint64_t* public_inputs,
-                          uint32_t n_public_inputs, const BlindKey& key, uint64_t* proof, uint64_t proof_capacity_words);
-
+// ---- single-proof entries: one unit through the lock-step prover (prover_batch.hip) ---------------------------------------
 extern "C" int32_t gl355_prove(gl355_ctx* h, const gl355_prover_data* pd, const uint64_t* wires, const uint64_t* public_inputs,
                                uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof, uint64_t proof_capacity_words) {
     Ctx* ctx = ctx_of(h);
@@ -236,9 +197,9 @@ extern "C" int32_t gl355_prove(gl355_ctx* h, const gl355_prover_data* pd, const 
     if (!pd || !pd->circuit || !wires) return ctx->fail(GL355_E_INVALID_ARG, "prove: null argument");
     Staged s_wires(ctx);
     GL355_TRY(s_wires.open(wires, ((uint64_t)pd->circuit->num_wires << pd->circuit->degree_bits) * 8, 1));
-    BlindKey key;
-    GL355_TRY(resolve_blinding_key(ctx, blinding_key, &key));
-    return prove_core(h, ctx, pd, s_wires.as<uint64_t>(), public_inputs, n_public_inputs, key, proof, proof_capacity_words);
+    ProveUnit io{public_inputs, n_public_inputs, {0}, proof, proof_capacity_words};
+    GL355_TRY(resolve_blinding_key_words(ctx, blinding_key, io.key));
+    return prove_units(ctx, pd, 1, s_wires.as<uint64_t>(), nullptr, nullptr, 0, 0, 0, 0, 0, &io);
 }
 
 // Witness given as its non-zero rows only (the rest of the 2^degree_bits rows are Noop rows): rows[r] lists
@@ -249,189 +210,34 @@ extern "C" int32_t gl355_prove_sparse(gl355_ctx* h, const gl355_prover_data* pd,
                                       uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
                                       const uint64_t* public_inputs, uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof,
                                       uint64_t proof_capacity_words) {
+    return gl355_prove_sparse_units(h, pd, 1, row_idx, rows, n_rows, blind_start, n_blind, z_start, n_z_pairs, public_inputs, n_public_inputs,
+                                    blinding_key, proof, proof_capacity_words);
+}
+
+// the same for n_units independent witnesses of ONE circuit, proven in lock-step on this context (every stage's kernels carry
+// a unit dimension; per-unit transcripts, keys and proofs): rows = [n_units][n_rows][num_wires], public_inputs = [n_units][n_public_inputs],
+// proofs = [n_units][proof_capacity_words], blinding_keys = [n_units][32] or NULL (a fresh OS-random key for every unit)
+extern "C" int32_t gl355_prove_sparse_units(gl355_ctx* h, const gl355_prover_data* pd, uint32_t n_units, const uint32_t* row_idx, const uint64_t* rows,
+                                            uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
+                                            const uint64_t* public_inputs, uint32_t n_public_inputs, const uint8_t* blinding_keys,
+                                            uint64_t* proofs, uint64_t proof_capacity_words) {
     Ctx* ctx = ctx_of(h);
     if (!ctx) return GL355_E_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
-    if (!pd || !pd->circuit || (!row_idx && n_rows) || (!rows && n_rows)) return ctx->fail(GL355_E_INVALID_ARG, "prove_sparse: null argument");
-    const uint32_t nw = pd->circuit->num_wires;
+    if (!pd || !pd->circuit || (!row_idx && n_rows) || (!rows && n_rows) || !proofs || (!public_inputs && n_public_inputs))
+        return ctx->fail(GL355_E_INVALID_ARG, "prove_sparse: null argument");
+    if (n_units == 0 || n_units > GL355_MAX_UNITS) return ctx->fail(GL355_E_INVALID_ARG, "prove_sparse: 1..GL355_MAX_UNITS units per call");
     const uint64_t n = 1ull << pd->circuit->degree_bits;
     if ((uint64_t)blind_start + n_blind > n || (uint64_t)z_start + 2ull * n_z_pairs > n) return ctx->fail(GL355_E_INVALID_ARG, "prove_sparse: blinding rows out of range");
     for (uint32_t r = 0; r < n_rows; r++)
         if (row_idx[r] >= n) return ctx->fail(GL355_E_INVALID_ARG, "prove_sparse: row index out of range");
-    BlindKey key;
-    GL355_TRY(resolve_blinding_key(ctx, blinding_key, &key));
-    Scratch w(ctx), rbuf(ctx);
-    GL355_TRY(w.get((uint64_t)nw * n * 8));
-    GL355_HIP(ctx, hipMemsetAsync(w.p, 0, (uint64_t)nw * n * 8, ctx->stream));
-    if (n_rows) {
-        GL355_TRY(rbuf.get((uint64_t)n_rows * nw * 8 + (uint64_t)n_rows * 4 + 16));
-        uint64_t* d_vals = rbuf.as<uint64_t>();
-        uint32_t* d_idx = reinterpret_cast<uint32_t*>(d_vals + (uint64_t)n_rows * nw);
-        GL355_HIP(ctx, hipMemcpyAsync(d_vals, rows, (uint64_t)n_rows * nw * 8, hipMemcpyHostToDevice, ctx->stream));
-        GL355_HIP(ctx, hipMemcpyAsync(d_idx, row_idx, (uint64_t)n_rows * 4, hipMemcpyHostToDevice, ctx->stream));
-        const uint64_t cnt = (uint64_t)n_rows * nw;
-        ProfScope ps(ctx, "witness_scatter", cnt * 16);
-        hipLaunchKernelGGL(witness_rows_kernel, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, w.as<uint64_t>(), n, nw,
-                           d_idx, d_vals, n_rows);
-        GL355_HIP(ctx, hipGetLastError());
+    ProveUnit io[GL355_MAX_UNITS];
+    for (uint32_t u = 0; u < n_units; u++) {
+        io[u] = ProveUnit{public_inputs ? public_inputs + (uint64_t)u * n_public_inputs : nullptr, n_public_inputs, {0},
+                          proofs + (uint64_t)u * proof_capacity_words, proof_capacity_words};
+        GL355_TRY(resolve_blinding_key_words(ctx, blinding_keys ? blinding_keys + 32ull * u : nullptr, io[u].key));
     }
-    const uint64_t cnt_b = (uint64_t)n_blind * nw + n_z_pairs;
-    if (cnt_b) {
-        ProfScope ps(ctx, "witness_blind", cnt_b * 8);
-        hipLaunchKernelGGL(witness_blind_kernel, dim3((uint32_t)((cnt_b / 4 + 256) / 256)), dim3(256), 0, ctx->stream, w.as<uint64_t>(), n, nw,
-                           blind_start, n_blind, z_start, n_z_pairs, key);
-        GL355_HIP(ctx, hipGetLastError());
-    }
-    GL355_HIP(ctx, ctx->wait());  // host row buffers may be reused by the caller
-    return prove_core(h, ctx, pd, w.as<uint64_t>(), public_inputs, n_public_inputs, key, proof, proof_capacity_words);
-}
-
-static int32_t prove_core(gl355_ctx* h, Ctx* ctx, const gl355_prover_data* pd, const uint64_t* d_wires, const uint64_t* public_inputs,
-                          uint32_t n_public_inputs, const BlindKey& key, uint64_t* proof, uint64_t proof_capacity_words) {
-    const uint64_t* wires = d_wires;
-    if (!pd || !pd->circuit || !pd->constants_sigmas || !pd->sigmas || !pd->k_is || !wires || !proof || (!public_inputs && n_public_inputs))
-        return ctx->fail(GL355_E_INVALID_ARG, "prove: null argument");
-    const gl355_circuit& c = *pd->circuit;
-    const uint32_t nch = c.num_challenges, qdf = c.max_degree, npp = c.num_partial_products, routed = c.num_routed_wires;
-    const uint32_t lde_bits = c.degree_bits + c.rate_bits, cap_h = pd->cap_height;
-    const uint64_t n = 1ull << c.degree_bits, N = 1ull << lde_bits, n_cap = 1ull << cap_h;
-    if (nch == 0 || nch > 4 || pd->n_fri_layers > 32) return ctx->fail(GL355_E_UNSUPPORTED, "prove: unsupported shape");
-    const uint64_t need = gl355_proof_words(pd);
-    if (proof_capacity_words < need) return ctx->fail(GL355_E_INVALID_ARG, "prove: proof buffer too small (see gl355_proof_words)");
-    const gl355_oracle* cs = pd->constants_sigmas;
-    if (cs->log_n != c.degree_bits || cs->rate_bits != c.rate_bits || cs->cap_height != cap_h)
-        return ctx->fail(GL355_E_INVALID_ARG, "prove: constants_sigmas oracle does not match the circuit");
-    const bool zk = pd->zero_knowledge != 0;
-
-    uint64_t* out = proof;
-    uint64_t* hdr = out; out += 8;
-    hdr[0] = need; hdr[1] = c.degree_bits; hdr[2] = pd->n_fri_layers; hdr[3] = pd->num_queries; hdr[4] = n_public_inputs;
-    hdr[5] = zk; hdr[6] = cap_h; hdr[7] = nch;
-
-    const int32_t hasher = pd->hasher;
-    if (hasher != GL355_HASH_POSEIDON && hasher != GL355_HASH_BN254_POSEIDON) return ctx->fail(GL355_E_INVALID_ARG, "prove: unknown hasher");
-    if (cs->hasher != hasher) return ctx->fail(GL355_E_INVALID_ARG, "prove: constants_sigmas was committed with another hasher");
-    gl355_challenger ch;
-    gl355_challenger_init_h(&ch, hasher);
-    uint64_t pi_hash[4];
-    gl355_host_hash_no_pad(public_inputs, n_public_inputs, pi_hash);
-    gl355_challenger_observe(&ch, pd->circuit_digest, 4);
-    gl355_challenger_observe(&ch, pi_hash, 4);
-
-    // device staging: sigma values, k_is, salt (the witness is already resident)
-    Staged s_sig(ctx), s_k(ctx);
-    GL355_TRY(s_sig.open(pd->sigmas, (uint64_t)routed * n * 8, 1));
-    GL355_TRY(s_k.open(pd->k_is, (uint64_t)routed * 8, 1));
-    Scratch salt(ctx);
-    if (zk) GL355_TRY(salt.get((uint64_t)GL355_SALT_SIZE * N * 8));
-    auto fresh_salt = [&](uint32_t stream_id) -> int32_t {
-        const uint64_t cnt = (uint64_t)GL355_SALT_SIZE * N;
-        ProfScope ps(ctx, "salt", cnt * 8);
-        hipLaunchKernelGGL(salt_kernel, dim3((uint32_t)((cnt / 4 + 255) / 256)), dim3(256), 0, ctx->stream, salt.as<uint64_t>(), cnt, key, stream_id);
-        GL355_HIP(ctx, hipGetLastError());
-        return GL355_OK;
-    };
-
-    // ---- wires ----------------------------------------------------------------------------------
-    OracleGuard g_w, g_z, g_q;
-    if (zk) GL355_TRY(fresh_salt(GL355_BLIND_STREAM_WIRES_SALT));
-    GL355_TRY(gl355_commit_h(h, hasher, wires, c.degree_bits, c.num_wires, c.rate_bits, 0, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_w.o));
-    uint64_t* p_wires_cap = out; out += n_cap * 4;
-    GL355_TRY(observe_cap(ctx, g_w.o, &ch, p_wires_cap));
-    uint64_t betas[4], gammas[4], alphas[4];
-    gl355_challenger_squeeze(&ch, betas, nch);
-    gl355_challenger_squeeze(&ch, gammas, nch);
-    // ---- Z / partial products ----------------------------------------------------------------------
-    Scratch zbuf(ctx);
-    const uint32_t z_width = nch * (1 + npp);
-    GL355_TRY(zbuf.get((uint64_t)z_width * n * 8));
-    for (uint32_t k = 0; k < nch; k++) {
-        uint64_t* z = zbuf.as<uint64_t>() + (uint64_t)k * n;
-        uint64_t* pp = zbuf.as<uint64_t>() + ((uint64_t)nch + (uint64_t)k * npp) * n;
-        GL355_TRY(zs_partial_products_dev(ctx, wires, s_sig.as<uint64_t>(), s_k.as<uint64_t>(), c.degree_bits, routed, qdf,
-                                          betas[k], gammas[k], z, pp));
-    }
-    if (zk) GL355_TRY(fresh_salt(GL355_BLIND_STREAM_ZS_SALT));
-    GL355_TRY(gl355_commit_h(h, hasher, zbuf.as<uint64_t>(), c.degree_bits, z_width, c.rate_bits, 0, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_z.o));
-    uint64_t* p_zs_cap = out; out += n_cap * 4;
-    GL355_TRY(observe_cap(ctx, g_z.o, &ch, p_zs_cap));
-    gl355_challenger_squeeze(&ch, alphas, nch);
-    // ---- quotient ------------------------------------------------------------------------------------
-    uint32_t qdb = 0;
-    while ((1u << qdb) < qdf) qdb++;
-    const uint64_t nq = n << qdb;
-    Scratch qv(ctx), qc(ctx);
-    GL355_TRY(qv.get((uint64_t)nch * nq * 8));
-    GL355_TRY(qc.get((uint64_t)nch * nq * 8));
-    GL355_TRY(quotient_dev(ctx, &c, cs->lde, g_w.o->lde, g_z.o->lde, N, s_k.as<uint64_t>(), betas, gammas, alphas, pi_hash, qv.as<uint64_t>()));
-    GL355_TRY(intt_from_bitrev_dev(ctx, qv.as<uint64_t>(), nq, qc.as<uint64_t>(), nq, c.degree_bits + qdb, nch, GL355_COSET_SHIFT));
-    if (zk) GL355_TRY(fresh_salt(GL355_BLIND_STREAM_QUOTIENT_SALT));
-    GL355_TRY(gl355_commit_h(h, hasher, qc.as<uint64_t>(), c.degree_bits, nch * qdf, c.rate_bits, 1, zk ? salt.as<uint64_t>() : nullptr, cap_h, &g_q.o));
-    uint64_t* p_q_cap = out; out += n_cap * 4;
-    GL355_TRY(observe_cap(ctx, g_q.o, &ch, p_q_cap));
-    uint64_t zeta[2], zeta_next[2];
-    gl355_challenger_squeeze(&ch, zeta, 2);
-    const uint64_t g = gl_root_of_unity(c.degree_bits);
-    zeta_next[0] = gl_canon(gl_mul(zeta[0], g)); zeta_next[1] = gl_canon(gl_mul(zeta[1], g));
-    // ---- openings (OpeningSet::new): every polynomial at zeta, the Z polynomials at g*zeta ----------------
-    const gl355_oracle* oracles[4] = {cs, g_w.o, g_z.o, g_q.o};
-    std::vector<const uint64_t*> all_ptrs, z_ptrs;
-    for (int o = 0; o < 4; o++)
-        for (uint32_t i = 0; i < oracles[o]->batch; i++) all_ptrs.push_back(oracles[o]->coeffs + ((uint64_t)i << c.degree_bits));
-    for (uint32_t i = 0; i < nch; i++) z_ptrs.push_back(g_z.o->coeffs + ((uint64_t)i << c.degree_bits));
-    const uint64_t n_open = all_ptrs.size();
-    Scratch evb(ctx);
-    GL355_TRY(evb.get((n_open + nch) * 16));
-    GL355_TRY(eval_polys_ext_dev(ctx, all_ptrs.data(), (uint32_t)n_open, c.degree_bits, zeta, evb.as<uint64_t>()));
-    GL355_TRY(eval_polys_ext_dev(ctx, z_ptrs.data(), nch, c.degree_bits, zeta_next, evb.as<uint64_t>() + 2 * n_open));
-    uint64_t* p_open = out; out += 2 * (n_open + nch);
-    GL355_HIP(ctx, ctx->d2h(p_open, evb.as<uint64_t>(), (n_open + nch) * 16));
-    GL355_HIP(ctx, ctx->wait());
-    gl355_challenger_observe(&ch, p_open, 2 * (n_open + nch));
-    uint64_t fri_alpha[2];
-    gl355_challenger_squeeze(&ch, fri_alpha, 2);
-    // ---- DEEP quotient (prove_openings) ----------------------------------------------------------------------
-    Scratch acc(ctx);
-    GL355_TRY(acc.get(n * 16));
-    GL355_HIP(ctx, hipMemsetAsync(acc.as<uint64_t>(), 0, n * 16, ctx->stream));
-    GL355_TRY(deep_batch_dev(ctx, all_ptrs.data(), (uint32_t)n_open, c.degree_bits, fri_alpha, zeta, acc.as<uint64_t>()));
-    GL355_TRY(deep_batch_dev(ctx, z_ptrs.data(), nch, c.degree_bits, fri_alpha, zeta_next, acc.as<uint64_t>()));
-    // ---- FRI ----------------------------------------------------------------------------------------------------
-    std::vector<uint32_t> arity(pd->n_fri_layers, 1);
-    uint64_t* p_fri_caps = out; out += (uint64_t)pd->n_fri_layers * n_cap * 4;
-    uint64_t* p_final = out; out += 2 * (n >> pd->n_fri_layers);
-    uint64_t* p_pow = out; out += 1;
-    std::vector<uint64_t> q_idx(pd->num_queries);
-    uint64_t sib_total = 0;
-    for (uint32_t l = 0; l < pd->n_fri_layers; l++) sib_total += (uint64_t)(lde_bits - 1 - l - cap_h) * 4;
-    std::vector<uint64_t> step_evals((uint64_t)pd->num_queries * pd->n_fri_layers * 4 + 4), step_sibs((uint64_t)pd->num_queries * sib_total + 4);
-    GL355_TRY(gl355_fri_prove(h, acc.as<uint64_t>(), c.degree_bits, c.rate_bits, cap_h, arity.data(), pd->n_fri_layers, pd->pow_bits,
-                              pd->num_queries, &ch, p_fri_caps, p_final, p_pow, q_idx.data(), step_evals.data(), step_sibs.data()));
-    // ---- initial-tree openings for every query ---------------------------------------------------------------------
-    const uint32_t depth0 = lde_bits - cap_h;
-    std::vector<std::vector<uint64_t>> leaves(4), sibs(4);
-    for (int o = 0; o < 4; o++) {
-        leaves[o].resize((uint64_t)pd->num_queries * oracles[o]->leaf_len + 4);
-        sibs[o].resize((uint64_t)pd->num_queries * depth0 * 4 + 4);
-        GL355_TRY(oracle_open_batch_on(ctx, oracles[o], q_idx.data(), pd->num_queries, leaves[o].data(), sibs[o].data()));
-    }
-    for (uint32_t q = 0; q < pd->num_queries; q++) {
-        *out++ = q_idx[q];
-        for (int o = 0; o < 4; o++) {
-            const uint32_t ll = oracles[o]->leaf_len;
-            memcpy(out, leaves[o].data() + (uint64_t)q * ll, (uint64_t)ll * 8); out += ll;
-            memcpy(out, sibs[o].data() + (uint64_t)q * depth0 * 4, (uint64_t)depth0 * 32); out += (uint64_t)depth0 * 4;
-        }
-        uint64_t so = 0;
-        for (uint32_t l = 0; l < pd->n_fri_layers; l++) {
-            memcpy(out, step_evals.data() + ((uint64_t)q * pd->n_fri_layers + l) * 4, 32); out += 4;
-            const uint64_t d = (uint64_t)(lde_bits - 1 - l - cap_h) * 4;
-            memcpy(out, step_sibs.data() + (uint64_t)q * sib_total + so, d * 8); out += d;
-            so += d;
-        }
-    }
-    if ((uint64_t)(out - proof) != need) return ctx->fail(GL355_E_HIP, "prove: internal proof-size mismatch");
-    return GL355_OK;
+    return prove_units(ctx, pd, n_units, nullptr, row_idx, rows, n_rows, blind_start, n_blind, z_start, n_z_pairs, io);
 }
 
 // ---- blinding-stream surface (blinding.cuh) ----------------------------------------------------------------------------

@@ -33,12 +33,14 @@ struct QuotArgs {
     const uint64_t* xw_hi;
     uint64_t zh_inv[16];      // 1 / (x^n - 1) for the 2^qdb classes of i mod 2^qdb
     uint64_t zh[16];          // x^n - 1
-    uint64_t betas[4], gammas[4], alphas[4];
-    uint64_t pi_hash[4];
     uint64_t n_inv;           // 1/n
-    uint64_t* out;            // [num_challenges][Nq], storage (bit-reversed) order
-    const uint64_t* alpha_pw; // alpha_c^k at [c * pw_stride + k], k < pw_stride (alpha_table_kernel)
+    uint64_t* out;            // [unit][num_challenges][Nq], storage (bit-reversed) order
+    const uint64_t* alpha_pw; // alpha_{u,c}^k at [(u * num_challenges + c) * pw_stride + k], k < pw_stride (alpha_table_kernel)
     uint32_t pw_stride;
+    // the lock-step units of one prover context (blockIdx.y): constants_sigmas is shared, wires / zs / out have unit strides,
+    // every unit has its own challenges and public-input hash
+    uint64_t wires_us, zs_us;
+    uint64_t betas[GL355_MAX_UNITS * 4], gammas[GL355_MAX_UNITS * 4], pi_hash[GL355_MAX_UNITS * 4];
 };
 
 // alpha-power accumulation of the constraint stream: term k of the stream is weighted alpha_c^k.  The powers are the same for
@@ -52,10 +54,10 @@ struct AlphaAcc {
     uint64_t acc[NCH];
     PwTable tab;
     uint32_t stride, idx;
-    GL_DEV void init(const QuotArgs& a, uint32_t first = 0) {
+    GL_DEV void init(const QuotArgs& a, uint32_t unit, uint32_t first = 0) {
 #pragma unroll
         for (int c = 0; c < NCH; c++) acc[c] = 0;
-        tab = (PwTable)a.alpha_pw; stride = a.pw_stride; idx = first;
+        tab = (PwTable)(a.alpha_pw + (uint64_t)unit * NCH * a.pw_stride); stride = a.pw_stride; idx = first;
     }
     GL_DEV void push(uint64_t term) {
 #pragma unroll
@@ -68,19 +70,19 @@ template <int NCH>
 using GateAccT = AlphaAcc<NCH>;
 
 // alpha_c^k for k < stride, one thread per entry (square-and-multiply over the bits of k)
-__global__ void alpha_table_kernel(uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3, uint32_t nch, uint32_t stride, uint64_t* out) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= stride) return;
-    const uint64_t al[4] = {a0, a1, a2, a3};
-    for (uint32_t c = 0; c < nch; c++) out[c * stride + k] = gl_canon(gl_pow(al[c], k));
+struct AlphaTabArgs { uint64_t alphas[GL355_MAX_UNITS * 4]; uint32_t nch, stride; uint64_t* out; };
+__global__ void alpha_table_kernel(AlphaTabArgs a) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, u = blockIdx.y;
+    if (k >= a.stride) return;
+    for (uint32_t c = 0; c < a.nch; c++) a.out[((uint64_t)u * a.nch + c) * a.stride + k] = gl_canon(gl_pow(a.alphas[u * 4 + c], k));
 }
 
-#define WIRE(j) (a.wires[(uint64_t)(j) * a.lde_stride + t])
+#define WIRE(j) (w[(uint64_t)(j) * a.lde_stride + t])
 #define CONST(j) (a.cs[(uint64_t)(j) * a.lde_stride + t])
 
 // PoseidonGate: 123 constraints (gates/poseidon.rs:592-698); wire layout :329-380
 template <class GateAcc>
-GL_DEV void gate_poseidon(const QuotArgs& a, uint64_t t, GateAcc& g) {
+GL_DEV void gate_poseidon(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g) {
     const uint64_t swap = WIRE(24);
     g.push(gl_sub(gl_mul(swap, swap), swap));
     uint64_t s[12];
@@ -136,7 +138,7 @@ GL_DEV void gate_poseidon(const QuotArgs& a, uint64_t t, GateAcc& g) {
 
 // BaseSumGate<2>{num_limbs}: sum_i limb_i 2^i - sum ; limb (limb - 1)   (gates/base_sum.rs:37-60)
 template <class GateAcc>
-GL_DEV void gate_base_sum(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num_limbs) {
+GL_DEV void gate_base_sum(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t num_limbs) {
     uint64_t acc = 0;
     for (uint32_t i = num_limbs; i-- > 0;) acc = gl_add(gl_add(acc, acc), WIRE(1 + i));
     g.push(gl_sub(acc, WIRE(0)));
@@ -147,17 +149,17 @@ GL_DEV void gate_base_sum(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t nu
 }
 // ConstantGate{n}: const_i - wire_i   (gates/constant.rs:31-36); gate constants follow the selectors
 template <class GateAcc>
-GL_DEV void gate_constant(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t n) {
+GL_DEV void gate_constant(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) g.push(gl_sub(CONST(a.c.num_selectors + i), WIRE(i)));
 }
 // PublicInputGate: wire_i - pi_hash_i   (gates/public_input.rs:32-39)
 template <class GateAcc>
-GL_DEV void gate_public_input(const QuotArgs& a, uint64_t t, GateAcc& g) {
-    for (uint32_t i = 0; i < 4; i++) g.push(gl_sub(WIRE(i), a.pi_hash[i]));
+GL_DEV void gate_public_input(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t unit) {
+    for (uint32_t i = 0; i < 4; i++) g.push(gl_sub(WIRE(i), a.pi_hash[unit * 4 + i]));
 }
 // ArithmeticGate{num_ops}: out - (c0 m0 m1 + c1 addend)   (gates/arithmetic.rs:47-68)
 template <class GateAcc>
-GL_DEV void gate_arithmetic(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num_ops) {
+GL_DEV void gate_arithmetic(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t num_ops) {
     const uint64_t c0 = CONST(a.c.num_selectors), c1 = CONST(a.c.num_selectors + 1);
     for (uint32_t i = 0; i < num_ops; i++) {
         const uint64_t m0 = WIRE(4 * i), m1 = WIRE(4 * i + 1), ad = WIRE(4 * i + 2), out = WIRE(4 * i + 3);
@@ -174,7 +176,7 @@ GL_DEV void push2(GateAcc& g, gl2 v) { g.push(v.c0); g.push(v.c1); }
 
 // ArithmeticExtensionGate{num_ops}: out - (c0 m0 m1 + c1 addend)   (gates/arithmetic_extension.rs:22-80)
 template <class GateAcc>
-GL_DEV void gate_arithmetic_ext(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num_ops) {
+GL_DEV void gate_arithmetic_ext(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t num_ops) {
     const uint64_t c0 = CONST(a.c.num_selectors), c1 = CONST(a.c.num_selectors + 1);
     for (uint32_t i = 0; i < num_ops; i++) {
         const gl2 m0 = WIRE2(8 * i), m1 = WIRE2(8 * i + 2), ad = WIRE2(8 * i + 4), out = WIRE2(8 * i + 6);
@@ -184,7 +186,7 @@ GL_DEV void gate_arithmetic_ext(const QuotArgs& a, uint64_t t, GateAcc& g, uint3
 }
 // MulExtensionGate{num_ops}: out - c0 m0 m1   (gates/multiplication_extension.rs:22-68)
 template <class GateAcc>
-GL_DEV void gate_mul_ext(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num_ops) {
+GL_DEV void gate_mul_ext(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t num_ops) {
     const uint64_t c0 = CONST(a.c.num_selectors);
     for (uint32_t i = 0; i < num_ops; i++) {
         const gl2 m0 = WIRE2(6 * i), m1 = WIRE2(6 * i + 2), out = WIRE2(6 * i + 4);
@@ -193,7 +195,7 @@ GL_DEV void gate_mul_ext(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t num
 }
 // PoseidonMdsGate: out_r - sum_i CIRC[i] in[(i+r)%12] - DIAG[r] in[r]   (gates/poseidon_mds.rs:26-126)
 template <class GateAcc>
-GL_DEV void gate_poseidon_mds(const QuotArgs& a, uint64_t t, GateAcc& g) {
+GL_DEV void gate_poseidon_mds(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g) {
     constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     for (uint32_t r = 0; r < 12; r++) {
         gl2 acc = gl2_make(0, 0);
@@ -210,7 +212,7 @@ GL_DEV void gate_poseidon_mds(const QuotArgs& a, uint64_t t, GateAcc& g) {
 }
 // RandomAccessGate{bits, copies, extra}   (gates/random_access.rs:27-147)
 template <class GateAcc>
-GL_DEV void gate_random_access(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t param) {
+GL_DEV void gate_random_access(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t param) {
     const uint32_t bits = param & 0xFF, copies = (param >> 8) & 0xFF, extra = (param >> 16) & 0xFF;
     const uint32_t vec = 1u << bits, routed = (2 + vec) * copies + extra;
     for (uint32_t c = 0; c < copies; c++) {
@@ -240,7 +242,7 @@ GL_DEV void gate_random_access(const QuotArgs& a, uint64_t t, GateAcc& g, uint32
 // ReducingGate{n} / ReducingExtensionGate{n}: acc*alpha + coeff - acc_i   (gates/reducing.rs:20-85,
 // gates/reducing_extension.rs:20-87); the last accumulator is the output (wires 0..1)
 template <bool EXT, class GateAcc>
-GL_DEV void gate_reducing(const QuotArgs& a, uint64_t t, GateAcc& g, uint32_t n) {
+GL_DEV void gate_reducing(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t n) {
     const gl2 alpha = WIRE2(2);
     gl2 acc = WIRE2(4);
     const uint32_t start_accs = 6 + (EXT ? 2 * n : n);
@@ -257,6 +259,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
     const uint64_t nq = 1ull << a.qbits;
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= nq) return;
+    const uint32_t unit = blockIdx.y;
+    const uint64_t* __restrict__ w = a.wires + (uint64_t)unit * a.wires_us;
+    const uint64_t* __restrict__ zs = a.zs + (uint64_t)unit * a.zs_us;
     const uint32_t qdb = a.qbits - a.c.degree_bits;
     const uint64_t iq = __brevll(t) >> (64 - a.qbits);   // natural index of storage row t
     const uint64_t x = gl_mul_small(gl_mul(a.xw_lo[iq & 4095], a.xw_hi[iq >> 12]), 7);
@@ -269,31 +274,31 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
     const uint32_t n_sel = a.c.num_selectors, n_cst = a.c.num_constants;
 
     AlphaAcc<NCH> total;
-    total.init(a);
+    total.init(a, unit);
     // ---- L0(x) (Z_c(x) - 1);  L0(x) = (x^n - 1) / (n (x - 1))  (vanishing_poly.rs:155-178) ---------
     const uint64_t zh_inv = a.zh_inv[iq & ((1u << qdb) - 1)];
     const uint64_t zh = a.zh[iq & ((1u << qdb) - 1)];  // x^n - 1 (never zero on the coset)
     const uint64_t l0 = gl_mul(gl_mul(zh, a.n_inv), gl_inv(gl_sub(x, 1)));
     for (uint32_t c = 0; c < nch; c++) {
-        const uint64_t z = a.zs[(uint64_t)c * a.lde_stride + t];
+        const uint64_t z = zs[(uint64_t)c * a.lde_stride + t];
         total.push(gl_sub(gl_mul(l0, z), l0));
     }
     // ---- partial products (vanishing_poly.rs:54-108, 183-218) -------------------------------------
     for (uint32_t c = 0; c < nch; c++) {
-        const uint64_t beta = a.betas[c], gamma = a.gammas[c];
+        const uint64_t beta = a.betas[unit * 4 + c], gamma = a.gammas[unit * 4 + c];
         const uint64_t bx = gl_mul(beta, x);
-        uint64_t prev = a.zs[(uint64_t)c * a.lde_stride + t];
+        uint64_t prev = zs[(uint64_t)c * a.lde_stride + t];
         const uint32_t n_chunks = (routed + chunk - 1) / chunk;
         for (uint32_t ch = 0; ch < n_chunks; ch++) {
             uint64_t num = 1, den = 1;
             for (uint32_t j = ch * chunk; j < (ch + 1) * chunk && j < routed; j++) {
-                const uint64_t w = gl_add(WIRE(j), gamma);
-                num = gl_mul(num, gl_add(w, gl_mul(bx, a.k_is[j])));
-                den = gl_mul(den, gl_add(w, gl_mul(beta, CONST(n_sel + n_cst + j))));
+                const uint64_t wg = gl_add(WIRE(j), gamma);
+                num = gl_mul(num, gl_add(wg, gl_mul(bx, a.k_is[j])));
+                den = gl_mul(den, gl_add(wg, gl_mul(beta, CONST(n_sel + n_cst + j))));
             }
             const uint64_t next = (ch + 1 < n_chunks)
-                                      ? a.zs[(uint64_t)(nch + c * npp + ch) * a.lde_stride + t]
-                                      : a.zs[(uint64_t)c * a.lde_stride + t_next];
+                                      ? zs[(uint64_t)(nch + c * npp + ch) * a.lde_stride + t]
+                                      : zs[(uint64_t)c * a.lde_stride + t_next];
             total.push(gl_sub(gl_mul(prev, num), gl_mul(next, den)));
             prev = next;
         }
@@ -306,19 +311,19 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
         const gl355_gate gt = a.c.gates[gi];
         if (gt.type == GL355_GATE_NOOP) continue;
         GateAccT<NCH> g;
-        g.init(a, total.idx);
+        g.init(a, unit, total.idx);
         switch (gt.type) {
-            case GL355_GATE_POSEIDON: gate_poseidon(a, t, g); break;
-            case GL355_GATE_BASE_SUM: gate_base_sum(a, t, g, gt.param); break;
-            case GL355_GATE_CONSTANT: gate_constant(a, t, g, gt.param); break;
-            case GL355_GATE_PUBLIC_INPUT: gate_public_input(a, t, g); break;
-            case GL355_GATE_ARITHMETIC: gate_arithmetic(a, t, g, gt.param); break;
-            case GL355_GATE_ARITHMETIC_EXT: gate_arithmetic_ext(a, t, g, gt.param); break;
-            case GL355_GATE_MUL_EXT: gate_mul_ext(a, t, g, gt.param); break;
-            case GL355_GATE_POSEIDON_MDS: gate_poseidon_mds(a, t, g); break;
-            case GL355_GATE_RANDOM_ACCESS: gate_random_access(a, t, g, gt.param); break;
-            case GL355_GATE_REDUCING: gate_reducing<false>(a, t, g, gt.param); break;
-            case GL355_GATE_REDUCING_EXT: gate_reducing<true>(a, t, g, gt.param); break;
+            case GL355_GATE_POSEIDON: gate_poseidon(a, w, t, g); break;
+            case GL355_GATE_BASE_SUM: gate_base_sum(a, w, t, g, gt.param); break;
+            case GL355_GATE_CONSTANT: gate_constant(a, w, t, g, gt.param); break;
+            case GL355_GATE_PUBLIC_INPUT: gate_public_input(a, w, t, g, unit); break;
+            case GL355_GATE_ARITHMETIC: gate_arithmetic(a, w, t, g, gt.param); break;
+            case GL355_GATE_ARITHMETIC_EXT: gate_arithmetic_ext(a, w, t, g, gt.param); break;
+            case GL355_GATE_MUL_EXT: gate_mul_ext(a, w, t, g, gt.param); break;
+            case GL355_GATE_POSEIDON_MDS: gate_poseidon_mds(a, w, t, g); break;
+            case GL355_GATE_RANDOM_ACCESS: gate_random_access(a, w, t, g, gt.param); break;
+            case GL355_GATE_REDUCING: gate_reducing<false>(a, w, t, g, gt.param); break;
+            case GL355_GATE_REDUCING_EXT: gate_reducing<true>(a, w, t, g, gt.param); break;
             default: break;
         }
         const uint64_t sel = CONST(gt.selector_index);
@@ -331,22 +336,32 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
     for (uint32_t c = 0; c < nch; c++) {
         const uint64_t v = gl_mul(gl_add(total.acc[c], gate_sum[c]), zh_inv);
-        a.out[(uint64_t)c * nq + t] = gl_canon(v);
+        a.out[((uint64_t)unit * nch + c) * nq + t] = gl_canon(v);
     }
 }
 
 int32_t quotient_dev(Ctx* ctx, const gl355_circuit* c, const uint64_t* cs_lde, const uint64_t* wires_lde,
                      const uint64_t* zs_lde, uint64_t lde_stride, const uint64_t* k_is_dev, const uint64_t* betas,
                      const uint64_t* gammas, const uint64_t* alphas, const uint64_t pi_hash[4], uint64_t* out_values) {
+    uint64_t b[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0}, al[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < c->num_challenges && i < 4; i++) { b[i] = betas[i]; g[i] = gammas[i]; al[i] = alphas[i]; }
+    return quotient_units_dev(ctx, c, 1, cs_lde, wires_lde, 0, zs_lde, 0, lde_stride, k_is_dev, b, g, al, pi_hash, out_values);
+}
+
+// B lock-step units (blockIdx.y): betas / gammas / alphas / pi_hashes are [B][4]
+int32_t quotient_units_dev(Ctx* ctx, const gl355_circuit* c, uint32_t B, const uint64_t* cs_lde, const uint64_t* wires_lde, uint64_t wires_us,
+                           const uint64_t* zs_lde, uint64_t zs_us, uint64_t lde_stride, const uint64_t* k_is_dev, const uint64_t* betas,
+                           const uint64_t* gammas, const uint64_t* alphas, const uint64_t* pi_hashes, uint64_t* out_values) {
     uint32_t qdb = 0;
     while ((1u << qdb) < c->max_degree) qdb++;
     if ((1u << qdb) != c->max_degree || qdb > c->rate_bits || qdb > 4) return ctx->fail(GL355_E_UNSUPPORTED, "quotient: degree factor must be a power of two <= 2^rate_bits");
     if (c->num_challenges == 0 || c->num_challenges > 4) return ctx->fail(GL355_E_UNSUPPORTED, "quotient: 1..4 challenges");
     if (c->num_gates > GL355_MAX_GATES) return ctx->fail(GL355_E_INVALID_ARG, "quotient: too many gates");
+    if (B == 0 || B > GL355_MAX_UNITS) return ctx->fail(GL355_E_INVALID_ARG, "quotient: 1..GL355_MAX_UNITS units");
     QuotArgs a;
     memset(&a, 0, sizeof a);
     a.c = *c;
-    a.cs = cs_lde; a.wires = wires_lde; a.zs = zs_lde; a.lde_stride = lde_stride;
+    a.cs = cs_lde; a.wires = wires_lde; a.zs = zs_lde; a.lde_stride = lde_stride; a.wires_us = wires_us; a.zs_us = zs_us;
     a.qbits = c->degree_bits + qdb;
     a.k_is = k_is_dev;
     GL355_TRY(ctx->pow_tables(gl_root_of_unity(a.qbits), &a.xw_lo, &a.xw_hi));
@@ -359,10 +374,15 @@ int32_t quotient_dev(Ctx* ctx, const gl355_circuit* c, const uint64_t* cs_lde, c
         a.zh_inv[k] = gl_canon(gl_inv(a.zh[k]));
         w = gl_mul(w, wq);
     }
-    for (uint32_t i = 0; i < c->num_challenges; i++) {
-        a.betas[i] = gl_canon(betas[i]); a.gammas[i] = gl_canon(gammas[i]); a.alphas[i] = gl_canon(alphas[i]);
+    AlphaTabArgs ta;
+    memset(&ta, 0, sizeof ta);
+    for (uint32_t u = 0; u < B; u++) {
+        for (uint32_t i = 0; i < c->num_challenges; i++) {
+            a.betas[u * 4 + i] = gl_canon(betas[u * 4 + i]); a.gammas[u * 4 + i] = gl_canon(gammas[u * 4 + i]);
+            ta.alphas[u * 4 + i] = gl_canon(alphas[u * 4 + i]);
+        }
+        for (int i = 0; i < 4; i++) a.pi_hash[u * 4 + i] = gl_canon(pi_hashes[u * 4 + i]);
     }
-    for (int i = 0; i < 4; i++) a.pi_hash[i] = gl_canon(pi_hash[i]);
     a.n_inv = gl_canon(gl_inv((1ull << c->degree_bits) % GL_P));
     a.out = out_values;
     // length of the constraint stream = the permutation-argument prefix + the longest gate (constraint counts as in
@@ -387,16 +407,16 @@ int32_t quotient_dev(Ctx* ctx, const gl355_circuit* c, const uint64_t* cs_lde, c
     const uint32_t n_chunks = (c->num_routed_wires + c->max_degree - 1) / c->max_degree;
     a.pw_stride = ((c->num_challenges * (1 + n_chunks) + longest + 1) + 63) & ~63u;
     Scratch pw(ctx);
-    GL355_TRY(pw.get((size_t)c->num_challenges * a.pw_stride * 8));
+    GL355_TRY(pw.get((size_t)B * c->num_challenges * a.pw_stride * 8));
     a.alpha_pw = pw.as<uint64_t>();
-    hipLaunchKernelGGL(alpha_table_kernel, dim3((a.pw_stride + 255) / 256), dim3(256), 0, ctx->stream, a.alphas[0], a.alphas[1], a.alphas[2],
-                       a.alphas[3], c->num_challenges, a.pw_stride, pw.as<uint64_t>());
+    ta.nch = c->num_challenges; ta.stride = a.pw_stride; ta.out = pw.as<uint64_t>();
+    hipLaunchKernelGGL(alpha_table_kernel, dim3((a.pw_stride + 255) / 256, B), dim3(256), 0, ctx->stream, ta);
     GL355_HIP(ctx, hipGetLastError());
     const uint64_t nq = 1ull << a.qbits;
     // every column of the three oracles once per point of the quotient coset + the result
-    ProfScope ps(ctx, "quotient_kernel", nq * 8 * ((uint64_t)c->num_selectors + c->num_constants + c->num_routed_wires + c->num_wires +
+    ProfScope ps(ctx, "quotient_kernel", (uint64_t)B * nq * 8 * ((uint64_t)c->num_selectors + c->num_constants + c->num_routed_wires + c->num_wires +
                                                    (uint64_t)c->num_challenges * (2 + c->num_partial_products)));
-    const dim3 grid((uint32_t)((nq + 127) / 128));
+    const dim3 grid((uint32_t)((nq + 127) / 128), B);
     switch (c->num_challenges) {
         case 1: hipLaunchKernelGGL(quotient_kernel<1>, grid, dim3(128), 0, ctx->stream, a); break;
         case 2: hipLaunchKernelGGL(quotient_kernel<2>, grid, dim3(128), 0, ctx->stream, a); break;

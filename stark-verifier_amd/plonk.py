@@ -568,6 +568,25 @@ def prove_sparse(ctx, data, row_idx, rows, public_inputs, seed, flat_only=False)
     return proof
 
 
+def prove_sparse_units(ctx, data, row_idx, rows, public_inputs, seeds):
+    """gl355_prove_sparse_units: len(rows) independent witnesses of one circuit proven in lock-step on `ctx`; seeds: one blinding
+    key (int / 32 bytes) per unit, or None for OS randomness.  -> flat proofs [units][words]"""
+    lib = ctx.lib
+    pd = data.prover_data(ctx)
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    pis = np.ascontiguousarray(public_inputs, dtype=np.uint64).reshape(rows.shape[0], -1)
+    units = rows.shape[0]
+    words = lib.gl355_proof_words(C.byref(pd))
+    flat = np.empty((units, words), dtype=np.uint64)
+    idx = np.ascontiguousarray(row_idx, dtype=np.uint32)
+    start, n_blind, z_pairs, _ = data.blind_rows
+    z_start = z_pairs[0][0] if z_pairs else 0
+    keys = None if seeds is None else C.cast(C.create_string_buffer(b"".join(key_bytes(s) for s in seeds), 32 * units), C.c_void_p)
+    ctx.check(lib.gl355_prove_sparse_units(ctx.h, C.byref(pd), units, idx.ctypes.data_as(C.c_void_p), _ptr(rows), idx.size, start, n_blind,
+                                           z_start, len(z_pairs), _ptr(pis), pis.shape[1], keys, _ptr(flat), words))
+    return flat
+
+
 def prove_staged(ctx, data, wires, public_inputs, rng, timings=None):
     """The same proof sequenced stage by stage from Python over the individual C-ABI entry points (used for
     per-stage timings and to cross-check gl355_prove); wires[num_wires][n] is the full witness."""
