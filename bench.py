@@ -130,13 +130,16 @@ class RecursiveProvers:
         self.sets = [gl.Context(device) for _ in range(threads)]      # one prover context per host thread
         if blocking_sync:
             for c in self.sets:
-                c.set_option(2, 1)                                   # GL355_OPT_BLOCKING_SYNC
+                c.set_option(2, int(blocking_sync))                  # GL355_OPT_BLOCKING_SYNC: 1 blocking event, 2 poll + back-off
         if replay_threads > 1:                                       # GL355_OPT_REPLAY_THREADS
             for c in self.sets:
                 c.set_option(3, replay_threads)
         if os.environ.get("GL355_BENCH_NTT_SINGLE_MAX"):             # experiments: GL355_OPT_NTT_SINGLE_PASS_MAX_LOG
             for c in self.sets:
                 c.set_option(4, int(os.environ["GL355_BENCH_NTT_SINGLE_MAX"]))
+        if os.environ.get("GL355_BENCH_BATCH_UNITS"):                # GL355_OPT_BATCH_UNITS: units a context proves in lock-step
+            for c in self.sets:
+                c.set_option(5, int(os.environ["GL355_BENCH_BATCH_UNITS"]))
         if os.environ.get("GL355_BENCH_LANES_LOG"):                  # experiments: GL355_OPT_MERKLE_LANES_LOG
             for c in self.sets:
                 c.set_option(1, int(os.environ["GL355_BENCH_LANES_LOG"]))
@@ -383,7 +386,11 @@ def main_recursive(args):
     # so the contexts still keep the GPU fed (host work is ~10-12 ms of ~90 ms per unit and context)
     cores_per_rank = max(1, host_cores() // max(1, world))
     n_threads = max(1, int(os.environ.get("GL355_BENCH_CONTEXTS", args.threads)))
-    sleeping_waits = os.environ.get("GL355_BENCH_SLEEP_WAITS", "1" if cores_per_rank < n_threads else "0") == "1"
+    # how a context's host thread waits for its stream: "spin" (hipStreamSynchronize, a core per context), "poll" (GL355_OPT_BLOCKING_SYNC
+    # = 2: hipStreamQuery + 30-us sleeps, a few percent of a core per context), "sleep" (hipDeviceScheduleBlockingSync for the device)
+    wait_mode = os.environ.get("GL355_BENCH_WAIT", "sleep" if os.environ.get("GL355_BENCH_SLEEP_WAITS") == "1" else
+                               "poll")
+    sleeping_waits = wait_mode == "sleep"
     # gl355_runtime_config: hardware queues per context (unless GPU_MAX_HW_QUEUES is already set) and, if asked, sleeping waits
     # (hipDeviceScheduleBlockingSync); it has to run before the device's HIP context exists, i.e. before torch touches the GPU
     lib = importlib.import_module("stark-verifier_amd._lib").load(init_torch=False)
@@ -398,8 +405,8 @@ def main_recursive(args):
     blocking = sleeping_waits
     # the witness tape of the recursive proof is host work inside each context's thread (7 ms, the context's stream idles
     # meanwhile); its FRI-query segments replay on 2 threads when the waits sleep and cores are to spare (191 -> 195 proofs/s)
-    replay_threads = int(os.environ.get("GL355_BENCH_REPLAY_THREADS", 2 if (sleeping_waits and cores_per_rank >= 8) else 1))
-    pr = RecursiveProvers(gl, local_rank, n_threads, args.log_members, replay_threads=replay_threads)
+    replay_threads = int(os.environ.get("GL355_BENCH_REPLAY_THREADS", 2 if cores_per_rank >= 8 else 1))
+    pr = RecursiveProvers(gl, local_rank, n_threads, args.log_members, replay_threads=replay_threads, blocking_sync=2 if wait_mode == "poll" else 0)
     comm = open_comm(lib, par, pr.sets[0], rank, world, rehearsal, dev)
     per = args.proofs_per_step
     total = per * world
@@ -478,7 +485,7 @@ def main_recursive(args):
                        "parallelism": "independent proofs sharded over ranks, no data-path collective",
                        "exchange": getattr(comm, "backend_name", "none (one rank): gl355_aggregation_root over the local leaves"),
                        "host": "%d usable host cores per rank, %s device waits, %d tape-replay thread(s) per context" % (
-                           cores_per_rank, "sleeping (hipDeviceScheduleBlockingSync)" if blocking else "spinning", replay_threads),
+                           cores_per_rank, {"sleep": "sleeping (hipDeviceScheduleBlockingSync)", "poll": "polling (hipStreamQuery + 30-us sleeps)", "spin": "spinning"}[wait_mode], replay_threads),
                        "host_cpu_ms_per_unit": round(1e3 * host_cpu_s / max(1, (hi - lo) * args.steps), 2),
                        "host_split": host_split},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -540,9 +547,9 @@ def main():
                          "lde = configs[1]; semaphore = the signals alone")
     ap.add_argument("--proofs-per-step", type=int, default=128,
                     help="units (recursive) / proofs (semaphore) per GPU per step; 128 = BASELINE configs[4] (1024 proofs over 8 GPUs)")
-    ap.add_argument("--threads", type=int, default=22,
-                    help="concurrent prover contexts per GPU (one HIP stream + one host thread each).  22: measured best with sleeping "
-                         "waits (16: 170/s, 20: 174-178, 22: 178-182, 24: 162-168 -- past the device's hardware queues)")
+    ap.add_argument("--threads", type=int, default=8,
+                    help="concurrent prover contexts per GPU (one HIP stream + one host thread each); every context proves "
+                         "GL355_OPT_BATCH_UNITS = 8 units in lock-step.  Measured flat between 6 and 12 contexts (265-270 units/s)")
     ap.add_argument("--log-members", type=int, default=20, help="log2 of the access-set size (tree depth)")
     args = ap.parse_args()
     # one hardware queue per prover context: the HIP runtime's default is 4, streams then share queues and a latency-bound

@@ -64,8 +64,10 @@ int32_t gl355_ctx_sync(gl355_ctx* ctx);
  * 16-lanes-per-node kernel (lowest latency, ~3x the instructions of the one-lane-per-node kernel); default 14 suits a
  * single proof stream, 11..12 gives more proofs/s when many contexts share the GPU. */
 enum { GL355_OPT_MERKLE_LANES_LOG = 1,
-       GL355_OPT_BLOCKING_SYNC = 2,     /* != 0: wait for the device with a blocking event instead of a spinning hipStreamSynchronize
-                                           (gl355_runtime_config(.., sleeping_waits) is the effective way on this runtime) */
+       GL355_OPT_BLOCKING_SYNC = 2,     /* how the context's host thread waits for its stream: 0 hipStreamSynchronize (spins unless the
+                                           device runs gl355_runtime_config(.., sleeping_waits)), 1 a blocking event, 2 poll + back-off
+                                           (hipStreamQuery, 30-us sleeps): a few percent of a core per waiting context and ~30 us of
+                                           wake-up latency -- for ranks with more prover contexts than cores */
        GL355_OPT_REPLAY_THREADS = 3,    /* host threads gl355_circuit_prove_tape uses for a segmented tape (default 1) */
        GL355_OPT_NTT_SINGLE_PASS_MAX_LOG = 4, /* 12..14 (default 14): commit-path transforms of 2^13 / 2^14 points above this size run
                                            in two passes of 4096-point tiles instead of one pass that owns a whole CU */

@@ -6,6 +6,8 @@
 #include "gl355_internal.h"
 
 #include <atomic>
+#include <chrono>
+#include <future>
 #include <thread>
 #include <vector>
 
@@ -35,57 +37,130 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
     const uint64_t out_words = rec ? rec_words : sem_words;
     std::atomic<int32_t> first_error{GL355_OK};
     std::atomic<uint32_t> next_unit{0};     // units are handed out a batch at a time: a context that finishes early takes the next batch
+    // One context's loop is software-pipelined over its batches: while the tapes of batch k are replayed on host threads (the
+    // recursive circuit's witness generation, ~7 ms of one core per unit), the context's stream proves the recursive proofs of
+    // batch k-1 -- the stream never waits for the host phase of its own batch.
+    // The witness rows (~6.4 MB per unit) are replayed into PINNED host memory and uploaded on the context's copy stream by the
+    // same helper thread, so the proving stream receives them already resident (a pageable upload is staged in chunks on the
+    // proving stream itself: ~5 ms per batch of 8 during which it computes nothing).
+    struct Slot {
+        uint32_t j0 = 0, nb = 0;
+        std::vector<uint64_t> flat, pis, inputs, rpis, outer;
+        uint64_t* rows = nullptr;      // pinned host
+        uint64_t* d_rows = nullptr;    // device
+        std::vector<uint8_t> k_rec;
+        std::future<int32_t> replay;
+        uint64_t failed_unit = 0, failed_op = 0;
+    };
     auto worker = [&](uint32_t t) {
-        const uint32_t B = std::max<uint32_t>(1, std::min<uint32_t>(ctx_of(ctxs[t])->batch_units, GL355_MAX_UNITS));
-        std::vector<uint64_t> sib((size_t)B * height * 4 + 4), flat((size_t)B * sem_words), pis((size_t)B * 12), inputs(rec ? (size_t)B * (sem_words + 12) : 0),
-            outer(rec ? (size_t)B * rec_words : 0), opis((size_t)B * 12), sks((size_t)B * 4), topics((size_t)B * 4), idxs(B);
-        std::vector<uint8_t> k_sem((size_t)B * 32), k_rec((size_t)B * 32);
-        uint32_t done = 0;
-        for (;;) {
-            if (first_error.load() != GL355_OK) break;
-            const uint32_t j0 = next_unit.fetch_add(B);
-            if (j0 >= count) break;
-            const uint32_t nb = std::min<uint32_t>(B, count - j0);
-            for (uint32_t b = 0; b < nb; b++) {
-                const uint32_t j = j0 + b;
-                const uint64_t idx = member_indices[j];
-                idxs[b] = idx;
-                memcpy(&sks[4 * b], private_keys + 4 * idx, 32);
-                memcpy(&topics[4 * b], topic, 32);
-                // MerkleTree::prove on the plonky2 digest layout (cap height 0: one tree)
-                uint64_t pair = idx;
-                for (uint32_t i = 0; i < height; i++) {
-                    const uint64_t parity = pair & 1;
-                    pair >>= 1;
-                    const uint64_t slot = (pair << (i + 1)) + (1ull << i) - 1;
-                    memcpy(&sib[((size_t)b * height + i) * 4], tree_digests + (2 * slot + (1 - parity)) * 4, 32);
-                }
-                // per-proof blinding keys: derived from the batch key (reproducible batches), or NULL = fresh OS randomness per proof
-                if (key_base) { gl355_derive_key(key_base, 2ull * j, &k_sem[32 * b]); gl355_derive_key(key_base, 2ull * j + 1, &k_rec[32 * b]); }
-            }
-            int32_t rc = gl355_semaphore_prove_units(ctxs[t], sem, nb, sks.data(), topics.data(), idxs.data(), sib.data(), height,
-                                                     key_base ? k_sem.data() : nullptr, flat.data(), pis.data());
-            const uint64_t* result = flat.data();
-            if (rc == GL355_OK && rec) {
-                for (uint32_t b = 0; b < nb; b++) {
-                    memcpy(&inputs[(size_t)b * (sem_words + 12)], &flat[(size_t)b * sem_words], sem_words * 8);
-                    memcpy(&inputs[(size_t)b * (sem_words + 12) + sem_words], &pis[(size_t)b * 12], 96);
-                }
-                rc = gl355_circuit_prove_tape_units(ctxs[t], rec, nb, inputs.data(), sem_words + 12, key_base ? k_rec.data() : nullptr, outer.data(), opis.data());
-                result = outer.data();
-            } else if (rc == GL355_OK) {
-                memcpy(opis.data(), pis.data(), (size_t)nb * 96);
-            }
+        Ctx* cx = ctx_of(ctxs[t]);
+        const uint32_t B = std::max<uint32_t>(1, std::min<uint32_t>(cx->batch_units, GL355_MAX_UNITS));
+        const uint64_t rec_row_words = rec ? circuit_rows_words(rec) : 0;
+        std::vector<uint64_t> sib((size_t)B * height * 4 + 4), sks((size_t)B * 4), topics((size_t)B * 4), idxs(B);
+        std::vector<uint8_t> k_sem((size_t)B * 32);
+        Slot slots[2];
+        hipStream_t copy_stream = nullptr;
+        for (auto& s : slots) {
+            s.flat.resize((size_t)B * sem_words); s.pis.resize((size_t)B * 12); s.k_rec.resize((size_t)B * 32);
+            if (rec) { s.inputs.resize((size_t)B * (sem_words + 12)); s.rpis.resize((size_t)B * 12); s.outer.resize((size_t)B * rec_words); }
+        }
+        if (rec) {
+            uint64_t *rows[2], *drows[2];
+            const int32_t rc = hipSetDevice(cx->device) == hipSuccess ? cx->runtime_buffers((size_t)B * rec_row_words * 8, rows, drows, &copy_stream) : GL355_E_HIP;
             if (rc != GL355_OK) {
                 int32_t expected = GL355_OK;
                 first_error.compare_exchange_strong(expected, rc);
+                if (units_per_ctx) units_per_ctx[t] = 0;
+                return;
+            }
+            for (int i = 0; i < 2; i++) { slots[i].rows = rows[i]; slots[i].d_rows = drows[i]; }
+        }
+        uint32_t done = 0;
+        auto fail = [&](int32_t rc) { int32_t expected = GL355_OK; first_error.compare_exchange_strong(expected, rc); };
+        // second half of a batch: wait for its witness rows, prove the recursive proofs, hand out the results
+        auto finish = [&](Slot& s) -> bool {
+            const uint64_t* result = s.flat.data();
+            const uint64_t* opis = s.pis.data();
+            if (rec) {
+                int32_t rc = s.replay.get();
+                if (rc != GL355_OK) {
+                    char msg[128];
+                    snprintf(msg, sizeof msg, "semaphore_units: witness generation of unit %llu failed at tape entry %llu",
+                             (unsigned long long)(s.j0 + s.failed_unit), (unsigned long long)s.failed_op);
+                    cx->fail(rc, msg);
+                    fail(rc);
+                    return false;
+                }
+                rc = gl355_circuit_prove_rows_units(ctxs[t], rec, s.nb, s.d_rows, s.rpis.data(), 12, key_base ? s.k_rec.data() : nullptr, s.outer.data());
+                if (rc != GL355_OK) { fail(rc); return false; }
+                result = s.outer.data(); opis = s.rpis.data();
+            }
+            for (uint32_t b = 0; b < s.nb; b++) {
+                memcpy(leaves_out + 8ull * (s.j0 + b), opis + (size_t)b * 12 + 4, 64);            // nullifier | topic
+                if (proofs_out) memcpy(proofs_out + (uint64_t)(s.j0 + b) * out_words, result + (uint64_t)b * out_words, out_words * 8);
+            }
+            done += s.nb;
+            s.nb = 0;
+            return true;
+        };
+        int cur = 0;
+        bool ok = true;
+        for (;;) {
+            Slot& s = slots[cur];
+            Slot& prev = slots[cur ^ 1];
+            const uint32_t j0 = (ok && first_error.load() == GL355_OK) ? next_unit.fetch_add(B) : count;
+            if (j0 < count) {
+                const uint32_t nb = std::min<uint32_t>(B, count - j0);
+                s.j0 = j0; s.nb = nb;
+                for (uint32_t b = 0; b < nb; b++) {
+                    const uint32_t j = j0 + b;
+                    const uint64_t idx = member_indices[j];
+                    idxs[b] = idx;
+                    memcpy(&sks[4 * b], private_keys + 4 * idx, 32);
+                    memcpy(&topics[4 * b], topic, 32);
+                    // MerkleTree::prove on the plonky2 digest layout (cap height 0: one tree)
+                    uint64_t pair = idx;
+                    for (uint32_t i = 0; i < height; i++) {
+                        const uint64_t parity = pair & 1;
+                        pair >>= 1;
+                        const uint64_t slot = (pair << (i + 1)) + (1ull << i) - 1;
+                        memcpy(&sib[((size_t)b * height + i) * 4], tree_digests + (2 * slot + (1 - parity)) * 4, 32);
+                    }
+                    // per-proof blinding keys: derived from the batch key (reproducible batches), or NULL = fresh OS randomness per proof
+                    if (key_base) { gl355_derive_key(key_base, 2ull * j, &k_sem[32 * b]); gl355_derive_key(key_base, 2ull * j + 1, &s.k_rec[32 * b]); }
+                }
+                const int32_t rc = gl355_semaphore_prove_units(ctxs[t], sem, nb, sks.data(), topics.data(), idxs.data(), sib.data(), height,
+                                                               key_base ? k_sem.data() : nullptr, s.flat.data(), s.pis.data());
+                if (rc != GL355_OK) { fail(rc); s.nb = 0; ok = false; }
+                else if (rec) {
+                    for (uint32_t b = 0; b < nb; b++) {
+                        memcpy(&s.inputs[(size_t)b * (sem_words + 12)], &s.flat[(size_t)b * sem_words], sem_words * 8);
+                        memcpy(&s.inputs[(size_t)b * (sem_words + 12) + sem_words], &s.pis[(size_t)b * 12], 96);
+                    }
+                    const uint32_t threads = cx->replay_threads;
+                    Slot* sp = &s;
+                    const int device = cx->device;
+                    s.replay = std::async(std::launch::async, [sp, rec, threads, device, copy_stream, rec_row_words]() -> int32_t {
+                        const int32_t rc = circuit_replay_units(rec, threads, sp->nb, sp->inputs.data(), sp->rows, sp->rpis.data(), &sp->failed_unit, &sp->failed_op);
+                        if (rc != GL355_OK) return rc;
+                        if (hipSetDevice(device) != hipSuccess ||
+                            hipMemcpyAsync(sp->d_rows, sp->rows, (size_t)sp->nb * rec_row_words * 8, hipMemcpyHostToDevice, copy_stream) != hipSuccess) return GL355_E_HIP;
+                        for (;;) {                        // wait for the upload without holding a core
+                            const hipError_t q = hipStreamQuery(copy_stream);
+                            if (q == hipSuccess) return GL355_OK;
+                            if (q != hipErrorNotReady) return GL355_E_HIP;
+                            (void)hipGetLastError();
+                            std::this_thread::sleep_for(std::chrono::microseconds(50));
+                        }
+                    });
+                }
+            }
+            if (prev.nb) { if (!finish(prev)) ok = false; }
+            if (j0 >= count) {                       // nothing new was started: drain the current slot and stop
+                if (s.nb) { if (rec && !ok) { (void)s.replay.get(); s.nb = 0; } else finish(s); }
                 break;
             }
-            for (uint32_t b = 0; b < nb; b++) {
-                memcpy(leaves_out + 8ull * (j0 + b), &opis[(size_t)b * 12 + 4], 64);            // nullifier | topic
-                if (proofs_out) memcpy(proofs_out + (uint64_t)(j0 + b) * out_words, result + (uint64_t)b * out_words, out_words * 8);
-            }
-            done += nb;
+            cur ^= 1;
         }
         if (units_per_ctx) units_per_ctx[t] = done;
     };

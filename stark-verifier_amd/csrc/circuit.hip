@@ -182,14 +182,14 @@ int32_t gl355_circuit_prove_rows_units(gl355_ctx* h, const gl355_circuit_handle*
 
 // witness generation of n_units units: tape replays spread over the context's replay threads (one unit per thread at a time;
 // a single unit still uses its segments in parallel)
-static int32_t replay_units(Ctx* ctx, const gl355_circuit_handle* ch, uint32_t n_units, const uint64_t* inputs, uint64_t* rows, uint64_t n_words,
+static int32_t replay_units(uint32_t threads, const gl355_circuit_handle* ch, uint32_t n_units, const uint64_t* inputs, uint64_t* rows, uint64_t n_words,
                             uint64_t* failed_unit, uint64_t* failed_op) {
-    const uint32_t nt = std::max<uint32_t>(1, std::min<uint32_t>(ctx->replay_threads, n_units));
+    const uint32_t nt = std::max<uint32_t>(1, std::min<uint32_t>(threads, n_units));
     if (n_units == 1 || nt == 1) {
         for (uint32_t u = 0; u < n_units; u++) {
             uint64_t f = 0;
             const int32_t rc = gl355_witness_replay_segmented(ch->tape.data(), ch->tape.size() / 5, ch->n_seq, ch->seg_lens.data(), (uint32_t)ch->seg_lens.size(),
-                                                              n_units == 1 ? ctx->replay_threads : 1, inputs + (uint64_t)u * ch->n_inputs, ch->n_inputs,
+                                                              n_units == 1 ? threads : 1, inputs + (uint64_t)u * ch->n_inputs, ch->n_inputs,
                                                               rows + (uint64_t)u * n_words, n_words, ch->c.num_wires, &f);
             if (rc != GL355_OK) { *failed_unit = u; *failed_op = f; return rc; }
         }
@@ -213,6 +213,21 @@ static int32_t replay_units(Ctx* ctx, const gl355_circuit_handle* ch, uint32_t n
     return GL355_OK;
 }
 
+}  // extern "C"
+// for the batch runtime (batch.cpp), which overlaps the witness generation of one batch with the proving of the previous one
+namespace gl355 {
+uint64_t circuit_rows_words(const gl355_circuit_handle* ch) { return (uint64_t)ch->row_idx.size() * ch->c.num_wires; }
+int32_t circuit_replay_units(const gl355_circuit_handle* ch, uint32_t threads, uint32_t n_units, const uint64_t* inputs, uint64_t* rows, uint64_t* pis_out,
+                             uint64_t* failed_unit, uint64_t* failed_op) {
+    const uint64_t n_words = circuit_rows_words(ch);
+    GL355_TRY(replay_units(threads, ch, n_units, inputs, rows, n_words, failed_unit, failed_op));
+    for (uint32_t u = 0; u < n_units; u++)
+        for (uint32_t i = 0; i < ch->n_pi; i++) pis_out[(size_t)u * ch->n_pi + i] = rows[(uint64_t)u * n_words + ch->pi_pos[i]];
+    return GL355_OK;
+}
+}  // namespace gl355
+extern "C" {
+
 int32_t gl355_circuit_prove_tape_units(gl355_ctx* h, const gl355_circuit_handle* ch, uint32_t n_units, const uint64_t* inputs, uint64_t n_inputs,
                                        const uint8_t* blinding_keys, uint64_t* proofs, uint64_t* public_inputs_out) {
     Ctx* ctx = ctx_of(h);
@@ -225,7 +240,7 @@ int32_t gl355_circuit_prove_tape_units(gl355_ctx* h, const gl355_circuit_handle*
     const uint64_t n_words = (uint64_t)ch->row_idx.size() * ch->c.num_wires;
     rows.resize(n_words * n_units);
     uint64_t failed_unit = 0, failed_op = 0;
-    const int32_t rc = replay_units(ctx, ch, n_units, inputs, rows.data(), n_words, &failed_unit, &failed_op);
+    const int32_t rc = replay_units(ctx->replay_threads, ch, n_units, inputs, rows.data(), n_words, &failed_unit, &failed_op);
     if (rc != GL355_OK) {
         char msg[128];
         snprintf(msg, sizeof msg, "circuit_prove_tape: witness generation of unit %llu failed at tape entry %llu", (unsigned long long)failed_unit,

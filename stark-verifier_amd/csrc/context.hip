@@ -1,6 +1,7 @@
 // Context, stream, scratch allocator, host/device buffer staging and cached tables of libgl355.
 #include "gl355_internal.h"
 #include <chrono>
+#include <time.h>
 #include <cstdlib>
 
 namespace gl355 {
@@ -32,7 +33,27 @@ hipError_t Ctx::d2h(void* dst, const void* src, size_t bytes) {
     wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     return e;
 }
+// Three ways to wait for the stream:
+//   0  hipStreamSynchronize: the runtime's wait (a spin unless the device runs hipDeviceScheduleBlockingSync) -- lowest latency,
+//      one core per waiting context;
+//   1  a blocking event (the runtime sleeps on the completion interrupt);
+//   2  poll + back-off: hipStreamQuery in a loop, spinning for the first ~20 us and then sleeping 30 us between polls -- a waiting
+//      context costs a few percent of a core and wakes within ~30 us of completion, whatever the runtime's interrupt path does.
+//      This is what lets a rank run more prover contexts than it has cores.
 hipError_t Ctx::wait_impl() {
+    if (blocking_sync == 2) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+            (void)hipGetLastError();
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(20)) {
+                struct timespec ts = {0, 30000};
+                nanosleep(&ts, nullptr);
+            }
+        }
+    }
     if (!blocking_sync) return hipStreamSynchronize(stream);
     if (!sync_ev) {
         hipError_t e = hipEventCreateWithFlags(&sync_ev, hipEventBlockingSync | hipEventDisableTiming);
@@ -89,6 +110,29 @@ int32_t Ctx::pinned(size_t bytes, void** out) {
         pinned_size = want;
     }
     *out = pinned_buf;
+    return GL355_OK;
+}
+void Ctx::runtime_buffers_free() {
+    for (int i = 0; i < 2; i++) {
+        if (rt_rows[i]) (void)hipHostFree(rt_rows[i]);
+        if (rt_drows[i]) (void)hipFree(rt_drows[i]);
+        rt_rows[i] = rt_drows[i] = nullptr;
+    }
+    rt_bytes = 0;
+}
+int32_t Ctx::runtime_buffers(size_t bytes, uint64_t* rows[2], uint64_t* drows[2], hipStream_t* copy_stream) {
+    if (!rt_copy_stream) GL355_HIP(this, hipStreamCreateWithFlags(&rt_copy_stream, hipStreamNonBlocking));
+    if (bytes > rt_bytes) {
+        runtime_buffers_free();
+        for (int i = 0; i < 2; i++) {
+            hipError_t e = hipHostMalloc(&rt_rows[i], bytes, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipMalloc(&rt_drows[i], bytes);
+            if (e != hipSuccess) { (void)hipGetLastError(); runtime_buffers_free(); return fail_hip(e, "witness staging buffers", __FILE__, __LINE__); }
+        }
+        rt_bytes = bytes;
+    }
+    for (int i = 0; i < 2; i++) { rows[i] = reinterpret_cast<uint64_t*>(rt_rows[i]); drows[i] = reinterpret_cast<uint64_t*>(rt_drows[i]); }
+    *copy_stream = rt_copy_stream;
     return GL355_OK;
 }
 void Ctx::release_all() {
@@ -237,6 +281,8 @@ int32_t gl355_ctx_destroy(gl355_ctx* ctx) {
     for (auto& kv : c.full_cache) (void)hipFree(kv.second);
     if (c.tw_fwd) (void)hipFree(c.tw_fwd);
     if (c.pinned_buf) (void)hipHostFree(c.pinned_buf);
+    c.runtime_buffers_free();
+    if (c.rt_copy_stream) (void)hipStreamDestroy(c.rt_copy_stream);
     if (c.sync_ev) (void)hipEventDestroy(c.sync_ev);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
@@ -258,7 +304,8 @@ int32_t gl355_ctx_set_option(gl355_ctx* ctx, int32_t option, int64_t value) {
         ctx->c.batch_units = (uint32_t)value;
         return GL355_OK;
     case GL355_OPT_BLOCKING_SYNC:
-        ctx->c.blocking_sync = value != 0;
+        if (value < 0 || value > 2) return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: BLOCKING_SYNC is 0 (runtime wait), 1 (blocking event) or 2 (poll + back-off)");
+        ctx->c.blocking_sync = (int)value;
         return GL355_OK;
     case GL355_OPT_NTT_SINGLE_PASS_MAX_LOG:
         if (value < 12 || value > 14) return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: NTT_SINGLE_PASS_MAX_LOG must be in 12..14");

@@ -72,7 +72,7 @@ struct Ctx {
     uint32_t replay_threads = 1;      // GL355_OPT_REPLAY_THREADS
     uint32_t batch_units = 8;         // GL355_OPT_BATCH_UNITS
     uint32_t ntt_single_pass_max_log = 14;   // GL355_OPT_NTT_SINGLE_PASS_MAX_LOG (12..14)
-    bool blocking_sync = false;
+    int blocking_sync = 0;            // GL355_OPT_BLOCKING_SYNC: 0 runtime wait, 1 blocking event, 2 poll + back-off
     hipEvent_t sync_ev = nullptr;
     hipError_t wait();
     hipError_t wait_impl();
@@ -93,6 +93,13 @@ struct Ctx {
     void* pinned_buf = nullptr;
     size_t pinned_size = 0;
     int32_t pinned(size_t bytes, void** out);
+    // batch runtime (batch.cpp): two witness-row slots (pinned host + device) and a copy stream, kept across calls
+    void* rt_rows[2] = {nullptr, nullptr};
+    void* rt_drows[2] = {nullptr, nullptr};
+    size_t rt_bytes = 0;
+    hipStream_t rt_copy_stream = nullptr;
+    int32_t runtime_buffers(size_t bytes, uint64_t* rows[2], uint64_t* drows[2], hipStream_t* copy_stream);
+    void runtime_buffers_free();
     void release_all();
     // lo[c*4096 + j] = bases[c]^j, hi[c*4096 + j] = bases[c]^(4096 j)
     int32_t pow_tables_multi(const std::vector<uint64_t>& bases, const uint64_t** lo, const uint64_t** hi);
@@ -249,6 +256,9 @@ struct ProveUnit {
 int32_t prove_units(Ctx* ctx, const gl355_prover_data* pd, uint32_t B, const uint64_t* d_wires_dense, const uint32_t* row_idx,
                     const uint64_t* rows_host, uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
                     const ProveUnit* io);
+uint64_t circuit_rows_words(const gl355_circuit_handle* ch);
+int32_t circuit_replay_units(const gl355_circuit_handle* ch, uint32_t threads, uint32_t n_units, const uint64_t* inputs, uint64_t* rows, uint64_t* pis_out,
+                             uint64_t* failed_unit, uint64_t* failed_op);
 int32_t resolve_blinding_key_words(Ctx* ctx, const uint8_t* key, uint32_t out[8]);
 int32_t quotient_units_dev(Ctx* ctx, const gl355_circuit* c, uint32_t B, const uint64_t* cs_lde, const uint64_t* wires_lde, uint64_t wires_us,
                            const uint64_t* zs_lde, uint64_t zs_us, uint64_t lde_stride, const uint64_t* k_is_dev, const uint64_t* betas /* [B][4] */,

@@ -575,10 +575,11 @@ int32_t prove_units(Ctx* ctx, const gl355_prover_data* pd, uint32_t B, const uin
         Scratch rbuf(ctx);
         if (n_rows) {
             const uint64_t per = (uint64_t)n_rows * nw;
-            GL355_TRY(rbuf.get((uint64_t)B * per * 8 + (uint64_t)n_rows * 4 + 16));
-            uint64_t* d_vals = rbuf.as<uint64_t>();
-            uint32_t* d_idx = reinterpret_cast<uint32_t*>(d_vals + (uint64_t)B * per);
-            GL355_HIP(ctx, hipMemcpyAsync(d_vals, rows_host, (uint64_t)B * per * 8, hipMemcpyHostToDevice, ctx->stream));
+            const bool rows_on_device = ptr_is_device(rows_host);       // the batch runtime uploads the next batch's rows on its copy stream
+            GL355_TRY(rbuf.get((rows_on_device ? 0 : (uint64_t)B * per * 8) + (uint64_t)n_rows * 4 + 16));
+            const uint64_t* d_vals = rows_on_device ? rows_host : rbuf.as<uint64_t>();
+            uint32_t* d_idx = reinterpret_cast<uint32_t*>(rbuf.as<uint64_t>() + (rows_on_device ? 0 : (uint64_t)B * per));
+            if (!rows_on_device) GL355_HIP(ctx, hipMemcpyAsync(rbuf.p, rows_host, (uint64_t)B * per * 8, hipMemcpyHostToDevice, ctx->stream));
             GL355_HIP(ctx, hipMemcpyAsync(d_idx, row_idx, (uint64_t)n_rows * 4, hipMemcpyHostToDevice, ctx->stream));
             ProfScope ps(ctx, "witness_scatter", (uint64_t)B * per * 16);
             hipLaunchKernelGGL(witness_rows_units_kernel, dim3((uint32_t)((per + 255) / 256), B), dim3(256), 0, ctx->stream, wires, n, nw, d_idx, d_vals, n_rows);
