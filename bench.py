@@ -239,10 +239,10 @@ def cpu_baseline_recursive(pr, units=1):
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (bench.py cannot collect PMC counters
     itself); None when no pass covers the kernel."""
-    path = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         d = json.load(open(path))
-        return d["kernels"][kernel]["bytes_per_launch_corrected"], "profiles/r01f_pmc_traffic.json: " + d["_source"]
+        return d["kernels"][kernel]["bytes_per_launch_corrected"], "profiles/r02_pmc_traffic.json: " + d["_source"]
     except Exception:
         return None, None
 
@@ -252,7 +252,7 @@ def pmc_valu(kernel, avg_launch_ms):
     committed --pmc pass) over the launch duration measured here, against the chip's issue rate (1 024 SIMDs, one instruction per
     ~4.2 clk for this instruction mix (tools/ubench), ~2.05 GHz sustained under this load)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
         insts = d["kernels"][kernel]["valu_insts_per_launch"]
     except Exception:
         return None
