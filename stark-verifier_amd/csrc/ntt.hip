@@ -195,8 +195,11 @@ struct PassArgs {
 };
 
 // Row pass: each row = 2^LOG_T contiguous elements; a tile packs 2^(LT-LOG_T) rows.
-template <int LT, int LOG_T, bool INV>
-__global__ void __launch_bounds__(1 << (LT - 4)) __attribute__((amdgpu_waves_per_eu(LT == 12 ? 3 : 1))) ntt_rows_kernel(PassArgs a) {
+// FAST = the commit-path shape with every optional multiplier compiled out: rows pass = no pre / post multiplier, no scaling,
+// natural tile order in and out, canonical store; cols pass = full pre and step tables, nothing else.  The general kernels test
+// those options per element at run time (~110 branches per phase); the LDE of a commitment never uses them.
+template <int LT, int LOG_T, bool INV, bool FAST = false, int WPE = (LT == 12 ? 3 : 1)>
+__global__ void __launch_bounds__(1 << (LT - 4)) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_rows_kernel(PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     constexpr int NT = 1 << (LT - 4);
     constexpr int RPT = 1 << (LT - LOG_T);  // rows per tile
@@ -218,10 +221,12 @@ __global__ void __launch_bounds__(1 << (LT - 4)) __attribute__((amdgpu_waves_per
         if (row < total_rows) {
             const uint64_t col = row >> a.log_rows, rin = row & (rows_per_col - 1);
             v = a.in[col * a.in_col_stride + (rin << LOG_T) + e];
-            if (a.pre_full) v = gl_mul(v, a.pre_full[(uint64_t)coset * a.pre_full_stride + (rin << LOG_T) + e]);
-            else if (pre_lo) v = gl_mul(v, pow2lvl(pre_lo, pre_hi, (rin << LOG_T) + e));
+            if constexpr (!FAST) {
+                if (a.pre_full) v = gl_mul(v, a.pre_full[(uint64_t)coset * a.pre_full_stride + (rin << LOG_T) + e]);
+                else if (pre_lo) v = gl_mul(v, pow2lvl(pre_lo, pre_hi, (rin << LOG_T) + e));
+            }
         }
-        const uint32_t le = a.in_bitrev ? brev(e, LOG_T) : e;
+        const uint32_t le = (!FAST && a.in_bitrev) ? brev(e, LOG_T) : e;
         lds[lds_phys((lr << LOG_T) | le)] = v;
     }
     __syncthreads();
@@ -234,11 +239,13 @@ __global__ void __launch_bounds__(1 << (LT - 4)) __attribute__((amdgpu_waves_per
         const uint64_t row = row0 + lr;
         if (row < total_rows) {
             const uint64_t col = row >> a.log_rows, rin = row & (rows_per_col - 1);
-            const uint32_t le = a.out_natural ? brev(e, LOG_T) : e;
+            const uint32_t le = (!FAST && a.out_natural) ? brev(e, LOG_T) : e;
             uint64_t v = lds[lds_phys((lr << LOG_T) | le)];
-            if (a.post_lo) v = gl_mul(v, pow2lvl(a.post_lo, a.post_hi, (rin << LOG_T) + e));
-            if (a.scale != 1) v = gl_mul(v, a.scale);
-            if (a.canon) v = gl_canon(v);
+            if constexpr (!FAST) {
+                if (a.post_lo) v = gl_mul(v, pow2lvl(a.post_lo, a.post_hi, (rin << LOG_T) + e));
+                if (a.scale != 1) v = gl_mul(v, a.scale);
+                if (a.canon) v = gl_canon(v);
+            } else v = gl_canon(v);
             a.out[out_base + col * a.out_col_stride + (rin << LOG_T) + e] = v;
         }
     }
@@ -246,7 +253,7 @@ __global__ void __launch_bounds__(1 << (LT - 4)) __attribute__((amdgpu_waves_per
 
 // Column pass: transform over the row index of an [2^LOG_T][N2] matrix (N2 = 2^log_rows... here
 // a.log_rows holds log2(N2)); a tile is all 2^LOG_T rows x TC = 2^(12-LOG_T) adjacent columns.
-template <int LOG_T, bool INV>
+template <int LOG_T, bool INV, bool FAST = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) ntt_cols_kernel(PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     constexpr int LT = 12, NT = 256;
@@ -271,10 +278,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) n
         const uint32_t r = g >> LOG_TC, cc = g & (TC - 1);
         const uint64_t gi = ((uint64_t)r << log_n2) + c0 + cc;
         uint64_t v = in[gi];
-        const uint32_t lr = a.in_bitrev ? brev(r, LOG_T) : r;  // logical transform index
-        if (a.pre_full) v = gl_mul(v, a.pre_full[(uint64_t)coset * a.pre_full_stride + gi]);
-        else if (pre_lo) v = gl_mul(v, pow2lvl(pre_lo, pre_hi, gi));
-        if (step_at_load && a.step_lo) v = gl_mul(v, pow2lvl(a.step_lo, a.step_hi, (uint64_t)lr * (c0 + cc)));
+        uint32_t lr = r;  // logical transform index
+        if constexpr (FAST) {
+            v = gl_mul(v, a.pre_full[(uint64_t)coset * a.pre_full_stride + gi]);
+        } else {
+            lr = a.in_bitrev ? brev(r, LOG_T) : r;
+            if (a.pre_full) v = gl_mul(v, a.pre_full[(uint64_t)coset * a.pre_full_stride + gi]);
+            else if (pre_lo) v = gl_mul(v, pow2lvl(pre_lo, pre_hi, gi));
+            if (step_at_load && a.step_lo) v = gl_mul(v, pow2lvl(a.step_lo, a.step_hi, (uint64_t)lr * (c0 + cc)));
+        }
         lds[lds_phys((lr << LOG_TC) | cc)] = v;
     }
     __syncthreads();
@@ -283,17 +295,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) n
     for (int i = 0; i < 16; i++) {
         const uint32_t g = tid + i * NT;
         const uint32_t r = g >> LOG_TC, cc = g & (TC - 1);
-        const uint32_t lr = a.out_natural ? brev(r, LOG_T) : r;  // LDS row holding output row r
+        const uint32_t lr = (!FAST && a.out_natural) ? brev(r, LOG_T) : r;  // LDS row holding output row r
         uint64_t v = lds[lds_phys((lr << LOG_TC) | cc)];
         const uint64_t go = ((uint64_t)r << log_n2) + c0 + cc;
-        if (!step_at_load && a.step_full) v = gl_mul(v, a.step_full[go]);
-        else if (!step_at_load && a.step_lo) {
-            const uint32_t k1 = a.out_natural ? r : brev(r, LOG_T);  // transform output index
-            v = gl_mul(v, pow2lvl(a.step_lo, a.step_hi, (uint64_t)k1 * (c0 + cc)));
+        if constexpr (FAST) {
+            v = gl_mul(v, a.step_full[go]);
+        } else {
+            if (!step_at_load && a.step_full) v = gl_mul(v, a.step_full[go]);
+            else if (!step_at_load && a.step_lo) {
+                const uint32_t k1 = a.out_natural ? r : brev(r, LOG_T);  // transform output index
+                v = gl_mul(v, pow2lvl(a.step_lo, a.step_hi, (uint64_t)k1 * (c0 + cc)));
+            }
+            if (a.post_lo) v = gl_mul(v, pow2lvl(a.post_lo, a.post_hi, go));
+            if (a.scale != 1) v = gl_mul(v, a.scale);
+            if (a.canon) v = gl_canon(v);
         }
-        if (a.post_lo) v = gl_mul(v, pow2lvl(a.post_lo, a.post_hi, go));
-        if (a.scale != 1) v = gl_mul(v, a.scale);
-        if (a.canon) v = gl_canon(v);
         out[go] = v;
     }
 }
@@ -321,6 +337,40 @@ __global__ void bitrev_permute_kernel(const uint64_t* in, uint64_t* out, uint32_
             for (uint32_t w = 0; w < width; w++)
                 out[col * out_col_stride + i * width + w] = in[col * in_col_stride + j * width + w];
         }
+    }
+}
+
+// The same permutation for width == 1 and log_n >= 10 at HBM speed: index i = (a | m | b) with 5-bit a, b maps to
+// (rev b | rev m | rev a), so for a fixed middle part m the 32 x 32 block over (a, b) is read as 32 contiguous 256-byte rows,
+// transposed (with both coordinates bit-reversed) through LDS, and written as 32 contiguous rows of block rev(m).  In place,
+// block m and block rev(m) are exchanged by one workgroup (the one with m <= rev m).  The element-wise kernel above scatters
+// 8-byte accesses and takes longer than the transform it follows (3.7 ms vs 2.8 ms at 2^20 x 135).
+__global__ void __launch_bounds__(256) bitrev_tiled_kernel(const uint64_t* in, uint64_t* out, uint32_t log_n, uint64_t in_col_stride,
+                                                         uint64_t out_col_stride) {
+    __shared__ uint64_t t0[32][33], t1[32][33];
+    const uint32_t mid_bits = log_n - 10;
+    const uint32_t m = blockIdx.x, rm = brev(m, mid_bits);
+    const bool in_place = in == out;
+    if (in_place && m > rm) return;
+    const uint64_t col = blockIdx.y;
+    const uint64_t* src = in + col * in_col_stride;
+    uint64_t* dst = out + col * out_col_stride;
+    const uint32_t x = threadIdx.x & 31, y0 = threadIdx.x >> 5;
+    const uint32_t hi_shift = log_n - 5;
+    const bool both = in_place && m != rm;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t a = y0 + 8 * k;
+        t0[a][x] = src[((uint64_t)a << hi_shift) | ((uint64_t)m << 5) | x];
+        if (both) t1[a][x] = src[((uint64_t)a << hi_shift) | ((uint64_t)rm << 5) | x];
+    }
+    __syncthreads();
+    const uint32_t rx = brev(x, 5);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t bp = y0 + 8 * k;                 // output row = rev(b), output column x = rev(a)
+        dst[((uint64_t)bp << hi_shift) | ((uint64_t)rm << 5) | x] = t0[rx][brev(bp, 5)];
+        if (both) dst[((uint64_t)bp << hi_shift) | ((uint64_t)m << 5) | x] = t1[rx][brev(bp, 5)];
     }
 }
 
@@ -372,7 +422,16 @@ template <int LT, int LOG_T>
 static hipError_t launch_rows_lt(const PassArgs& a, bool inv, uint64_t blocks, hipStream_t s) {
     const size_t shmem = ((1u << LT) + (1u << (LT - 4))) * sizeof(uint64_t);
     constexpr int NT = 1 << (LT - 4);
-    if (inv) {
+    const bool fast = !inv && !a.pre_full && !a.pre_lo && !a.post_lo && a.scale == 1 && a.canon && !a.in_bitrev && !a.out_natural;
+    static const int exp_wpe = getenv("GL355_EXP_NTT_WPE") ? atoi(getenv("GL355_EXP_NTT_WPE")) : 0;      // experiments only
+    if (fast && LT == 12 && exp_wpe == 4) {
+        auto k = ntt_rows_kernel<LT, LOG_T, false, true, 4>;
+        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
+    } else if (fast) {
+        auto k = ntt_rows_kernel<LT, LOG_T, false, true>;
+        if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
+    } else if (inv) {
         auto k = ntt_rows_kernel<LT, LOG_T, true>;
         if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
@@ -404,7 +463,9 @@ static hipError_t launch_rows(const PassArgs& a, uint32_t log_t, bool inv, hipSt
 template <int LOG_T>
 static hipError_t launch_cols_t(const PassArgs& a, bool inv, uint64_t blocks, hipStream_t s) {
     const size_t shmem = (4096 + 256) * sizeof(uint64_t);
-    if (inv) hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, true>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
+    const bool fast = !inv && a.pre_full && a.step_full && !a.in_bitrev && !a.out_natural && !a.post_lo && a.scale == 1 && !a.canon;
+    if (fast) hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, false, true>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
+    else if (inv) hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, true>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
     else hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, false>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
     return hipGetLastError();
 }
@@ -526,12 +587,8 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         }
         if (!p.out_bitrev) {
             // natural order requested: one extra permutation pass (not used on the commit path)
-            const uint64_t total = ((uint64_t)p.batch * p.n_cosets) << p.log_n;
-            const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 16);
             if (p.n_cosets != 1) return ctx->fail(GL355_E_UNSUPPORTED, "ntt: natural-order multi-coset output is done by the caller");
-            hipLaunchKernelGGL(bitrev_permute_kernel, dim3(blocks), dim3(256), 0, ctx->stream, p.out, p.out,
-                               p.log_n, 1u, p.out_col_stride, p.out_col_stride, p.batch);
-            GL355_HIP(ctx, hipGetLastError());
+            GL355_TRY(bitrev_permute(ctx, p.out, p.out, p.log_n, 1, p.out_col_stride, p.out_col_stride, p.batch));
         }
         if (p.post_lo) return ctx->fail(GL355_E_UNSUPPORTED, "ntt: post-multiplier needs natural-order output from the bitrev-input flow");
         return GL355_OK;
@@ -563,6 +620,11 @@ int32_t bitrev_permute(Ctx* ctx, const uint64_t* in, uint64_t* out, uint32_t log
     if (total == 0) return GL355_OK;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 16);
     ProfScope ps(ctx, "bitrev_permute", total * 16);
+    if (width == 1 && log_n >= 10 && batch <= 65535) {
+        hipLaunchKernelGGL(bitrev_tiled_kernel, dim3(1u << (log_n - 10), batch), dim3(256), 0, ctx->stream, in, out, log_n, in_col_stride, out_col_stride);
+        GL355_HIP(ctx, hipGetLastError());
+        return GL355_OK;
+    }
     hipLaunchKernelGGL(bitrev_permute_kernel, dim3(blocks), dim3(256), 0, ctx->stream, in, out, log_n, width,
                        in_col_stride, out_col_stride, batch);
     GL355_HIP(ctx, hipGetLastError());
