@@ -140,6 +140,9 @@ class RecursiveProvers:
         if os.environ.get("GL355_BENCH_BATCH_UNITS"):                # GL355_OPT_BATCH_UNITS: units a context proves in lock-step
             for c in self.sets:
                 c.set_option(5, int(os.environ["GL355_BENCH_BATCH_UNITS"]))
+        if os.environ.get("GL355_BENCH_DEVICE_REPLAY"):              # GL355_OPT_DEVICE_REPLAY (default on): witness tape on the device
+            for c in self.sets:
+                c.set_option(6, int(os.environ["GL355_BENCH_DEVICE_REPLAY"]))
         if os.environ.get("GL355_BENCH_LANES_LOG"):                  # experiments: GL355_OPT_MERKLE_LANES_LOG
             for c in self.sets:
                 c.set_option(1, int(os.environ["GL355_BENCH_LANES_LOG"]))
@@ -330,6 +333,21 @@ class _TorchComm:
         self.dist.destroy_process_group()
 
 
+def thread_cpu_snapshot():
+    """{tid: (comm, cpu seconds)} of the process's live threads (diagnostic: which threads burn host CPU; GL355_BENCH_THREAD_CPU=1)"""
+    out = {}
+    tck = os.sysconf("SC_CLK_TCK")
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            st = open("/proc/self/task/%s/stat" % tid).read()
+            comm = st[st.index("(") + 1:st.rindex(")")]
+            f = st[st.rindex(")") + 2:].split()
+            out[int(tid)] = (comm, (int(f[11]) + int(f[12])) / tck)
+        except Exception:
+            pass
+    return out
+
+
 def open_comm(lib, par, ctx, rank, world, rehearsal, dev=None):
     """The exchange of the N > 1 job through the C ABI (gl355_comm_*): RCCL over xGMI, or TCP between the host processes in the
     one-device rehearsal.  The 128-byte communicator id travels through the launcher's key-value store (torchrun's TCPStore,
@@ -406,6 +424,9 @@ def main_recursive(args):
     # the witness tape of the recursive proof is host work inside each context's thread (7 ms, the context's stream idles
     # meanwhile); its FRI-query segments replay on 2 threads when the waits sleep and cores are to spare (191 -> 195 proofs/s)
     replay_threads = int(os.environ.get("GL355_BENCH_REPLAY_THREADS", 2 if cores_per_rank >= 8 else 1))
+    # witness generation of the recursive circuit: on the device (tape interpreter on the context's side stream: 2 host cores per
+    # rank are enough, 255 units/s) or on host threads (4 % more throughput when the rank has cores to spare: 270 vs 259 units/s)
+    os.environ.setdefault("GL355_BENCH_DEVICE_REPLAY", "0" if cores_per_rank >= 8 else "1")
     pr = RecursiveProvers(gl, local_rank, n_threads, args.log_members, replay_threads=replay_threads, blocking_sync=2 if wait_mode == "poll" else 0)
     comm = open_comm(lib, par, pr.sets[0], rank, world, rehearsal, dev)
     per = args.proofs_per_step
@@ -424,6 +445,7 @@ def main_recursive(args):
     barrier()
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    th0 = thread_cpu_snapshot() if os.environ.get("GL355_BENCH_THREAD_CPU") else None
     t0 = time.perf_counter()
     root = None
     for step in range(args.steps):
@@ -435,6 +457,10 @@ def main_recursive(args):
     elapsed = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)   # rank 0's process, spinning waits included
+    if th0 is not None:
+        th1 = thread_cpu_snapshot()
+        d = sorted(((th1[t][1] - th0.get(t, (None, 0.0))[1], th1[t][0], t) for t in th1), reverse=True)[:10]
+        sys.stderr.write("[bench] process CPU %.2f s over %.2f s wall; long-lived threads: %s\n" % (host_cpu_s, elapsed, ["%s:%.2fs" % (c, v) for v, c, _ in d]))
     prof, local_units = pr.profile_read()
     pr.profile(False)
     if comm is not None:
@@ -460,11 +486,16 @@ def main_recursive(args):
         # host/device split of one context: wall time in Ctx::wait() ("host:stream_wait" pseudo-scope) against the wall time per unit
         iso_wait = iso.pop("host:stream_wait", (0, 0.0, 0))
         tr_wait = prof.pop("host:stream_wait", (0, 0.0, 0))
+        iso.pop("host:cpu_in_wait", None); iso.pop("host:cpu_in_prove", None)
+        tr_cpu_wait = prof.pop("host:cpu_in_wait", (0, 0.0, 0))
+        tr_cpu_prove = prof.pop("host:cpu_in_prove", (0, 0.0, 0))
         host_split = {"what": "wall ms per unit of one prover context's host thread: waiting for its stream (Ctx::wait) vs everything else "
                               "(witness generation, tape replay, transcript, copies, launches)",
                       "isolated_one_context": {"wall": round(1e3 * t_iso / 8, 2), "waiting": round(iso_wait[1] / 8, 2)},
                       "timed_region_%d_contexts" % n_threads: {"wall": round(1e3 * elapsed * 1 / max(1, local_units), 2) if local_units else None,
-                                                                "waiting": round(tr_wait[1] / max(1, local_units), 2)}}
+                                                                "waiting": round(tr_wait[1] / max(1, local_units), 2),
+                                                                "cpu_ms_inside_prove_calls": round(tr_cpu_prove[1] / max(1, local_units), 2),
+                                                                "cpu_ms_of_that_inside_waits": round(tr_cpu_wait[1] / max(1, local_units), 2)}}
         dname, (dcnt, dms, dbytes) = max(iso.items(), key=lambda kv: kv[1][1]) if iso else ("none", (1, 0.0, 0))
         ach = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
 
@@ -485,7 +516,8 @@ def main_recursive(args):
                        "parallelism": "independent proofs sharded over ranks, no data-path collective",
                        "exchange": getattr(comm, "backend_name", "none (one rank): gl355_aggregation_root over the local leaves"),
                        "host": "%d usable host cores per rank, %s device waits, %d tape-replay thread(s) per context" % (
-                           cores_per_rank, {"sleep": "sleeping (hipDeviceScheduleBlockingSync)", "poll": "polling (hipStreamQuery + 30-us sleeps)", "spin": "spinning"}[wait_mode], replay_threads),
+                           cores_per_rank, {"sleep": "sleeping (hipDeviceScheduleBlockingSync)", "poll": "polling (hipStreamQuery + 30-us sleeps)", "spin": "spinning"}[wait_mode], replay_threads) +
+                               ("; witness tape replayed on the device" if os.environ.get("GL355_BENCH_DEVICE_REPLAY") == "1" else "; witness tape replayed on host threads"),
                        "host_cpu_ms_per_unit": round(1e3 * host_cpu_s / max(1, (hi - lo) * args.steps), 2),
                        "host_split": host_split},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -552,10 +584,10 @@ def main():
                          "GL355_OPT_BATCH_UNITS = 8 units in lock-step.  Measured flat between 6 and 12 contexts (265-270 units/s)")
     ap.add_argument("--log-members", type=int, default=20, help="log2 of the access-set size (tree depth)")
     args = ap.parse_args()
-    # one hardware queue per prover context: the HIP runtime's default is 4, streams then share queues and a latency-bound
+    # two hardware queues per prover context (proving stream + side stream): the HIP runtime's default is 4, streams then share queues and a latency-bound
     # Merkle-top kernel on one stream holds up the streams behind it (measured 164 -> 172 proofs/s at 16 contexts).  Read when
     # the HIP runtime initialises, i.e. before torch / libgl355 touch the device (they are imported by the main_* functions).
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, int(os.environ.get("GL355_BENCH_CONTEXTS", args.threads)))))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, 2 * int(os.environ.get("GL355_BENCH_CONTEXTS", args.threads)))))
     if args.workload == "semaphore":
         return main_semaphore(args)
     if args.workload == "recursive":

@@ -50,7 +50,8 @@ typedef struct gl355_oracle gl355_oracle; /* a committed polynomial batch reside
 /* ---- context ------------------------------------------------------------------------------ */
 /* Process-level runtime settings for the many-provers-per-GPU regime of the reference's rayon loop (recursion.rs:214-227,
  * 300-308); call ONCE PER DEVICE BEFORE anything initialises the HIP runtime for it (first gl355_ctx_create, torch, ...):
- *   contexts > 0      one hardware queue per prover context (GPU_MAX_HW_QUEUES, unless the variable is already set);
+ *   contexts > 0      two hardware queues per prover context -- its proving stream and the batch runtime's side stream
+ *                     (GPU_MAX_HW_QUEUES = 2 * contexts, unless the variable is already set);
  *   sleeping_waits    hipDeviceScheduleBlockingSync: every device wait of the process sleeps on the completion interrupt
  *                     instead of spinning -- needed when there are more contexts than usable cores.
  * GL355_E_HIP if the runtime refuses (typically: the device was already initialised). */
@@ -71,7 +72,9 @@ enum { GL355_OPT_MERKLE_LANES_LOG = 1,
        GL355_OPT_REPLAY_THREADS = 3,    /* host threads gl355_circuit_prove_tape uses for a segmented tape (default 1) */
        GL355_OPT_NTT_SINGLE_PASS_MAX_LOG = 4, /* 12..14 (default 14): commit-path transforms of 2^13 / 2^14 points above this size run
                                            in two passes of 4096-point tiles instead of one pass that owns a whole CU */
-       GL355_OPT_BATCH_UNITS = 5 };     /* 1..GL355_MAX_UNITS (default 8): units gl355_semaphore_units proves in lock-step per context */
+       GL355_OPT_BATCH_UNITS = 5,       /* 1..GL355_MAX_UNITS (default 8): units gl355_semaphore_units proves in lock-step per context */
+       GL355_OPT_DEVICE_REPLAY = 6 };   /* != 0 (default): gl355_semaphore_units generates the recursive circuit's witness rows on the
+                                           device (tape interpreter kernel) instead of on host threads; same rows, same failures */
 int32_t gl355_ctx_set_option(gl355_ctx* ctx, int32_t option, int64_t value);
 const char* gl355_last_error(gl355_ctx* ctx);
 const char* gl355_version(void);
@@ -418,6 +421,11 @@ int32_t gl355_circuit_destroy(gl355_circuit_handle* c);
 int32_t gl355_circuit_info(const gl355_circuit_handle* c, uint64_t* proof_words, uint32_t* n_public_inputs, uint32_t* n_rows,
                            uint64_t* n_inputs, uint32_t* degree_bits);
 const uint64_t* gl355_circuit_digest(const gl355_circuit_handle* c);
+/* the witness rows [n_units][n_rows][num_wires] and public inputs [n_units][n_public_inputs] the circuit's tape generates from
+ * `inputs` [n_units][n_inputs] -- on host threads (on_device = 0) or by the device interpreter (on_device = 1); both must agree
+ * (parity surface of SURVEY 8(f) N3).  GL355_E_WITNESS + *failed_entry when the inputs do not satisfy the circuit. */
+int32_t gl355_circuit_witness_rows(gl355_ctx* ctx, const gl355_circuit_handle* c, uint32_t n_units, const uint64_t* inputs, uint64_t n_inputs,
+                                   int32_t on_device, uint64_t* rows, uint64_t* public_inputs_out, uint64_t* failed_entry);
 int32_t gl355_circuit_prove_rows(gl355_ctx* ctx, const gl355_circuit_handle* c, const uint64_t* rows, const uint64_t* public_inputs,
                                  uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof, uint64_t proof_capacity_words);
 int32_t gl355_circuit_prove_tape(gl355_ctx* ctx, const gl355_circuit_handle* c, const uint64_t* inputs, uint64_t n_inputs, const uint8_t* blinding_key,

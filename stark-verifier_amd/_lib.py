@@ -113,6 +113,7 @@ SIGNATURES = {
     "gl355_circuit_info": (C.c_int32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint32)]),
     "gl355_circuit_digest": (C.POINTER(C.c_uint64), [vp]),
+    "gl355_circuit_witness_rows": (C.c_int32, [vp, vp, C.c_uint32, vp, C.c_uint64, C.c_int32, vp, vp, C.POINTER(C.c_uint64)]),
     "gl355_circuit_prove_rows": (C.c_int32, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64]),
     "gl355_circuit_prove_tape": (C.c_int32, [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp]),
     "gl355_semaphore_prove": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, vp, C.c_uint32, vp, vp, C.c_uint64, vp]),

@@ -46,8 +46,9 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
     struct Slot {
         uint32_t j0 = 0, nb = 0;
         std::vector<uint64_t> flat, pis, inputs, rpis, outer;
-        uint64_t* rows = nullptr;      // pinned host
+        uint64_t* rows = nullptr;      // pinned host (host replay only)
         uint64_t* d_rows = nullptr;    // device
+        void* d_aux = nullptr;         // device replay: inputs | status | public inputs
         std::vector<uint8_t> k_rec;
         std::future<int32_t> replay;
         uint64_t failed_unit = 0, failed_op = 0;
@@ -66,14 +67,17 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
         }
         if (rec) {
             uint64_t *rows[2], *drows[2];
-            const int32_t rc = hipSetDevice(cx->device) == hipSuccess ? cx->runtime_buffers((size_t)B * rec_row_words * 8, rows, drows, &copy_stream) : GL355_E_HIP;
+            void* aux[2];
+            const int32_t rc = hipSetDevice(cx->device) == hipSuccess
+                                   ? cx->runtime_buffers((size_t)B * rec_row_words * 8, cx->device_replay ? circuit_replay_aux_bytes(rec, B) : 0, rows, drows, aux, &copy_stream)
+                                   : GL355_E_HIP;
             if (rc != GL355_OK) {
                 int32_t expected = GL355_OK;
                 first_error.compare_exchange_strong(expected, rc);
                 if (units_per_ctx) units_per_ctx[t] = 0;
                 return;
             }
-            for (int i = 0; i < 2; i++) { slots[i].rows = rows[i]; slots[i].d_rows = drows[i]; }
+            for (int i = 0; i < 2; i++) { slots[i].rows = rows[i]; slots[i].d_rows = drows[i]; slots[i].d_aux = aux[i]; }
         }
         uint32_t done = 0;
         auto fail = [&](int32_t rc) { int32_t expected = GL355_OK; first_error.compare_exchange_strong(expected, rc); };
@@ -140,7 +144,12 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
                     const uint32_t threads = cx->replay_threads;
                     Slot* sp = &s;
                     const int device = cx->device;
-                    s.replay = std::async(std::launch::async, [sp, rec, threads, device, copy_stream, rec_row_words]() -> int32_t {
+                    const bool on_device = cx->device_replay;
+                    s.replay = std::async(std::launch::async, [sp, rec, threads, device, copy_stream, rec_row_words, on_device]() -> int32_t {
+                        // witness generation: the tape interpreter on the side stream (default), or host threads + upload
+                        if (on_device)
+                            return circuit_replay_units_dev(rec, device, copy_stream, sp->nb, sp->inputs.data(), sp->d_rows, sp->d_aux, sp->rpis.data(),
+                                                            &sp->failed_unit, &sp->failed_op);
                         const int32_t rc = circuit_replay_units(rec, threads, sp->nb, sp->inputs.data(), sp->rows, sp->rpis.data(), &sp->failed_unit, &sp->failed_op);
                         if (rc != GL355_OK) return rc;
                         if (hipSetDevice(device) != hipSuccess ||

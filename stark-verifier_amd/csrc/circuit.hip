@@ -9,6 +9,7 @@
 #include "gl355_internal.h"
 
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -21,6 +22,9 @@ struct gl355_circuit_handle {
     gl355_oracle* cs = nullptr;
     uint64_t* d_sigmas = nullptr;
     uint64_t* d_kis = nullptr;
+    uint64_t* d_tape = nullptr;        // device copy of the tape | segment starts | public-input positions (witness_tape_dev.hip)
+    uint64_t* d_seg_start = nullptr;
+    uint64_t* d_pi_pos = nullptr;
     std::vector<uint32_t> row_idx;
     std::vector<uint64_t> pi_pos, tape, seg_lens;
     uint64_t n_seq = 0;
@@ -100,9 +104,25 @@ int32_t gl355_circuit_load(gl355_ctx* h, const uint64_t* blob, uint64_t words, g
     if ((uint64_t)ch->blind_start + ch->n_blind > n || (uint64_t)ch->z_start + 2ull * ch->n_z_pairs > n) {
         delete ch; return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: blinding rows out of range");
     }
+    // every offset of the tape is checked here, once: the replays (host and device) of a loaded circuit cannot leave the rows
+    if (n_ops) {
+        const uint64_t bad = tape_validate(ch->tape.data(), n_ops, n_inputs, n_rows * c.num_wires, c.num_wires);
+        if (bad != ~0ull) { delete ch; return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: malformed witness tape"); }
+    }
     // device copies of the sigma values / k_is (plain allocations: shared by every context of the device)
     int32_t rc = GL355_OK;
     do {
+        if (n_ops) {
+            std::vector<uint64_t> seg_start(n_segs + 1, n_seq);
+            for (uint64_t k = 0; k < n_segs; k++) seg_start[k + 1] = seg_start[k] + ch->seg_lens[k];
+            const uint64_t words = 5 * n_ops + (n_segs + 1) + n_pi;
+            if (hipMalloc((void**)&ch->d_tape, words * 8 + 8) != hipSuccess) { rc = ctx->fail(GL355_E_OOM, "circuit_load: hipMalloc"); break; }
+            ch->d_seg_start = ch->d_tape + 5 * n_ops;
+            ch->d_pi_pos = ch->d_seg_start + (n_segs + 1);
+            if (hipMemcpy(ch->d_tape, ch->tape.data(), 5 * n_ops * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(ch->d_seg_start, seg_start.data(), (n_segs + 1) * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                (n_pi && hipMemcpy(ch->d_pi_pos, ch->pi_pos.data(), n_pi * 8, hipMemcpyHostToDevice) != hipSuccess)) { rc = ctx->fail(GL355_E_HIP, "circuit_load: upload"); break; }
+        }
         if (hipMalloc(&ch->d_sigmas, routed * n * 8) != hipSuccess || hipMalloc(&ch->d_kis, routed * 8 + 8) != hipSuccess) { rc = ctx->fail(GL355_E_OOM, "circuit_load: hipMalloc"); break; }
         if (hipMemcpyAsync(ch->d_sigmas, sigmas, routed * n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(ch->d_kis, k_is, routed * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = ctx->fail(GL355_E_HIP, "circuit_load: upload"); break; }
@@ -124,6 +144,7 @@ int32_t gl355_circuit_load(gl355_ctx* h, const uint64_t* blob, uint64_t words, g
         if (ch->cs) gl355_oracle_destroy(ch->cs);
         if (ch->d_sigmas) (void)hipFree(ch->d_sigmas);
         if (ch->d_kis) (void)hipFree(ch->d_kis);
+        if (ch->d_tape) (void)hipFree(ch->d_tape);
         delete ch;
         return rc;
     }
@@ -145,6 +166,7 @@ int32_t gl355_circuit_destroy(gl355_circuit_handle* ch) {
     (void)hipSetDevice(ch->owner->device);
     if (ch->d_sigmas) (void)hipFree(ch->d_sigmas);
     if (ch->d_kis) (void)hipFree(ch->d_kis);
+    if (ch->d_tape) (void)hipFree(ch->d_tape);
     delete ch;
     return GL355_OK;
 }
@@ -217,6 +239,32 @@ static int32_t replay_units(uint32_t threads, const gl355_circuit_handle* ch, ui
 // for the batch runtime (batch.cpp), which overlaps the witness generation of one batch with the proving of the previous one
 namespace gl355 {
 uint64_t circuit_rows_words(const gl355_circuit_handle* ch) { return (uint64_t)ch->row_idx.size() * ch->c.num_wires; }
+// device scratch of one device replay: inputs | status | public inputs
+uint64_t circuit_replay_aux_bytes(const gl355_circuit_handle* ch, uint32_t n_units) { return (uint64_t)n_units * (ch->n_inputs + 1 + ch->n_pi) * 8 + 64; }
+int32_t circuit_replay_units_dev(const gl355_circuit_handle* ch, int device, hipStream_t stream, uint32_t n_units, const uint64_t* inputs, uint64_t* d_rows,
+                                 void* d_aux, uint64_t* pis_out, uint64_t* failed_unit, uint64_t* failed_op) {
+    if (!ch->d_tape) return GL355_E_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return GL355_E_HIP;
+    uint64_t* d_inputs = reinterpret_cast<uint64_t*>(d_aux);
+    uint64_t* d_status = d_inputs + (uint64_t)n_units * ch->n_inputs;
+    uint64_t* d_pis = d_status + n_units;
+    if (hipMemcpyAsync(d_inputs, inputs, (size_t)n_units * ch->n_inputs * 8, hipMemcpyHostToDevice, stream) != hipSuccess) return GL355_E_HIP;
+    GL355_TRY(tape_replay_dev(stream, ch->d_tape, ch->d_seg_start, ch->n_seq, (uint32_t)ch->seg_lens.size(), n_units, d_inputs, ch->n_inputs, d_rows,
+                              circuit_rows_words(ch), ch->d_pi_pos, ch->n_pi, d_status, d_pis));
+    std::vector<uint64_t> back((size_t)n_units * (1 + ch->n_pi));
+    if (hipMemcpyAsync(back.data(), d_status, back.size() * 8, hipMemcpyDeviceToHost, stream) != hipSuccess) return GL355_E_HIP;
+    for (;;) {                        // wait for the side stream without holding a core
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return GL355_E_HIP;
+        (void)hipGetLastError();
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    for (uint32_t u = 0; u < n_units; u++)
+        if (back[u] != ~0ull) { *failed_unit = u; *failed_op = back[u]; return GL355_E_WITNESS; }
+    memcpy(pis_out, back.data() + n_units, (size_t)n_units * ch->n_pi * 8);
+    return GL355_OK;
+}
 int32_t circuit_replay_units(const gl355_circuit_handle* ch, uint32_t threads, uint32_t n_units, const uint64_t* inputs, uint64_t* rows, uint64_t* pis_out,
                              uint64_t* failed_unit, uint64_t* failed_op) {
     const uint64_t n_words = circuit_rows_words(ch);
@@ -227,6 +275,36 @@ int32_t circuit_replay_units(const gl355_circuit_handle* ch, uint32_t threads, u
 }
 }  // namespace gl355
 extern "C" {
+
+int32_t gl355_circuit_witness_rows(gl355_ctx* h, const gl355_circuit_handle* ch, uint32_t n_units, const uint64_t* inputs, uint64_t n_inputs,
+                                   int32_t on_device, uint64_t* rows, uint64_t* public_inputs_out, uint64_t* failed_entry) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (!ch || !inputs || !rows) return ctx->fail(GL355_E_INVALID_ARG, "circuit_witness_rows: null argument");
+    if (ch->tape.empty()) return ctx->fail(GL355_E_INVALID_ARG, "circuit_witness_rows: this artifact carries no witness tape");
+    if (n_inputs != ch->n_inputs || n_units == 0 || n_units > GL355_MAX_UNITS) return ctx->fail(GL355_E_INVALID_ARG, "circuit_witness_rows: bad input shape");
+    const uint64_t n_words = circuit_rows_words(ch);
+    std::vector<uint64_t> pis((size_t)n_units * ch->n_pi + 1);
+    uint64_t fu = 0, fo = ~0ull;
+    int32_t rc;
+    if (!on_device) {
+        rc = circuit_replay_units(ch, ctx->replay_threads, n_units, inputs, rows, pis.data(), &fu, &fo);
+    } else {
+        if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+        Scratch d_rows(ctx), aux(ctx);
+        GL355_TRY(d_rows.get(n_units * n_words * 8));
+        GL355_TRY(aux.get(circuit_replay_aux_bytes(ch, n_units)));
+        rc = circuit_replay_units_dev(ch, ctx->device, ctx->stream, n_units, inputs, d_rows.as<uint64_t>(), aux.p, pis.data(), &fu, &fo);
+        if (rc == GL355_OK || rc == GL355_E_WITNESS) {
+            GL355_HIP(ctx, ctx->d2h(rows, d_rows.p, n_units * n_words * 8));
+            GL355_HIP(ctx, ctx->wait());
+        }
+    }
+    if (failed_entry) *failed_entry = fo;
+    if (rc != GL355_OK) return ctx->fail(rc, "circuit_witness_rows: the inputs do not satisfy the circuit");
+    if (public_inputs_out) memcpy(public_inputs_out, pis.data(), (size_t)n_units * ch->n_pi * 8);
+    return GL355_OK;
+}
 
 int32_t gl355_circuit_prove_tape_units(gl355_ctx* h, const gl355_circuit_handle* ch, uint32_t n_units, const uint64_t* inputs, uint64_t n_inputs,
                                        const uint8_t* blinding_keys, uint64_t* proofs, uint64_t* public_inputs_out) {

@@ -16,11 +16,18 @@ int32_t Ctx::fail_hip(hipError_t e, const char* expr, const char* file, int line
     return GL355_E_HIP;
 }
 
+uint64_t thread_cpu_ns() {
+    struct timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
 hipError_t Ctx::wait() {
-    if (prof_on) {      // host-side accounting: wall time this context's thread spends waiting for its stream
+    if (prof_on) {      // host-side accounting: wall time this context's thread spends waiting for its stream, and the CPU time of that wait
         const auto t0 = std::chrono::steady_clock::now();
+        const uint64_t c0 = thread_cpu_ns();
         const hipError_t e = wait_impl();
         wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        wait_cpu_ns += thread_cpu_ns() - c0;
         wait_calls++;
         return e;
     }
@@ -116,22 +123,24 @@ void Ctx::runtime_buffers_free() {
     for (int i = 0; i < 2; i++) {
         if (rt_rows[i]) (void)hipHostFree(rt_rows[i]);
         if (rt_drows[i]) (void)hipFree(rt_drows[i]);
-        rt_rows[i] = rt_drows[i] = nullptr;
+        if (rt_aux[i]) (void)hipFree(rt_aux[i]);
+        rt_rows[i] = rt_drows[i] = rt_aux[i] = nullptr;
     }
-    rt_bytes = 0;
+    rt_bytes = rt_aux_bytes = 0;
 }
-int32_t Ctx::runtime_buffers(size_t bytes, uint64_t* rows[2], uint64_t* drows[2], hipStream_t* copy_stream) {
+int32_t Ctx::runtime_buffers(size_t bytes, size_t aux_bytes, uint64_t* rows[2], uint64_t* drows[2], void* aux[2], hipStream_t* copy_stream) {
     if (!rt_copy_stream) GL355_HIP(this, hipStreamCreateWithFlags(&rt_copy_stream, hipStreamNonBlocking));
-    if (bytes > rt_bytes) {
+    if (bytes > rt_bytes || aux_bytes > rt_aux_bytes) {
         runtime_buffers_free();
         for (int i = 0; i < 2; i++) {
-            hipError_t e = hipHostMalloc(&rt_rows[i], bytes, hipHostMallocDefault);
+            hipError_t e = device_replay ? hipSuccess : hipHostMalloc(&rt_rows[i], bytes, hipHostMallocDefault);   // host replay only: pinned rows
             if (e == hipSuccess) e = hipMalloc(&rt_drows[i], bytes);
+            if (e == hipSuccess) e = hipMalloc(&rt_aux[i], aux_bytes ? aux_bytes : 256);
             if (e != hipSuccess) { (void)hipGetLastError(); runtime_buffers_free(); return fail_hip(e, "witness staging buffers", __FILE__, __LINE__); }
         }
-        rt_bytes = bytes;
+        rt_bytes = bytes; rt_aux_bytes = aux_bytes;
     }
-    for (int i = 0; i < 2; i++) { rows[i] = reinterpret_cast<uint64_t*>(rt_rows[i]); drows[i] = reinterpret_cast<uint64_t*>(rt_drows[i]); }
+    for (int i = 0; i < 2; i++) { rows[i] = reinterpret_cast<uint64_t*>(rt_rows[i]); drows[i] = reinterpret_cast<uint64_t*>(rt_drows[i]); aux[i] = rt_aux[i]; }
     *copy_stream = rt_copy_stream;
     return GL355_OK;
 }
@@ -257,7 +266,9 @@ int32_t gl355_runtime_config(int32_t device, uint32_t contexts, int32_t sleeping
     if (device < 0) return GL355_E_INVALID_ARG;
     if (contexts) {
         char buf[16];
-        snprintf(buf, sizeof buf, "%u", contexts < 4 ? 4u : contexts);
+        // a context owns two streams: the proving stream and the side stream of the batch runtime (witness generation, uploads).  A
+        // long interpreter kernel sharing a hardware queue with another context's proving stream would hold that stream up.
+        snprintf(buf, sizeof buf, "%u", 2 * contexts < 4 ? 4u : 2 * contexts);
         setenv("GPU_MAX_HW_QUEUES", buf, 0);      // read by the HIP runtime when it initialises
     }
     if (sleeping_waits) {
@@ -298,6 +309,10 @@ int32_t gl355_ctx_set_option(gl355_ctx* ctx, int32_t option, int64_t value) {
     case GL355_OPT_REPLAY_THREADS:
         if (value < 1 || value > 64) return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: REPLAY_THREADS must be in 1..64");
         ctx->c.replay_threads = (uint32_t)value;
+        return GL355_OK;
+    case GL355_OPT_DEVICE_REPLAY:
+        if (ctx->c.device_replay != (value != 0)) ctx->c.runtime_buffers_free();
+        ctx->c.device_replay = value != 0;
         return GL355_OK;
     case GL355_OPT_BATCH_UNITS:
         if (value < 1 || value > GL355_MAX_UNITS) return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: BATCH_UNITS must be in 1..GL355_MAX_UNITS");
@@ -386,7 +401,9 @@ int32_t gl355_profile_read(gl355_ctx* ctx, char* buf, size_t buf_len) {
     std::string out;
     if (c.wait_calls) {     // pseudo-entry: calls and total wall milliseconds of Ctx::wait() while profiling was on
         out += "host:stream_wait " + std::to_string(c.wait_calls) + " " + std::to_string(c.wait_ns * 1e-6) + " 0\n";
-        c.wait_calls = 0; c.wait_ns = 0;
+        out += "host:cpu_in_wait " + std::to_string(c.wait_calls) + " " + std::to_string(c.wait_cpu_ns * 1e-6) + " 0\n";
+        out += "host:cpu_in_prove " + std::to_string(c.prove_calls) + " " + std::to_string(c.prove_cpu_ns * 1e-6) + " 0\n";
+        c.wait_calls = 0; c.wait_ns = 0; c.wait_cpu_ns = 0; c.prove_calls = 0; c.prove_cpu_ns = 0;
     }
     for (auto& kv : agg) out += kv.first + " " + std::to_string(kv.second.n) + " " + std::to_string(kv.second.ms) + " " + std::to_string(kv.second.bytes) + "\n";
     if (out.size() + 1 > buf_len) out.resize(buf_len - 1);

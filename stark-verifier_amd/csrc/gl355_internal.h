@@ -79,6 +79,7 @@ struct Ctx {
     // device -> host copy on the stream; into pageable memory the call itself waits for the stream, so it is accounted like wait()
     hipError_t d2h(void* dst, const void* src, size_t bytes);
     uint64_t wait_ns = 0, wait_calls = 0;   // accumulated by wait() while prof_on
+    uint64_t wait_cpu_ns = 0, prove_cpu_ns = 0, prove_calls = 0;   // thread CPU time inside wait() / inside prove_units (waits included)
     uint32_t merkle_lanes_log = 14;   // Merkle levels with <= 2^this nodes use the 16-lanes-per-node kernel (GL355_OPT_MERKLE_LANES_LOG)
     bool prof_on = false;
     std::vector<ProfRec> prof;
@@ -96,9 +97,11 @@ struct Ctx {
     // batch runtime (batch.cpp): two witness-row slots (pinned host + device) and a copy stream, kept across calls
     void* rt_rows[2] = {nullptr, nullptr};
     void* rt_drows[2] = {nullptr, nullptr};
-    size_t rt_bytes = 0;
+    void* rt_aux[2] = {nullptr, nullptr};
+    size_t rt_bytes = 0, rt_aux_bytes = 0;
+    bool device_replay = true;        // GL355_OPT_DEVICE_REPLAY
     hipStream_t rt_copy_stream = nullptr;
-    int32_t runtime_buffers(size_t bytes, uint64_t* rows[2], uint64_t* drows[2], hipStream_t* copy_stream);
+    int32_t runtime_buffers(size_t bytes, size_t aux_bytes, uint64_t* rows[2], uint64_t* drows[2], void* aux[2], hipStream_t* copy_stream);
     void runtime_buffers_free();
     void release_all();
     // lo[c*4096 + j] = bases[c]^j, hi[c*4096 + j] = bases[c]^(4096 j)
@@ -243,6 +246,7 @@ int32_t quotient_dev(Ctx* ctx, const gl355_circuit* c, const uint64_t* cs_lde, c
                      const uint64_t* zs_lde, uint64_t lde_stride, const uint64_t* k_is_dev, const uint64_t* betas,
                      const uint64_t* gammas, const uint64_t* alphas, const uint64_t pi_hash[4], uint64_t* out_values);
 Ctx* ctx_of(gl355_ctx* h);
+uint64_t thread_cpu_ns();
 
 // ---- prover_batch.hip: CircuitData::prove for B lock-step units of one circuit ---------------------------------------------
 struct BlindKey;
@@ -256,6 +260,15 @@ struct ProveUnit {
 int32_t prove_units(Ctx* ctx, const gl355_prover_data* pd, uint32_t B, const uint64_t* d_wires_dense, const uint32_t* row_idx,
                     const uint64_t* rows_host, uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
                     const ProveUnit* io);
+uint64_t tape_validate(const uint64_t* tape, uint64_t n_ops, uint64_t n_inputs, uint64_t n_words, uint32_t num_wires);
+int32_t tape_replay_dev(hipStream_t stream, const uint64_t* d_tape, const uint64_t* d_seg_start, uint64_t n_seq, uint32_t n_segs, uint32_t n_units,
+                        const uint64_t* d_inputs, uint64_t n_inputs, uint64_t* d_rows, uint64_t n_words, const uint64_t* d_pi_pos, uint32_t n_pi,
+                        uint64_t* d_status, uint64_t* d_pis);
+// witness rows of n_units units generated on the device on `stream` (inputs: host [units][n_inputs]); d_aux: device scratch of
+// circuit_replay_aux_bytes(); the call returns after the stream has finished (polling, no spinning)
+uint64_t circuit_replay_aux_bytes(const gl355_circuit_handle* ch, uint32_t n_units);
+int32_t circuit_replay_units_dev(const gl355_circuit_handle* ch, int device, hipStream_t stream, uint32_t n_units, const uint64_t* inputs, uint64_t* d_rows,
+                                 void* d_aux, uint64_t* pis_out, uint64_t* failed_unit, uint64_t* failed_op);
 uint64_t circuit_rows_words(const gl355_circuit_handle* ch);
 int32_t circuit_replay_units(const gl355_circuit_handle* ch, uint32_t threads, uint32_t n_units, const uint64_t* inputs, uint64_t* rows, uint64_t* pis_out,
                              uint64_t* failed_unit, uint64_t* failed_op);

@@ -497,6 +497,11 @@ int32_t prove_units(Ctx* ctx, const gl355_prover_data* pd, uint32_t B, const uin
                     const ProveUnit* io) {
     if (!pd || !pd->circuit || !pd->constants_sigmas || !pd->sigmas || !pd->k_is || !io || B == 0 || B > MAXB)
         return ctx->fail(GL355_E_INVALID_ARG, "prove: null argument or more than GL355_MAX_UNITS units");
+    struct CpuScope {      // thread CPU time of the whole call, for gl355_profile_read's host:cpu_in_prove
+        Ctx* c; uint64_t t0;
+        explicit CpuScope(Ctx* cx) : c(cx), t0(cx->prof_on ? thread_cpu_ns() : 0) {}
+        ~CpuScope() { if (c->prof_on) { c->prove_cpu_ns += thread_cpu_ns() - t0; c->prove_calls++; } }
+    } cpu_scope(ctx);
     const gl355_circuit& c = *pd->circuit;
     const uint32_t nch = c.num_challenges, qdf = c.max_degree, npp = c.num_partial_products, routed = c.num_routed_wires, nw = c.num_wires;
     const uint32_t lde_bits = c.degree_bits + c.rate_bits, cap_h = pd->cap_height, L = pd->n_fri_layers, nq_idx = pd->num_queries;

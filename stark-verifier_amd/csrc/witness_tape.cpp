@@ -145,6 +145,36 @@ static int32_t run_entries(const uint64_t* tape, uint64_t begin, uint64_t end, c
     return GL355_OK;
 }
 
+// Static check of every offset a tape entry touches (what run_entries checks while it executes): done once when an artifact is
+// loaded, so that the device interpreter (witness_tape_dev.hip) can run without bounds checks.  Returns the first bad entry or ~0.
+namespace gl355 {
+uint64_t tape_validate(const uint64_t* tape, uint64_t n_ops, uint64_t n_inputs, uint64_t n_words, uint32_t num_wires) {
+    auto ok = [&](uint64_t i, uint64_t span) { return i < n_words && span <= n_words - i; };
+    auto row = [&](uint64_t i) { return ok(i, num_wires) && i % num_wires == 0; };
+    if (num_wires < 135) return 0;
+    for (uint64_t t = 0; t < n_ops; t++) {
+        const uint64_t* e = tape + 5 * t;
+        const uint64_t a = e[1], b = e[2], c = e[3], d = e[4];
+        bool good = false;
+        switch (e[0]) {
+        case GL355_TAPE_CONST: good = ok(a, 1); break;
+        case GL355_TAPE_INPUT: good = ok(a, 1) && b < n_inputs; break;
+        case GL355_TAPE_COPY: case GL355_TAPE_ASSERT_EQ: case GL355_TAPE_LO32: case GL355_TAPE_HI32: good = ok(a, 1) && ok(b, 1); break;
+        case GL355_TAPE_ARITH: good = ok(a, 4); break;
+        case GL355_TAPE_ARITH_EXT: good = ok(a, 8); break;
+        case GL355_TAPE_POSEIDON: case GL355_TAPE_MDS_EXT: good = row(a); break;
+        case GL355_TAPE_BASE_SUM: good = row(a) && b <= 63 && 1 + b <= num_wires; break;
+        case GL355_TAPE_RANDOM_ACCESS: good = row(a) && b < 4; break;
+        case GL355_TAPE_REDUCING: good = row(a) && b != 0 && b <= num_wires && 6 + (c ? 2 * b : b) + 2 * (b - 1) <= num_wires; break;
+        case GL355_TAPE_EXT_INV: good = ok(a, 1) && ok(b, 1) && ok(c, 1) && ok(d, 1); break;
+        default: good = false;
+        }
+        if (!good) return t;
+    }
+    return ~0ull;
+}
+}  // namespace gl355
+
 extern "C" int32_t gl355_witness_replay(const uint64_t* tape, uint64_t n_ops, const uint64_t* inputs, uint64_t n_inputs,
                                         uint64_t* rows, uint64_t n_words, uint32_t num_wires, uint64_t* failed_op) {
     if (!tape || !rows || (!inputs && n_inputs) || num_wires < 135) return GL355_E_INVALID_ARG;

@@ -490,6 +490,21 @@ class NativeCircuit:
                                                    _ptr(pis)))
         return flat, pis
 
+    def witness_rows(self, ctx, inputs, on_device):
+        """gl355_circuit_witness_rows: (rows [units][n_rows][num_wires], public inputs [units][n_pi]) of `inputs` [units][n_inputs]
+        by the host replay or the device tape interpreter; raises Gl355Error(GL355_E_WITNESS) with .failed_entry on invalid inputs"""
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint64).reshape(-1, self.n_inputs)
+        units = inputs.shape[0]
+        rows = np.empty((units, self.n_rows, 135), dtype=np.uint64)
+        pis = np.empty((units, self.n_public_inputs), dtype=np.uint64)
+        failed = C.c_uint64(0)
+        rc = ctx.lib.gl355_circuit_witness_rows(ctx.h, self.h, units, _ptr(inputs), self.n_inputs, int(on_device), _ptr(rows), _ptr(pis), C.byref(failed))
+        if rc != 0:
+            err = _lib.Gl355Error(rc, (ctx.lib.gl355_last_error(ctx.h) or b"").decode())
+            err.failed_entry = failed.value
+            raise err
+        return rows, pis
+
     def semaphore_prove(self, ctx, private_key, topic, index, siblings, seed):
         sk, tp, sib = _u64(private_key), _u64(topic), _u64(siblings)
         flat = np.empty(self.proof_words, dtype=np.uint64)

@@ -154,7 +154,7 @@ import torch                                   # imported (its libamdhip64 is th
 lib = importlib.import_module("stark-verifier_amd._lib").load(init_torch=False)
 assert lib.gl355_runtime_config(0, 8, 1) == 0
 getenv = C.CDLL(None).getenv; getenv.restype = C.c_char_p
-assert getenv(b"GPU_MAX_HW_QUEUES") == b"8"       # set in the C environment (os.environ is Python's own copy)
+assert getenv(b"GPU_MAX_HW_QUEUES") == b"16"      # two queues per context: proving stream + side stream       # set in the C environment (os.environ is Python's own copy)
 gl = importlib.import_module("stark-verifier_amd")
 ctx = gl.Context(0)
 x = torch.arange(12 << 22, dtype=torch.int64, device="cuda").reshape(-1, 12)
