@@ -333,6 +333,47 @@ class _TorchComm:
         self.dist.destroy_process_group()
 
 
+def bn254_figures(gl, device):
+    """SURVEY 8(f) N4 first slice: bn256::Fr FFT (k = 20, 22) and bn256::G1 MSM (2^20 points) on resident operands"""
+    import torch
+    ctx = gl.Context(device)
+    lib = ctx.lib
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x254)
+    out = {"what": "halo2 best_fft over bn256::Fr and best_multiexp over bn256::G1 (verifier_api.rs:77-92), operands resident; first slice, untuned"}
+    for k in (20, 22):
+        x = torch.randint(0, (1 << 60) - 1, (1 << k, 4), dtype=torch.int64, device="cuda", generator=g)
+        torch.cuda.synchronize()
+        ctx.check(lib.gl355_bn254_fr_ntt(ctx.h, C.c_void_p(x.data_ptr()), k, 0))
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(3):
+            ctx.check(lib.gl355_bn254_fr_ntt(ctx.h, C.c_void_p(x.data_ptr()), k, 0))
+        ms = ctx.timer_stop() / 3
+        out["fr_ntt_k%d" % k] = {"ms": round(ms, 3), "butterflies_per_s": round((1 << (k - 1)) * k / ms * 1e3 / 1e9, 2), "unit": "G butterflies/s"}
+        del x
+    n = 1 << 20
+    # timing only needs valid curve points: the bases are G and 2 G at random (the bucket method's work does not depend on the bases'
+    # values); parity at this size uses distinct known multiples of G (tests/test_gpu_bn254_curve.py)
+    base = torch.tensor([[1, 0, 0, 0, 2, 0, 0, 0],                                     # G and 2 G (the EIP-196 vector), limbs as int64
+                         [-3187975959365562413, -2776444254790673240, -7240376035293260411, 217937391675185666,
+                          -54395613263387964, 7540895263331946439, -1764180053174871030, 1580046089645096082]],
+                        dtype=torch.int64, device="cuda")
+    pts = base[torch.randint(0, 2, (n,), device="cuda", generator=g)].contiguous()
+    sc = torch.randint(0, (1 << 60) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    res = torch.zeros(8, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.check(lib.gl355_bn254_g1_msm(ctx.h, C.c_void_p(pts.data_ptr()), C.c_void_p(sc.data_ptr()), n, C.c_void_p(res.data_ptr())))
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(2):
+        ctx.check(lib.gl355_bn254_g1_msm(ctx.h, C.c_void_p(pts.data_ptr()), C.c_void_p(sc.data_ptr()), n, C.c_void_p(res.data_ptr())))
+    ms = ctx.timer_stop() / 2
+    out["g1_msm_2p20"] = {"ms": round(ms, 2), "points_per_s": round(n / ms * 1e3 / 1e6, 2), "unit": "M points/s"}
+    ctx.close()
+    return out
+
+
 def thread_cpu_snapshot():
     """{tid: (comm, cpu seconds)} of the process's live threads (diagnostic: which threads burn host CPU; GL355_BENCH_THREAD_CPU=1)"""
     out = {}
@@ -562,6 +603,10 @@ def main_recursive(args):
                 line["ntt_lde"] = lde_figure(gl, local_rank)
             except Exception as exc:
                 line["ntt_lde"] = {"error": repr(exc)}
+            try:
+                line["bn254_finalisation_kernels"] = bn254_figures(gl, local_rank)
+            except Exception as exc:
+                line["bn254_finalisation_kernels"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     if comm is not None:
         comm.barrier()

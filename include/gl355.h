@@ -487,6 +487,16 @@ int32_t gl355_comm_max_f64(gl355_comm* comm, double* inout);
  * MerkleTree::new(leaves, 0).cap[0], the "aggregation root" over the gathered (nullifier | topic) leaves */
 int32_t gl355_aggregation_root(gl355_ctx* ctx, const uint64_t* leaves, uint64_t n_leaves, uint32_t leaf_len, uint64_t root[4]);
 
+/* ---- SURVEY 8(f) N4, first slice: the two kernels of the Halo2 / KZG finalisation (verifier_api.rs:57-96: ParamsKZG::setup :77,
+ * keygen_vk / keygen_pk :78-79, create_proof :90, at k = 20..23 per chip/native_chip/test_utils.rs:57-95) -- halo2_proofs'
+ * `best_fft` over halo2curves bn256::Fr and `best_multiexp` over bn256::G1.  Values are canonical integers as 4 little-endian u64
+ * (any 256-bit value is accepted and reduced); G1 points are affine x | y (8 u64), (0, 0) encodes the identity.
+ *   gl355_bn254_fr_ntt   in place, natural order in and out: a[k] <- sum_i a[i] w^(ik), w = ROOT_OF_UNITY^(2^(28 - log_n));
+ *                        inverse != 0: with w^-1 and the 1/n scaling (EvaluationDomain::ifft)
+ *   gl355_bn254_g1_msm   result = sum_i scalars[i] * points[i]  (Pippenger buckets) */
+int32_t gl355_bn254_fr_ntt(gl355_ctx* ctx, uint64_t* data /* n x 4 */, uint32_t log_n, int32_t inverse);
+int32_t gl355_bn254_g1_msm(gl355_ctx* ctx, const uint64_t* points /* n x 8 */, const uint64_t* scalars /* n x 4 */, uint64_t n, uint64_t result[8]);
+
 /* ---- a9: wires_permutation_partial_products_and_zs (vanishing_poly.rs:54-108,183-218) --------- */
 int32_t gl355_zs_partial_products(gl355_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas,
                                   const uint64_t* k_is, uint32_t log_n, uint32_t n_routed,

@@ -212,6 +212,16 @@ int orc_prove_sparse(const orc_prover_data *pd, const uint32_t *row_idx, const u
                      uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs, const uint64_t *public_inputs, uint32_t n_pi,
                      const uint8_t key[32], uint64_t *proof);
 
+/* ---- SURVEY 8(f) N4 (bn254_curve_oracle.c): bn256::Fr FFT and bn256::G1 MSM, canonical little-endian 4-limb values ---- */
+void orc_bn254_fr_ntt(uint64_t *data, uint32_t log_n, int inverse);
+void orc_bn254_fr_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
+void orc_bn254_fr_add(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
+int orc_bn254_g1_on_curve(const uint64_t xy[8]);
+void orc_bn254_g1_mul(const uint64_t p[8], const uint64_t k[4], uint64_t out[8]);
+void orc_bn254_g1_add(const uint64_t p[8], const uint64_t q[8], uint64_t out[8]);
+void orc_bn254_g1_msm(const uint64_t *points, const uint64_t *scalars, size_t n, uint64_t out[8]);
+void orc_bn254_g1_multiples(uint64_t first, uint64_t step, size_t n, uint64_t *points);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);   /* launchers such as torchrun export OMP_NUM_THREADS=1 */
 

@@ -387,3 +387,78 @@ class Bn254Oracle:
         cap = np.zeros((1 << cap_height, 4), np.uint64)
         self.L.orc_merkle_build_h(C.c_int(1), _p(lv), C.c_size_t(n), C.c_uint32(ll), C.c_uint32(cap_height), _p(dig), _p(cap))
         return dig, cap
+
+
+class Bn254Curve:
+    """oracle/bn254_curve_oracle.c: bn256::Fr FFT and bn256::G1 arithmetic / MSM on Python integers (affine points, None = identity)"""
+
+    def __init__(self, orc):
+        self.L = orc.L
+        self.L.orc_bn254_g1_on_curve.restype = C.c_int
+
+    @staticmethod
+    def _pt(p):
+        a = np.zeros(8, dtype=np.uint64)
+        if p is not None:
+            for i in range(4):
+                a[i] = (p[0] >> (64 * i)) & ((1 << 64) - 1)
+                a[4 + i] = (p[1] >> (64 * i)) & ((1 << 64) - 1)
+        return a
+
+    @staticmethod
+    def _unpt(a):
+        x = sum(int(a[i]) << (64 * i) for i in range(4))
+        y = sum(int(a[4 + i]) << (64 * i) for i in range(4))
+        return None if x == 0 and y == 0 else (x, y)
+
+    @staticmethod
+    def scalars(vals):
+        a = np.zeros((len(vals), 4), dtype=np.uint64)
+        for j, v in enumerate(vals):
+            for i in range(4):
+                a[j, i] = (int(v) >> (64 * i)) & ((1 << 64) - 1)
+        return a
+
+    @staticmethod
+    def ints(a):
+        a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+        return [sum(int(r[i]) << (64 * i) for i in range(4)) for r in a]
+
+    def on_curve(self, p):
+        return bool(self.L.orc_bn254_g1_on_curve(_p(self._pt(p))))
+
+    def mul(self, p, k):
+        out = np.zeros(8, dtype=np.uint64)
+        self.L.orc_bn254_g1_mul(_p(self._pt(p)), _p(self.scalars([k])), _p(out))
+        return self._unpt(out)
+
+    def add(self, p, q):
+        out = np.zeros(8, dtype=np.uint64)
+        self.L.orc_bn254_g1_add(_p(self._pt(p)), _p(self._pt(q)), _p(out))
+        return self._unpt(out)
+
+    def msm_arrays(self, points, scalars):
+        out = np.zeros(8, dtype=np.uint64)
+        pts, sc = u64(points), u64(scalars)
+        self.L.orc_bn254_g1_msm(_p(pts), _p(sc), C.c_size_t(pts.size // 8), _p(out))
+        return out
+
+    def msm(self, points, scalars):
+        pts = np.stack([self._pt(p) for p in points])
+        return self._unpt(self.msm_arrays(pts, self.scalars(scalars)))
+
+    def multiples_array(self, first, step, n):
+        out = np.zeros((n, 8), dtype=np.uint64)
+        self.L.orc_bn254_g1_multiples(C.c_uint64(first), C.c_uint64(step), C.c_size_t(n), _p(out))
+        return out
+
+    def multiples(self, first, step, n):
+        return [self._unpt(r) for r in self.multiples_array(first, step, n)]
+
+    def ntt_array(self, a, inverse=False):
+        d = u64(a).copy()
+        self.L.orc_bn254_fr_ntt(_p(d), C.c_uint32(int(d.size // 4).bit_length() - 1), C.c_int(int(inverse)))
+        return d
+
+    def ntt(self, vals, inverse=False):
+        return self.ints(self.ntt_array(self.scalars(vals), inverse))

@@ -1,0 +1,105 @@
+"""GPU: SURVEY 8(f) N4 first slice -- bn256::Fr FFT and bn256::G1 MSM kernels against the oracle (pinned by halo2curves'
+ROOT_OF_UNITY and the EIP-196 2*G vector, tests/test_bn254_curve_oracle.py), bit-exact; at the reference's sizes (k = 20, MSM of
+2^20 points) through properties that need no slow oracle pass: round trip / linearity / known spectrum for the FFT, and for the
+MSM points that are known multiples of G, so the result is one scalar multiplication."""
+import numpy as np
+import pytest
+
+import pymodel_bn254_curve as pm
+from oracle_lib import Bn254Curve
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_scalars(rng, n, below_r=True):
+    a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64, endpoint=False)
+    if below_r:
+        a[:, 3] &= np.uint64((1 << 60) - 1)              # < 2^252 < r
+    return a
+
+
+def gpu_ntt(ctx, a, inverse=False):
+    d = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    ctx.check(ctx.lib.gl355_bn254_fr_ntt(ctx.h, d.ctypes.data, int(d.shape[0]).bit_length() - 1, int(inverse)))
+    return d
+
+
+def gpu_msm(ctx, pts, sc):
+    pts, sc = np.ascontiguousarray(pts, dtype=np.uint64), np.ascontiguousarray(sc, dtype=np.uint64)
+    out = np.zeros(8, dtype=np.uint64)
+    ctx.check(ctx.lib.gl355_bn254_g1_msm(ctx.h, pts.ctypes.data, sc.ctypes.data, pts.shape[0], out.ctypes.data))
+    return out
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 5, 9, 12, 16])
+def test_fr_ntt_vs_oracle(ctx, orc, log_n):
+    cv = Bn254Curve(orc)
+    rng = np.random.default_rng(0x4E0 + log_n)
+    a = rand_scalars(rng, 1 << log_n, below_r=False)          # any 256-bit value is accepted and reduced
+    a[0] = 0
+    a[-1] = cv.scalars([pm.R - 1])[0]
+    assert np.array_equal(gpu_ntt(ctx, a), cv.ntt_array(a))
+    assert np.array_equal(gpu_ntt(ctx, a, inverse=True), cv.ntt_array(a, inverse=True))
+
+
+def test_fr_ntt_k20_properties(ctx, orc):
+    cv = Bn254Curve(orc)
+    n = 1 << 20
+    rng = np.random.default_rng(0x4E1)
+    a = rand_scalars(rng, n)
+    fa = gpu_ntt(ctx, a)
+    assert np.array_equal(gpu_ntt(ctx, fa, inverse=True), a)                      # round trip
+    imp = np.zeros((n, 4), dtype=np.uint64)
+    imp[1, 0] = 1
+    spec = gpu_ntt(ctx, imp)                                                     # spectrum of the shifted impulse = powers of omega
+    w = pm.omega(20)
+    for k in (0, 1, 2, 3, 12345, n // 2, n - 1):
+        assert cv.ints(spec[k])[0] == pow(w, k, pm.R)
+    # linearity on sampled outputs: F(a + imp)[k] = F(a)[k] + w^k
+    b = a.copy()
+    s = cv.ints(b[1])[0] + 1
+    b[1] = cv.scalars([s])[0]
+    fb = gpu_ntt(ctx, b)
+    for k in (0, 7, 99999, n - 1):
+        assert cv.ints(fb[k])[0] == (cv.ints(fa[k])[0] + pow(w, k, pm.R)) % pm.R
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 300, 1025, 4096])
+def test_g1_msm_vs_oracle(ctx, orc, n):
+    cv = Bn254Curve(orc)
+    rng = np.random.default_rng(0x4E2 + n)
+    pts = cv.multiples_array(int(rng.integers(1, 1 << 40)), int(rng.integers(1, 1 << 40)), n)
+    sc = rand_scalars(rng, n, below_r=False)
+    if n > 3:
+        pts[2] = 0                        # the identity among the bases
+        sc[1] = 0                         # a zero scalar
+        pts[3] = pts[0]                   # a repeated base
+    assert np.array_equal(gpu_msm(ctx, pts, sc), cv.msm_arrays(pts, sc))
+
+
+def test_g1_msm_edge_cases(ctx, orc):
+    cv = Bn254Curve(orc)
+    g = cv._pt(pm.G)
+    one = cv.scalars([1])
+    assert cv._unpt(gpu_msm(ctx, g.reshape(1, 8), one)) == pm.G
+    assert cv._unpt(gpu_msm(ctx, g.reshape(1, 8), cv.scalars([2]))) == pm.EIP196_2G          # published vector
+    assert cv._unpt(gpu_msm(ctx, g.reshape(1, 8), cv.scalars([pm.R]))) is None                 # r * G = identity
+    # P + (-P) and P + P inside one bucket
+    neg = cv._pt((1, pm.Q - 2))
+    assert cv._unpt(gpu_msm(ctx, np.stack([g, neg]), cv.scalars([5, 5]))) is None
+    assert cv._unpt(gpu_msm(ctx, np.stack([g, g]), cv.scalars([5, 5]))) == pm.mul(pm.G, 10)
+    assert ctx.lib.gl355_bn254_g1_msm(ctx.h, None, None, 4, g.ctypes.data) == -1
+
+
+def test_g1_msm_2p20_known_multiples(ctx, orc):
+    """2^20 bases (i + 1) * 7 G and random scalars: the MSM must equal (sum_i s_i * 7 (i + 1) mod r) * G"""
+    cv = Bn254Curve(orc)
+    n = 1 << 20
+    rng = np.random.default_rng(0x4E3)
+    pts = cv.multiples_array(7, 7, n)
+    sc = rand_scalars(rng, n)
+    vals = np.zeros(n, dtype=object)
+    for limb in range(4):
+        vals += sc[:, limb].astype(object) << (64 * limb)
+    k = int(sum(int(v) * (7 * (i + 1)) for i, v in enumerate(vals)) % pm.R)
+    assert cv._unpt(gpu_msm(ctx, pts, sc)) == cv.mul(pm.G, k)
