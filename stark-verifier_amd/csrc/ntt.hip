@@ -26,7 +26,9 @@
 // Field products: the compiler-scheduled formulation (gl_field.cuh, GL_MUL_VARIANT 2).  These kernels run 2-4 waves per SIMD
 // between LDS exchanges, so what matters is that the 16 independent butterflies of a thread interleave freely; the
 // inline-asm formulation has fewer instructions but serialises each product (measured: 4-7 % slower single-pass tiles).
+#ifndef GL_MUL_VARIANT
 #define GL_MUL_VARIANT 2
+#endif
 #include "gl355_internal.h"
 
 namespace gl355 {
@@ -422,7 +424,9 @@ template <int LT, int LOG_T>
 static hipError_t launch_rows_lt(const PassArgs& a, bool inv, uint64_t blocks, hipStream_t s) {
     const size_t shmem = ((1u << LT) + (1u << (LT - 4))) * sizeof(uint64_t);
     constexpr int NT = 1 << (LT - 4);
-    const bool fast = !inv && !a.pre_full && !a.pre_lo && !a.post_lo && a.scale == 1 && a.canon && !a.in_bitrev && !a.out_natural;
+    // the rows pass gains nothing from the FAST instantiation (measured 1.32 -> 1.45 ms: fewer registers, less overlap): off unless asked
+    static const bool rows_fast = getenv("GL355_EXP_NTT_ROWS_FAST") != nullptr;
+    const bool fast = rows_fast && !inv && !a.pre_full && !a.pre_lo && !a.post_lo && a.scale == 1 && a.canon && !a.in_bitrev && !a.out_natural;
     static const int exp_wpe = getenv("GL355_EXP_NTT_WPE") ? atoi(getenv("GL355_EXP_NTT_WPE")) : 0;      // experiments only
     if (fast && LT == 12 && exp_wpe == 4) {
         auto k = ntt_rows_kernel<LT, LOG_T, false, true, 4>;

@@ -64,6 +64,10 @@ struct AlphaAcc {
         for (int c = 0; c < NCH; c++) acc[c] = gl_add(acc[c], gl_mul(term, tab[c * stride + idx]));
         idx++;
     }
+    GL_DEV void push_at(uint64_t term, uint32_t k) {       // term k of the stream, out of order
+#pragma unroll
+        for (int c = 0; c < NCH; c++) acc[c] = gl_add(acc[c], gl_mul(term, tab[c * stride + k]));
+    }
 };
 // per-gate accumulation: sum_k alpha^(base+k) * c_k, later multiplied by the gate's filter
 template <int NCH>
@@ -77,12 +81,14 @@ __global__ void alpha_table_kernel(AlphaTabArgs a) {
     for (uint32_t c = 0; c < a.nch; c++) a.out[((uint64_t)u * a.nch + c) * a.stride + k] = gl_canon(gl_pow(a.alphas[u * 4 + c], k));
 }
 
-#define WIRE(j) (w[(uint64_t)(j) * a.lde_stride + t])
+// a point's wire row: column j of the wires LDE at this lane's row (global memory), or of the LDS copy of the row (STAGE variant)
+struct WireSrc { const uint64_t* p; uint64_t stride, idx; };
+#define WIRE(j) (w.p[(uint64_t)(j) * w.stride + w.idx])
 #define CONST(j) (a.cs[(uint64_t)(j) * a.lde_stride + t])
 
 // PoseidonGate: 123 constraints (gates/poseidon.rs:592-698); wire layout :329-380
 template <class GateAcc>
-GL_DEV void gate_poseidon(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g) {
+GL_DEV void gate_poseidon(const QuotArgs& a, const WireSrc& w, uint64_t t, GateAcc& g) {
     const uint64_t swap = WIRE(24);
     g.push(gl_sub(gl_mul(swap, swap), swap));
     uint64_t s[12];
@@ -138,7 +144,7 @@ GL_DEV void gate_poseidon(const QuotArgs& a, const uint64_t* __restrict__ w, uin
 
 // BaseSumGate<2>{num_limbs}: sum_i limb_i 2^i - sum ; limb (limb - 1)   (gates/base_sum.rs:37-60)
 template <class GateAcc>
-GL_DEV void gate_base_sum(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t num_limbs) {
+GL_DEV void gate_base_sum(const QuotArgs& a, const WireSrc& w, uint64_t t, GateAcc& g, uint32_t num_limbs) {
     uint64_t acc = 0;
     for (uint32_t i = num_limbs; i-- > 0;) acc = gl_add(gl_add(acc, acc), WIRE(1 + i));
     g.push(gl_sub(acc, WIRE(0)));
@@ -149,17 +155,17 @@ GL_DEV void gate_base_sum(const QuotArgs& a, const uint64_t* __restrict__ w, uin
 }
 // ConstantGate{n}: const_i - wire_i   (gates/constant.rs:31-36); gate constants follow the selectors
 template <class GateAcc>
-GL_DEV void gate_constant(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t n) {
+GL_DEV void gate_constant(const QuotArgs& a, const WireSrc& w, uint64_t t, GateAcc& g, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) g.push(gl_sub(CONST(a.c.num_selectors + i), WIRE(i)));
 }
 // PublicInputGate: wire_i - pi_hash_i   (gates/public_input.rs:32-39)
 template <class GateAcc>
-GL_DEV void gate_public_input(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t unit) {
+GL_DEV void gate_public_input(const QuotArgs& a, const WireSrc& w, uint64_t t, GateAcc& g, uint32_t unit) {
     for (uint32_t i = 0; i < 4; i++) g.push(gl_sub(WIRE(i), a.pi_hash[unit * 4 + i]));
 }
 // ArithmeticGate{num_ops}: out - (c0 m0 m1 + c1 addend)   (gates/arithmetic.rs:47-68)
 template <class GateAcc>
-GL_DEV void gate_arithmetic(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t num_ops) {
+GL_DEV void gate_arithmetic(const QuotArgs& a, const WireSrc& w, uint64_t t, GateAcc& g, uint32_t num_ops) {
     const uint64_t c0 = CONST(a.c.num_selectors), c1 = CONST(a.c.num_selectors + 1);
     for (uint32_t i = 0; i < num_ops; i++) {
         const uint64_t m0 = WIRE(4 * i), m1 = WIRE(4 * i + 1), ad = WIRE(4 * i + 2), out = WIRE(4 * i + 3);
@@ -176,7 +182,7 @@ GL_DEV void push2(GateAcc& g, gl2 v) { g.push(v.c0); g.push(v.c1); }
 
 // ArithmeticExtensionGate{num_ops}: out - (c0 m0 m1 + c1 addend)   (gates/arithmetic_extension.rs:22-80)
 template <class GateAcc>
-GL_DEV void gate_arithmetic_ext(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t num_ops) {
+GL_DEV void gate_arithmetic_ext(const QuotArgs& a, const WireSrc& w, uint64_t t, GateAcc& g, uint32_t num_ops) {
     const uint64_t c0 = CONST(a.c.num_selectors), c1 = CONST(a.c.num_selectors + 1);
     for (uint32_t i = 0; i < num_ops; i++) {
         const gl2 m0 = WIRE2(8 * i), m1 = WIRE2(8 * i + 2), ad = WIRE2(8 * i + 4), out = WIRE2(8 * i + 6);
@@ -186,7 +192,7 @@ GL_DEV void gate_arithmetic_ext(const QuotArgs& a, const uint64_t* __restrict__ 
 }
 // MulExtensionGate{num_ops}: out - c0 m0 m1   (gates/multiplication_extension.rs:22-68)
 template <class GateAcc>
-GL_DEV void gate_mul_ext(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t num_ops) {
+GL_DEV void gate_mul_ext(const QuotArgs& a, const WireSrc& w, uint64_t t, GateAcc& g, uint32_t num_ops) {
     const uint64_t c0 = CONST(a.c.num_selectors);
     for (uint32_t i = 0; i < num_ops; i++) {
         const gl2 m0 = WIRE2(6 * i), m1 = WIRE2(6 * i + 2), out = WIRE2(6 * i + 4);
@@ -195,7 +201,7 @@ GL_DEV void gate_mul_ext(const QuotArgs& a, const uint64_t* __restrict__ w, uint
 }
 // PoseidonMdsGate: out_r - sum_i CIRC[i] in[(i+r)%12] - DIAG[r] in[r]   (gates/poseidon_mds.rs:26-126)
 template <class GateAcc>
-GL_DEV void gate_poseidon_mds(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g) {
+GL_DEV void gate_poseidon_mds(const QuotArgs& a, const WireSrc& w, uint64_t t, GateAcc& g) {
     constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     for (uint32_t r = 0; r < 12; r++) {
         gl2 acc = gl2_make(0, 0);
@@ -212,7 +218,7 @@ GL_DEV void gate_poseidon_mds(const QuotArgs& a, const uint64_t* __restrict__ w,
 }
 // RandomAccessGate{bits, copies, extra}   (gates/random_access.rs:27-147)
 template <class GateAcc>
-GL_DEV void gate_random_access(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t param) {
+GL_DEV void gate_random_access(const QuotArgs& a, const WireSrc& w, uint64_t t, GateAcc& g, uint32_t param) {
     const uint32_t bits = param & 0xFF, copies = (param >> 8) & 0xFF, extra = (param >> 16) & 0xFF;
     const uint32_t vec = 1u << bits, routed = (2 + vec) * copies + extra;
     for (uint32_t c = 0; c < copies; c++) {
@@ -242,7 +248,7 @@ GL_DEV void gate_random_access(const QuotArgs& a, const uint64_t* __restrict__ w
 // ReducingGate{n} / ReducingExtensionGate{n}: acc*alpha + coeff - acc_i   (gates/reducing.rs:20-85,
 // gates/reducing_extension.rs:20-87); the last accumulator is the output (wires 0..1)
 template <bool EXT, class GateAcc>
-GL_DEV void gate_reducing(const QuotArgs& a, const uint64_t* __restrict__ w, uint64_t t, GateAcc& g, uint32_t n) {
+GL_DEV void gate_reducing(const QuotArgs& a, const WireSrc& w, uint64_t t, GateAcc& g, uint32_t n) {
     const gl2 alpha = WIRE2(2);
     gl2 acc = WIRE2(4);
     const uint32_t start_accs = 6 + (EXT ? 2 * n : n);
@@ -254,13 +260,21 @@ GL_DEV void gate_reducing(const QuotArgs& a, const uint64_t* __restrict__ w, uin
     }
 }
 
-template <int NCH>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) quotient_kernel(QuotArgs a) {
+// STAGE (experiment, GL355_EXP_QUOT_STAGE=1): the wave first copies its 64 points' wire rows (num_wires x 64 x 8 B = 69 KB) into LDS and
+// every evaluator reads them from there -- each wire column crosses the fabric once instead of ~4 times, at 2 waves per CU.
+template <int NCH, bool STAGE = false>
+__global__ void __launch_bounds__(STAGE ? 64 : 128) __attribute__((amdgpu_waves_per_eu(STAGE ? 1 : 3, 3))) quotient_kernel(QuotArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t wire_lds[];
     const uint64_t nq = 1ull << a.qbits;
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= nq) return;
     const uint32_t unit = blockIdx.y;
-    const uint64_t* __restrict__ w = a.wires + (uint64_t)unit * a.wires_us;
+    const uint64_t* __restrict__ wglob = a.wires + (uint64_t)unit * a.wires_us;
+    WireSrc w{wglob, a.lde_stride, t};
+    if constexpr (STAGE) {
+        for (uint32_t j = 0; j < a.c.num_wires; j++) wire_lds[j * 64 + threadIdx.x] = wglob[(uint64_t)j * a.lde_stride + t];
+        w = WireSrc{wire_lds, 64, threadIdx.x};        // one wave per block: no barrier needed, each lane reads only its own column entries
+    }
     const uint64_t* __restrict__ zs = a.zs + (uint64_t)unit * a.zs_us;
     const uint32_t qdb = a.qbits - a.c.degree_bits;
     const uint64_t iq = __brevll(t) >> (64 - a.qbits);   // natural index of storage row t
@@ -284,24 +298,39 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
         total.push(gl_sub(gl_mul(l0, z), l0));
     }
     // ---- partial products (vanishing_poly.rs:54-108, 183-218) -------------------------------------
-    for (uint32_t c = 0; c < nch; c++) {
-        const uint64_t beta = a.betas[unit * 4 + c], gamma = a.gammas[unit * 4 + c];
-        const uint64_t bx = gl_mul(beta, x);
-        uint64_t prev = zs[(uint64_t)c * a.lde_stride + t];
+    // every routed wire and its sigma value are loaded ONCE and serve all challenges (the term of (challenge c, chunk ch) keeps
+    // its place c * n_chunks + ch in the stream: push_at)
+    {
         const uint32_t n_chunks = (routed + chunk - 1) / chunk;
-        for (uint32_t ch = 0; ch < n_chunks; ch++) {
-            uint64_t num = 1, den = 1;
-            for (uint32_t j = ch * chunk; j < (ch + 1) * chunk && j < routed; j++) {
-                const uint64_t wg = gl_add(WIRE(j), gamma);
-                num = gl_mul(num, gl_add(wg, gl_mul(bx, a.k_is[j])));
-                den = gl_mul(den, gl_add(wg, gl_mul(beta, CONST(n_sel + n_cst + j))));
-            }
-            const uint64_t next = (ch + 1 < n_chunks)
-                                      ? zs[(uint64_t)(nch + c * npp + ch) * a.lde_stride + t]
-                                      : zs[(uint64_t)c * a.lde_stride + t_next];
-            total.push(gl_sub(gl_mul(prev, num), gl_mul(next, den)));
-            prev = next;
+        uint64_t prev[NCH], bx[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            prev[c] = zs[(uint64_t)c * a.lde_stride + t];
+            bx[c] = gl_mul(a.betas[unit * 4 + c], x);
         }
+        const uint32_t first = total.idx;
+        for (uint32_t ch = 0; ch < n_chunks; ch++) {
+            uint64_t num[NCH], den[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) { num[c] = 1; den[c] = 1; }
+            for (uint32_t j = ch * chunk; j < (ch + 1) * chunk && j < routed; j++) {
+                const uint64_t wj = WIRE(j), sj = CONST(n_sel + n_cst + j), kj = a.k_is[j];
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    const uint64_t wg = gl_add(wj, a.gammas[unit * 4 + c]);
+                    num[c] = gl_mul(num[c], gl_add(wg, gl_mul(bx[c], kj)));
+                    den[c] = gl_mul(den[c], gl_add(wg, gl_mul(a.betas[unit * 4 + c], sj)));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const uint64_t next = (ch + 1 < n_chunks) ? zs[(uint64_t)(nch + c * npp + ch) * a.lde_stride + t]
+                                                          : zs[(uint64_t)c * a.lde_stride + t_next];
+                total.push_at(gl_sub(gl_mul(prev[c], num[c]), gl_mul(next, den[c])), first + c * n_chunks + ch);
+                prev[c] = next;
+            }
+        }
+        total.idx = first + nch * n_chunks;
     }
     // ---- gate constraints, each gate's stream multiplied by its filter (gates/mod.rs:87-132) ---------
     uint64_t gate_sum[NCH];
@@ -416,6 +445,15 @@ int32_t quotient_units_dev(Ctx* ctx, const gl355_circuit* c, uint32_t B, const u
     // every column of the three oracles once per point of the quotient coset + the result
     ProfScope ps(ctx, "quotient_kernel", (uint64_t)B * nq * 8 * ((uint64_t)c->num_selectors + c->num_constants + c->num_routed_wires + c->num_wires +
                                                    (uint64_t)c->num_challenges * (2 + c->num_partial_products)));
+    static const bool stage = getenv("GL355_EXP_QUOT_STAGE") != nullptr;       // experiment only
+    if (stage && c->num_challenges == 2) {
+        const size_t shmem = (size_t)c->num_wires * 64 * 8;
+        auto k = quotient_kernel<2, true>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3((uint32_t)((nq + 63) / 64), B), dim3(64), shmem, ctx->stream, a);
+        GL355_HIP(ctx, hipGetLastError());
+        return GL355_OK;
+    }
     const dim3 grid((uint32_t)((nq + 127) / 128), B);
     switch (c->num_challenges) {
         case 1: hipLaunchKernelGGL(quotient_kernel<1>, grid, dim3(128), 0, ctx->stream, a); break;
