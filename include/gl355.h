@@ -38,6 +38,7 @@ extern "C" {
 #define GL355_E_HIP (-4)
 #define GL355_E_UNSUPPORTED (-5)
 #define GL355_E_WITNESS (-6)     /* witness generation hit an unsatisfiable constraint (invalid inner proof) */
+#define GL355_E_VERIFY (-7)      /* gl355_verify: the proof is not valid for this circuit / these public inputs */
 
 #define GL355_P UINT64_C(0xFFFFFFFF00000001) /* chip/native_chip/arithmetic_chip.rs:19 */
 #define GL355_COSET_SHIFT UINT64_C(7)        /* chip/plonk/plonk_verifier_chip.rs:225-227 */
@@ -365,6 +366,24 @@ int32_t gl355_prove_sparse_units(gl355_ctx* ctx, const gl355_prover_data* pd, ui
                                  uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
                                  const uint64_t* public_inputs, uint32_t n_public_inputs, const uint8_t* blinding_keys,
                                  uint64_t* proofs, uint64_t proof_capacity_words);
+/* ---- CircuitData::verify (access_set.rs:170-175: `self.verifier_data.verify(signal.proof)`) ------------------------------------
+ * Host-only check of a flat proof (the layout above) against the verifier data of its circuit: transcript replay, the vanishing
+ * identity at zeta with every gate evaluator, proof of work, and every FRI query (initial-tree and layer Merkle paths, batch
+ * combination, folds, final polynomial) -- the equations of chip/plonk/plonk_verifier_chip.rs:55-242, vanishing_poly.rs:18-218,
+ * fri_chip.rs:58-376, merkle_proof_chip.rs:39-87.  GL355_OK = valid; GL355_E_VERIFY = rejected (gl355_verify_last_error says which
+ * check); GL355_E_INVALID_ARG = unusable verifier data. */
+typedef struct {
+    const gl355_circuit* circuit;
+    const uint64_t* constants_sigmas_cap;   /* [2^cap_height][4]: the preprocessed commitment (VerifierOnlyCircuitData) */
+    const uint64_t* k_is;                   /* [num_routed_wires] */
+    uint64_t circuit_digest[4];
+    uint32_t cap_height, pow_bits, num_queries, n_fri_layers;
+    int32_t zero_knowledge, hasher;
+} gl355_verifier_data;
+int32_t gl355_verify(const gl355_verifier_data* vd, const uint64_t* proof, uint64_t proof_words, const uint64_t* public_inputs,
+                     uint32_t n_public_inputs);
+const char* gl355_verify_last_error(void);   /* of the calling thread's last gl355_verify / gl355_circuit_verify */
+
 /* host-side witness rows of the Semaphore circuit (circuit.rs:67-99): (height + 7) rows x 135 wires in the
  * order PublicInput | pi-hash 1 | pi-hash 2 | BaseSum{height} | leaf hash | height Merkle levels | nullifier |
  * Constant; public_inputs = merkle_root | nullifier | topic (circuit.rs:27-32). */
@@ -426,6 +445,9 @@ const uint64_t* gl355_circuit_digest(const gl355_circuit_handle* c);
  * (parity surface of SURVEY 8(f) N3).  GL355_E_WITNESS + *failed_entry when the inputs do not satisfy the circuit. */
 int32_t gl355_circuit_witness_rows(gl355_ctx* ctx, const gl355_circuit_handle* c, uint32_t n_units, const uint64_t* inputs, uint64_t n_inputs,
                                    int32_t on_device, uint64_t* rows, uint64_t* public_inputs_out, uint64_t* failed_entry);
+/* gl355_verify with the verifier data of a loaded circuit */
+int32_t gl355_circuit_verify(const gl355_circuit_handle* c, const uint64_t* proof, uint64_t proof_words, const uint64_t* public_inputs,
+                             uint32_t n_public_inputs);
 int32_t gl355_circuit_prove_rows(gl355_ctx* ctx, const gl355_circuit_handle* c, const uint64_t* rows, const uint64_t* public_inputs,
                                  uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof, uint64_t proof_capacity_words);
 int32_t gl355_circuit_prove_tape(gl355_ctx* ctx, const gl355_circuit_handle* c, const uint64_t* inputs, uint64_t n_inputs, const uint8_t* blinding_key,

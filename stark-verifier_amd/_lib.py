@@ -25,6 +25,12 @@ class Challenger(C.Structure):
                 ("out_buf", C.c_uint64 * 8), ("out_len", C.c_uint32), ("hasher", C.c_int32)]
 
 
+class VerifierData(C.Structure):
+    _fields_ = [("circuit", vp), ("constants_sigmas_cap", vp), ("k_is", vp), ("circuit_digest", C.c_uint64 * 4),
+                ("cap_height", C.c_uint32), ("pow_bits", C.c_uint32), ("num_queries", C.c_uint32), ("n_fri_layers", C.c_uint32),
+                ("zero_knowledge", C.c_int32), ("hasher", C.c_int32)]
+
+
 class ProverData(C.Structure):
     _fields_ = [("circuit", vp), ("constants_sigmas", vp), ("sigmas", vp), ("k_is", vp), ("circuit_digest", C.c_uint64 * 4),
                 ("cap_height", C.c_uint32), ("pow_bits", C.c_uint32), ("num_queries", C.c_uint32), ("n_fri_layers", C.c_uint32),
@@ -113,6 +119,9 @@ SIGNATURES = {
     "gl355_circuit_info": (C.c_int32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint32)]),
     "gl355_circuit_digest": (C.POINTER(C.c_uint64), [vp]),
+    "gl355_verify": (C.c_int32, [C.POINTER(VerifierData), vp, C.c_uint64, vp, C.c_uint32]),
+    "gl355_verify_last_error": (C.c_char_p, []),
+    "gl355_circuit_verify": (C.c_int32, [vp, vp, C.c_uint64, vp, C.c_uint32]),
     "gl355_circuit_witness_rows": (C.c_int32, [vp, vp, C.c_uint32, vp, C.c_uint64, C.c_int32, vp, vp, C.POINTER(C.c_uint64)]),
     "gl355_circuit_prove_rows": (C.c_int32, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64]),
     "gl355_circuit_prove_tape": (C.c_int32, [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp]),

@@ -27,6 +27,7 @@ struct gl355_circuit_handle {
     uint64_t* d_pi_pos = nullptr;
     std::vector<uint32_t> row_idx;
     std::vector<uint64_t> pi_pos, tape, seg_lens;
+    std::vector<uint64_t> cs_cap, k_is_host;     // verifier data (gl355_circuit_verify)
     uint64_t n_seq = 0;
     uint32_t blind_start = 0, n_blind = 0, z_start = 0, n_z_pairs = 0, n_pi = 0;
     uint64_t n_inputs = 0;
@@ -133,6 +134,8 @@ int32_t gl355_circuit_load(gl355_ctx* h, const uint64_t* blob, uint64_t words, g
         std::vector<uint64_t> pre(n_cap * 4 + 3 + c.num_gates);
         rc = gl355_oracle_cap(ch->cs, pre.data());
         if (rc) break;
+        ch->cs_cap.assign(pre.begin(), pre.begin() + n_cap * 4);
+        ch->k_is_host.assign(k_is, k_is + routed);
         uint64_t* s = pre.data() + n_cap * 4;
         s[0] = c.degree_bits; s[1] = c.num_gates; s[2] = c.num_selectors;
         for (uint32_t g = 0; g < c.num_gates; g++) s[3 + g] = ((uint64_t)c.gates[g].type << 32) | c.gates[g].param;   // no aliasing between (type, param) pairs
@@ -182,6 +185,18 @@ int32_t gl355_circuit_info(const gl355_circuit_handle* ch, uint64_t* proof_words
     return GL355_OK;
 }
 const uint64_t* gl355_circuit_digest(const gl355_circuit_handle* ch) { return ch ? ch->pd.circuit_digest : nullptr; }
+
+int32_t gl355_circuit_verify(const gl355_circuit_handle* ch, const uint64_t* proof, uint64_t proof_words, const uint64_t* public_inputs,
+                             uint32_t n_public_inputs) {
+    if (!ch) return GL355_E_INVALID_ARG;
+    gl355_verifier_data vd;
+    memset(&vd, 0, sizeof vd);
+    vd.circuit = &ch->c; vd.constants_sigmas_cap = ch->cs_cap.data(); vd.k_is = ch->k_is_host.data();
+    memcpy(vd.circuit_digest, ch->pd.circuit_digest, 32);
+    vd.cap_height = ch->pd.cap_height; vd.pow_bits = ch->pd.pow_bits; vd.num_queries = ch->pd.num_queries; vd.n_fri_layers = ch->pd.n_fri_layers;
+    vd.zero_knowledge = ch->pd.zero_knowledge; vd.hasher = ch->pd.hasher;
+    return gl355_verify(&vd, proof, proof_words, public_inputs, n_public_inputs);
+}
 
 int32_t gl355_circuit_prove_rows(gl355_ctx* h, const gl355_circuit_handle* ch, const uint64_t* rows, const uint64_t* public_inputs,
                                  uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof, uint64_t proof_capacity_words) {

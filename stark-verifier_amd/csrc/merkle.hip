@@ -211,6 +211,7 @@ __global__ void __launch_bounds__(256) two_to_one_kernel(const uint64_t* l, cons
 __global__ void __launch_bounds__(256) pow_grind_kernel(const uint64_t* state, uint32_t pos, uint32_t bits,
                                                        uint64_t start, unsigned long long* best) {
     const uint64_t w = start + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (w > __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;      // cannot be the smallest witness any more
     uint64_t s[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) s[k] = state[k];

@@ -410,6 +410,10 @@ __global__ void __launch_bounds__(256) pow_grind_units_kernel(PowArgs a) {
     const uint32_t u = blockIdx.y;
     if (!a.todo[u]) return;
     const uint64_t w = a.start + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    // the smallest witness wins, so a candidate above the best one found so far cannot matter: workgroups are dispatched in
+    // roughly increasing order, and once a witness is known the rest of the launch exits here (expected work ~2^bits instead of the
+    // 2^(bits+1) candidates of the launch); candidates below the current best are never skipped, so the result is still the minimum
+    if (w > __hip_atomic_load(a.best + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     uint64_t s[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) s[k] = a.state[u * 12 + k];

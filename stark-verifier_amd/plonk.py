@@ -349,6 +349,26 @@ class CircuitData:
         return np.concatenate([hdr, _u64(self.constants).reshape(-1), _u64(self.sigmas).reshape(-1), _u64(self.k_is), row_idx,
                                pi_pos, tape.reshape(-1), np.asarray(seg_lens, dtype=np.uint64)])
 
+    def verify(self, flat_proof, public_inputs):
+        """CircuitData::verify (access_set.rs:170-175) through gl355_verify (host only): raises Gl355Error(GL355_E_VERIFY) with the
+        failed check, returns True otherwise"""
+        lib = _lib.load()
+        cfg = self.config
+        vd = _lib.VerifierData()
+        cap = np.ascontiguousarray(self.constants_sigmas_cap, dtype=np.uint64)
+        kis = np.ascontiguousarray(self.k_is, dtype=np.uint64)
+        vd.circuit = C.cast(C.pointer(self.c_circuit), C.c_void_p)
+        vd.constants_sigmas_cap, vd.k_is = cap.ctypes.data, kis.ctypes.data
+        for i in range(4):
+            vd.circuit_digest[i] = int(self.circuit_digest[i])
+        vd.cap_height, vd.pow_bits, vd.num_queries = cfg.cap_height, cfg.proof_of_work_bits, cfg.num_query_rounds
+        vd.n_fri_layers, vd.zero_knowledge, vd.hasher = len(self.fri_arity_bits), int(cfg.zero_knowledge), int(getattr(cfg, "hasher", 0))
+        flat, pi = _u64(flat_proof), _u64(public_inputs)
+        rc = lib.gl355_verify(C.byref(vd), _ptr(flat), flat.size, _ptr(pi), pi.size)
+        if rc != 0:
+            raise _lib.Gl355Error(rc, (lib.gl355_verify_last_error() or b"").decode())
+        return True
+
     def common(self):
         """Plain-dict common data for the verifier restatement in tests/."""
         cfg = self.config

@@ -43,3 +43,25 @@ def test_units_argument_errors(gl, ctx):
     idx, vals, pi = aset.witness_rows(rows, sks[1], rand_field(rng, 4), 1)
     with pytest.raises(gl.Gl355Error):
         plonk.prove_sparse_units(ctx, data, idx, np.stack([vals] * 17), np.stack([pi] * 17), [1] * 17)
+
+
+def test_gpu_proofs_pass_the_product_verifier(gl, ctx):
+    """gl355_circuit_verify / CircuitData.verify (CircuitData::verify, access_set.rs:170-175) on proofs of the lock-step prover"""
+    import ctypes as C
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    aset, sks, rng = make_access_set(gl, ctx, 3, 0x813)
+    data, rows = aset.build(rng)
+    wit = [aset.witness_rows(rows, sks[m], rand_field(rng, 4), m) for m in (1, 6, 3)]
+    idx = wit[0][0]
+    flats = plonk.prove_sparse_units(ctx, data, idx, np.stack([w[1] for w in wit]), np.stack([w[2] for w in wit]), None)   # OS-random blinding
+    nat = plonk.NativeCircuit(ctx, data.export_blob(idx))
+    for f, w in zip(flats, wit):
+        assert data.verify(f, w[2])
+        pi = np.ascontiguousarray(w[2], dtype=np.uint64)
+        assert ctx.lib.gl355_circuit_verify(nat.h, f.ctypes.data, f.size, pi.ctypes.data, pi.size) == 0
+    bad = flats[0].copy()
+    bad[-7] ^= np.uint64(4)
+    pi = np.ascontiguousarray(wit[0][2], dtype=np.uint64)
+    assert ctx.lib.gl355_circuit_verify(nat.h, bad.ctypes.data, bad.size, pi.ctypes.data, pi.size) == -7
+    assert b"verify" in ctx.lib.gl355_verify_last_error() or ctx.lib.gl355_verify_last_error()
+    assert ctx.lib.gl355_circuit_verify(nat.h, flats[1].ctypes.data, flats[1].size, pi.ctypes.data, pi.size) == -7     # another unit's public inputs

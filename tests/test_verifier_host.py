@@ -1,0 +1,79 @@
+"""CPU: the product-side verifier gl355_verify (csrc/verifier.cpp, `CircuitData::verify`, access_set.rs:170-175) against the Python
+restatement of the reference's verifier (tests/plonk_verifier.py): both accept the CPU prover's proofs -- the Semaphore circuit and
+the recursive verifier circuit, which exercises every gate evaluator incl. the extension-algebra gates -- and both reject the same
+tampered proofs / public inputs."""
+import importlib
+
+import numpy as np
+import pytest
+
+import cpu_semaphore as cs
+import cpu_unit as cu
+import plonk_verifier as pv
+
+
+def both(orc, data, plonk, flat, pi):
+    """-> (C++ verdict, Python verdict)"""
+    gl = importlib.import_module("stark-verifier_amd")
+    try:
+        data.verify(flat, pi)
+        c_ok = True
+    except gl.Gl355Error as e:
+        assert e.code == -7, e
+        c_ok = False
+    try:
+        proof = plonk.parse_proof(data, flat)
+        proof["public_inputs"] = pi
+        pv.verify(orc, data.common(), proof)
+        p_ok = True
+    except pv.VerifyError:
+        p_ok = False
+    return c_ok, p_ok
+
+
+def tamper_cases(flat, pi, rng):
+    yield "untouched", flat, pi
+    for name, pos in (("a cap word", 9), ("an opening", 8 + 3 * 64 + 11), ("a late opening", 8 + 3 * 64 + 400), ("final poly / pow region", flat.size // 3),
+                      ("a query leaf", flat.size - flat.size // 5), ("a sibling near the end", flat.size - 3)):
+        f = flat.copy()
+        f[pos] ^= np.uint64(1)
+        yield name, f, pi
+    p2 = pi.copy()
+    p2[5] ^= np.uint64(2)
+    yield "a public input", flat, p2
+    for _ in range(6):
+        f = flat.copy()
+        f[int(rng.integers(8, flat.size))] ^= np.uint64(1 << int(rng.integers(0, 60)))
+        yield "a random word", f, pi
+
+
+def test_semaphore_proof_accept_and_reject(orc):
+    case, topic, (idx, vals, pi), flat = cs.golden_proof(orc)
+    rng = np.random.default_rng(0x7E71)
+    for name, f, p in tamper_cases(flat, pi, rng):
+        c_ok, p_ok = both(orc, case["data"], case["plonk"], f, p)
+        assert c_ok == p_ok, name
+        assert c_ok == (name == "untouched"), name
+    # a non-canonical encoding of a valid element is refused (plonky2's deserialisation does)
+    f = flat.copy()
+    f[8 + 3 * 64] = f[8 + 3 * 64] + np.uint64(0xFFFFFFFF00000001) if int(f[8 + 3 * 64]) < (1 << 32) - 1 else f[8 + 3 * 64]
+    if not np.array_equal(f, flat):
+        with pytest.raises(Exception):
+            case["data"].verify(f, pi)
+    with pytest.raises(Exception):
+        case["data"].verify(flat[:-1], pi)
+
+
+def test_recursive_proof_accept_and_reject(orc):
+    """log_members = 2 inner proof -> recursive verifier circuit (all 11 gate kinds, n = 2^14) -> outer proof by the CPU prover"""
+    case, topic, (idx, vals, pi), flat = cs.golden_proof(orc)
+    rc = cu.recursive_cpu_circuit(orc, case["data"].common(), flat, pi)
+    rows, opis = cu.replay(rc, np.concatenate([flat, pi]))
+    outer = rc["cpu"].prove_sparse(rc["row_idx"], rows, opis, 4242)
+    rng = np.random.default_rng(0x7E72)
+    kinds = {t for t, _ in rc["data"].gates}
+    assert len(kinds) >= 11
+    for name, f, p in tamper_cases(outer, opis, rng):
+        c_ok, p_ok = both(orc, rc["data"], case["plonk"], f, p)
+        assert c_ok == p_ok, name
+        assert c_ok == (name == "untouched"), name
