@@ -108,25 +108,33 @@ def aggregation_root(ctx, leaves, cap_height=0):
     return MerkleTree(ctx, pad_pow2(lv), cap_height).cap
 
 
-def aggregate_distributed(aggregator, local_signals, dist=None, device=None, ctxs=None, seed=1, rng=None):
+def aggregate_distributed(aggregator, local_signals, dist=None, device=None, ctxs=None, seed=1, rng=None, comm=None):
     """recursion.rs:187-247 across GPUs: every rank aggregates its own block of signals into one proof (the lower
     log2(len(local_signals)) levels of the tree, no communication), the per-rank proofs -- flat words | public inputs, the wire
-    format of SURVEY N3 -- are exchanged with ONE all_gather (about 0.2 MB per rank over RCCL / xGMI), and rank 0 aggregates them
-    through the upper log2(world) levels.  Every rank builds the same level circuits (deterministic builder), so a proof made on
-    one GPU is an input of a circuit loaded on another.  Returns (proof, public inputs, common data) on rank 0, None elsewhere."""
-    import torch
+    format of SURVEY N3 -- are exchanged with ONE all-gather (about 0.2 MB per rank: gl355_gather_digests over RCCL / xGMI when
+    `comm` is a Comm; a torch.distributed group `dist` is accepted for the gloo tests), and rank 0 aggregates them through the
+    upper log2(world) levels.  Every rank builds the same level circuits (deterministic builder), so a proof made on one GPU is an
+    input of a circuit loaded on another.  Returns (proof, public inputs, common data) on rank 0, None elsewhere."""
     proof, pis, cd = aggregator.aggregate(local_signals, seed=seed, rng=rng, ctxs=ctxs)
-    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    if comm is not None:
+        world, rank = comm.world, comm.rank
+    else:
+        world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
     if world == 1:
         return proof, pis, cd
     assert world & (world - 1) == 0, "the aggregation tree is binary: a power-of-two number of ranks"
     local_levels = len(local_signals).bit_length() - 1
     packed = np.concatenate([np.ascontiguousarray(proof, dtype=np.uint64), np.ascontiguousarray(pis, dtype=np.uint64)])
-    t = torch.from_numpy(packed.view(np.int64)).reshape(1, -1)
-    if device is not None:
-        t = t.to(device)
-    allp = gather_leaves(t, dist).cpu().numpy().view(np.uint64)
-    if dist.get_rank() != 0:
+    if comm is not None:
+        allp = comm.gather(packed.reshape(1, -1))
+    else:
+        import torch
+        t = torch.from_numpy(packed.view(np.int64)).reshape(1, -1)
+        if device is not None:
+            t = t.to(device)
+        allp = gather_leaves(t, dist).cpu().numpy().view(np.uint64)
+    if rank != 0:
         return None
     n_words = proof.size
     signals = [(allp[r, :n_words].copy(), allp[r, n_words:].copy()) for r in range(world)]
