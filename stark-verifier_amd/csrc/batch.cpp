@@ -173,9 +173,23 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
         }
         if (units_per_ctx) units_per_ctx[t] = done;
     };
+    // nothing is thrown across the C boundary: a failed allocation / thread creation inside a worker becomes GL355_E_OOM
+    auto guarded = [&](uint32_t t) {
+        try {
+            worker(t);
+        } catch (...) {
+            int32_t expected = GL355_OK;
+            first_error.compare_exchange_strong(expected, GL355_E_OOM);
+        }
+    };
     std::vector<std::thread> pool;
-    for (uint32_t t = 1; t < n_ctx; t++) pool.emplace_back(worker, t);
-    worker(0);
+    try {
+        for (uint32_t t = 1; t < n_ctx; t++) pool.emplace_back(guarded, t);
+    } catch (...) {
+        int32_t expected = GL355_OK;
+        first_error.compare_exchange_strong(expected, GL355_E_OOM);
+    }
+    guarded(0);
     for (auto& th : pool) th.join();
     return first_error.load();
 }

@@ -21,6 +21,7 @@
 #include <netinet/tcp.h>
 #include <rccl/rccl.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -173,6 +174,8 @@ int32_t gl355_comm_create(gl355_ctx* h, int32_t backend, const uint8_t id[GL355_
             ::close(c->listen_fd); delete c;
             return GL355_E_UNSUPPORTED;
         }
+        timeval tmo{120, 0};                              // a rank that never arrives must not hang the others for ever
+        setsockopt(c->listen_fd, SOL_SOCKET, SO_RCVTIMEO, &tmo, sizeof tmo);
         for (int k = 1; k < world; k++) {
             const int fd = ::accept(c->listen_fd, nullptr, nullptr);
             int32_t peer = -1;
@@ -183,6 +186,8 @@ int32_t gl355_comm_create(gl355_ctx* h, int32_t backend, const uint8_t id[GL355_
                 return GL355_E_INVALID_ARG;
             }
             setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+            const timeval none{0, 0};                      // the accept time-out must not carry over to the data sockets
+            setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &none, sizeof none);
             c->peers[peer] = fd;
         }
     } else {

@@ -11,6 +11,7 @@
 #include "blinding.cuh"
 
 #include <errno.h>
+#include <new>
 #include <sys/random.h>
 
 using namespace gl355;
@@ -199,7 +200,13 @@ extern "C" int32_t gl355_prove(gl355_ctx* h, const gl355_prover_data* pd, const 
     GL355_TRY(s_wires.open(wires, ((uint64_t)pd->circuit->num_wires << pd->circuit->degree_bits) * 8, 1));
     ProveUnit io{public_inputs, n_public_inputs, {0}, proof, proof_capacity_words};
     GL355_TRY(resolve_blinding_key_words(ctx, blinding_key, io.key));
-    return prove_units(ctx, pd, 1, s_wires.as<uint64_t>(), nullptr, nullptr, 0, 0, 0, 0, 0, &io);
+    try {
+        return prove_units(ctx, pd, 1, s_wires.as<uint64_t>(), nullptr, nullptr, 0, 0, 0, 0, 0, &io);
+    } catch (const std::bad_alloc&) {
+        return ctx->fail(GL355_E_OOM, "prove: out of host memory");
+    } catch (...) {
+        return ctx->fail(GL355_E_HIP, "prove: unexpected host failure");
+    }
 }
 
 // Witness given as its non-zero rows only (the rest of the 2^degree_bits rows are Noop rows): rows[r] lists
@@ -237,7 +244,13 @@ extern "C" int32_t gl355_prove_sparse_units(gl355_ctx* h, const gl355_prover_dat
                           proofs + (uint64_t)u * proof_capacity_words, proof_capacity_words};
         GL355_TRY(resolve_blinding_key_words(ctx, blinding_keys ? blinding_keys + 32ull * u : nullptr, io[u].key));
     }
-    return prove_units(ctx, pd, n_units, nullptr, row_idx, rows, n_rows, blind_start, n_blind, z_start, n_z_pairs, io);
+    try {
+        return prove_units(ctx, pd, n_units, nullptr, row_idx, rows, n_rows, blind_start, n_blind, z_start, n_z_pairs, io);
+    } catch (const std::bad_alloc&) {
+        return ctx->fail(GL355_E_OOM, "prove: out of host memory");
+    } catch (...) {
+        return ctx->fail(GL355_E_HIP, "prove: unexpected host failure");      // nothing is thrown across the C boundary
+    }
 }
 
 // ---- blinding-stream surface (blinding.cuh) ----------------------------------------------------------------------------

@@ -205,8 +205,19 @@ extern "C" {
 
 const char* gl355_verify_last_error(void) { return g_verify_error.c_str(); }
 
+static int32_t verify_impl(const gl355_verifier_data* vd, const uint64_t* proof, uint64_t proof_words, const uint64_t* public_inputs,
+                           uint32_t n_public_inputs);
 int32_t gl355_verify(const gl355_verifier_data* vd, const uint64_t* proof, uint64_t proof_words, const uint64_t* public_inputs,
                      uint32_t n_public_inputs) {
+    try {
+        return verify_impl(vd, proof, proof_words, public_inputs, n_public_inputs);
+    } catch (...) {                      // allocation failure: nothing is thrown across the C boundary
+        g_verify_error = "verify: out of host memory";
+        return GL355_E_OOM;
+    }
+}
+static int32_t verify_impl(const gl355_verifier_data* vd, const uint64_t* proof, uint64_t proof_words, const uint64_t* public_inputs,
+                           uint32_t n_public_inputs) {
     g_verify_error.clear();
     if (!vd || !vd->circuit || !vd->constants_sigmas_cap || !vd->k_is || !proof || (!public_inputs && n_public_inputs)) { g_verify_error = "verify: null argument"; return GL355_E_INVALID_ARG; }
     const gl355_circuit& c = *vd->circuit;
