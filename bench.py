@@ -333,6 +333,42 @@ class _TorchComm:
         self.dist.destroy_process_group()
 
 
+def cfg2_sweep(ctx, dev):
+    """BASELINE configs[1] / SURVEY cfg-2: (A) forward NTT N = 2^20, natural order in and out, batch 1 / 16 / 135; (B) LDE 2^17 -> 2^20
+    (rate_bits 3, coset 7), same batches, bit-reversed (commitment) order; (C) forward NTT N = 2^16 .. 2^23, batch 16.  Operands resident;
+    HIP-event time per call; algorithmic bytes 16 B N (A, C) and 8 B (n + N) (B)."""
+    import torch
+    lib = ctx.lib
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x355)
+
+    def timed(fn, reps=4):
+        fn(); ctx.sync()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        return ctx.timer_stop() / reps
+    out = {"A_forward_ntt_2p20": {}, "B_lde_2p17_to_2p20": {}, "C_forward_ntt_batch16": {}}
+    for b in (1, 16, 135):
+        x = torch.randint(0, (1 << 63) - 1, (b, 1 << 20), dtype=torch.int64, device=dev, generator=g)
+        torch.cuda.synchronize()
+        ms = timed(lambda: ctx.check(lib.gl355_ntt(ctx.h, C.c_void_p(x.data_ptr()), 20, b, 1 << 20, 0)))
+        out["A_forward_ntt_2p20"]["batch_%d" % b] = {"ms": round(ms, 4), "GBps": round(16.0 * b * (1 << 20) / ms / 1e6, 1)}
+        c = x[:, :1 << 17].contiguous()
+        o = torch.empty((b, 1 << 20), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        ms = timed(lambda: ctx.check(lib.gl355_lde_bitrev(ctx.h, C.c_void_p(c.data_ptr()), 17, 3, 7, b, C.c_void_p(o.data_ptr()))))
+        out["B_lde_2p17_to_2p20"]["batch_%d" % b] = {"ms": round(ms, 4), "GBps": round(8.0 * b * ((1 << 17) + (1 << 20)) / ms / 1e6, 1)}
+        del x, c, o
+    for lg in range(16, 24):
+        x = torch.randint(0, (1 << 63) - 1, (16, 1 << lg), dtype=torch.int64, device=dev, generator=g)
+        torch.cuda.synchronize()
+        ms = timed(lambda: ctx.check(lib.gl355_ntt(ctx.h, C.c_void_p(x.data_ptr()), lg, 16, 1 << lg, 0)))
+        out["C_forward_ntt_batch16"]["2p%d" % lg] = {"ms": round(ms, 4), "GBps": round(16.0 * 16 * (1 << lg) / ms / 1e6, 1)}
+        del x
+    return out
+
+
 def bn254_figures(gl, device):
     """SURVEY 8(f) N4 first slice: bn256::Fr FFT (k = 20, 22) and bn256::G1 MSM (2^20 points) on resident operands"""
     import torch
@@ -738,8 +774,21 @@ def main_lde(args):
                          "kernels_ms_per_launch": {k: round(v[1] / max(1, v[0]), 4) for k, v in prof.items()},
                          "kernel_time_fraction_of_wall": round(total_kernel_ms * 1e-3 / elapsed, 3)},
         }
+        # the bound that applies: wave-level VALU instructions of the two passes (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r01_lde_pmc_v1.txt:
+        # 5.30e8 + 5.52e8 per LDE before the round-2 diet of pass 1) against the chip's issue rate
+        line["roofline"]["valu_issue"] = {"unit": "G wave-instructions/s", "insts_per_lde_round1": 1.082e9,
+                                          "achieved_if_unchanged": round(1.082e9 / (lde_ms * 1e-3) / 1e9, 1) if lde_ms > 0 else None,
+                                          "peak": round(1024 * 2.05e9 / 4.2 / 1e9, 1),
+                                          "note": "the LDE is bound by integer VALU issue (~490 lane-instructions per output element in round 1), not by HBM"}
         if root is not None:
             line["aggregation_root"] = ["%016x" % x for x in root]
+        if world == 1:
+            try:
+                del coeffs, out
+                torch.cuda.empty_cache()
+                line["cfg2_sweep"] = cfg2_sweep(ctx, dev)
+            except Exception as exc:
+                line["cfg2_sweep"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -491,14 +491,13 @@ static hipError_t launch_cols(const PassArgs& a, uint32_t log_t, bool inv, hipSt
 // Split of a two-pass transform: N = N1 * N2, first-pass dimension N1 (columns kernel in the
 // natural->bitrev flow, rows kernel in the bitrev->natural flow).
 static void split_two_pass(uint32_t log_n, bool natural_in, uint32_t* log_n1, uint32_t* log_n2) {
-    if (natural_in) {  // cols over N1 (<= 2^12, prefers >= 16 cols per tile), rows over N2 <= 2^12
-        uint32_t l2 = 12;
-        uint32_t l1 = log_n - l2;
-        *log_n1 = l1; *log_n2 = l2;
-    } else {           // rows over N1 (contiguous, <= 2^12), then cols over N2 (<= 2^12)
-        uint32_t l1 = 12;
-        uint32_t l2 = log_n - l1;
-        *log_n1 = l1; *log_n2 = l2;
+    // the column pass works on tiles of 2^(12 - LOG_T) adjacent columns: with 4096-point rows a 2^22 / 2^23-point transform leaves it
+    // 4 / 2 columns (32- / 16-byte accesses: 570 / 450 GB/s against 860 at 2^21), so from 2^22 on the row dimension is 2^14
+    const uint32_t row = log_n >= 22 ? 14 : 12;
+    if (natural_in) {  // cols over N1 (<= 2^12, prefers >= 16 cols per tile), rows over N2
+        *log_n1 = log_n - row; *log_n2 = row;
+    } else {           // rows over N1 (contiguous), then cols over N2 (<= 2^12)
+        *log_n1 = row; *log_n2 = log_n - row;
     }
 }
 
@@ -557,7 +556,8 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         a.pre_lo = p.pre_lo; a.pre_hi = p.pre_hi;
         a.step_lo = step_lo; a.step_hi = step_hi;
         if (p.log_n <= 20) {
-            // full-size tables (<= 8 MiB each): 1 load + 1 modmul per element instead of 2 + 2
+            // full-size tables (<= 8 MiB each): 1 load + 1 modmul per element instead of 2 + 2 (beyond 2^20 measured a wash: 2^21
+            // slower, 2^22 / 2^23 +2-3 %)
             if (p.pre_lo && ((uint64_t)p.n_cosets << p.log_n) <= (1ull << 21)) {
                 GL355_TRY(ctx->full_pow_table(p.pre_lo, p.pre_hi, p.n_cosets, p.log_n, &a.pre_full));
                 a.pre_full_stride = 1ull << p.log_n;
