@@ -329,20 +329,31 @@ int32_t gl355_circuit_prove_tape_units(gl355_ctx* h, const gl355_circuit_handle*
     if (ch->tape.empty()) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: this artifact carries no witness tape");
     if (n_inputs != ch->n_inputs) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: wrong number of input words");
     if (n_units == 0 || n_units > GL355_MAX_UNITS) return ctx->fail(GL355_E_INVALID_ARG, "circuit_prove_tape: 1..GL355_MAX_UNITS units per call");
-    static thread_local std::vector<uint64_t> rows;      // one prover thread per context: reuse the row buffer
     const uint64_t n_words = (uint64_t)ch->row_idx.size() * ch->c.num_wires;
-    rows.resize(n_words * n_units);
+    std::vector<uint64_t> pis((size_t)ch->n_pi * n_units);
     uint64_t failed_unit = 0, failed_op = 0;
-    const int32_t rc = replay_units(ctx->replay_threads, ch, n_units, inputs, rows.data(), n_words, &failed_unit, &failed_op);
-    if (rc != GL355_OK) {
+    auto witness_error = [&](int32_t rc) {
         char msg[128];
         snprintf(msg, sizeof msg, "circuit_prove_tape: witness generation of unit %llu failed at tape entry %llu", (unsigned long long)failed_unit,
                  (unsigned long long)failed_op);
         return ctx->fail(rc, msg);
+    };
+    if (ctx->device_replay && ch->d_tape && n_units > 1) {
+        // witness rows generated where the prover reads them (witness_tape_dev.hip): the host uploads the inputs only.  A single unit
+        // keeps the host replay: its latency (2-7 ms) beats the interpreter's (~20 ms, one lane for the sequential part)
+        if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+        Scratch d_rows(ctx), aux(ctx);
+        GL355_TRY(d_rows.get(n_units * n_words * 8));
+        GL355_TRY(aux.get(circuit_replay_aux_bytes(ch, n_units)));
+        const int32_t rc = circuit_replay_units_dev(ch, ctx->device, ctx->stream, n_units, inputs, d_rows.as<uint64_t>(), aux.p, pis.data(), &failed_unit, &failed_op);
+        if (rc != GL355_OK) return rc == GL355_E_WITNESS ? witness_error(rc) : ctx->fail(rc, "circuit_prove_tape: device witness generation failed");
+        if (public_inputs_out) memcpy(public_inputs_out, pis.data(), pis.size() * 8);
+        return gl355_circuit_prove_rows_units(h, ch, n_units, d_rows.as<uint64_t>(), pis.data(), ch->n_pi, blinding_keys, proofs);
     }
-    std::vector<uint64_t> pis((size_t)ch->n_pi * n_units);
-    for (uint32_t u = 0; u < n_units; u++)
-        for (uint32_t i = 0; i < ch->n_pi; i++) pis[(size_t)u * ch->n_pi + i] = rows[(uint64_t)u * n_words + ch->pi_pos[i]];
+    static thread_local std::vector<uint64_t> rows;      // one prover thread per context: reuse the row buffer
+    rows.resize(n_words * n_units);
+    const int32_t rc = circuit_replay_units(ch, ctx->replay_threads, n_units, inputs, rows.data(), pis.data(), &failed_unit, &failed_op);
+    if (rc != GL355_OK) return witness_error(rc);
     if (public_inputs_out) memcpy(public_inputs_out, pis.data(), pis.size() * 8);
     return gl355_circuit_prove_rows_units(h, ch, n_units, rows.data(), pis.data(), ch->n_pi, blinding_keys, proofs);
 }

@@ -510,6 +510,17 @@ class NativeCircuit:
                                                    _ptr(pis)))
         return flat, pis
 
+    def prove_tape_units(self, ctx, inputs, seeds):
+        """gl355_circuit_prove_tape_units: inputs [units][n_inputs] (each unit: its inner proofs' flat words | public inputs) proven in
+        lock-step on `ctx`; seeds: one blinding key per unit, or None.  -> (proofs [units][words], public inputs [units][n_pi])"""
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint64).reshape(-1, self.n_inputs)
+        units = inputs.shape[0]
+        flat = np.empty((units, self.proof_words), dtype=np.uint64)
+        pis = np.empty((units, self.n_public_inputs), dtype=np.uint64)
+        keys = None if seeds is None else C.cast(C.create_string_buffer(b"".join(key_bytes(s) for s in seeds), 32 * units), C.c_void_p)
+        ctx.check(ctx.lib.gl355_circuit_prove_tape_units(ctx.h, self.h, units, _ptr(inputs), self.n_inputs, keys, _ptr(flat), _ptr(pis)))
+        return flat, pis
+
     def witness_rows(self, ctx, inputs, on_device):
         """gl355_circuit_witness_rows: (rows [units][n_rows][num_wires], public inputs [units][n_pi]) of `inputs` [units][n_inputs]
         by the host replay or the device tape interpreter; raises Gl355Error(GL355_E_WITNESS) with .failed_entry on invalid inputs"""

@@ -545,12 +545,19 @@ class Aggregator:
             nxt, errors = [None] * n_nodes, []
             cur = signals
 
-            def worker(t, cur=cur, nxt=nxt, nat=nat, n_nodes=n_nodes):
+            # the nodes of a level are independent proofs of one circuit: every context proves its share in lock-step batches
+            # (gl355_circuit_prove_tape_units: one launch per stage for up to `units` nodes)
+            units = max(1, min(8, -(-n_nodes // len(ctxs))))
+
+            def worker(t, cur=cur, nxt=nxt, nat=nat, n_nodes=n_nodes, units=units):
                 try:
-                    for j in range(t, n_nodes, len(ctxs)):
-                        pair = cur[2 * j:2 * j + 2]
-                        # one native call per node: tape replay + proof (gl355_circuit_prove_tape)
-                        nxt[j] = nat.prove_tape(ctxs[t], np.concatenate([np.concatenate([_u64(f), _u64(p)]) for f, p in pair]), seed + 2 * j)
+                    mine = list(range(t, n_nodes, len(ctxs)))
+                    for b in range(0, len(mine), units):
+                        js = mine[b:b + units]
+                        inputs = np.stack([np.concatenate([np.concatenate([_u64(f), _u64(p)]) for f, p in cur[2 * j:2 * j + 2]]) for j in js])
+                        flats, pis = nat.prove_tape_units(ctxs[t], inputs, [seed + 2 * j for j in js])
+                        for k, j in enumerate(js):
+                            nxt[j] = (flats[k], pis[k])
                 except Exception as exc:
                     errors.append(exc)
             ths = [threading.Thread(target=worker, args=(t,)) for t in range(min(len(ctxs), n_nodes))]
