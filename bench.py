@@ -263,9 +263,9 @@ def pmc_valu(kernel, avg_launch_ms):
     ach = insts / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     return {"unit": "G wave-instructions/s", "insts_per_launch": insts, "achieved": round(ach, 1), "peak": round(peak, 1),
             "frac": round(ach / peak, 3),
-            "note": "one prover context alone: a launch of 2^16-2^17 leaves is 1-2 waves per SIMD, so part of the issue rate is "
-                    "dependent-issue latency; under the multi-context load the SIMDs are shared (DESIGN.md section 5: the whole "
-                    "job runs at ~95 % of the VALU issue rate)"}
+            "note": "instructions per launch averaged over the launches of the committed --pmc pass (lock-step batches of 8: leaf hashing of "
+                    "2^19-2^20 rows and the tiny FRI-layer launches alike), duration from this run's one-context pass; in the timed region "
+                    "the device has a kernel resident 99.5 % of the time (profiles/r02_timeline.txt) and the job runs at the VALU issue rate"}
 
 
 def lde_figure(gl, device, steps=8):
