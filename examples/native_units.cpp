@@ -46,9 +46,9 @@ static uint64_t splitmix(uint64_t& s) {
     } while (0)
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s <artifact dir> [log_members=20] [contexts=22] [units=128]\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s <artifact dir> [log_members=20] [contexts=8] [units=128]\n", argv[0]); return 2; }
     const std::string dir = argv[1];
-    const uint32_t log_members = argc > 2 ? atoi(argv[2]) : 20, n_ctx = argc > 3 ? atoi(argv[3]) : 22;
+    const uint32_t log_members = argc > 2 ? atoi(argv[2]) : 20, n_ctx = argc > 3 ? atoi(argv[3]) : 8;
     uint32_t units = argc > 4 ? atoi(argv[4]) : 128;
     const uint64_t n = 1ull << log_members;
     int world = 1, rank = 0, host_port = 0;
@@ -60,11 +60,14 @@ int main(int argc, char** argv) {
     int32_t n_dev = 0;
     gl355_device_count(&n_dev);
     const int device = n_dev > 0 ? rank % n_dev : 0;
-    // one hardware queue per prover context, and sleeping device waits (more contexts than cores is the normal case)
-    if (gl355_runtime_config(device, n_ctx, 1) != GL355_OK) { fprintf(stderr, "gl355_runtime_config failed\n"); return 1; }
+    // two hardware queues per prover context (proving stream + side stream); every context waits for its stream by polling with
+    // back-off (a few percent of a core per waiting context, ~30 us wake-up) and proves 8 units in lock-step
+    if (gl355_runtime_config(device, n_ctx, 0) != GL355_OK) { fprintf(stderr, "gl355_runtime_config failed\n"); return 1; }
     std::vector<gl355_ctx*> ctxs(n_ctx);
-    for (auto& c : ctxs)
+    for (auto& c : ctxs) {
         if (gl355_ctx_create(device, &c) != GL355_OK) { fprintf(stderr, "no MI355X context\n"); return 1; }
+        gl355_ctx_set_option(c, GL355_OPT_BLOCKING_SYNC, 2);
+    }
     gl355_ctx* c0 = ctxs[0];
     // access set: secret keys from a seeded stream (values < 2^63 are canonical), public keys, Merkle tree (cap height 0)
     uint64_t seed = 0x357;
