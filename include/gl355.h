@@ -422,7 +422,8 @@ int32_t gl355_witness_replay_segmented(const uint64_t* tape, uint64_t n_ops, uin
 /* ---- circuit artifacts: the native per-proof path --------------------------------------------------------------
  * A circuit is BUILT once (plonky2's CircuitBuilder::build at access_set.rs:91, recursion.rs:167, wrapper.rs:41; here the
  * host-side builder stark-verifier_amd/plonk.py) and serialised with CircuitData.export_blob(): u64 words
- *   [0] magic "GL355CIR" [1] version 2 [2..11] the gl355_circuit scalars [12..91] 16 gates x {type, param, selector_index,
+ *   [0] magic "GL355CIR" [1] version 2 (3: the digest at [106..109] was computed elsewhere, e.g. by plonky2's CircuitBuilder::build,
+ *   and the artifact ends with the expected constants_sigmas cap [2^cap_height][4], which is checked instead of the digest) [2..11] the gl355_circuit scalars [12..91] 16 gates x {type, param, selector_index,
  *   group_start, group_end} [92] cap_height [93] pow_bits [94] num_queries [95] n_fri_layers [96] zero_knowledge [97] hasher
  *   [98] blind_start [99] n_blind [100] z_start [101] n_z_pairs [102] n_rows [103] n_tape_ops [104] n_inputs [105] n_public_inputs
  *   [106..109] circuit digest [110] sequential tape entries [111] independent tape segments, then constants[num_selectors + num_constants][n] | sigmas[routed][n] | k_is[routed] |

@@ -46,7 +46,8 @@ int32_t gl355_circuit_load(gl355_ctx* h, const uint64_t* blob, uint64_t words, g
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
     if (!blob || !out || words < HDR) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: null or truncated artifact");
     *out = nullptr;
-    if (blob[0] != MAGIC || blob[1] != 2) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: not a version-2 gl355 circuit artifact");
+    if (blob[0] != MAGIC || (blob[1] != 2 && blob[1] != 3)) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: not a version-2/3 gl355 circuit artifact");
+    const bool external_digest = blob[1] == 3;      // the digest was computed elsewhere; the artifact carries the expected cap instead
     gl355_circuit c;
     memset(&c, 0, sizeof c);
     c.degree_bits = (uint32_t)blob[2]; c.rate_bits = (uint32_t)blob[3]; c.num_wires = (uint32_t)blob[4];
@@ -70,7 +71,8 @@ int32_t gl355_circuit_load(gl355_ctx* h, const uint64_t* blob, uint64_t words, g
     if (n_rows > n || n_ops > (1ull << 28) || n_pi > (1u << 20)) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: implausible sizes");
     const uint64_t n_seq = blob[110], n_segs = blob[111];
     if (n_seq > n_ops || n_segs > n_ops) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: implausible tape segmentation");
-    const uint64_t need = HDR + (n_sc + routed) * n + routed + n_rows + n_pi + 5 * n_ops + n_segs;
+    if (blob[92] > 20) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: implausible cap height");
+    const uint64_t need = HDR + (n_sc + routed) * n + routed + n_rows + n_pi + 5 * n_ops + n_segs + (external_digest ? (4ull << blob[92]) : 0);
     if (words != need) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: artifact length does not match its header");
     const int32_t hasher = (int32_t)blob[97];
     if (hasher != GL355_HASH_POSEIDON && hasher != GL355_HASH_BN254_POSEIDON) return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: unknown hasher");
@@ -139,9 +141,14 @@ int32_t gl355_circuit_load(gl355_ctx* h, const uint64_t* blob, uint64_t words, g
         uint64_t* s = pre.data() + n_cap * 4;
         s[0] = c.degree_bits; s[1] = c.num_gates; s[2] = c.num_selectors;
         for (uint32_t g = 0; g < c.num_gates; g++) s[3 + g] = ((uint64_t)c.gates[g].type << 32) | c.gates[g].param;   // no aliasing between (type, param) pairs
-        uint64_t dg[4];
-        gl355_host_hash_no_pad_h(hasher, pre.data(), pre.size(), dg);
-        if (memcmp(dg, blob + 106, 32) != 0) { rc = ctx->fail(GL355_E_INVALID_ARG, "circuit_load: circuit digest of the artifact does not match its tables"); break; }
+        if (external_digest) {
+            // version 3: the transcript uses the digest as given (e.g. plonky2's own); what ties the tables to it is the commitment
+            if (memcmp(pre.data(), blob + words - n_cap * 4, n_cap * 32) != 0) { rc = ctx->fail(GL355_E_INVALID_ARG, "circuit_load: the artifact's constants_sigmas cap does not match its tables"); break; }
+        } else {
+            uint64_t dg[4];
+            gl355_host_hash_no_pad_h(hasher, pre.data(), pre.size(), dg);
+            if (memcmp(dg, blob + 106, 32) != 0) { rc = ctx->fail(GL355_E_INVALID_ARG, "circuit_load: circuit digest of the artifact does not match its tables"); break; }
+        }
     } while (0);
     if (rc != GL355_OK) {
         if (ch->cs) gl355_oracle_destroy(ch->cs);

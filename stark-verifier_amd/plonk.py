@@ -324,9 +324,12 @@ class CircuitData:
             cache[key] = pd
         return cache[key]
 
-    def export_blob(self, row_idx, tape=None, pi_pos=None, n_inputs=0, tape_layout=None):
+    def export_blob(self, row_idx, tape=None, pi_pos=None, n_inputs=0, tape_layout=None, external_digest=None):
         """Serialise the built circuit (+ the sparse witness-row map and optionally a witness tape) as the u64 artifact
-        gl355_circuit_load reads (layout in include/gl355.h)."""
+        gl355_circuit_load reads (layout in include/gl355.h).  external_digest: 4 words of a circuit digest computed elsewhere (e.g.
+        by plonky2's own CircuitBuilder::build, whose digest also covers its domain separator): the artifact is then version 3 and
+        carries the expected constants_sigmas cap, which the loader checks against its own commitment of the tables instead of
+        re-deriving this framework's digest."""
         cfg = self.config
         cc = self.c_circuit
         hdr = np.zeros(112, dtype=np.uint64)
@@ -343,11 +346,15 @@ class CircuitData:
         hdr[92:106] = [cfg.cap_height, cfg.proof_of_work_bits, cfg.num_query_rounds, len(self.fri_arity_bits), int(cfg.zero_knowledge),
                        cfg.hasher, start, n_blind, z_pairs[0][0] if z_pairs else 0, len(z_pairs), row_idx.size, tape.shape[0],
                        n_inputs, pi_pos.size]
-        hdr[106:110] = self.circuit_digest
+        hdr[106:110] = self.circuit_digest if external_digest is None else _u64(external_digest)
         n_seq, seg_lens = tape_layout if tape_layout is not None else (tape.shape[0], [])
         hdr[110], hdr[111] = n_seq, len(seg_lens)
+        tail = []
+        if external_digest is not None:
+            hdr[1] = 3
+            tail = [_u64(self.constants_sigmas_cap).reshape(-1)]
         return np.concatenate([hdr, _u64(self.constants).reshape(-1), _u64(self.sigmas).reshape(-1), _u64(self.k_is), row_idx,
-                               pi_pos, tape.reshape(-1), np.asarray(seg_lens, dtype=np.uint64)])
+                               pi_pos, tape.reshape(-1), np.asarray(seg_lens, dtype=np.uint64)] + tail)
 
     def verify(self, flat_proof, public_inputs):
         """CircuitData::verify (access_set.rs:170-175) through gl355_verify (host only): raises Gl355Error(GL355_E_VERIFY) with the

@@ -174,3 +174,29 @@ print("RESULT", wall, cpu, int(ref[1, 0]))
     assert out.returncode == 0, out.stderr[-2000:]
     wall, cpu, v = out.stdout.split("RESULT")[1].split()
     assert float(cpu) < 0.5 * float(wall), (wall, cpu)          # a spinning wait would make them equal
+
+
+def test_artifact_with_an_external_digest(gl, ctx, orc):
+    """version-3 artifacts: the circuit digest comes from elsewhere (plonky2's own build), the loader ties the tables to it through
+    the constants_sigmas cap; the transcript -- and therefore prover and verifier -- use the given digest"""
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    aset, sks, rng = make_access_set(gl, ctx, 3, 0x904)
+    topic = rand_field(rng, 4)
+    data, rows = aset.build(None)
+    idx, vals, pi = aset.witness_rows(rows, sks[2], topic, 2)
+    ext = rand_field(rng, 4)
+    blob = data.export_blob(idx, external_digest=ext)
+    nat = plonk.NativeCircuit(ctx, blob)
+    flat, pis = nat.semaphore_prove(ctx, sks[2], topic, 2, aset.tree.prove_host(2), 5)
+    p = np.ascontiguousarray(pis, dtype=np.uint64)
+    assert ctx.lib.gl355_circuit_verify(nat.h, flat.ctypes.data, flat.size, p.ctypes.data, p.size) == 0
+    own = plonk.NativeCircuit(ctx, data.export_blob(idx))           # the same circuit under this framework's digest: another transcript
+    assert ctx.lib.gl355_circuit_verify(own.h, flat.ctypes.data, flat.size, p.ctypes.data, p.size) == -7
+    bad = blob.copy()
+    bad[200] ^= np.uint64(1)                                          # a table word: the commitment no longer matches the carried cap
+    with pytest.raises(gl.Gl355Error):
+        plonk.NativeCircuit(ctx, bad)
+    bad = blob.copy()
+    bad[-1] ^= np.uint64(1)                                           # the carried cap itself
+    with pytest.raises(gl.Gl355Error):
+        plonk.NativeCircuit(ctx, bad)
