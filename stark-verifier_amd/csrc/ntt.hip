@@ -435,6 +435,9 @@ static hipError_t launch_rows_lt(const PassArgs& a, bool inv, uint64_t blocks, h
         auto k = ntt_rows_kernel<LT, LOG_T, false, true>;
         if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
+    } else if (!inv && LT == 12 && exp_wpe == 4) {
+        auto k = ntt_rows_kernel<LT, LOG_T, false, false, 4>;
+        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
     } else if (inv) {
         auto k = ntt_rows_kernel<LT, LOG_T, true>;
         if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
