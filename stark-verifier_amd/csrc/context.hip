@@ -210,10 +210,19 @@ static int32_t ctx_init(Ctx* c) {
     GL355_HIP(c, hipEventCreate(&c->ev0));
     GL355_HIP(c, hipEventCreate(&c->ev1));
     // omega_{2^14}^(+-e) tables for the in-tile twiddles
-    std::vector<uint64_t> h(2 * 16384);
+    std::vector<uint64_t> h(2 * 16384 + 4 * 32768, 1);
     const uint64_t w = gl_root_of_unity(14), wi = gl_inv(w);
     uint64_t x = 1, y = 1;
     for (int e = 0; e < 16384; e++) { h[e] = gl_canon(x); h[16384 + e] = gl_canon(y); x = gl_mul(x, w); y = gl_mul(y, wi); }
+    // the same values in the order the LDS rounds read them (Ctx::twr): [2^m + (k0 << (m - rho)) + r] = omega_{2^m}^(+-r * k0)
+    for (uint32_t rho = 3; rho <= 4; rho++)
+        for (uint32_t dir = 0; dir < 2; dir++) {
+            uint64_t* t = h.data() + 32768 + ((rho - 3) * 2 + dir) * 32768;
+            for (uint32_t m = rho + 1; m <= 14; m++)
+                for (uint32_t k0 = 0; k0 < (1u << rho); k0++)
+                    for (uint32_t r = 0; r < (1u << (m - rho)); r++)
+                        t[(1u << m) + (k0 << (m - rho)) + r] = h[dir * 16384 + ((r * k0) << (14 - m))];
+        }
     GL355_HIP(c, hipMalloc((void**)&c->tw_fwd, h.size() * 8));
     c->tw_inv = c->tw_fwd + 16384;
     GL355_HIP(c, hipMemcpyAsync(c->tw_fwd, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream));

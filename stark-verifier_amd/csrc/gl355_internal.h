@@ -52,6 +52,8 @@ struct Ctx {
     std::string err;
     uint64_t* tw_fwd = nullptr;  // omega_{2^14}^e, e < 2^14
     uint64_t* tw_inv = nullptr;  // omega_{2^14}^-e
+    // round-major copy for the LDS rounds of radix 2^rho (rho = 3, 4), stored behind the two tables above
+    const uint64_t* twr(uint32_t rho, bool inv) const { return tw_fwd + 32768 + ((rho - 3) * 2 + (inv ? 1 : 0)) * 32768; }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // cached two-level power tables, keyed by the list of bases

@@ -1,0 +1,398 @@
+// Device side of the Goldilocks NTT passes (a2, a3 of SURVEY.md 8): radix-16 / radix-8 butterfly networks on registers, the LDS
+// rounds of a tile and the two pass kernels.  Included by ntt.hip (the product) and by tools/ubench/ubench_ntt_rows.hip (timing
+// experiments on exactly this code).  Conventions and the design notes are at the top of ntt.hip.
+#pragma once
+#include "gl355_internal.h"
+// GL355_NTT_KO (tools/ubench only; results are wrong with any bit set): 1 = twiddles from a register instead of the table,
+// 2 = no global loads of the tile, 4 = no twiddle products, 8 = no butterfly network, 16 = pre / step multipliers from registers
+// instead of their tables, 32 = no pre / step products
+#ifndef GL355_NTT_KO
+#define GL355_NTT_KO 0
+#endif
+
+namespace gl355 {
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+GL_DEV uint32_t brev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+// LDS index padding: one extra element every 16 keeps the stride-16 / stride-256 register rounds
+// conflict-free for ds_read_b64 (NTT section)
+GL_DEV uint32_t lds_phys(uint32_t idx) { return idx + (idx >> 4); }
+
+// g^e from a two-level table: lo[j] = g^j (j < 4096), hi[j] = g^(4096 j)
+GL_DEV uint64_t pow2lvl(const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi, uint64_t e) {
+    uint64_t v = lo[e & 4095];
+    if (hi) v = gl_mul(v, hi[e >> 12]);
+    return v;
+}
+
+// omega_16^j for the in-register radix-16 butterflies (forward / inverse), filled at ctx creation
+__constant__ uint64_t c_w16[2][8];
+
+// (a - b) * omega_16^(+-E) with shifts only: omega_16 = 2^156 = -2^60, omega_16^-1 = 2^36, so
+//   forward  E=1..7: -2^60, -2^24, +2^84, +2^48, +2^12, -2^72, -2^36
+//   inverse  E=1..7: +2^36, +2^72, -2^12, -2^48, -2^84, +2^24, +2^60
+// (a negative sign is absorbed by computing b - a instead of a - b).
+template <bool INV, int E>
+GL_DEV uint64_t sub_mul_w16(uint64_t a, uint64_t b) {
+    constexpr int FWD_S[8] = {0, 60, 24, 84, 48, 12, 72, 36};
+    constexpr bool FWD_NEG[8] = {false, true, true, false, false, false, true, true};
+    constexpr int INV_S[8] = {0, 36, 72, 12, 48, 84, 24, 60};
+    constexpr bool INV_NEG[8] = {false, false, false, true, true, true, false, false};
+    constexpr int S = INV ? INV_S[E] : FWD_S[E];
+    constexpr bool NEG = INV ? INV_NEG[E] : FWD_NEG[E];
+    const uint64_t d = NEG ? gl_sub(b, a) : gl_sub(a, b);
+    return gl_mul_2exp<S>(d);
+}
+
+// In-register DIF butterfly network on 2^RHO values: x[pos] <- X[bitrev(pos)].
+template <int RHO, bool INV>
+GL_DEV void dif_regs_generic(uint64_t (&x)[16]) {
+#pragma unroll
+    for (int s = 0; s < RHO; s++) {
+        const int half = 1 << (RHO - 1 - s);
+#pragma unroll
+        for (int blk = 0; blk < (1 << s); blk++) {
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                const int i0 = blk * 2 * half + j, i1 = i0 + half;
+                uint64_t a = x[i0], b = x[i1];
+                x[i0] = gl_add(a, b);
+                uint64_t d = gl_sub(a, b);
+                // twiddle omega_{2*half}^j = omega_16^(j * 8 / half)
+                const int e = j * (8 / half);
+                x[i1] = (e == 0) ? d : gl_mul(d, c_w16[INV ? 1 : 0][e]);
+            }
+        }
+    }
+}
+
+template <bool INV, int HALF, int J>
+GL_DEV void dif_pair(uint64_t (&x)[16], int i0) {
+    const uint64_t a = x[i0], b = x[i0 + HALF];
+    x[i0] = gl_add(a, b);
+    x[i0 + HALF] = sub_mul_w16<INV, J * (8 / HALF)>(a, b);
+}
+template <bool INV, int HALF, int BLK, int J>
+GL_DEV void dif_stage_unrolled(uint64_t (&x)[16]) {
+    if constexpr (J < HALF) {
+        dif_pair<INV, HALF, J>(x, BLK * 2 * HALF + J);
+        dif_stage_unrolled<INV, HALF, BLK, J + 1>(x);
+    }
+}
+template <bool INV, int HALF, int NBLK, int BLK>
+GL_DEV void dif_stage_blocks(uint64_t (&x)[16]) {
+    if constexpr (BLK < NBLK) {
+        dif_stage_unrolled<INV, HALF, BLK, 0>(x);
+        dif_stage_blocks<INV, HALF, NBLK, BLK + 1>(x);
+    }
+}
+// shift-twiddle version of the same network (all internal twiddles are powers of two)
+template <int RHO, bool INV>
+GL_DEV void dif_regs(uint64_t (&x)[16]) {
+    if constexpr (RHO >= 4) dif_stage_blocks<INV, 8, 1, 0>(x);
+    if constexpr (RHO >= 3) dif_stage_blocks<INV, 4, 1 << (RHO - 3), 0>(x);
+    if constexpr (RHO >= 2) dif_stage_blocks<INV, 2, 1 << (RHO - 2), 0>(x);
+    dif_stage_blocks<INV, 1, 1 << (RHO - 1), 0>(x);
+}
+
+// One DIF round of radix 2^RHO on an LDS tile.  The transform currently consists of independent
+// blocks of 2^m (transform units); transform bit 0 sits at tile-index bit LO.  `tw` is the ROUND-MAJOR twiddle table of this
+// radix and direction (Ctx::twr): tw[2^m + (k0 << (m - RHO)) + r] = omega_{2^m}^(+-r * k0), so that the 64 lanes of a wave
+// (consecutive r) read 64 consecutive words per register q.  With the plain omega_{2^14}^e table the same loads were gathers
+// at a stride of k0 * 2^(14-m) words -- up to 64 cache lines per wave instruction, and a third of the row pass's time
+// (tools/ubench/ubench_ntt_rows.hip, knock-out 1).
+template <int LT, int RHO, bool INV>
+GL_DEV void dif_round(uint64_t* lds, const uint64_t* __restrict__ tw, int m, int LO, int tid, int nthreads) {
+    constexpr int R = 1 << RHO;
+    const int tasks = (1 << LT) >> RHO;
+    const int fbit = LO + m - RHO;  // lowest tile-index bit of the radix field
+    for (int t = tid; t < tasks; t += nthreads) {
+        const uint32_t low = t & ((1u << fbit) - 1), high = t >> fbit;
+        const uint32_t idx0 = (high << (fbit + RHO)) | low;
+        uint64_t x[16];
+#pragma unroll
+        for (int q = 0; q < R; q++) x[q] = lds[lds_phys(idx0 + ((uint32_t)q << fbit))];
+        if constexpr (!(GL355_NTT_KO & 8)) dif_regs<RHO, INV>(x);
+        if ((GL355_NTT_KO & 4) == 0 && m > RHO) {
+            // output k0 = bitrev(q) of this butterfly is multiplied by omega_{2^m}^(r*k0)
+            const uint32_t r = (idx0 >> LO) & ((1u << (m - RHO)) - 1);
+            const uint64_t* __restrict__ twm = tw + (1u << m) + r;   // round-major table: lanes with consecutive r read consecutive words
+#pragma unroll
+            for (int q = 1; q < R; q++) {
+                const uint32_t k0 = brev(q, RHO);
+                if constexpr (GL355_NTT_KO & 1) x[q] = gl_mul(x[q], x[0] + r * k0);
+                else x[q] = gl_mul(x[q], twm[k0 << (m - RHO)]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; q++) lds[lds_phys(idx0 + ((uint32_t)q << fbit))] = x[q];
+    }
+}
+
+// all rounds for LOG_T transform bits starting at tile bit LO
+template <int LT, int LOG_T, bool INV>
+GL_DEV void dif_tile(uint64_t* lds, const uint64_t* __restrict__ tw, int LO, int tid, int nthreads) {
+    int m = LOG_T;
+#pragma unroll
+    for (int round = 0; round < LOG_T / 4; round++) {
+        dif_round<LT, 4, INV>(lds, tw, m, LO, tid, nthreads);
+        m -= 4;
+        __syncthreads();
+    }
+    constexpr int REM = LOG_T % 4;
+    if constexpr (REM == 3) dif_round<LT, 3, INV>(lds, tw, 3, LO, tid, nthreads);
+    if constexpr (REM == 2) dif_round<LT, 2, INV>(lds, tw, 2, LO, tid, nthreads);
+    if constexpr (REM == 1) dif_round<LT, 1, INV>(lds, tw, 1, LO, tid, nthreads);
+    if constexpr (REM != 0) __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass kernels
+// ------------------------------------------------------------------------------------------------
+struct PassArgs {
+    const uint64_t* in;
+    uint64_t* out;
+    uint64_t in_col_stride;    // elements between polynomial columns (input)
+    uint64_t out_col_stride;   // elements between polynomial columns (output)
+    uint32_t batch;            // polynomial columns
+    uint32_t n_cosets;         // independent (table, output-offset) variants per column (LDE); >= 1
+    uint64_t coset_out_stride; // output offset of coset c = coset_slot[c] * coset_out_stride
+    uint8_t coset_slot[16];
+    uint32_t log_n;            // log2 of the whole transform (per column, per coset)
+    uint32_t log_rows;         // row kernel: rows per column = 2^log_rows; col kernel: log2(N2)
+    const uint64_t* tw;        // round-major twiddles of the kernel's radix and direction (Ctx::twr)
+    const uint64_t* tw_r8;     // the same for the radix-8 kernels
+    const uint64_t* pre_lo;    // optional multiplier g^i on natural-order INPUT index i
+    const uint64_t* pre_hi;    //   tables of coset c at pre_lo + c*4096, pre_hi + c*4096
+    const uint64_t* post_lo;   // optional multiplier on natural-order OUTPUT index
+    const uint64_t* post_hi;
+    const uint64_t* step_lo;   // 4-step twiddle omega_N^(+-e): lo/hi tables (col kernel only)
+    const uint64_t* step_hi;
+    const uint64_t* pre_full;  // optional full table g_c^i (coset c at + c*pre_full_stride): 1 load + 1 mul
+    uint64_t pre_full_stride;
+    const uint64_t* step_full; // optional full 4-step twiddle table in STORE order (col kernel, first pass)
+    uint64_t scale;            // constant multiplier at store (1 = none)
+    uint32_t in_bitrev;        // input transform index is bit-reversed in memory
+    uint32_t out_natural;      // write natural order (else DIF-native bit-reversed order)
+    uint32_t canon;            // canonicalise at store (last pass)
+};
+
+// radix-8 commit-path kernels, compiled in ntt_r8.hip
+hipError_t launch_rows_r8(const PassArgs& a, uint32_t log_t, hipStream_t s);
+hipError_t launch_cols_r8(const PassArgs& a, uint32_t log_t, hipStream_t s);
+
+// Row pass: each row = 2^LOG_T contiguous elements; a tile packs 2^(LT-LOG_T) rows.
+// FAST = the commit-path shape with every optional multiplier compiled out: rows pass = no pre / post multiplier, no scaling,
+// natural tile order in and out, canonical store; cols pass = full pre and step tables, nothing else.  The general kernels test
+// those options per element at run time (~110 branches per phase); the LDE of a commitment never uses them.
+template <int LT, int LOG_T, bool INV, bool FAST = false, int WPE = (LT == 12 ? 3 : 1)>
+__global__ void __launch_bounds__(1 << (LT - 4)) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_rows_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    constexpr int NT = 1 << (LT - 4);
+    constexpr int RPT = 1 << (LT - LOG_T);  // rows per tile
+    const int tid = threadIdx.x;
+    const uint32_t coset = blockIdx.x % a.n_cosets;
+    const uint64_t tile = blockIdx.x / a.n_cosets;
+    const uint64_t row0 = tile * RPT;  // global row id over (column, row-in-column)
+    const uint64_t rows_per_col = 1ull << a.log_rows;
+    const uint64_t total_rows = rows_per_col * a.batch;
+    const uint64_t* pre_lo = a.pre_lo ? a.pre_lo + (uint64_t)coset * 4096 : nullptr;
+    const uint64_t* pre_hi = (a.pre_lo && a.pre_hi) ? a.pre_hi + (uint64_t)coset * 4096 : nullptr;
+
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t g = tid + i * NT;
+        const uint32_t lr = g >> LOG_T, e = g & ((1u << LOG_T) - 1);
+        const uint64_t row = row0 + lr;
+        uint64_t v = 0;
+        if (row < total_rows) {
+            const uint64_t col = row >> a.log_rows, rin = row & (rows_per_col - 1);
+            if constexpr (GL355_NTT_KO & 2) v = col * a.in_col_stride + (rin << LOG_T) + e;
+            else v = a.in[col * a.in_col_stride + (rin << LOG_T) + e];
+            if constexpr (!FAST) {
+                if (a.pre_full) v = gl_mul(v, a.pre_full[(uint64_t)coset * a.pre_full_stride + (rin << LOG_T) + e]);
+                else if (pre_lo) v = gl_mul(v, pow2lvl(pre_lo, pre_hi, (rin << LOG_T) + e));
+            }
+        }
+        const uint32_t le = (!FAST && a.in_bitrev) ? brev(e, LOG_T) : e;
+        lds[lds_phys((lr << LOG_T) | le)] = v;
+    }
+    __syncthreads();
+    dif_tile<LT, LOG_T, INV>(lds, a.tw, 0, tid, NT);
+    const uint64_t out_base = (uint64_t)a.coset_slot[coset] * a.coset_out_stride;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t g = tid + i * NT;
+        const uint32_t lr = g >> LOG_T, e = g & ((1u << LOG_T) - 1);
+        const uint64_t row = row0 + lr;
+        if (row < total_rows) {
+            const uint64_t col = row >> a.log_rows, rin = row & (rows_per_col - 1);
+            const uint32_t le = (!FAST && a.out_natural) ? brev(e, LOG_T) : e;
+            uint64_t v = lds[lds_phys((lr << LOG_T) | le)];
+            if constexpr (!FAST) {
+                if (a.post_lo) v = gl_mul(v, pow2lvl(a.post_lo, a.post_hi, (rin << LOG_T) + e));
+                if (a.scale != 1) v = gl_mul(v, a.scale);
+                if (a.canon) v = gl_canon(v);
+            } else v = gl_canon(v);
+            a.out[out_base + col * a.out_col_stride + (rin << LOG_T) + e] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Radix-8 kernels for the commit-path shapes (forward, natural order in, bit-reversed out, at most a full pre table): 8 elements
+// per thread and task.  One more LDS exchange than radix 16 (12 layers = 4 rounds instead of 3) and 7/8 instead of 15/16 twiddle
+// products per element and round -- but 64-72 VGPRs instead of 168, i.e. 6-8 waves per SIMD instead of 3 to cover tile load,
+// tile store and the barriers, fewer shift-twiddles per layer (5 per 8 elements and round instead of 17 per 16), and with that
+// many waves the 15-instruction inline-asm product (GL_MUL_VARIANT 1, ntt_r8.hip) pays: measured in tools/ubench/ubench_ntt_rows.hip
+// 1.25 -> 0.83 ms for the row pass and 0.75 -> 0.58 ms for the column pass of the 2^17 -> 2^20 x 135 LDE.
+// ------------------------------------------------------------------------------------------------
+template <int LT, int LOG_T, bool INV>
+GL_DEV void dif_tile_r8(uint64_t* lds, const uint64_t* __restrict__ tw, int LO, int tid, int nthreads) {
+    int m = LOG_T;
+#pragma unroll
+    for (int round = 0; round < LOG_T / 3; round++) {
+        dif_round<LT, 3, INV>(lds, tw, m, LO, tid, nthreads);
+        m -= 3;
+        __syncthreads();
+    }
+    constexpr int REM = LOG_T % 3;
+    if constexpr (REM == 2) dif_round<LT, 2, INV>(lds, tw, 2, LO, tid, nthreads);
+    if constexpr (REM == 1) dif_round<LT, 1, INV>(lds, tw, 1, LO, tid, nthreads);
+    if constexpr (REM != 0) __syncthreads();
+}
+// Row pass / single pass: one 2^LT-point row per tile; PRE = multiply by the full table a.pre_full (coset powers) at the load.
+// blockIdx = tile * n_cosets + coset like the radix-16 kernel (each XCD keeps one coset's table in its L2).
+template <int LT, bool PRE, int WPE>
+__global__ void __launch_bounds__(LT >= 13 ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_rows_r8_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    constexpr int NT = LT >= 13 ? 1024 : 512, EPT = (1 << LT) / NT;
+    const int tid = threadIdx.x;
+    const uint32_t coset = blockIdx.x % a.n_cosets;
+    const uint64_t row = blockIdx.x / a.n_cosets;           // global row id over (column, row in column)
+    const uint64_t col = row >> a.log_rows, rin = row & ((1ull << a.log_rows) - 1);
+    const uint64_t* in = a.in + col * a.in_col_stride + (rin << LT);
+    const uint64_t* pre = PRE ? a.pre_full + (uint64_t)coset * a.pre_full_stride + (rin << LT) : nullptr;
+    uint64_t* out = a.out + (uint64_t)a.coset_slot[coset] * a.coset_out_stride + col * a.out_col_stride + (rin << LT);
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const uint32_t g = tid + i * NT;
+        uint64_t v = (GL355_NTT_KO & 2) ? (uint64_t)g + row : in[g];
+        if constexpr (PRE) v = gl_mul(v, pre[g]);
+        lds[lds_phys(g)] = v;
+    }
+    __syncthreads();
+    dif_tile_r8<LT, LT, false>(lds, a.tw_r8, 0, tid, NT);
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const uint32_t g = tid + i * NT;
+        out[g] = gl_canon(lds[lds_phys(g)]);
+    }
+}
+
+// Column pass: transform over the row index of an [2^LOG_T][N2] matrix (N2 = 2^log_rows... here
+// a.log_rows holds log2(N2)); a tile is all 2^LOG_T rows x TC = 2^(12-LOG_T) adjacent columns.
+template <int LOG_T, bool INV, bool FAST = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) ntt_cols_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    constexpr int LT = 12, NT = 256;
+    constexpr int LOG_TC = LT - LOG_T, TC = 1 << LOG_TC;
+    const int tid = threadIdx.x;
+    const uint32_t log_n2 = a.log_rows;
+    const uint64_t n2 = 1ull << log_n2;
+    const uint32_t coset = blockIdx.x % a.n_cosets;
+    const uint64_t tile = blockIdx.x / a.n_cosets;
+    const uint64_t tiles_per_col = n2 >> LOG_TC;
+    const uint64_t col = tile / tiles_per_col;
+    const uint64_t c0 = (tile % tiles_per_col) << LOG_TC;  // first matrix column of the tile
+    const uint64_t* in = a.in + col * a.in_col_stride;
+    uint64_t* out = a.out + (uint64_t)a.coset_slot[coset] * a.coset_out_stride + col * a.out_col_stride;
+    const uint64_t* pre_lo = a.pre_lo ? a.pre_lo + (uint64_t)coset * 4096 : nullptr;
+    const uint64_t* pre_hi = (a.pre_lo && a.pre_hi) ? a.pre_hi + (uint64_t)coset * 4096 : nullptr;
+    const bool step_at_load = a.in_bitrev != 0;  // second pass of the bitrev -> natural flow
+
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t g = tid + i * NT;
+        const uint32_t r = g >> LOG_TC, cc = g & (TC - 1);
+        const uint64_t gi = ((uint64_t)r << log_n2) + c0 + cc;
+        uint64_t v = in[gi];
+        uint32_t lr = r;  // logical transform index
+        if constexpr (FAST) {
+            v = gl_mul(v, a.pre_full[(uint64_t)coset * a.pre_full_stride + gi]);
+        } else {
+            lr = a.in_bitrev ? brev(r, LOG_T) : r;
+            if (a.pre_full) v = gl_mul(v, a.pre_full[(uint64_t)coset * a.pre_full_stride + gi]);
+            else if (pre_lo) v = gl_mul(v, pow2lvl(pre_lo, pre_hi, gi));
+            if (step_at_load && a.step_lo) v = gl_mul(v, pow2lvl(a.step_lo, a.step_hi, (uint64_t)lr * (c0 + cc)));
+        }
+        lds[lds_phys((lr << LOG_TC) | cc)] = v;
+    }
+    __syncthreads();
+    dif_tile<LT, LOG_T, INV>(lds, a.tw, LOG_TC, tid, NT);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t g = tid + i * NT;
+        const uint32_t r = g >> LOG_TC, cc = g & (TC - 1);
+        const uint32_t lr = (!FAST && a.out_natural) ? brev(r, LOG_T) : r;  // LDS row holding output row r
+        uint64_t v = lds[lds_phys((lr << LOG_TC) | cc)];
+        const uint64_t go = ((uint64_t)r << log_n2) + c0 + cc;
+        if constexpr (FAST) {
+            v = gl_mul(v, a.step_full[go]);
+        } else {
+            if (!step_at_load && a.step_full) v = gl_mul(v, a.step_full[go]);
+            else if (!step_at_load && a.step_lo) {
+                const uint32_t k1 = a.out_natural ? r : brev(r, LOG_T);  // transform output index
+                v = gl_mul(v, pow2lvl(a.step_lo, a.step_hi, (uint64_t)k1 * (c0 + cc)));
+            }
+            if (a.post_lo) v = gl_mul(v, pow2lvl(a.post_lo, a.post_hi, go));
+            if (a.scale != 1) v = gl_mul(v, a.scale);
+            if (a.canon) v = gl_canon(v);
+        }
+        out[go] = v;
+    }
+}
+
+// Column pass of the commit path (full step table, PRE = full pre table, nothing else) with radix-8 rounds: 8 elements per thread, 512 threads per tile.
+template <int LOG_T, bool PRE, int WPE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_cols_r8_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    constexpr int LT = 12, NT = 512;
+    constexpr int LOG_TC = LT - LOG_T, TC = 1 << LOG_TC;
+    const int tid = threadIdx.x;
+    const uint32_t log_n2 = a.log_rows;
+    const uint64_t n2 = 1ull << log_n2;
+    const uint32_t coset = blockIdx.x % a.n_cosets;
+    const uint64_t tile = blockIdx.x / a.n_cosets;
+    const uint64_t tiles_per_col = n2 >> LOG_TC;
+    const uint64_t col = tile / tiles_per_col;
+    const uint64_t c0 = (tile % tiles_per_col) << LOG_TC;
+    const uint64_t* in = a.in + col * a.in_col_stride;
+    const uint64_t* pre = PRE ? a.pre_full + (uint64_t)coset * a.pre_full_stride : nullptr;
+    uint64_t* out = a.out + (uint64_t)a.coset_slot[coset] * a.coset_out_stride + col * a.out_col_stride;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t g = tid + i * NT;
+        const uint32_t r = g >> LOG_TC, cc = g & (TC - 1);
+        const uint64_t gi = ((uint64_t)r << log_n2) + c0 + cc;
+        uint64_t v = (GL355_NTT_KO & 2) ? gi : in[gi];
+        if constexpr (PRE && !(GL355_NTT_KO & 32)) v = gl_mul(v, (GL355_NTT_KO & 16) ? gi + 3 : pre[gi]);
+        lds[lds_phys(g)] = v;
+    }
+    __syncthreads();
+    dif_tile_r8<LT, LOG_T, false>(lds, a.tw_r8, LOG_TC, tid, NT);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t g = tid + i * NT;
+        const uint32_t r = g >> LOG_TC, cc = g & (TC - 1);
+        const uint64_t go = ((uint64_t)r << log_n2) + c0 + cc;
+        uint64_t v = lds[lds_phys(g)];
+        if constexpr (!(GL355_NTT_KO & 32)) v = gl_mul(v, (GL355_NTT_KO & 16) ? go + 5 : a.step_full[go]);
+        out[go] = v;
+    }
+}
+
+}  // namespace gl355

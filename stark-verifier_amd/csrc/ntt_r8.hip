@@ -1,0 +1,59 @@
+// The radix-8 pass kernels of the commit path (csrc/ntt_kernels.cuh), compiled with the 15-instruction inline-asm field product:
+// at 6-8 waves per SIMD its hazard wait states are hidden and the shorter instruction stream wins (ntt.hip keeps the
+// compiler-scheduled product for the radix-16 kernels, which run at 3 waves per SIMD).  a2 / a3 of SURVEY.md 8; reference call
+// sites as in ntt.hip (plonky2 fft_with_options / coset_fft_with_options inside CircuitData::prove, access_set.rs:94).
+#define GL_MUL_VARIANT 1
+#include "gl355_internal.h"
+#include "ntt_kernels.cuh"
+
+namespace gl355 {
+
+template <int LT>
+static hipError_t launch_rows8_lt(const PassArgs& a, uint64_t blocks, hipStream_t s) {
+    constexpr int NT = LT >= 13 ? 1024 : 512;
+    // 4096-point tiles: three 512-thread blocks per CU; 8192-point tiles: two 1024-thread blocks per CU need <= 64 VGPRs (0.65 -> 0.53 ms
+    // for 8 units' 2^13 -> 2^16 LDEs, a couple of spilled dwords included); a 16384-point tile has the CU to itself
+    constexpr int WPE = LT == 12 ? 6 : (LT == 13 ? 8 : 4);
+    const size_t shmem = ((1u << LT) + (1u << (LT - 4))) * sizeof(uint64_t);
+    if (a.pre_full) {
+        auto k = ntt_rows_r8_kernel<LT, true, WPE>;
+        if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
+    } else {
+        auto k = ntt_rows_r8_kernel<LT, false, WPE>;
+        if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
+    }
+    return hipGetLastError();
+}
+
+// rows of 2^log_t points (log_t = 12, 13, 14), a.batch << a.log_rows of them, times a.n_cosets
+hipError_t launch_rows_r8(const PassArgs& a, uint32_t log_t, hipStream_t s) {
+    const uint64_t blocks = (((uint64_t)a.batch) << a.log_rows) * a.n_cosets;
+    switch (log_t) {
+        case 12: return launch_rows8_lt<12>(a, blocks, s);
+        case 13: return launch_rows8_lt<13>(a, blocks, s);
+        case 14: return launch_rows8_lt<14>(a, blocks, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_cols_r8(const PassArgs& a, uint32_t log_t, hipStream_t s) {
+    const uint64_t n2 = 1ull << a.log_rows;
+    const uint64_t tc = 1ull << (12 - log_t);
+    const uint64_t blocks = (n2 / tc) * a.batch * a.n_cosets;
+    const size_t shmem = (4096 + 256) * sizeof(uint64_t);
+    switch (log_t) {
+#define GL355_COL8_CASE(L) case L:                                                                                            \
+        if (a.pre_full) hipLaunchKernelGGL((ntt_cols_r8_kernel<L, true, 4>), dim3((uint32_t)blocks), dim3(512), shmem, s, a);  \
+        else hipLaunchKernelGGL((ntt_cols_r8_kernel<L, false, 4>), dim3((uint32_t)blocks), dim3(512), shmem, s, a);            \
+        break;
+        GL355_COL8_CASE(1) GL355_COL8_CASE(2) GL355_COL8_CASE(3) GL355_COL8_CASE(4) GL355_COL8_CASE(5) GL355_COL8_CASE(6)
+        GL355_COL8_CASE(7) GL355_COL8_CASE(8) GL355_COL8_CASE(9) GL355_COL8_CASE(10) GL355_COL8_CASE(11) GL355_COL8_CASE(12)
+#undef GL355_COL8_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gl355
