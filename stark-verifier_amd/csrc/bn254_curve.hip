@@ -16,11 +16,15 @@
 // structure for the hardware (integer VALU bound like everything else here), not yet a tuned one: no signed digits, no batched
 // affine additions, FFT stages one global pass each.
 #include "gl355_internal.h"
+#include <vector>
 
 #define BN254C_QUAL __device__ __constant__ const
 #include "bn254_curve_tables.h"
 
 namespace gl355 {
+
+// host_bn254_curve.cpp: sum_w 2^(c w) (S_w + Wt_w) as an affine point (canonical integers; zeros = the identity)
+void bn254_g1_horner_host(const uint32_t* s, const uint32_t* wt, uint32_t n_windows, uint32_t c, uint64_t result[8]);
 
 struct u256 { uint32_t l[8]; };
 enum { F_R = 0, F_Q = 1 };
@@ -284,17 +288,19 @@ struct MsmArgs {
     const uint64_t* points;     // [n][8] affine x | y, canonical integers; (0, 0) = identity
     const uint64_t* scalars;    // [n][4]
     uint64_t n;
-    uint32_t c, n_windows;      // window bits, windows
+    uint32_t c, n_windows;      // window bits, windows (signed digits: |digit| <= 2^(c-1), one more window takes the last carry)
+    uint32_t cb;                // c - 1: a window has 2^cb buckets, bucket j collects the points whose digit is +-(j + 1)
     uint32_t* pm;               // [n][16] points in Montgomery form
-    uint32_t* hist;             // [W][2^c]      counts, then exclusive offsets
-    uint32_t* cursor;           // [W][2^c]      scatter cursors
-    uint32_t* idx;              // [W][n]        point indices sorted by digit
-    uint32_t* buckets;          // [W][2^c][24]  Jacobian bucket sums
-    uint32_t* partial;          // [W][chunks][24]
-    uint32_t* wsum;             // [W][24]
-    uint32_t chunk;             // buckets per lane in the window reduction
+    uint32_t* hist;             // [W][2^cb]     counts, then exclusive offsets
+    uint32_t* cursor;           // [W][2^cb]     scatter cursors
+    uint32_t* idx;              // [W][n]        point indices sorted by bucket, bit 31 = the digit is negative
+    uint32_t* buckets;          // [W][2^cb][24] Jacobian bucket sums
+    uint32_t* order;            // [W * 2^cb]    bucket ids (w << cb | j) by decreasing size
+    uint32_t* size_hist;        // [MSM_SIZE_BINS] buckets per size, then the write cursor of each size class
+    uint32_t* wsum;             // [W][24]       window sums
     uint64_t* result;           // [8]
 };
+#define MSM_SIZE_BINS 128
 GL_DEV uint32_t msm_digit(const uint64_t* k, uint32_t w, uint32_t c) {
     const uint32_t bit = w * c;
     if (bit >= 256) return 0;
@@ -302,6 +308,14 @@ GL_DEV uint32_t msm_digit(const uint64_t* k, uint32_t w, uint32_t c) {
     uint64_t v = k[limb] >> off;
     if (off + c > 64 && limb + 1 < 4) v |= k[limb + 1] << (64 - off);
     return (uint32_t)(v & ((1ull << c) - 1));
+}
+// signed digit of window w given the carry out of the windows below: magnitude (0 = nothing to add) and sign; raw digits of
+// 2^(c-1) and more become negative and carry one into the next window, which halves the buckets of a window
+GL_DEV uint32_t msm_signed_digit(const uint64_t* k, uint32_t w, uint32_t c, uint32_t& carry, bool& neg) {
+    const uint32_t raw = msm_digit(k, w, c) + carry;
+    neg = raw >= (1u << (c - 1));
+    carry = neg ? 1u : 0u;
+    return neg ? (1u << c) - raw : raw;
 }
 __global__ void msm_prepare_kernel(MsmArgs a) {          // points to Montgomery form + digit histograms
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -314,17 +328,19 @@ __global__ void msm_prepare_kernel(MsmArgs a) {          // points to Montgomery
     for (int j = 0; j < 8; j++) { d[j] = xm.l[j]; d[8 + j] = ym.l[j]; }
     if (ident) return;
     const uint64_t* k = a.scalars + 4 * i;
+    uint32_t carry = 0;
     for (uint32_t w = 0; w < a.n_windows; w++) {
-        const uint32_t dg = msm_digit(k, w, a.c);
-        if (dg) atomicAdd(a.hist + ((uint64_t)w << a.c) + dg, 1u);
+        bool neg;
+        const uint32_t mag = msm_signed_digit(k, w, a.c, carry, neg);
+        if (mag) atomicAdd(a.hist + ((uint64_t)w << a.cb) + (mag - 1), 1u);
     }
 }
-// per window: exclusive scan of the 2^c counts (one workgroup), offsets copied to the cursors
+// per window: exclusive scan of the 2^cb counts (one workgroup), offsets copied to the cursors
 __global__ void __launch_bounds__(1024) msm_scan_kernel(MsmArgs a) {
     __shared__ uint32_t sh[1024];
-    const uint32_t w = blockIdx.x, nb = 1u << a.c, tid = threadIdx.x;
-    uint32_t* h = a.hist + ((uint64_t)w << a.c);
-    uint32_t* cur = a.cursor + ((uint64_t)w << a.c);
+    const uint32_t w = blockIdx.x, nb = 1u << a.cb, tid = threadIdx.x;
+    uint32_t* h = a.hist + ((uint64_t)w << a.cb);
+    uint32_t* cur = a.cursor + ((uint64_t)w << a.cb);
     const uint32_t per = (nb + 1023) / 1024, lo = tid * per, hi = min(nb, lo + per);
     uint32_t s = 0;
     for (uint32_t b = lo; b < hi; b++) s += h[b];
@@ -352,82 +368,168 @@ __global__ void msm_scatter_kernel(MsmArgs a) {
     for (int j = 0; j < 16; j++) o |= d[j];
     if (!o) return;                                       // the identity contributes nothing
     const uint64_t* k = a.scalars + 4 * i;
+    uint32_t carry = 0;
     for (uint32_t w = 0; w < a.n_windows; w++) {
-        const uint32_t dg = msm_digit(k, w, a.c);
-        if (!dg) continue;
-        const uint32_t pos = atomicAdd(a.cursor + ((uint64_t)w << a.c) + dg, 1u);
-        a.idx[(uint64_t)w * a.n + pos] = (uint32_t)i;
+        bool neg;
+        const uint32_t mag = msm_signed_digit(k, w, a.c, carry, neg);
+        if (!mag) continue;
+        const uint32_t pos = atomicAdd(a.cursor + ((uint64_t)w << a.cb) + (mag - 1), 1u);
+        a.idx[(uint64_t)w * a.n + pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
     }
 }
-// one lane per (window, bucket): sum of the bucket's points
-__global__ void __launch_bounds__(128) msm_bucket_kernel(MsmArgs a) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
-    if (b >= (1u << a.c)) return;
-    jac acc = j_identity();
-    if (b) {
-        const uint32_t lo = a.hist[((uint64_t)w << a.c) + b], hi = a.cursor[((uint64_t)w << a.c) + b];   // cursor = end after the scatter
-        for (uint32_t k = lo; k < hi; k++) {
-            const uint32_t* p = a.pm + 16ull * a.idx[(uint64_t)w * a.n + k];
-            u256 x, y;
-#pragma unroll
-            for (int j = 0; j < 8; j++) { x.l[j] = p[j]; y.l[j] = p[8 + j]; }
-            acc = j_madd(acc, x, y);
-        }
-    }
-    j_store(a.buckets + (((uint64_t)w << a.c) + b) * 24, acc);
+// Buckets by decreasing size.  A lane sums one bucket, so a wave takes as long as its largest bucket: with 2^20 points in 2^16
+// buckets per window the sizes are Poisson(16) and the largest of 64 is ~27 -- 40 % of the lanes' time idle.  Sizes are small
+// integers, so a counting sort (per-workgroup LDS histogram, one global atomic per class and workgroup) puts equal sizes side by side.
+GL_DEV uint32_t msm_bucket_size(const MsmArgs& a, uint32_t id) {
+    const uint32_t sz = a.cursor[id] - a.hist[id];                 // cursor = end of the bucket's range after the scatter
+    return sz < MSM_SIZE_BINS ? sz : MSM_SIZE_BINS - 1;
 }
-// window sum  sum_b b * B_b : lane t takes buckets [t * chunk, (t + 1) * chunk) from the top down with a running sum R and an
-// accumulator A (A = sum (b - lo + 1) B_b), adds (lo - 1) * R by double-and-add; lane 0 of the window then adds the partials
-__global__ void __launch_bounds__(256) msm_window_kernel(MsmArgs a) {
-    const uint32_t w = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nb = 1u << a.c, n_chunks = (nb + a.chunk - 1) / a.chunk;
-    if (t >= n_chunks) return;
-    const uint32_t lo = t * a.chunk, hi = min(nb, lo + a.chunk);
-    jac run = j_identity(), acc = j_identity();
-    for (uint32_t b = hi; b-- > lo;) {
-        run = j_add(run, j_load(a.buckets + (((uint64_t)w << a.c) + b) * 24));
-        acc = j_add(acc, run);
-    }
-    // acc = sum_{b in chunk} (b - lo + 1) B_b  ->  + (lo - 1) * run   (lo = 0: acc counts bucket 0, the identity, once: harmless;
-    // and (0 - 1) * run must then be SUBTRACTED: handle lo = 0 by removing `run` once instead)
-    if (lo == 0) {
-        jac neg = run;
-        neg.y = m_sub<F_Q>(u_zero(), run.y);
-        acc = j_add(acc, neg);
-    } else {
-        jac add = j_identity();
-        const uint32_t k = lo - 1;
-        for (int bit = 31; bit >= 0; bit--) {
-            add = j_double(add);
-            if ((k >> bit) & 1) add = j_add(add, run);
-        }
-        acc = j_add(acc, add);
-    }
-    j_store(a.partial + ((uint64_t)w * n_chunks + t) * 24, acc);
+__global__ void __launch_bounds__(256) msm_size_hist_kernel(MsmArgs a) {
+    __shared__ uint32_t h[MSM_SIZE_BINS];
+    if (threadIdx.x < MSM_SIZE_BINS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x, total = a.n_windows << a.cb;
+    if (id < total) atomicAdd(&h[msm_bucket_size(a, id)], 1u);
+    __syncthreads();
+    if (threadIdx.x < MSM_SIZE_BINS && h[threadIdx.x]) atomicAdd(a.size_hist + threadIdx.x, h[threadIdx.x]);
 }
-__global__ void msm_window_sum_kernel(MsmArgs a) {
-    const uint32_t w = blockIdx.x;
-    if (threadIdx.x) return;
-    const uint32_t nb = 1u << a.c, n_chunks = (nb + a.chunk - 1) / a.chunk;
-    jac s = j_identity();
-    for (uint32_t t = 0; t < n_chunks; t++) s = j_add(s, j_load(a.partial + ((uint64_t)w * n_chunks + t) * 24));
-    j_store(a.wsum + (uint64_t)w * 24, s);
-}
-// result = sum_w 2^(c w) W_w (Horner from the top window), to affine, out of Montgomery form
-__global__ void msm_final_kernel(MsmArgs a) {
+__global__ void msm_size_scan_kernel(MsmArgs a) {                   // counts -> start of each size class, largest size first
     if (threadIdx.x || blockIdx.x) return;
-    jac r = j_identity();
-    for (uint32_t w = a.n_windows; w-- > 0;) {
-        for (uint32_t k = 0; k < a.c; k++) r = j_double(r);
-        r = j_add(r, j_load(a.wsum + (uint64_t)w * 24));
+    uint32_t run = 0;
+    for (int sz = MSM_SIZE_BINS - 1; sz >= 0; sz--) { const uint32_t cnt = a.size_hist[sz]; a.size_hist[sz] = run; run += cnt; }
+}
+__global__ void __launch_bounds__(256) msm_order_kernel(MsmArgs a) {
+    __shared__ uint32_t h[MSM_SIZE_BINS], base[MSM_SIZE_BINS];
+    if (threadIdx.x < MSM_SIZE_BINS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x, total = a.n_windows << a.cb;
+    uint32_t sz = 0, slot = 0;
+    if (id < total) { sz = msm_bucket_size(a, id); slot = atomicAdd(&h[sz], 1u); }
+    __syncthreads();
+    if (threadIdx.x < MSM_SIZE_BINS && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(a.size_hist + threadIdx.x, h[threadIdx.x]);
+    __syncthreads();
+    if (id < total) a.order[base[sz] + slot] = id;
+}
+// one lane per (window, bucket), taken in the order above: sum of the bucket's points
+__global__ void __launch_bounds__(256) msm_bucket_kernel(MsmArgs a) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (a.n_windows << a.cb)) return;
+    const uint32_t id = a.order[g], w = id >> a.cb;
+    jac acc = j_identity();
+    const uint32_t lo = a.hist[id], hi = a.cursor[id];
+    for (uint32_t k = lo; k < hi; k++) {
+        const uint32_t e = a.idx[(uint64_t)w * a.n + k];
+        const uint32_t* p = a.pm + 16ull * (e & 0x7fffffffu);
+        u256 x, y;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { x.l[j] = p[j]; y.l[j] = p[8 + j]; }
+        if (e >> 31) y = m_sub<F_Q>(u_zero(), y);                 // negative digit: subtract the point
+        acc = j_madd(acc, x, y);
     }
-    if (j_is_identity(r)) {
-        for (int i = 0; i < 8; i++) a.result[i] = 0;
+    j_store(a.buckets + (uint64_t)id * 24, acc);
+}
+
+// Window sum  sum_j (j + 1) * B_j = Wt + S  by a recursion on pairs (S, Wt) = (sum of the items, sum of local index * item) over groups of 2^kbits
+// items: a group of buckets gives S = sum B_b and Wt = sum (b - b0) B_b by the running-sum trick (S_run += B_b from the top,
+// L += S_run); a group of pairs at the next level gives  S' = sum S_u,  Wt' = sum Wt_u + width * sum (u - u0) S_u  with
+// width = the number of buckets one item spans (a power of two: `shift` doublings).  Every level is one launch of (windows x groups)
+// lanes whose dependent chain is ~3 * 2^kbits additions; the single-lane tails of the first version (256 + 48 and then 256 dependent
+// additions per window: 19 of 34 ms at 2^20 points) are gone.  The last level's single group gives the window sum Wt + S.
+struct MsmLevel {
+    const uint32_t* in_s;       // [W][t_in][24]
+    const uint32_t* in_w;       // [W][t_in][24] or null (level 0: the items are the buckets themselves)
+    uint32_t* out_s;            // [W][t_in >> kbits][24]
+    uint32_t* out_w;
+    uint32_t t_in, kbits, shift, n_windows;
+};
+__global__ void __launch_bounds__(64) msm_level_kernel(MsmLevel l) {
+    const uint32_t groups = l.t_in >> l.kbits;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups * l.n_windows) return;
+    const uint32_t w = g / groups, v = g % groups, k = 1u << l.kbits;
+    const uint32_t* s_in = l.in_s + ((uint64_t)w * l.t_in + (uint64_t)v * k) * 24;
+    jac run = j_identity(), acc = j_identity();
+    for (uint32_t u = k; u-- > 0;) {
+        run = j_add(run, j_load(s_in + u * 24));
+        if (u) acc = j_add(acc, run);                             // acc = sum_u u * S_u: item u is counted in the u sums taken at u' = u .. 1
+    }
+    for (uint32_t d = 0; d < l.shift; d++) acc = j_double(acc);
+    if (l.in_w) {
+        const uint32_t* w_in = l.in_w + ((uint64_t)w * l.t_in + (uint64_t)v * k) * 24;
+        for (uint32_t u = 0; u < k; u++) acc = j_add(acc, j_load(w_in + u * 24));
+    }
+    j_store(l.out_s + ((uint64_t)w * groups + v) * 24, run);
+    j_store(l.out_w + ((uint64_t)w * groups + v) * 24, acc);
+}
+
+// ================================================================ fixed-base batch multiplication ===================
+// out[i] = scalars[i] * base for one base point: what ParamsKZG::setup does for the powers of tau ([s^i] G, verifier_api.rs:77).
+// 8-bit windows over a table T[w][d] = d * 2^(8 w) * base (32 x 256 affine points, built per call): one mixed addition per non-zero
+// byte of the scalar and one inversion per output -- no doublings in the main loop.
+struct FbArgs {
+    const uint64_t* base;       // [8] affine, canonical integers
+    const uint64_t* scalars;    // [n][4]
+    uint64_t n;
+    uint32_t* win;              // [32][24]       2^(8 w) * base, Jacobian
+    uint32_t* table;            // [32][256][16]  affine Montgomery x | y; d = 0 unused
+    uint64_t* out;              // [n][8]
+};
+GL_DEV void j_to_affine_mont(const jac& p, u256& x, u256& y) {           // p not the identity
+    const u256 zi = m_inv<F_Q>(p.z), zi2 = m_mul<F_Q>(zi, zi);
+    x = m_mul<F_Q>(p.x, zi2);
+    y = m_mul<F_Q>(p.y, m_mul<F_Q>(zi2, zi));
+}
+__global__ void fb_windows_kernel(FbArgs a) {                            // lane w: 8 w doublings of the base
+    const uint32_t w = threadIdx.x;
+    if (w >= 32) return;
+    const u256 x = load256(a.base), y = load256(a.base + 4);
+    jac p;
+    if (u_is_zero(x) && u_is_zero(y)) p = j_identity();
+    else { p.x = m_from_int<F_Q>(x); p.y = m_from_int<F_Q>(y); p.z = u_const(BN254C_FQ_ONE); }
+    for (uint32_t k = 0; k < 8 * w; k++) p = j_double(p);
+    j_store(a.win + 24 * w, p);
+}
+__global__ void __launch_bounds__(256) fb_table_kernel(FbArgs a) {       // lane (w, d): d * B_w by double-and-add, to affine
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 32 * 256) return;
+    const uint32_t d = g & 255;
+    const jac b = j_load(a.win + 24 * (g >> 8));
+    jac acc = j_identity();
+    for (int bit = 7; bit >= 0; bit--) {
+        acc = j_double(acc);
+        if ((d >> bit) & 1) acc = j_add(acc, b);
+    }
+    u256 x = u_zero(), y = u_zero();
+    if (!j_is_identity(acc)) j_to_affine_mont(acc, x, y);
+    uint32_t* t = a.table + 16ull * g;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { t[j] = x.l[j]; t[8 + j] = y.l[j]; }
+}
+__global__ void __launch_bounds__(256) fb_mul_kernel(FbArgs a) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const uint64_t* k = a.scalars + 4 * i;
+    jac acc = j_identity();
+    for (uint32_t w = 0; w < 32; w++) {
+        const uint32_t d = (uint32_t)(k[w >> 3] >> (8 * (w & 7))) & 255u;
+        if (!d) continue;
+        const uint32_t* t = a.table + 16ull * (w * 256 + d);
+        u256 x, y;
+        uint32_t o = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { x.l[j] = t[j]; y.l[j] = t[8 + j]; o |= t[j] | t[8 + j]; }
+        if (o) acc = j_madd(acc, x, y);                                // a zero entry: d * B_w is the identity (base of small order)
+    }
+    uint64_t* dst = a.out + 8 * i;
+    if (j_is_identity(acc)) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) dst[j] = 0;
         return;
     }
-    const u256 zi = m_inv<F_Q>(r.z), zi2 = m_mul<F_Q>(zi, zi);
-    store256(a.result, m_to_int<F_Q>(m_mul<F_Q>(r.x, zi2)));
-    store256(a.result + 4, m_to_int<F_Q>(m_mul<F_Q>(r.y, m_mul<F_Q>(zi2, zi))));
+    u256 x, y;
+    j_to_affine_mont(acc, x, y);
+    store256(dst, m_to_int<F_Q>(x));
+    store256(dst + 4, m_to_int<F_Q>(y));
 }
 
 }  // namespace gl355
@@ -518,51 +620,107 @@ int32_t gl355_bn254_g1_msm(gl355_ctx* h, const uint64_t* points, const uint64_t*
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
     if (!result || ((!points || !scalars) && n)) return ctx->fail(GL355_E_INVALID_ARG, "bn254_g1_msm: null argument");
     if (n > (1ull << 26)) return ctx->fail(GL355_E_UNSUPPORTED, "bn254_g1_msm: more than 2^26 points");
-    if (n == 0) { memset(result, 0, 64); return GL355_OK; }
+    const bool dev_result = ptr_is_device(result);
+    if (n == 0) {
+        if (dev_result) { GL355_HIP(ctx, hipMemsetAsync(result, 0, 64, ctx->stream)); GL355_HIP(ctx, ctx->wait()); }
+        else memset(result, 0, 64);
+        return GL355_OK;
+    }
     uint32_t lg = 0;
     while ((1ull << lg) < n) lg++;
     MsmArgs a;
     memset(&a, 0, sizeof a);
     a.n = n;
-    a.c = lg <= 6 ? 4 : (lg - 2 > 16 ? 16 : lg - 2);             // window bits: ~4 points per bucket, at most 2^16 buckets
-    a.n_windows = (256 + a.c - 1) / a.c;
-    const uint64_t nb = 1ull << a.c;
-    a.chunk = nb >= 4096 ? (uint32_t)(nb / 256) : 16;           // up to 256 lanes per window in the reduction
-    const uint32_t n_chunks = (uint32_t)((nb + a.chunk - 1) / a.chunk);
+    a.c = lg <= 6 ? 4 : (lg - 2 > 16 ? 16 : lg - 2);             // window bits: ~8 points per bucket, at most 2^15 buckets per window
+    a.cb = a.c - 1;
+    a.n_windows = 256 / a.c + 1;                                 // signed digits: the carry out of bit 255 needs a window of its own
+    const uint64_t nb = 1ull << a.cb, W = a.n_windows;
     Staged sp(ctx), ss(ctx);
     GL355_TRY(sp.open(points, n * 64, 1));
     GL355_TRY(ss.open(scalars, n * 32, 1));
     a.points = sp.as<uint64_t>(); a.scalars = ss.as<uint64_t>();
+    // reduction levels: groups of 8 items, the last level takes what is left
+    struct Lv { uint32_t t_in, kbits, shift; };
+    std::vector<Lv> levels;
+    uint64_t lvl_words = 0;
+    for (uint32_t t = (uint32_t)nb, shift = 0; t > 1;) {
+        uint32_t kb = 3;
+        while ((1u << kb) > t) kb--;
+        levels.push_back({t, kb, shift});
+        t >>= kb; shift += kb;
+        lvl_words += 2ull * W * t * 24;
+    }
     Scratch buf(ctx);
-    const uint64_t W = a.n_windows;
-    const uint64_t words32 = n * 16 + 2 * W * nb + W * n + W * nb * 24 + W * n_chunks * 24 + W * 24 + 16;
+    const uint64_t words32 = n * 16 + 3 * W * nb + W * n + W * nb * 24 + MSM_SIZE_BINS + lvl_words + 64;
     GL355_TRY(buf.get(words32 * 4 + 64));
     uint32_t* p = buf.as<uint32_t>();
     a.pm = p; p += n * 16;
     a.hist = p; p += W * nb;
+    a.size_hist = p; p += MSM_SIZE_BINS;                          // cleared together with the histograms
     a.cursor = p; p += W * nb;
+    a.order = p; p += W * nb;
     a.idx = p; p += W * n;
     a.buckets = p; p += W * nb * 24;
-    a.partial = p; p += W * n_chunks * 24;
-    a.wsum = p; p += W * 24;
-    a.result = reinterpret_cast<uint64_t*>(p);
-    GL355_HIP(ctx, hipMemsetAsync(a.hist, 0, W * nb * 4, ctx->stream));
-    const uint32_t blk = (uint32_t)((n + 255) / 256);
+    uint32_t* lvl = p;
+    GL355_HIP(ctx, hipMemsetAsync(a.hist, 0, (W * nb + MSM_SIZE_BINS) * 4, ctx->stream));
+    const uint32_t blk = (uint32_t)((n + 255) / 256), bblk = (uint32_t)((W * nb + 255) / 256);
+    const uint32_t *fin_s = a.buckets, *fin_w = nullptr;
     {
         ProfScope ps(ctx, "bn254_g1_msm", n * 96);
         hipLaunchKernelGGL(msm_prepare_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(msm_scan_kernel, dim3((uint32_t)W), dim3(1024), 0, ctx->stream, a);
         hipLaunchKernelGGL(msm_scatter_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_bucket_kernel, dim3((uint32_t)((nb + 127) / 128), (uint32_t)W), dim3(128), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_window_kernel, dim3((n_chunks + 255) / 256, (uint32_t)W), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_window_sum_kernel, dim3((uint32_t)W), dim3(64), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(msm_size_hist_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(msm_order_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
+        for (const Lv& lv : levels) {
+            MsmLevel l;
+            l.in_s = fin_s; l.in_w = fin_w; l.t_in = lv.t_in; l.kbits = lv.kbits; l.shift = lv.shift; l.n_windows = (uint32_t)W;
+            const uint64_t groups = lv.t_in >> lv.kbits;
+            l.out_s = lvl; lvl += W * groups * 24;
+            l.out_w = lvl; lvl += W * groups * 24;
+            hipLaunchKernelGGL(msm_level_kernel, dim3((uint32_t)((W * groups + 63) / 64)), dim3(64), 0, ctx->stream, l);
+            fin_s = l.out_s; fin_w = l.out_w;
+        }
         GL355_HIP(ctx, hipGetLastError());
     }
-    if (ptr_is_device(result)) GL355_HIP(ctx, hipMemcpyAsync(result, a.result, 64, hipMemcpyDeviceToDevice, ctx->stream));
-    else GL355_HIP(ctx, ctx->d2h(result, a.result, 64));
+    // per window S (and Wt when there was at least one level): 2 x W Jacobian points to the host, which combines the windows
+    std::vector<uint32_t> hs(W * 24), hw(W * 24, 0);
+    GL355_HIP(ctx, ctx->d2h(hs.data(), fin_s, W * 96));
+    if (fin_w) GL355_HIP(ctx, ctx->d2h(hw.data(), fin_w, W * 96));
     GL355_HIP(ctx, ctx->wait());
+    uint64_t res[8];
+    bn254_g1_horner_host(hs.data(), fin_w ? hw.data() : nullptr, (uint32_t)W, a.c, res);
+    if (dev_result) { GL355_HIP(ctx, hipMemcpyAsync(result, res, 64, hipMemcpyHostToDevice, ctx->stream)); GL355_HIP(ctx, ctx->wait()); }
+    else memcpy(result, res, 64);
     return GL355_OK;
+}
+
+int32_t gl355_bn254_g1_fixed_base_mul(gl355_ctx* h, const uint64_t base[8], const uint64_t* scalars, uint64_t n, uint64_t* out) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+    if (!base || ((!scalars || !out) && n)) return ctx->fail(GL355_E_INVALID_ARG, "bn254_g1_fixed_base_mul: null argument");
+    if (n > (1ull << 26)) return ctx->fail(GL355_E_UNSUPPORTED, "bn254_g1_fixed_base_mul: more than 2^26 scalars");
+    if (n == 0) return GL355_OK;
+    Staged sb(ctx), ss(ctx), so(ctx);
+    GL355_TRY(sb.open(base, 64, 1));
+    GL355_TRY(ss.open(scalars, n * 32, 1));
+    GL355_TRY(so.open(out, n * 64, 2));
+    Scratch buf(ctx);
+    GL355_TRY(buf.get((32 * 24 + 32 * 256 * 16) * 4 + 64));
+    FbArgs a;
+    a.base = sb.as<uint64_t>(); a.scalars = ss.as<uint64_t>(); a.n = n; a.out = so.as<uint64_t>();
+    a.win = buf.as<uint32_t>(); a.table = a.win + 32 * 24;
+    {
+        ProfScope ps(ctx, "bn254_g1_fixed_base_mul", n * 96);
+        hipLaunchKernelGGL(fb_windows_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(fb_table_kernel, dim3(32), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(fb_mul_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+        GL355_HIP(ctx, hipGetLastError());
+    }
+    return so.finish();
 }
 
 }  // extern "C"

@@ -11,9 +11,9 @@ namespace gl355 {
 template <int LT>
 static hipError_t launch_rows8_lt(const PassArgs& a, uint64_t blocks, hipStream_t s) {
     constexpr int NT = LT >= 13 ? 1024 : 512;
-    // 4096-point tiles: three 512-thread blocks per CU; 8192-point tiles: two 1024-thread blocks per CU need <= 64 VGPRs (0.65 -> 0.53 ms
+    // 8192-point tiles: two 1024-thread blocks per CU need <= 64 VGPRs (0.65 -> 0.53 ms
     // for 8 units' 2^13 -> 2^16 LDEs, a couple of spilled dwords included); a 16384-point tile has the CU to itself
-    constexpr int WPE = LT == 12 ? 6 : (LT == 13 ? 8 : 4);
+    constexpr int WPE = LT <= 13 ? 8 : 4;                     // 4096-point tiles: four 512-thread blocks per CU (0.79 -> 0.76 ms against three at 68 VGPRs)
     const size_t shmem = ((1u << LT) + (1u << (LT - 4))) * sizeof(uint64_t);
     if (a.pre_full) {
         auto k = ntt_rows_r8_kernel<LT, true, WPE>;

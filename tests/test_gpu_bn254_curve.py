@@ -103,3 +103,50 @@ def test_g1_msm_2p20_known_multiples(ctx, orc):
         vals += sc[:, limb].astype(object) << (64 * limb)
     k = int(sum(int(v) * (7 * (i + 1)) for i, v in enumerate(vals)) % pm.R)
     assert cv._unpt(gpu_msm(ctx, pts, sc)) == cv.mul(pm.G, k)
+
+
+def gpu_fixed_base(ctx, base, sc):
+    base, sc = np.ascontiguousarray(base, dtype=np.uint64), np.ascontiguousarray(sc, dtype=np.uint64)
+    out = np.full((sc.shape[0], 8), 0xAA, dtype=np.uint64)
+    ctx.check(ctx.lib.gl355_bn254_g1_fixed_base_mul(ctx.h, base.ctypes.data, sc.ctypes.data, sc.shape[0], out.ctypes.data))
+    return out
+
+
+def test_g1_fixed_base_mul_vs_oracle(ctx, orc):
+    """out[i] = scalars[i] * base (the powers-of-tau loop of ParamsKZG::setup) against the oracle's double-and-add, edge scalars included"""
+    cv = Bn254Curve(orc)
+    rng = np.random.default_rng(0x4E4)
+    for base in (pm.G, cv.mul(pm.G, 0xC0FFEE1234567)):
+        vals = [0, 1, 2, 255, 256, pm.R - 1, pm.R, pm.R + 1, (1 << 256) - 1, 1 << 248, 0xFF << 120]
+        sc = np.concatenate([cv.scalars(vals), rand_scalars(rng, 200, below_r=False)])
+        out = gpu_fixed_base(ctx, cv._pt(base), sc)
+        ints = cv.ints(sc)
+        for i in list(range(len(vals))) + [len(vals) + 3, len(vals) + 77, len(sc) - 1]:
+            assert cv._unpt(out[i]) == cv.mul(base, ints[i] % pm.R), i
+        assert cv._unpt(out[2]) == (pm.EIP196_2G if base == pm.G else cv.add(base, base))       # published vector for 2 G
+    ident = gpu_fixed_base(ctx, np.zeros(8, dtype=np.uint64), rand_scalars(rng, 5))
+    assert not ident.any()                                                                       # k * identity = identity
+    assert ctx.lib.gl355_bn254_g1_fixed_base_mul(ctx.h, None, None, 4, None) == -1
+
+
+def test_g1_msm_2p20_distinct_bases_linearity(ctx, orc):
+    """2^20 distinct bases s_i * G made by the fixed-base kernel (so the gathers of the bucket phase are not cache hits) and random
+    scalars a, b: MSM(a) + MSM(b) = MSM(a + b mod r), and MSM(a) = (sum a_i s_i) * G"""
+    cv = Bn254Curve(orc)
+    n = 1 << 20
+    rng = np.random.default_rng(0x4E5)
+    s = rand_scalars(rng, n)
+    pts = gpu_fixed_base(ctx, cv._pt(pm.G), s)
+    a, b = rand_scalars(rng, n), rand_scalars(rng, n)
+
+    def to_obj(x):
+        v = np.zeros(n, dtype=object)
+        for limb in range(4):
+            v += x[:, limb].astype(object) << (64 * limb)
+        return v
+
+    sv, av, bv = to_obj(s), to_obj(a), to_obj(b)
+    ma, mb = cv._unpt(gpu_msm(ctx, pts, a)), cv._unpt(gpu_msm(ctx, pts, b))
+    assert ma == cv.mul(pm.G, int(sum(int(x) * int(y) for x, y in zip(av, sv)) % pm.R))
+    ab = cv.scalars([(int(x) + int(y)) % pm.R for x, y in zip(av, bv)])
+    assert cv._unpt(gpu_msm(ctx, pts, ab)) == cv.add(ma, mb)
