@@ -71,7 +71,7 @@ int32_t lde_dev(Ctx* ctx, const uint64_t* coeffs, uint64_t in_stride, uint32_t l
     NttPlan p;
     p.in = coeffs; p.out = out; p.in_col_stride = in_stride; p.out_col_stride = out_stride;
     p.log_n = log_n; p.batch = batch; p.inverse = false; p.in_bitrev = false; p.out_bitrev = true;
-    p.n_cosets = n_cosets; p.coset_out_stride = n;
+    p.n_cosets = n_cosets; p.coset_out_stride = n; p.coset_ratio = gl_canon(wN);
     for (uint32_t c = 0; c < n_cosets; c++) p.coset_slot[c] = (uint8_t)host_brev(c, rate_bits);
     GL355_TRY(ctx->pow_tables_multi(bases, &p.pre_lo, &p.pre_hi));
     if (log_n == 0) {

@@ -170,6 +170,7 @@ struct NttPlan {
     bool in_bitrev = false;    // input is in bit-reversed order
     bool out_bitrev = false;   // leave output in bit-reversed order
     uint32_t n_cosets = 1;     // > 1: LDE-style, coset c reads tables c and writes slot coset_slot[c]
+    uint64_t coset_ratio = 0;  // != 0: the cosets' bases are base[0] * coset_ratio^c (lets one block run all cosets of a tile)
     uint8_t coset_slot[16] = {0};
     uint64_t coset_out_stride = 0;
     const uint64_t* pre_lo = nullptr;  // multiplier tables on natural-order input index

@@ -204,6 +204,8 @@ static hipError_t launch_cols_t(const PassArgs& a, bool inv, uint64_t blocks, hi
     const size_t shmem = (4096 + 256) * sizeof(uint64_t);
     const bool fast = !inv && a.pre_full && a.step_full && !a.in_bitrev && !a.out_natural && !a.post_lo && a.scale == 1 && !a.canon;
     const bool r8 = !inv && a.step_full && (a.pre_full || !a.pre_lo) && !a.in_bitrev && !a.out_natural && !a.post_lo && a.scale == 1 && !a.canon;
+    static const bool per_coset = getenv("GL355_EXP_NTT_PER_COSET") != nullptr;     // A/B: one block per (tile, coset) as before
+    if (r8 && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset) return launch_cols_r8_cosets(a, LOG_T, s);
     if (r8 && !ntt_r16_only()) return launch_cols_r8(a, LOG_T, s);
     if (fast) hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, false, true>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
     else if (inv) hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, true>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
@@ -301,13 +303,18 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
                 a.pre_full_stride = 1ull << p.log_n;
             }
             GL355_TRY(ctx->full_step_table(step_lo, step_hi, l1, l2, inv, &a.step_full));
+            if (a.pre_full && p.n_cosets > 1 && p.coset_ratio) {
+                const uint64_t *rlo, *rhi;
+                GL355_TRY(ctx->pow_tables(p.coset_ratio, &rlo, &rhi));
+                GL355_TRY(ctx->full_pow_table(rlo, rhi, 1, p.log_n, &a.ratio_full));
+            }
         }
         a.in_bitrev = 0; a.out_natural = 0; a.canon = 0;
         { ProfScope ps(ctx, "ntt_cols_pass1", ((uint64_t)p.batch << p.log_n) * 8); GL355_HIP(ctx, launch_cols(a, l1, inv, ctx->stream)); }
         PassArgs b = a;
         b.in = p.out; b.in_col_stride = p.out_col_stride;
         // each coset's intermediate lives in its own output block: rows pass runs per coset slot
-        b.pre_lo = b.pre_hi = nullptr; b.step_lo = b.step_hi = nullptr; b.pre_full = nullptr; b.step_full = nullptr;
+        b.pre_lo = b.pre_hi = nullptr; b.step_lo = b.step_hi = nullptr; b.pre_full = nullptr; b.step_full = nullptr; b.ratio_full = nullptr;
         b.log_rows = l1;  // rows per column = N1
         b.scale = p.scale; b.canon = 1;
         if (p.n_cosets == 1) {

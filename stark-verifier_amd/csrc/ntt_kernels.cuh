@@ -5,7 +5,7 @@
 #include "gl355_internal.h"
 // GL355_NTT_KO (tools/ubench only; results are wrong with any bit set): 1 = twiddles from a register instead of the table,
 // 2 = no global loads of the tile, 4 = no twiddle products, 8 = no butterfly network, 16 = pre / step multipliers from registers
-// instead of their tables, 32 = no pre / step products
+// instead of their tables, 32 = no pre / step products, 64 = column pass writes rows at a padded stride
 #ifndef GL355_NTT_KO
 #define GL355_NTT_KO 0
 #endif
@@ -174,6 +174,7 @@ struct PassArgs {
     const uint64_t* pre_full;  // optional full table g_c^i (coset c at + c*pre_full_stride): 1 load + 1 mul
     uint64_t pre_full_stride;
     const uint64_t* step_full; // optional full 4-step twiddle table in STORE order (col kernel, first pass)
+    const uint64_t* ratio_full; // LDE column pass over all cosets in one block: (base[c+1] / base[c])^i, constant over c (Ctx::full_pow_table)
     uint64_t scale;            // constant multiplier at store (1 = none)
     uint32_t in_bitrev;        // input transform index is bit-reversed in memory
     uint32_t out_natural;      // write natural order (else DIF-native bit-reversed order)
@@ -183,6 +184,7 @@ struct PassArgs {
 // radix-8 commit-path kernels, compiled in ntt_r8.hip
 hipError_t launch_rows_r8(const PassArgs& a, uint32_t log_t, hipStream_t s);
 hipError_t launch_cols_r8(const PassArgs& a, uint32_t log_t, hipStream_t s);
+hipError_t launch_cols_r8_cosets(const PassArgs& a, uint32_t log_t, hipStream_t s);
 
 // Row pass: each row = 2^LOG_T contiguous elements; a tile packs 2^(LT-LOG_T) rows.
 // FAST = the commit-path shape with every optional multiplier compiled out: rows pass = no pre / post multiplier, no scaling,
@@ -391,7 +393,52 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
         const uint64_t go = ((uint64_t)r << log_n2) + c0 + cc;
         uint64_t v = lds[lds_phys(g)];
         if constexpr (!(GL355_NTT_KO & 32)) v = gl_mul(v, (GL355_NTT_KO & 16) ? go + 5 : a.step_full[go]);
-        out[go] = v;
+        if constexpr (GL355_NTT_KO & 64) out[go + r * 16] = v;      // padded row stride (timing experiment: channel camping?)
+        else out[go] = v;
+    }
+}
+
+// Column pass of an LDE whose coset bases form a geometric sequence (base[c] = shift * w^c: PolynomialCoeffs::lde): ONE block takes a
+// tile through ALL cosets.  The per-coset kernel above reads the coefficients once per coset (8 x 141 MB through the fabric at
+// 2^17 x 135) and a 1-MiB pre table per coset; here the coefficients and two tables (base[0]^i and w^i) are read once, the value of
+// coset c + 1 is the value of coset c times w^i (the same one product per element and coset), and only the outputs stream.
+template <int LOG_T, int WPE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_cols_r8_cosets_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    constexpr int LT = 12, NT = 512;
+    constexpr int LOG_TC = LT - LOG_T, TC = 1 << LOG_TC;
+    const int tid = threadIdx.x;
+    const uint32_t log_n2 = a.log_rows;
+    const uint64_t n2 = 1ull << log_n2;
+    const uint64_t tiles_per_col = n2 >> LOG_TC;
+    const uint64_t col = blockIdx.x / tiles_per_col;
+    const uint64_t c0 = (blockIdx.x % tiles_per_col) << LOG_TC;
+    const uint64_t* in = a.in + col * a.in_col_stride;
+    uint64_t v[8], rt[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t g = tid + i * NT;
+        const uint64_t gi = ((uint64_t)(g >> LOG_TC) << log_n2) + c0 + (g & (TC - 1));
+        v[i] = gl_mul(in[gi], a.pre_full[gi]);
+        rt[i] = a.ratio_full[gi];
+    }
+    for (uint32_t c = 0; c < a.n_cosets; c++) {
+        if (c) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = gl_mul(v[i], rt[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) lds[lds_phys(tid + i * NT)] = v[i];
+        __syncthreads();
+        dif_tile_r8<LT, LOG_T, false>(lds, a.tw_r8, LOG_TC, tid, NT);
+        uint64_t* out = a.out + (uint64_t)a.coset_slot[c] * a.coset_out_stride + col * a.out_col_stride;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t g = tid + i * NT;
+            const uint64_t go = ((uint64_t)(g >> LOG_TC) << log_n2) + c0 + (g & (TC - 1));
+            out[go] = gl_mul(lds[lds_phys(g)], a.step_full[go]);
+        }
+        __syncthreads();
     }
 }
 

@@ -56,4 +56,20 @@ hipError_t launch_cols_r8(const PassArgs& a, uint32_t log_t, hipStream_t s) {
     return hipGetLastError();
 }
 
+// all cosets of a tile in one block (a.ratio_full set): blocks over (column, tile)
+hipError_t launch_cols_r8_cosets(const PassArgs& a, uint32_t log_t, hipStream_t s) {
+    const uint64_t n2 = 1ull << a.log_rows;
+    const uint64_t tc = 1ull << (12 - log_t);
+    const uint64_t blocks = (n2 / tc) * a.batch;
+    const size_t shmem = (4096 + 256) * sizeof(uint64_t);
+    switch (log_t) {
+#define GL355_COL8C_CASE(L) case L: hipLaunchKernelGGL((ntt_cols_r8_cosets_kernel<L, 4>), dim3((uint32_t)blocks), dim3(512), shmem, s, a); break;
+        GL355_COL8C_CASE(1) GL355_COL8C_CASE(2) GL355_COL8C_CASE(3) GL355_COL8C_CASE(4) GL355_COL8C_CASE(5) GL355_COL8C_CASE(6)
+        GL355_COL8C_CASE(7) GL355_COL8C_CASE(8) GL355_COL8C_CASE(9) GL355_COL8C_CASE(10) GL355_COL8C_CASE(11) GL355_COL8C_CASE(12)
+#undef GL355_COL8C_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 }  // namespace gl355

@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
     const uint64_t N = 1ull << 20, n = 1ull << 17;
     const uint64_t big = std::max<uint64_t>(batch * N, 8ull * 135 * 8 * (1ull << 14));
     uint64_t *buf, *tw, *cin, *pre, *step;
-    CK(hipMalloc(&buf, big * 8));
+    CK(hipMalloc(&buf, (big + (1 << 20)) * 8));
     CK(hipMalloc(&tw, (1 << 15) * 8));   // stands in for the round-major twiddle table
     CK(hipMalloc(&cin, std::max<uint64_t>(batch * n, 8ull * 135 * (1ull << 14)) * 8));
     CK(hipMalloc(&pre, 8 * n * 8));
