@@ -303,6 +303,8 @@ def lde_figure(gl, device, steps=8):
     return {"value": round(alg * steps / dt / 1e9, 2), "unit": "GB/s", "steps": steps,
             "workload": "lde n=2^17 -> N=2^20, 135 columns, bit-reversed output, resident operands",
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "traffic": 3563000000, "traffic_source": "profiles/r02_lde_pmc.txt (FETCH_SIZE x 2 + WRITE_SIZE of both passes, separate --pmc runs)",
+                         "hbm_moved_GBps": round(3.563e9 / (kern_ms * 1e-3) / 1e9, 1) if kern_ms > 0 else None,
                          "kernels_ms_per_launch": {k: round(v[1] / max(1, v[0]), 4) for k, v in prof.items()}}}
 
 
@@ -769,8 +771,12 @@ def main_lde(args):
                                    "bit-reversed (commitment) output order, operands resident in HBM",
                        "algorithmic_bytes_per_step_per_gpu": alg_bytes_step, "parallelism": "independent batches per GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "lde = ntt_cols_kernel<5> (pass 1) + ntt_rows_kernel<12,12> (pass 2)",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": 3563000000,
+                         "traffic_source": "profiles/r02_lde_pmc.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes over tools/prof_lde.py), "
+                                           "FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, both kernels of one LDE summed: 0.17 + 1.13 GB (pass 1) "
+                                           "+ 1.13 + 1.13 GB (pass 2); the intermediate of the two-pass split is the excess over the algorithmic 1.27 GB",
+                         "kernel": "lde = ntt_cols_r8_cosets_kernel<5> (pass 1: 32-point transforms over 128-column tiles, all 8 cosets per block) + "
+                                   "ntt_rows_r8_kernel<12> (pass 2: 4096-point rows)",
                          "dominant_kernel": dom_name,
                          "dominant_avg_launch_ms": round(per_launch_ms, 4),
                          "dominant_alg_GBps": round(alg_by_kernel.get(dom_name, alg_bytes_step) / (per_launch_ms * 1e-3) / 1e9, 2)
@@ -778,12 +784,14 @@ def main_lde(args):
                          "kernels_ms_per_launch": {k: round(v[1] / max(1, v[0]), 4) for k, v in prof.items()},
                          "kernel_time_fraction_of_wall": round(total_kernel_ms * 1e-3 / elapsed, 3)},
         }
-        # the bound that applies: wave-level VALU instructions of the two passes (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r01_lde_pmc_v1.txt:
-        # 5.30e8 + 5.52e8 per LDE before the round-2 diet of pass 1) against the chip's issue rate
-        line["roofline"]["valu_issue"] = {"unit": "G wave-instructions/s", "insts_per_lde_round1": 1.082e9,
-                                          "achieved_if_unchanged": round(1.082e9 / (lde_ms * 1e-3) / 1e9, 1) if lde_ms > 0 else None,
+        # the other bound: wave-level VALU instructions of the two passes (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r02_lde_pmc.txt:
+        # 2.22e8 + 4.12e8 per LDE; 1.082e9 in round 1) against the chip's issue rate
+        line["roofline"]["valu_issue"] = {"unit": "G wave-instructions/s", "insts_per_lde": 6.34e8,
+                                          "achieved": round(6.34e8 / (lde_ms * 1e-3) / 1e9, 1) if lde_ms > 0 else None,
                                           "peak": round(1024 * 2.05e9 / 4.2 / 1e9, 1),
-                                          "note": "the LDE is bound by integer VALU issue (~490 lane-instructions per output element in round 1), not by HBM"}
+                                          "note": "peak = 1024 SIMDs x 2.05 GHz / 4.2 clk per multiply-add-heavy instruction (tools/ubench); the row pass's mix "
+                                                  "(adds, selects, moves) issues at 3.7 clk, so `achieved` can pass it: the row pass is instruction-bound at "
+                                                  "186 lane-instructions per element (225 with radix 16, ~490 per LDE output element in round 1)"}
         if root is not None:
             line["aggregation_root"] = ["%016x" % x for x in root]
         if world == 1:
