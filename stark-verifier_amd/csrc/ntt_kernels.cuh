@@ -9,6 +9,10 @@
 #ifndef GL355_NTT_KO
 #define GL355_NTT_KO 0
 #endif
+// 1 (default): the radix-8 rounds run the lazily reduced butterfly network (dif8_lazy); 0: the reduce-every-time network (A/B in the ubench)
+#ifndef GL355_NTT_R8_LAZY
+#define GL355_NTT_R8_LAZY 1
+#endif
 
 namespace gl355 {
 
@@ -98,13 +102,74 @@ GL_DEV void dif_regs(uint64_t (&x)[16]) {
     dif_stage_blocks<INV, 1, 1 << (RHO - 1), 0>(x);
 }
 
+// ---- radix-8 network on lazily reduced operands (the radix-8 commit-path kernels) ---------------------------------------------
+// Between the three butterfly layers a value is kept as v + k * 2^64 with a small non-negative k (a third 32-bit limb) instead of
+// being reduced after every addition: a sum is one 3-limb carry chain, a difference is a + (m p - b) with m p >= b (m = 2, 4, 8 by
+// layer, so k <= 14 at the end), the shift-twiddles (only 2^24, 2^48, 2^72 occur in radix 8) take the third limb in through one
+// funnel shift, and one multiply-add per output folds k back (k * 2^64 = k * EPS).  189 VALU instructions per 8 points instead of
+// 245 for the reduce-every-time form (compare-and-select corrections), bit for bit the same values mod p.
+struct L96 { uint64_t v; uint32_t k; };
+typedef unsigned __int128 gl_u128;
+GL_DEV L96 l96(uint64_t v) { L96 r; r.v = v; r.k = 0; return r; }
+GL_DEV gl_u128 l96_int(L96 a) { return ((gl_u128)a.k << 64) | a.v; }
+GL_DEV L96 l96_of(gl_u128 s) { L96 r; r.v = (uint64_t)s; r.k = (uint32_t)(s >> 64); return r; }
+GL_DEV L96 l96_add(L96 a, L96 b) { return l96_of(l96_int(a) + l96_int(b)); }
+template <int M> GL_DEV L96 l96_sub(L96 a, L96 b) {        // a + (M p - b); the caller guarantees b <= M p.  M p = (M-1) 2^64 + (2^32 - M) 2^32 + M
+    const gl_u128 mp = ((gl_u128)(M - 1) << 64) | ((uint64_t)(0x100000000ull - M) << 32) | (uint64_t)M;
+    return l96_of(l96_int(a) + (mp - l96_int(b)));
+}
+#if !defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the declarations to parse (gl_field.cuh defines these for the device pass)
+GL_DEV uint64_t gl_dev_add_mul_eps(uint64_t x, uint32_t k);
+GL_DEV uint64_t gl_dev_sub32(uint32_t lo0, uint32_t lo1, uint32_t sub32);
+#endif
+GL_DEV uint64_t l96_norm(L96 a) { return gl_dev_add_mul_eps(a.v, a.k); }
+// (v + k 2^64) * 2^S mod p as any u64, for the shifts of the radix-8 network and k < 2^8.  With T = 2^32: T^2 = EPS, T^3 = -1.
+template <int S> GL_DEV uint64_t l96_shift(L96 a) {
+    static_assert(S == 24 || S == 48 || S == 72, "radix-8 shift-twiddles only");
+    const uint32_t x0 = (uint32_t)a.v, x1 = (uint32_t)(a.v >> 32), x2 = a.k;
+    if constexpr (S == 24) {
+        return gl_dev_add_mul_eps(a.v << 24, __builtin_amdgcn_alignbit(x2, x1, 8));           // low 64 bits + (bits 64..95) * EPS
+    } else {
+        constexpr int sh = S == 48 ? 16 : 8;                                                    // y = x << sh = (y0, y1, y2), y2 < 2^32
+        const uint32_t y0 = x0 << sh, y1 = __builtin_amdgcn_alignbit(x1, x0, 32 - sh), y2 = __builtin_amdgcn_alignbit(x2, x1, 32 - sh);
+        if constexpr (S == 48) return gl_dev_add_mul_eps(gl_dev_sub32(0, y0, y2), y1);          // y T = y0 T + y1 EPS - y2
+        else return gl_sub((uint64_t)y0 * 0xFFFFFFFFull, ((uint64_t)y2 << 32) | y1);           // y T^2 = y0 EPS - (y1 + y2 T)
+    }
+}
+template <bool INV, int E, int M>
+GL_DEV void l96_bfly(L96& a, L96& b) {                      // (a, b) <- (a + b, (a - b) * omega_16^(+-E)), E even
+    constexpr int FWD_S[4] = {0, 24, 48, 72};
+    constexpr bool FWD_NEG[4] = {false, true, false, true};
+    constexpr int INV_S[4] = {0, 72, 48, 24};
+    constexpr bool INV_NEG[4] = {false, false, true, false};
+    constexpr int S = INV ? INV_S[E / 2] : FWD_S[E / 2];
+    constexpr bool NEG = INV ? INV_NEG[E / 2] : FWD_NEG[E / 2];
+    const L96 s = l96_add(a, b);
+    const L96 d = NEG ? l96_sub<M>(b, a) : l96_sub<M>(a, b);
+    a = s;
+    if constexpr (S == 0) b = d;
+    else b = l96(l96_shift<S>(d));
+}
+template <bool INV>
+GL_DEV void dif8_lazy(uint64_t (&x)[16]) {
+    L96 y[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) y[i] = l96(x[i]);
+    // bounds: inputs < 2^64; layer 1 out < 3 * 2^64; layer 2 out < 7 * 2^64 (subtrahends < 4 p); layer 3 out < 15 * 2^64 (subtrahends < 8 p)
+    l96_bfly<INV, 0, 2>(y[0], y[4]); l96_bfly<INV, 2, 2>(y[1], y[5]); l96_bfly<INV, 4, 2>(y[2], y[6]); l96_bfly<INV, 6, 2>(y[3], y[7]);
+    l96_bfly<INV, 0, 4>(y[0], y[2]); l96_bfly<INV, 4, 4>(y[1], y[3]); l96_bfly<INV, 0, 4>(y[4], y[6]); l96_bfly<INV, 4, 4>(y[5], y[7]);
+    l96_bfly<INV, 0, 8>(y[0], y[1]); l96_bfly<INV, 0, 8>(y[2], y[3]); l96_bfly<INV, 0, 8>(y[4], y[5]); l96_bfly<INV, 0, 8>(y[6], y[7]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = l96_norm(y[i]);
+}
+
 // One DIF round of radix 2^RHO on an LDS tile.  The transform currently consists of independent
 // blocks of 2^m (transform units); transform bit 0 sits at tile-index bit LO.  `tw` is the ROUND-MAJOR twiddle table of this
 // radix and direction (Ctx::twr): tw[2^m + (k0 << (m - RHO)) + r] = omega_{2^m}^(+-r * k0), so that the 64 lanes of a wave
 // (consecutive r) read 64 consecutive words per register q.  With the plain omega_{2^14}^e table the same loads were gathers
 // at a stride of k0 * 2^(14-m) words -- up to 64 cache lines per wave instruction, and a third of the row pass's time
 // (tools/ubench/ubench_ntt_rows.hip, knock-out 1).
-template <int LT, int RHO, bool INV>
+template <int LT, int RHO, bool INV, bool LAZY = false>
 GL_DEV void dif_round(uint64_t* lds, const uint64_t* __restrict__ tw, int m, int LO, int tid, int nthreads) {
     constexpr int R = 1 << RHO;
     const int tasks = (1 << LT) >> RHO;
@@ -115,7 +180,10 @@ GL_DEV void dif_round(uint64_t* lds, const uint64_t* __restrict__ tw, int m, int
         uint64_t x[16];
 #pragma unroll
         for (int q = 0; q < R; q++) x[q] = lds[lds_phys(idx0 + ((uint32_t)q << fbit))];
-        if constexpr (!(GL355_NTT_KO & 8)) dif_regs<RHO, INV>(x);
+        if constexpr (!(GL355_NTT_KO & 8)) {
+            if constexpr (LAZY && RHO == 3) dif8_lazy<INV>(x);
+            else dif_regs<RHO, INV>(x);
+        }
         if ((GL355_NTT_KO & 4) == 0 && m > RHO) {
             // output k0 = bitrev(q) of this butterfly is multiplied by omega_{2^m}^(r*k0)
             const uint32_t r = (idx0 >> LO) & ((1u << (m - RHO)) - 1);
@@ -257,7 +325,7 @@ GL_DEV void dif_tile_r8(uint64_t* lds, const uint64_t* __restrict__ tw, int LO, 
     int m = LOG_T;
 #pragma unroll
     for (int round = 0; round < LOG_T / 3; round++) {
-        dif_round<LT, 3, INV>(lds, tw, m, LO, tid, nthreads);
+        dif_round<LT, 3, INV, GL355_NTT_R8_LAZY != 0>(lds, tw, m, LO, tid, nthreads);
         m -= 3;
         __syncthreads();
     }
