@@ -402,7 +402,8 @@ def bn254_figures(gl, device):
     ctx.check(lib.gl355_bn254_g1_fixed_base_mul(ctx.h, C.c_void_p(gen.data_ptr()), C.c_void_p(s_i.data_ptr()), n, C.c_void_p(pts.data_ptr())))
     ms = ctx.timer_stop()
     out["g1_fixed_base_mul_2p20"] = {"ms": round(ms, 2), "points_per_s": round(n / ms * 1e3 / 1e6, 2), "unit": "M points/s"}
-    sc = torch.randint(0, (1 << 60) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    sc = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)     # uniform 64-bit limbs ...
+    sc[:, 3] &= (1 << 61) - 1                                                                                   # ... below 2^253 < r
     res = torch.zeros(8, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     ctx.check(lib.gl355_bn254_g1_msm(ctx.h, C.c_void_p(pts.data_ptr()), C.c_void_p(sc.data_ptr()), n, C.c_void_p(res.data_ptr())))

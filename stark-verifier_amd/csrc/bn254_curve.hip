@@ -299,8 +299,17 @@ struct MsmArgs {
     uint32_t* size_hist;        // [MSM_SIZE_BINS] buckets per size, then the write cursor of each size class
     uint32_t* wsum;             // [W][24]       window sums
     uint64_t* result;           // [8]
+    // buckets of more than MSM_BIG points (skewed scalars: selector columns of 0 / 1, constants, the sparse top window) are summed by
+    // whole workgroups instead of one lane
+    uint32_t* big_counters;     // [2]           work items, big buckets
+    uint32_t* big_items;        // [max_items][2] bucket id, first point of the item (relative to the bucket)
+    uint32_t* big_buckets;      // [max_big][3]  bucket id, first item, items
+    uint32_t* big_partial;      // [max_items][24]
+    uint32_t max_items, max_big;
 };
 #define MSM_SIZE_BINS 128
+#define MSM_BIG 256u            // a lane sums at most this many points; a normal bucket holds 8-64
+#define MSM_BIG_WG_POINTS 4096u // points per workgroup item of a big bucket (16 per lane), more when a bucket would need over 256 items
 GL_DEV uint32_t msm_digit(const uint64_t* k, uint32_t w, uint32_t c) {
     const uint32_t bit = w * c;
     if (bit >= 256) return 0;
@@ -317,22 +326,51 @@ GL_DEV uint32_t msm_signed_digit(const uint64_t* k, uint32_t w, uint32_t c, uint
     carry = neg ? 1u : 0u;
     return neg ? (1u << c) - raw : raw;
 }
+// counter[key] += 1 for every lane with `active`, returning the value before the lane's increment.  Lanes of a wave that share one of
+// up to three sampled keys are combined into one atomic: with skewed scalars (all equal, 0 / 1, the sparse top window) half a million
+// points hit ONE counter, and one-by-one atomics on it took 6 ms per pass; uniformly random keys cost three ballots more.
+GL_DEV uint32_t msm_wave_inc(uint32_t* counter, uint32_t key, bool active) {
+    uint32_t slot = 0;
+    bool done = !active;
+    uint64_t tried = 0;
+    const uint32_t lane = __lane_id();
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+        const uint64_t cand = __ballot(!done) & ~tried;
+        if (!cand) break;                                          // wave-uniform
+        const int leader = __ffsll((unsigned long long)cand) - 1;
+        tried |= 1ull << leader;
+        const uint32_t lk = __shfl(key, leader);
+        const uint64_t same = __ballot(!done && key == lk);
+        const uint32_t cnt = (uint32_t)__popcll(same);
+        if (cnt < 4) continue;                                     // not worth a round trip: leave them to the plain atomics
+        uint32_t b = 0;
+        if (lane == (uint32_t)leader) b = atomicAdd(counter + lk, cnt);
+        b = __shfl(b, leader);
+        if (!done && key == lk) { slot = b + (uint32_t)__popcll(same & ((1ull << lane) - 1)); done = true; }
+    }
+    if (!done) slot = atomicAdd(counter + key, 1u);
+    return slot;
+}
 __global__ void msm_prepare_kernel(MsmArgs a) {          // points to Montgomery form + digit histograms
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const u256 x = load256(a.points + 8 * i), y = load256(a.points + 8 * i + 4);
+    bool live = i < a.n;                                  // every lane stays for the wave-level combining below
+    const uint64_t ii = live ? i : 0;
+    const u256 x = load256(a.points + 8 * ii), y = load256(a.points + 8 * ii + 4);
     const bool ident = u_is_zero(x) && u_is_zero(y);
-    const u256 xm = ident ? u_zero() : m_from_int<F_Q>(x), ym = ident ? u_zero() : m_from_int<F_Q>(y);
-    uint32_t* d = a.pm + 16 * i;
+    if (live) {
+        const u256 xm = ident ? u_zero() : m_from_int<F_Q>(x), ym = ident ? u_zero() : m_from_int<F_Q>(y);
+        uint32_t* d = a.pm + 16 * i;
 #pragma unroll
-    for (int j = 0; j < 8; j++) { d[j] = xm.l[j]; d[8 + j] = ym.l[j]; }
-    if (ident) return;
-    const uint64_t* k = a.scalars + 4 * i;
+        for (int j = 0; j < 8; j++) { d[j] = xm.l[j]; d[8 + j] = ym.l[j]; }
+    }
+    live = live && !ident;
+    const uint64_t* k = a.scalars + 4 * ii;
     uint32_t carry = 0;
     for (uint32_t w = 0; w < a.n_windows; w++) {
         bool neg;
         const uint32_t mag = msm_signed_digit(k, w, a.c, carry, neg);
-        if (mag) atomicAdd(a.hist + ((uint64_t)w << a.cb) + (mag - 1), 1u);
+        (void)msm_wave_inc(a.hist + ((uint64_t)w << a.cb), mag ? mag - 1 : 0, live && mag != 0);
     }
 }
 // per window: exclusive scan of the 2^cb counts (one workgroup), offsets copied to the cursors
@@ -361,20 +399,21 @@ __global__ void __launch_bounds__(1024) msm_scan_kernel(MsmArgs a) {
 }
 __global__ void msm_scatter_kernel(MsmArgs a) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const uint32_t* d = a.pm + 16 * i;
+    bool live = i < a.n;
+    const uint64_t ii = live ? i : 0;
+    const uint32_t* d = a.pm + 16 * ii;
     uint32_t o = 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) o |= d[j];
-    if (!o) return;                                       // the identity contributes nothing
-    const uint64_t* k = a.scalars + 4 * i;
+    live = live && o != 0;                                // the identity contributes nothing
+    const uint64_t* k = a.scalars + 4 * ii;
     uint32_t carry = 0;
     for (uint32_t w = 0; w < a.n_windows; w++) {
         bool neg;
         const uint32_t mag = msm_signed_digit(k, w, a.c, carry, neg);
-        if (!mag) continue;
-        const uint32_t pos = atomicAdd(a.cursor + ((uint64_t)w << a.cb) + (mag - 1), 1u);
-        a.idx[(uint64_t)w * a.n + pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
+        const bool act = live && mag != 0;
+        const uint32_t pos = msm_wave_inc(a.cursor + ((uint64_t)w << a.cb), mag ? mag - 1 : 0, act);
+        if (act) a.idx[(uint64_t)w * a.n + pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
     }
 }
 // Buckets by decreasing size.  A lane sums one bucket, so a wave takes as long as its largest bucket: with 2^20 points in 2^16
@@ -410,23 +449,77 @@ __global__ void __launch_bounds__(256) msm_order_kernel(MsmArgs a) {
     __syncthreads();
     if (id < total) a.order[base[sz] + slot] = id;
 }
-// one lane per (window, bucket), taken in the order above: sum of the bucket's points
+GL_DEV jac msm_add_point(const MsmArgs& a, jac acc, uint32_t e) {      // e: point index, bit 31 = subtract
+    const uint32_t* p = a.pm + 16ull * (e & 0x7fffffffu);
+    u256 x, y;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { x.l[j] = p[j]; y.l[j] = p[8 + j]; }
+    if (e >> 31) y = m_sub<F_Q>(u_zero(), y);
+    return j_madd(acc, x, y);
+}
+// one lane per (window, bucket), taken in the order above: sum of the bucket's points (big buckets: the kernels below)
 __global__ void __launch_bounds__(256) msm_bucket_kernel(MsmArgs a) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (a.n_windows << a.cb)) return;
     const uint32_t id = a.order[g], w = id >> a.cb;
-    jac acc = j_identity();
     const uint32_t lo = a.hist[id], hi = a.cursor[id];
-    for (uint32_t k = lo; k < hi; k++) {
-        const uint32_t e = a.idx[(uint64_t)w * a.n + k];
-        const uint32_t* p = a.pm + 16ull * (e & 0x7fffffffu);
-        u256 x, y;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { x.l[j] = p[j]; y.l[j] = p[8 + j]; }
-        if (e >> 31) y = m_sub<F_Q>(u_zero(), y);                 // negative digit: subtract the point
-        acc = j_madd(acc, x, y);
-    }
+    if (hi - lo > MSM_BIG) return;
+    jac acc = j_identity();
+    for (uint32_t k = lo; k < hi; k++) acc = msm_add_point(a, acc, a.idx[(uint64_t)w * a.n + k]);
     j_store(a.buckets + (uint64_t)id * 24, acc);
+}
+// ---- big buckets: a work list (bucket, slice) built on the device, one workgroup per slice (lanes stride through the slice, then a
+// tree over the 256 lane sums in LDS), one workgroup per big bucket for the slices' sums.  One lane per bucket made a 2^20-point MSM
+// whose scalars were all equal -- or whose top window held one digit -- a matter of seconds (2^19 dependent additions).
+GL_DEV uint32_t msm_big_slice(uint32_t sz) {                       // points per item: at most 256 items per bucket
+    const uint32_t need = (sz + 255) / 256;
+    return need > MSM_BIG_WG_POINTS ? ((need + 255) & ~255u) : MSM_BIG_WG_POINTS;
+}
+__global__ void __launch_bounds__(256) msm_big_list_kernel(MsmArgs a) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (a.n_windows << a.cb)) return;
+    const uint32_t sz = a.cursor[id] - a.hist[id];
+    if (sz <= MSM_BIG) return;
+    const uint32_t slice = msm_big_slice(sz), cnt = (sz + slice - 1) / slice;
+    const uint32_t first = atomicAdd(a.big_counters, cnt), slot = atomicAdd(a.big_counters + 1, 1u);
+    if (first + cnt > a.max_items || slot >= a.max_big) return;   // cannot happen: the bounds are sums over all points (host side)
+    for (uint32_t c = 0; c < cnt; c++) { a.big_items[2 * (first + c)] = id; a.big_items[2 * (first + c) + 1] = c * slice; }
+    a.big_buckets[3 * slot] = id; a.big_buckets[3 * slot + 1] = first; a.big_buckets[3 * slot + 2] = cnt;
+}
+GL_DEV jac msm_wg_tree(jac acc, uint32_t* sh /* 256 x 24 */) {     // sum of the 256 lanes' points, valid on lane 0
+    const uint32_t t = threadIdx.x;
+    j_store(sh + 24 * t, acc);
+    __syncthreads();
+    for (uint32_t st = 128; st >= 1; st >>= 1) {
+        if (t < st) { acc = j_add(acc, j_load(sh + 24 * (t + st))); j_store(sh + 24 * t, acc); }
+        __syncthreads();
+    }
+    return acc;
+}
+__global__ void __launch_bounds__(256) msm_big_partial_kernel(MsmArgs a) {      // a fixed grid walks the work list (usually empty)
+    __shared__ uint32_t sh[256 * 24];
+    const uint32_t n_items = *a.big_counters;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const uint32_t id = a.big_items[2 * it], off = a.big_items[2 * it + 1], w = id >> a.cb;
+        const uint32_t lo = a.hist[id] + off, end = a.cursor[id];
+        const uint32_t hi = min(end, lo + msm_big_slice(end - a.hist[id]));
+        jac acc = j_identity();
+        for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) acc = msm_add_point(a, acc, a.idx[(uint64_t)w * a.n + k]);
+        acc = msm_wg_tree(acc, sh);
+        if (threadIdx.x == 0) j_store(a.big_partial + 24ull * it, acc);
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) msm_big_final_kernel(MsmArgs a) {
+    __shared__ uint32_t sh[256 * 24];
+    const uint32_t n_big = a.big_counters[1];
+    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const uint32_t id = a.big_buckets[3 * b], first = a.big_buckets[3 * b + 1], cnt = a.big_buckets[3 * b + 2];
+        jac acc = threadIdx.x < cnt ? j_load(a.big_partial + 24ull * (first + threadIdx.x)) : j_identity();
+        acc = msm_wg_tree(acc, sh);
+        if (threadIdx.x == 0) j_store(a.buckets + (uint64_t)id * 24, acc);
+        __syncthreads();
+    }
 }
 
 // Window sum  sum_j (j + 1) * B_j = Wt + S  by a recursion on pairs (S, Wt) = (sum of the items, sum of local index * item) over groups of 2^kbits
@@ -631,7 +724,13 @@ int32_t gl355_bn254_g1_msm(gl355_ctx* h, const uint64_t* points, const uint64_t*
     MsmArgs a;
     memset(&a, 0, sizeof a);
     a.n = n;
-    a.c = lg <= 6 ? 4 : (lg - 2 > 16 ? 16 : lg - 2);             // window bits: ~8 points per bucket, at most 2^15 buckets per window
+    // window bits.  Fewer, larger windows mean fewer additions in the bucket phase (n per window) and more buckets to reduce; and the
+    // TOP window should not be nearly empty: scalars are < r < 2^254, so a top window of only a few bits puts everything into a handful
+    // of buckets (workgroup path below, contended counters).  254 = 14 * 17 + 16 = 12 * 20 + 14.  Measured (uniform scalars, ms):
+    //   2^18: c = 15 / 16 / 17 -> 3.7 / 3.9 / 4.1;   2^20: 16 / 17 / 18 -> 7.3 / 7.1 / 8.3;   2^22: 16 / 17 / 18 / 19 -> 23.6 / 19.1 / 20.7 / 32.9
+    static const uint32_t c_force = getenv("GL355_EXP_MSM_C") ? (uint32_t)atoi(getenv("GL355_EXP_MSM_C")) : 0;     // experiments
+    a.c = lg <= 6 ? 4 : (lg <= 18 ? lg - 2 : (lg <= 22 ? 17 : 20));
+    if (c_force >= 4 && c_force <= 24) a.c = c_force;
     a.cb = a.c - 1;
     a.n_windows = 256 / a.c + 1;                                 // signed digits: the carry out of bit 255 needs a window of its own
     const uint64_t nb = 1ull << a.cb, W = a.n_windows;
@@ -650,19 +749,28 @@ int32_t gl355_bn254_g1_msm(gl355_ctx* h, const uint64_t* points, const uint64_t*
         t >>= kb; shift += kb;
         lvl_words += 2ull * W * t * 24;
     }
+    // big-bucket work list: a bucket of sz > MSM_BIG points makes ceil(sz / slice) items with slice >= MSM_BIG_WG_POINTS, so over all
+    // buckets at most W n / MSM_BIG_WG_POINTS + (number of big buckets) items, and at most W n / MSM_BIG big buckets
+    a.max_big = (uint32_t)(W * n / MSM_BIG + 1);
+    a.max_items = (uint32_t)(W * n / MSM_BIG_WG_POINTS + a.max_big + 1);
     Scratch buf(ctx);
-    const uint64_t words32 = n * 16 + 3 * W * nb + W * n + W * nb * 24 + MSM_SIZE_BINS + lvl_words + 64;
+    const uint64_t words32 = n * 16 + 3 * W * nb + W * n + W * nb * 24 + MSM_SIZE_BINS + lvl_words + 64 +
+                             2 + 2ull * a.max_items + 3ull * a.max_big + 24ull * a.max_items;
     GL355_TRY(buf.get(words32 * 4 + 64));
     uint32_t* p = buf.as<uint32_t>();
     a.pm = p; p += n * 16;
     a.hist = p; p += W * nb;
     a.size_hist = p; p += MSM_SIZE_BINS;                          // cleared together with the histograms
+    a.big_counters = p; p += 2;                                   // ... and so are these
     a.cursor = p; p += W * nb;
     a.order = p; p += W * nb;
     a.idx = p; p += W * n;
     a.buckets = p; p += W * nb * 24;
+    a.big_items = p; p += 2ull * a.max_items;
+    a.big_buckets = p; p += 3ull * a.max_big;
+    a.big_partial = p; p += 24ull * a.max_items;
     uint32_t* lvl = p;
-    GL355_HIP(ctx, hipMemsetAsync(a.hist, 0, (W * nb + MSM_SIZE_BINS) * 4, ctx->stream));
+    GL355_HIP(ctx, hipMemsetAsync(a.hist, 0, (W * nb + MSM_SIZE_BINS + 2) * 4, ctx->stream));
     const uint32_t blk = (uint32_t)((n + 255) / 256), bblk = (uint32_t)((W * nb + 255) / 256);
     const uint32_t *fin_s = a.buckets, *fin_w = nullptr;
     {
@@ -673,7 +781,10 @@ int32_t gl355_bn254_g1_msm(gl355_ctx* h, const uint64_t* points, const uint64_t*
         hipLaunchKernelGGL(msm_size_hist_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
         hipLaunchKernelGGL(msm_order_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(msm_big_list_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(msm_big_partial_kernel, dim3(std::min<uint32_t>(a.max_items, 1536)), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(msm_big_final_kernel, dim3(std::min<uint32_t>(a.max_big, 512)), dim3(256), 0, ctx->stream, a);
         for (const Lv& lv : levels) {
             MsmLevel l;
             l.in_s = fin_s; l.in_w = fin_w; l.t_in = lv.t_in; l.kbits = lv.kbits; l.shift = lv.shift; l.n_windows = (uint32_t)W;

@@ -150,3 +150,25 @@ def test_g1_msm_2p20_distinct_bases_linearity(ctx, orc):
     assert ma == cv.mul(pm.G, int(sum(int(x) * int(y) for x, y in zip(av, sv)) % pm.R))
     ab = cv.scalars([(int(x) + int(y)) % pm.R for x, y in zip(av, bv)])
     assert cv._unpt(gpu_msm(ctx, pts, ab)) == cv.add(ma, mb)
+
+
+@pytest.mark.parametrize("kind", ["all_equal", "zero_one", "small", "two_values_2p18"])
+def test_g1_msm_skewed_scalars(ctx, orc, kind):
+    """scalars that put most points into a handful of buckets (selector columns of 0 / 1, constants, small values): those buckets are
+    summed by whole workgroups (one lane per bucket would walk 10^5 dependent additions); bases (i + 1) * 3 G, so the answer is one
+    scalar multiplication"""
+    cv = Bn254Curve(orc)
+    n = 1 << (18 if kind == "two_values_2p18" else 16)
+    rng = np.random.default_rng(0x4E6)
+    pts = cv.multiples_array(3, 3, n)
+    if kind == "all_equal":
+        vals = [0x1234567890ABCDEF1122334455667788990011223344556677] * n
+    elif kind == "zero_one":
+        vals = [int(v) for v in rng.integers(0, 2, size=n)]
+    elif kind == "small":
+        vals = [int(v) for v in rng.integers(0, 5, size=n)]
+    else:
+        vals = [pm.R - 1 if v else 7 for v in rng.integers(0, 2, size=n)]
+    sc = cv.scalars(vals)
+    k = sum(v * 3 * (i + 1) for i, v in enumerate(vals)) % pm.R
+    assert cv._unpt(gpu_msm(ctx, pts, sc)) == cv.mul(pm.G, k)

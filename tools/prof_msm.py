@@ -26,7 +26,8 @@ t = time.time()
 ctx.check(ctx.lib.gl355_bn254_g1_fixed_base_mul(ctx.h, C.c_void_p(gen.data_ptr()), C.c_void_p(s_i.data_ptr()), n, C.c_void_p(pts.data_ptr())))
 ctx.sync()
 print("fixed-base mul 2^%d: %.2f ms" % (k, (time.time() - t) * 1e3))
-sc = torch.randint(0, (1 << 60) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+sc = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)     # uniform 64-bit limbs ...
+sc[:, 3] &= (1 << 61) - 1                                                                                   # ... below 2^253 < r
 res = torch.zeros(8, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 for it in range(3):
