@@ -193,11 +193,18 @@ __global__ void fr_from_mont_kernel(uint64_t* data, uint64_t n, u256 scale, int 
     const u256 x = load256(data + 4 * i);
     store256(data + 4 * i, use_scale ? m_canon<F_R>(m_mul<F_R>(x, scale)) : m_to_int<F_R>(x));
 }
-// tw[i] = w^i (Montgomery), i < count
-__global__ void fr_twiddle_kernel(uint64_t* tw, uint64_t count, u256 w_mont) {
+// tw[i] = w^i (Montgomery), i < count, in two steps: lo[j] = w^j (j < 1024) and hi[j] = w^(1024 j) by exponentiation (a few thousand
+// entries), then one product per entry.  (One exponentiation per entry -- ~30 products each -- cost more than the transform it served:
+// 1.5e7 against 1.0e7 field products at k = 20.)
+__global__ void fr_twiddle_seed_kernel(uint64_t* lo, uint64_t* hi, uint64_t n_hi, u256 w_mont) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < 1024) store256(lo + 4 * i, m_pow_u64<F_R>(w_mont, i));
+    else if (i - 1024 < n_hi) store256(hi + 4 * (i - 1024), m_pow_u64<F_R>(w_mont, (i - 1024) << 10));
+}
+__global__ void fr_twiddle_kernel(uint64_t* tw, uint64_t count, const uint64_t* lo, const uint64_t* hi) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= count) return;
-    store256(tw + 4 * i, m_pow_u64<F_R>(w_mont, i));
+    store256(tw + 4 * i, m_mul<F_R>(load256(lo + 4 * (i & 1023)), load256(hi + 4 * (i >> 10))));
 }
 __global__ void fr_bitrev_kernel(uint64_t* data, uint32_t log_n) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -221,6 +228,66 @@ __global__ void __launch_bounds__(256) fr_stage_kernel(uint64_t* data, const uin
     const u256 u = load256(pu), v = m_mul<F_R>(load256(pv), w);
     store256(pu, m_add<F_R>(u, v));
     store256(pv, m_sub<F_R>(u, v));
+}
+
+// Several decimation-in-time stages per pass over HBM: a workgroup takes a tile of 2^ns "rows" at stride 2^s0 times C adjacent
+// columns (1024 elements, 32 KB of LDS as 8 limb planes so that lanes hit consecutive banks) through stages s0+1 .. s0+ns.  The first
+// pass (s0 = 0: contiguous 1024-element blocks, ten stages) also does the bit reversal and the conversion to Montgomery form on its
+// loads, the last one the conversion back (and the 1/n of the inverse) on its stores: k = 20 is three passes (10 + 5 + 5 stages)
+// instead of 23 (conversion, bit reversal, 20 stages, conversion).
+struct FrPass {
+    const uint64_t* in;         // first pass: the caller's data (natural order, plain integers); later passes: == out
+    uint64_t* out;
+    const uint64_t* tw;         // w_n^k, k < n / 2, Montgomery form
+    uint32_t log_n, s0, ns;
+    uint32_t first, last, use_scale;
+    u256 scale;
+};
+__global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
+    __shared__ uint32_t lds[8][1024];
+    const uint32_t R = 1u << a.ns, tile_elems = min(1024u, 1u << a.log_n), C = tile_elems >> a.ns, log_c = 31 - __clz(C);
+    const uint32_t tid = threadIdx.x;
+    // tiles: (hi, c_blk) with c_blk < 2^s0 / C
+    const uint32_t cblks = (1u << a.s0) >> log_c;
+    const uint64_t hi = blockIdx.x / cblks, c0 = (uint64_t)(blockIdx.x % cblks) << log_c;
+    const uint64_t base = (hi << (a.s0 + a.ns)) + c0;
+    for (uint32_t e = tid; e < tile_elems; e += 256) {
+        const uint32_t r = e >> log_c, c = e & (C - 1);
+        const uint64_t i = base + ((uint64_t)r << a.s0) + c;
+        u256 x;
+        if (a.first) x = m_from_int<F_R>(load256(a.in + 4 * (__brevll(i) >> (64 - a.log_n))));
+        else x = load256(a.in + 4 * i);
+#pragma unroll
+        for (int l = 0; l < 8; l++) lds[l][e] = x.l[l];
+    }
+    __syncthreads();
+    for (uint32_t st = 1; st <= a.ns; st++) {
+        const uint32_t s = a.s0 + st, half = 1u << (st - 1);
+        for (uint32_t b = tid; b < tile_elems / 2; b += 256) {
+            const uint32_t q = b >> log_c, c = b & (C - 1);
+            const uint32_t r_lo = ((q / half) * 2 * half) + (q % half);
+            const uint32_t e0 = (r_lo << log_c) | c, e1 = e0 + (half << log_c);
+            const uint64_t j = ((uint64_t)(q % half) << a.s0) + c0 + c;
+            const u256 w = load256(a.tw + 4 * (j << (a.log_n - s)));
+            u256 u, v;
+#pragma unroll
+            for (int l = 0; l < 8; l++) { u.l[l] = lds[l][e0]; v.l[l] = lds[l][e1]; }
+            v = m_mul<F_R>(v, w);
+            const u256 p = m_add<F_R>(u, v), m = m_sub<F_R>(u, v);
+#pragma unroll
+            for (int l = 0; l < 8; l++) { lds[l][e0] = p.l[l]; lds[l][e1] = m.l[l]; }
+        }
+        __syncthreads();
+    }
+    for (uint32_t e = tid; e < tile_elems; e += 256) {
+        const uint32_t r = e >> log_c, c = e & (C - 1);
+        const uint64_t i = base + ((uint64_t)r << a.s0) + c;
+        u256 x;
+#pragma unroll
+        for (int l = 0; l < 8; l++) x.l[l] = lds[l][e];
+        if (a.last) x = a.use_scale ? m_canon<F_R>(m_mul<F_R>(x, a.scale)) : m_to_int<F_R>(x);
+        store256(a.out + 4 * i, x);
+    }
 }
 
 // ================================================================ G1 ================================================
@@ -691,17 +758,47 @@ int32_t gl355_bn254_fr_ntt(gl355_ctx* h, uint64_t* data, uint32_t log_n, int32_t
     Staged sd(ctx);
     GL355_TRY(sd.open(data, n * 32, 3));
     Scratch tw(ctx);
-    GL355_TRY(tw.get((n / 2) * 32 + 32));
+    const uint64_t n_hi = (n / 2 + 1023) / 1024;
+    GL355_TRY(tw.get((n / 2) * 32 + 32 + n * 32 + (1024 + n_hi) * 32));
     uint64_t* d = sd.as<uint64_t>();
-    const uint32_t blk = (uint32_t)((n + 255) / 256), hblk = (uint32_t)((n / 2 + 255) / 256);
+    uint64_t* twp = tw.as<uint64_t>();
+    uint64_t* work = twp + 4 * (n / 2) + 4;                 // the first pass reads the data bit-reversed: it cannot run in place
+    uint64_t* tw_lo = work + 4 * n;
+    uint64_t* tw_hi = tw_lo + 4 * 1024;
+    const uint32_t hblk = (uint32_t)((n / 2 + 255) / 256);
+    static const bool staged = getenv("GL355_EXP_FR_NTT_STAGES") != nullptr;      // A/B: one global pass per stage (the first slice)
     {
         ProfScope ps(ctx, "bn254_fr_ntt", n * 64);
-        hipLaunchKernelGGL(fr_twiddle_kernel, dim3(hblk ? hblk : 1), dim3(256), 0, ctx->stream, tw.as<uint64_t>(), n / 2, w_mont);
-        hipLaunchKernelGGL(fr_to_mont_kernel, dim3(blk), dim3(256), 0, ctx->stream, d, n);
-        hipLaunchKernelGGL(fr_bitrev_kernel, dim3(blk), dim3(256), 0, ctx->stream, d, log_n);
-        for (uint32_t s = 1; s <= log_n; s++)
-            hipLaunchKernelGGL(fr_stage_kernel, dim3(hblk ? hblk : 1), dim3(256), 0, ctx->stream, d, tw.as<uint64_t>(), log_n, s);
-        hipLaunchKernelGGL(fr_from_mont_kernel, dim3(blk), dim3(256), 0, ctx->stream, d, n, scale, inverse ? 1 : 0);
+        hipLaunchKernelGGL(fr_twiddle_seed_kernel, dim3((uint32_t)((1024 + n_hi + 255) / 256)), dim3(256), 0, ctx->stream, tw_lo, tw_hi, n_hi, w_mont);
+        hipLaunchKernelGGL(fr_twiddle_kernel, dim3(hblk ? hblk : 1), dim3(256), 0, ctx->stream, twp, n / 2, tw_lo, tw_hi);
+        if (staged) {
+            const uint32_t blk = (uint32_t)((n + 255) / 256);
+            hipLaunchKernelGGL(fr_to_mont_kernel, dim3(blk), dim3(256), 0, ctx->stream, d, n);
+            hipLaunchKernelGGL(fr_bitrev_kernel, dim3(blk), dim3(256), 0, ctx->stream, d, log_n);
+            for (uint32_t s = 1; s <= log_n; s++)
+                hipLaunchKernelGGL(fr_stage_kernel, dim3(hblk ? hblk : 1), dim3(256), 0, ctx->stream, d, twp, log_n, s);
+            hipLaunchKernelGGL(fr_from_mont_kernel, dim3(blk), dim3(256), 0, ctx->stream, d, n, scale, inverse ? 1 : 0);
+        } else {
+            // stages per pass: ten in the first (contiguous blocks), the rest in passes of at most six
+            std::vector<uint32_t> ns;
+            ns.push_back(std::min(10u, log_n));
+            const uint32_t rem = log_n - ns[0], more = (rem + 5) / 6;
+            for (uint32_t k = 0; k < more; k++) ns.push_back(rem / more + (k < rem % more ? 1 : 0));
+            uint32_t s0 = 0;
+            const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, n / 1024);
+            for (size_t k = 0; k < ns.size(); k++) {
+                FrPass pa;
+                pa.first = k == 0; pa.last = k + 1 == ns.size();
+                pa.in = pa.first ? d : work;
+                pa.out = pa.last ? d : work;
+                if (pa.first && pa.last) pa.out = work;          // a single pass (n <= 1024) still reads bit-reversed: copy back below
+                pa.tw = twp; pa.log_n = log_n; pa.s0 = s0; pa.ns = ns[k];
+                pa.use_scale = inverse ? 1 : 0; pa.scale = scale;
+                hipLaunchKernelGGL(fr_fft_pass_kernel, dim3(tiles), dim3(256), 0, ctx->stream, pa);
+                s0 += ns[k];
+            }
+            if (ns.size() == 1) GL355_HIP(ctx, hipMemcpyAsync(d, work, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+        }
         GL355_HIP(ctx, hipGetLastError());
     }
     return sd.finish();
