@@ -413,6 +413,16 @@ def bn254_figures(gl, device):
         ctx.check(lib.gl355_bn254_g1_msm(ctx.h, C.c_void_p(pts.data_ptr()), C.c_void_p(sc.data_ptr()), n, C.c_void_p(res.data_ptr())))
     ms = ctx.timer_stop() / 3
     out["g1_msm_2p20"] = {"ms": round(ms, 2), "points_per_s": round(n / ms * 1e3 / 1e6, 2), "unit": "M points/s", "bases": "distinct"}
+    m_sets = 8                                                       # the commitments of 8 columns under one SRS in one call
+    scb = torch.randint(-(1 << 63), (1 << 63) - 1, (m_sets, n, 4), dtype=torch.int64, device="cuda", generator=g)
+    scb[:, :, 3] &= (1 << 61) - 1
+    resb = torch.zeros((m_sets, 8), dtype=torch.int64, device="cuda")
+    ctx.check(lib.gl355_bn254_g1_msm_batch(ctx.h, C.c_void_p(pts.data_ptr()), C.c_void_p(scb.data_ptr()), n, m_sets, C.c_void_p(resb.data_ptr())))
+    ctx.sync()
+    ctx.timer_start()
+    ctx.check(lib.gl355_bn254_g1_msm_batch(ctx.h, C.c_void_p(pts.data_ptr()), C.c_void_p(scb.data_ptr()), n, m_sets, C.c_void_p(resb.data_ptr())))
+    ms = ctx.timer_stop()
+    out["g1_msm_batch_8x2p20"] = {"ms": round(ms, 2), "ms_per_msm": round(ms / m_sets, 2), "points_per_s": round(m_sets * n / ms * 1e3 / 1e6, 2), "unit": "M points/s"}
     ctx.close()
     return out
 

@@ -166,6 +166,7 @@ SIGNATURES = {
     "gl355_aggregation_root": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
     "gl355_bn254_fr_ntt": (C.c_int32, [vp, vp, C.c_uint32, C.c_int32]),
     "gl355_bn254_g1_msm": (C.c_int32, [vp, vp, vp, C.c_uint64, vp]),
+    "gl355_bn254_g1_msm_batch": (C.c_int32, [vp, vp, vp, C.c_uint64, C.c_uint32, vp]),
     "gl355_bn254_g1_fixed_base_mul": (C.c_int32, [vp, vp, vp, C.c_uint64, vp]),
     "gl355_zs_partial_products": (C.c_int32, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                               C.c_uint64, vp, vp]),

@@ -356,6 +356,7 @@ struct MsmArgs {
     const uint64_t* scalars;    // [n][4]
     uint64_t n;
     uint32_t c, n_windows;      // window bits, windows (signed digits: |digit| <= 2^(c-1), one more window takes the last carry)
+    uint32_t wps, n_sets;       // windows per scalar set, scalar sets sharing the bases (n_windows = wps * n_sets: a set's windows are just more windows)
     uint32_t cb;                // c - 1: a window has 2^cb buckets, bucket j collects the points whose digit is +-(j + 1)
     uint32_t* pm;               // [n][16] points in Montgomery form
     uint32_t* hist;             // [W][2^cb]     counts, then exclusive offsets
@@ -432,12 +433,14 @@ __global__ void msm_prepare_kernel(MsmArgs a) {          // points to Montgomery
         for (int j = 0; j < 8; j++) { d[j] = xm.l[j]; d[8 + j] = ym.l[j]; }
     }
     live = live && !ident;
-    const uint64_t* k = a.scalars + 4 * ii;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < a.n_windows; w++) {
-        bool neg;
-        const uint32_t mag = msm_signed_digit(k, w, a.c, carry, neg);
-        (void)msm_wave_inc(a.hist + ((uint64_t)w << a.cb), mag ? mag - 1 : 0, live && mag != 0);
+    for (uint32_t set = 0; set < a.n_sets; set++) {
+        const uint64_t* k = a.scalars + 4 * ((uint64_t)set * a.n + ii);
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < a.wps; w++) {
+            bool neg;
+            const uint32_t mag = msm_signed_digit(k, w, a.c, carry, neg);
+            (void)msm_wave_inc(a.hist + ((uint64_t)(set * a.wps + w) << a.cb), mag ? mag - 1 : 0, live && mag != 0);
+        }
     }
 }
 // per window: exclusive scan of the 2^cb counts (one workgroup), offsets copied to the cursors
@@ -473,14 +476,16 @@ __global__ void msm_scatter_kernel(MsmArgs a) {
 #pragma unroll
     for (int j = 0; j < 16; j++) o |= d[j];
     live = live && o != 0;                                // the identity contributes nothing
-    const uint64_t* k = a.scalars + 4 * ii;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < a.n_windows; w++) {
-        bool neg;
-        const uint32_t mag = msm_signed_digit(k, w, a.c, carry, neg);
-        const bool act = live && mag != 0;
-        const uint32_t pos = msm_wave_inc(a.cursor + ((uint64_t)w << a.cb), mag ? mag - 1 : 0, act);
-        if (act) a.idx[(uint64_t)w * a.n + pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
+    for (uint32_t set = 0; set < a.n_sets; set++) {
+        const uint64_t* k = a.scalars + 4 * ((uint64_t)set * a.n + ii);
+        uint32_t carry = 0;
+        for (uint32_t ww = 0; ww < a.wps; ww++) {
+            bool neg;
+            const uint32_t mag = msm_signed_digit(k, ww, a.c, carry, neg), w = set * a.wps + ww;
+            const bool act = live && mag != 0;
+            const uint32_t pos = msm_wave_inc(a.cursor + ((uint64_t)w << a.cb), mag ? mag - 1 : 0, act);
+            if (act) a.idx[(uint64_t)w * a.n + pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
+        }
     }
 }
 // Buckets by decreasing size.  A lane sums one bucket, so a wave takes as long as its largest bucket: with 2^20 points in 2^16
@@ -804,16 +809,18 @@ int32_t gl355_bn254_fr_ntt(gl355_ctx* h, uint64_t* data, uint32_t log_n, int32_t
     return sd.finish();
 }
 
-int32_t gl355_bn254_g1_msm(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint64_t result[8]) {
+static int32_t msm_run(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t m, uint64_t* result) {
     Ctx* ctx = ctx_of(h);
     if (!ctx) return GL355_E_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
     if (!result || ((!points || !scalars) && n)) return ctx->fail(GL355_E_INVALID_ARG, "bn254_g1_msm: null argument");
     if (n > (1ull << 26)) return ctx->fail(GL355_E_UNSUPPORTED, "bn254_g1_msm: more than 2^26 points");
+    if (m == 0) return GL355_OK;
+    if (m > 64 || (uint64_t)m * n > (1ull << 27)) return ctx->fail(GL355_E_UNSUPPORTED, "bn254_g1_msm_batch: more than 64 scalar sets or 2^27 scalars in all");
     const bool dev_result = ptr_is_device(result);
     if (n == 0) {
-        if (dev_result) { GL355_HIP(ctx, hipMemsetAsync(result, 0, 64, ctx->stream)); GL355_HIP(ctx, ctx->wait()); }
-        else memset(result, 0, 64);
+        if (dev_result) { GL355_HIP(ctx, hipMemsetAsync(result, 0, 64ull * m, ctx->stream)); GL355_HIP(ctx, ctx->wait()); }
+        else memset(result, 0, 64ull * m);
         return GL355_OK;
     }
     uint32_t lg = 0;
@@ -829,11 +836,13 @@ int32_t gl355_bn254_g1_msm(gl355_ctx* h, const uint64_t* points, const uint64_t*
     a.c = lg <= 6 ? 4 : (lg <= 18 ? lg - 2 : (lg <= 22 ? 17 : 20));
     if (c_force >= 4 && c_force <= 24) a.c = c_force;
     a.cb = a.c - 1;
-    a.n_windows = 256 / a.c + 1;                                 // signed digits: the carry out of bit 255 needs a window of its own
+    a.wps = 256 / a.c + 1;                                       // signed digits: the carry out of bit 255 needs a window of its own
+    a.n_sets = m;
+    a.n_windows = a.wps * m;
     const uint64_t nb = 1ull << a.cb, W = a.n_windows;
     Staged sp(ctx), ss(ctx);
     GL355_TRY(sp.open(points, n * 64, 1));
-    GL355_TRY(ss.open(scalars, n * 32, 1));
+    GL355_TRY(ss.open(scalars, (uint64_t)m * n * 32, 1));
     a.points = sp.as<uint64_t>(); a.scalars = ss.as<uint64_t>();
     // reduction levels: groups of 8 items, the last level takes what is left
     struct Lv { uint32_t t_in, kbits, shift; };
@@ -871,7 +880,7 @@ int32_t gl355_bn254_g1_msm(gl355_ctx* h, const uint64_t* points, const uint64_t*
     const uint32_t blk = (uint32_t)((n + 255) / 256), bblk = (uint32_t)((W * nb + 255) / 256);
     const uint32_t *fin_s = a.buckets, *fin_w = nullptr;
     {
-        ProfScope ps(ctx, "bn254_g1_msm", n * 96);
+        ProfScope ps(ctx, "bn254_g1_msm", n * (64 + 32ull * m));
         hipLaunchKernelGGL(msm_prepare_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(msm_scan_kernel, dim3((uint32_t)W), dim3(1024), 0, ctx->stream, a);
         hipLaunchKernelGGL(msm_scatter_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
@@ -898,12 +907,21 @@ int32_t gl355_bn254_g1_msm(gl355_ctx* h, const uint64_t* points, const uint64_t*
     GL355_HIP(ctx, ctx->d2h(hs.data(), fin_s, W * 96));
     if (fin_w) GL355_HIP(ctx, ctx->d2h(hw.data(), fin_w, W * 96));
     GL355_HIP(ctx, ctx->wait());
-    uint64_t res[8];
-    bn254_g1_horner_host(hs.data(), fin_w ? hw.data() : nullptr, (uint32_t)W, a.c, res);
-    if (dev_result) { GL355_HIP(ctx, hipMemcpyAsync(result, res, 64, hipMemcpyHostToDevice, ctx->stream)); GL355_HIP(ctx, ctx->wait()); }
-    else memcpy(result, res, 64);
+    std::vector<uint64_t> res(8ull * m);
+    for (uint32_t set = 0; set < m; set++)
+        bn254_g1_horner_host(hs.data() + 24ull * set * a.wps, fin_w ? hw.data() + 24ull * set * a.wps : nullptr, a.wps, a.c, res.data() + 8 * set);
+    if (dev_result) { GL355_HIP(ctx, hipMemcpyAsync(result, res.data(), 64ull * m, hipMemcpyHostToDevice, ctx->stream)); GL355_HIP(ctx, ctx->wait()); }
+    else memcpy(result, res.data(), 64ull * m);
     return GL355_OK;
 }
+
+int32_t gl355_bn254_g1_msm(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint64_t result[8]) {
+    return msm_run(h, points, scalars, n, 1, result);
+}
+int32_t gl355_bn254_g1_msm_batch(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t n_sets, uint64_t* results) {
+    return msm_run(h, points, scalars, n, n_sets, results);
+}
+
 
 int32_t gl355_bn254_g1_fixed_base_mul(gl355_ctx* h, const uint64_t base[8], const uint64_t* scalars, uint64_t n, uint64_t* out) {
     Ctx* ctx = ctx_of(h);

@@ -172,3 +172,22 @@ def test_g1_msm_skewed_scalars(ctx, orc, kind):
     sc = cv.scalars(vals)
     k = sum(v * 3 * (i + 1) for i, v in enumerate(vals)) % pm.R
     assert cv._unpt(gpu_msm(ctx, pts, sc)) == cv.mul(pm.G, k)
+
+
+def test_g1_msm_batch_equals_single_msms(ctx, orc):
+    """several scalar sets over the same bases in one call (commitments of several columns under one SRS) == the MSMs one by one;
+    small case against the oracle, 2^18 bases against single calls"""
+    cv = Bn254Curve(orc)
+    rng = np.random.default_rng(0x4E7)
+    for n, m in ((300, 3), (1 << 18, 4)):
+        pts = cv.multiples_array(5, 11, n)
+        sc = np.stack([rand_scalars(rng, n, below_r=False) for _ in range(m)])
+        if n == 300:
+            sc[1, :, :] = 0                                              # an all-zero column
+            sc[2, 7] = cv.scalars([pm.R - 1])[0]
+        out = np.zeros((m, 8), dtype=np.uint64)
+        ctx.check(ctx.lib.gl355_bn254_g1_msm_batch(ctx.h, pts.ctypes.data, np.ascontiguousarray(sc).ctypes.data, n, m, out.ctypes.data))
+        for j in range(m):
+            ref = cv.msm_arrays(pts, sc[j]) if n == 300 else gpu_msm(ctx, pts, sc[j])
+            assert np.array_equal(out[j], ref), (n, j)
+    assert ctx.lib.gl355_bn254_g1_msm_batch(ctx.h, pts.ctypes.data, sc.ctypes.data, 4, 65, out.ctypes.data) == -5       # GL355_E_UNSUPPORTED

@@ -35,3 +35,15 @@ for it in range(3):
     ctx.check(ctx.lib.gl355_bn254_g1_msm(ctx.h, C.c_void_p(pts.data_ptr()), C.c_void_p(sc.data_ptr()), n, C.c_void_p(res.data_ptr())))
     ctx.sync()
     print("msm 2^%d: %.2f ms" % (k, (time.time() - t) * 1e3))
+# several scalar sets over the same bases in one call (GL355_MSM_SETS=m)
+m = int(os.environ.get("GL355_MSM_SETS", "0"))
+if m:
+    scb = torch.randint(-(1 << 63), (1 << 63) - 1, (m, n, 4), dtype=torch.int64, device="cuda", generator=g)
+    scb[:, :, 3] &= (1 << 61) - 1
+    resb = torch.zeros((m, 8), dtype=torch.int64, device="cuda")
+    for it in range(2):
+        t = time.time()
+        ctx.check(ctx.lib.gl355_bn254_g1_msm_batch(ctx.h, C.c_void_p(pts.data_ptr()), C.c_void_p(scb.data_ptr()), n, m, C.c_void_p(resb.data_ptr())))
+        ctx.sync()
+        dt = (time.time() - t) * 1e3
+        print("msm batch of %d x 2^%d: %.2f ms = %.2f ms per MSM" % (m, k, dt, dt / m))
