@@ -796,13 +796,13 @@ def main_lde(args):
                          "kernel_time_fraction_of_wall": round(total_kernel_ms * 1e-3 / elapsed, 3)},
         }
         # the other bound: wave-level VALU instructions of the two passes (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r02_lde_pmc.txt:
-        # 2.22e8 + 4.12e8 per LDE; 1.082e9 in round 1) against the chip's issue rate
-        line["roofline"]["valu_issue"] = {"unit": "G wave-instructions/s", "insts_per_lde": 6.34e8,
-                                          "achieved": round(6.34e8 / (lde_ms * 1e-3) / 1e9, 1) if lde_ms > 0 else None,
+        # 2.19e8 + 3.58e8 per LDE; 1.082e9 in round 1) against the chip's issue rate
+        line["roofline"]["valu_issue"] = {"unit": "G wave-instructions/s", "insts_per_lde": 5.76e8,
+                                          "achieved": round(5.76e8 / (lde_ms * 1e-3) / 1e9, 1) if lde_ms > 0 else None,
                                           "peak": round(1024 * 2.05e9 / 4.2 / 1e9, 1),
                                           "note": "peak = 1024 SIMDs x 2.05 GHz / 4.2 clk per multiply-add-heavy instruction (tools/ubench); the row pass's mix "
                                                   "(adds, selects, moves) issues at 3.7 clk, so `achieved` can pass it: the row pass is instruction-bound at "
-                                                  "186 lane-instructions per element (225 with radix 16, ~490 per LDE output element in round 1)"}
+                                                  "162 lane-instructions per element (225 with radix 16, ~490 per LDE output element in round 1)"}
         if root is not None:
             line["aggregation_root"] = ["%016x" % x for x in root]
         if world == 1:
