@@ -65,6 +65,7 @@ __global__ void bitrev_permute_kernel(const uint64_t* in, uint64_t* out, uint32_
 // transposed (with both coordinates bit-reversed) through LDS, and written as 32 contiguous rows of block rev(m).  In place,
 // block m and block rev(m) are exchanged by one workgroup (the one with m <= rev m).  The element-wise kernel above scatters
 // 8-byte accesses and takes longer than the transform it follows (3.7 ms vs 2.8 ms at 2^20 x 135).
+// (64 x 64 tiles -- 512-byte rows on both sides, 66 KB of LDS per block -- measured twice as slow: 1.33 vs 0.61 ms at 2^20 x 135.)
 __global__ void __launch_bounds__(256) bitrev_tiled_kernel(const uint64_t* in, uint64_t* out, uint32_t log_n, uint64_t in_col_stride,
                                                          uint64_t out_col_stride) {
     __shared__ uint64_t t0[32][33], t1[32][33];
