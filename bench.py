@@ -378,7 +378,7 @@ def bn254_figures(gl, device):
     lib = ctx.lib
     g = torch.Generator(device="cuda")
     g.manual_seed(0x254)
-    out = {"what": "halo2 best_fft over bn256::Fr and best_multiexp over bn256::G1 (verifier_api.rs:77-92), operands resident; MSM: signed 16-bit windows, buckets by decreasing size, recursive bucket reduction, windows combined on the host"}
+    out = {"what": "halo2 best_fft over bn256::Fr and best_multiexp over bn256::G1 (verifier_api.rs:77-92), operands resident; MSM: signed 17-bit windows, buckets by decreasing size, recursive bucket reduction, windows combined on the host"}
     for k in (20, 22):
         x = torch.randint(0, (1 << 60) - 1, (1 << k, 4), dtype=torch.int64, device="cuda", generator=g)
         torch.cuda.synchronize()
