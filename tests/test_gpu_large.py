@@ -114,6 +114,18 @@ def test_lde_to_2p21_2p23(ctx, orc, log_n):
     eq(ctx.reverse_index_bits(br[0]), want[0])
 
 
+@pytest.mark.parametrize("log_n,rate_bits", [(15, 4), (16, 2), (18, 3), (19, 2), (19, 3), (15, 1)])
+def test_lde_two_pass_coset_shapes(ctx, orc, log_n, rate_bits):
+    """two-pass LDEs around the table-size limits of the all-cosets column pass: 16 / 4 / 2 cosets in one block, the largest sizes
+    that still get full pre tables (8 x 2^18, 4 x 2^19), and the first one that falls back to the per-element power tables (8 x 2^19)"""
+    rng = np.random.default_rng(0x456 + 8 * log_n + rate_bits)
+    c = rand_field(rng, (2, 1 << log_n))
+    c[0, :5] = [0, 0xFFFFFFFF00000000, 1, 0xFFFFFFFF00000000, 0]                      # zeros and p - 1 among the coefficients
+    want = orc.lde(c, rate_bits)
+    eq(ctx.lde(c, rate_bits), want)
+    eq(ctx.lde(c, rate_bits, bitrev=True), orc.reverse_index_bits(want.T.copy()).T)
+
+
 # ---- blinding stream -------------------------------------------------------------------------------------------------------
 def test_blinding_stream_kernel(ctx, orc):
     for seed, stream, count in ((1, 1, 4 << 16), (0xDEADBEEF << 64, 4, 6803 * 135 + 41), (99, 3, 5), (7, 2, 1)):
