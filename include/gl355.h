@@ -516,6 +516,9 @@ int32_t gl355_aggregation_root(gl355_ctx* ctx, const uint64_t* leaves, uint64_t 
  * (any 256-bit value is accepted and reduced); G1 points are affine x | y (8 u64), (0, 0) encodes the identity.
  *   gl355_bn254_fr_ntt   in place, natural order in and out: a[k] <- sum_i a[i] w^(ik), w = ROOT_OF_UNITY^(2^(28 - log_n));
  *                        inverse != 0: with w^-1 and the 1/n scaling (EvaluationDomain::ifft)
+ *   gl355_bn254_fr_coset_ntt   EvaluationDomain::coeff_to_extended / extended_to_coeff: forward, 2^log_small coefficients c_i ->
+ *                        out[k] = sum_i c_i shift^i w^(ik) for k < 2^log_n (zero-padded, w the 2^log_n-th root); inverse, 2^log_n evaluations ->
+ *                        the first 2^log_small coefficients, each divided by shift^i (and by 2^log_n).  in != out
  *   gl355_bn254_g1_msm   result = sum_i scalars[i] * points[i]  (Pippenger buckets, signed digits; the windows are combined on the host)
  *   gl355_bn254_g1_msm_batch   n_sets MSMs over the SAME bases (the commitments of several columns under one SRS: ParamsKZG::commit per
  *                        advice / fixed / permutation polynomial): the sets' windows run as more windows of one MSM, so the point conversion is
@@ -523,6 +526,8 @@ int32_t gl355_aggregation_root(gl355_ctx* ctx, const uint64_t* leaves, uint64_t 
  *   gl355_bn254_g1_fixed_base_mul   out[i] = scalars[i] * base: the powers-of-tau loop of ParamsKZG::setup (verifier_api.rs:77),
  *                        8-bit windows over a per-call table, one inversion per output; out is n x 8 affine points */
 int32_t gl355_bn254_fr_ntt(gl355_ctx* ctx, uint64_t* data /* n x 4 */, uint32_t log_n, int32_t inverse);
+int32_t gl355_bn254_fr_coset_ntt(gl355_ctx* ctx, const uint64_t* in, uint32_t log_small, uint32_t log_n, const uint64_t shift[4], int32_t inverse,
+                                 uint64_t* out);
 int32_t gl355_bn254_g1_msm(gl355_ctx* ctx, const uint64_t* points /* n x 8 */, const uint64_t* scalars /* n x 4 */, uint64_t n, uint64_t result[8]);
 int32_t gl355_bn254_g1_msm_batch(gl355_ctx* ctx, const uint64_t* points /* n x 8 */, const uint64_t* scalars /* n_sets x n x 4 */, uint64_t n,
                                  uint32_t n_sets, uint64_t* results /* n_sets x 8 */);

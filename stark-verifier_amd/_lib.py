@@ -165,6 +165,7 @@ SIGNATURES = {
     "gl355_comm_max_f64": (C.c_int32, [vp, C.POINTER(C.c_double)]),
     "gl355_aggregation_root": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
     "gl355_bn254_fr_ntt": (C.c_int32, [vp, vp, C.c_uint32, C.c_int32]),
+    "gl355_bn254_fr_coset_ntt": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_int32, vp]),
     "gl355_bn254_g1_msm": (C.c_int32, [vp, vp, vp, C.c_uint64, vp]),
     "gl355_bn254_g1_msm_batch": (C.c_int32, [vp, vp, vp, C.c_uint64, C.c_uint32, vp]),
     "gl355_bn254_g1_fixed_base_mul": (C.c_int32, [vp, vp, vp, C.c_uint64, vp]),

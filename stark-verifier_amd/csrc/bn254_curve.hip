@@ -206,6 +206,12 @@ __global__ void fr_twiddle_kernel(uint64_t* tw, uint64_t count, const uint64_t* 
     if (i >= count) return;
     store256(tw + 4 * i, m_mul<F_R>(load256(lo + 4 * (i & 1023)), load256(hi + 4 * (i >> 10))));
 }
+// the same powers as PLAIN integers times a plain factor f: (lo hi) R * f * R^-1 = lo hi f
+__global__ void fr_power_plain_kernel(uint64_t* tab, uint64_t count, const uint64_t* lo, const uint64_t* hi, u256 f) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    store256(tab + 4 * i, m_canon<F_R>(m_mul<F_R>(m_mul<F_R>(load256(lo + 4 * (i & 1023)), load256(hi + 4 * (i >> 10))), f)));
+}
 __global__ void fr_bitrev_kernel(uint64_t* data, uint32_t log_n) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= (1ull << log_n)) return;
@@ -242,6 +248,11 @@ struct FrPass {
     uint32_t log_n, s0, ns;
     uint32_t first, last, use_scale;
     u256 scale;
+    // coset forms (coeff_to_extended / extended_to_coeff): the first pass reads n_in <= n inputs (zero beyond) times pre[i] (Montgomery),
+    // the last pass writes n_out <= n outputs times post[i] (plain integers, the 1/n included) instead of `scale`
+    uint64_t n_in, n_out;
+    const uint64_t* pre;
+    const uint64_t* post;
 };
 __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
     __shared__ uint32_t lds[8][1024];
@@ -255,8 +266,13 @@ __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
         const uint32_t r = e >> log_c, c = e & (C - 1);
         const uint64_t i = base + ((uint64_t)r << a.s0) + c;
         u256 x;
-        if (a.first) x = m_from_int<F_R>(load256(a.in + 4 * (__brevll(i) >> (64 - a.log_n))));
-        else x = load256(a.in + 4 * i);
+        if (a.first) {
+            const uint64_t src = __brevll(i) >> (64 - a.log_n);
+            if (src < a.n_in) {
+                x = m_from_int<F_R>(load256(a.in + 4 * src));
+                if (a.pre) x = m_mul<F_R>(x, load256(a.pre + 4 * src));
+            } else x = u_zero();
+        } else x = load256(a.in + 4 * i);
 #pragma unroll
         for (int l = 0; l < 8; l++) lds[l][e] = x.l[l];
     }
@@ -285,7 +301,11 @@ __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
         u256 x;
 #pragma unroll
         for (int l = 0; l < 8; l++) x.l[l] = lds[l][e];
-        if (a.last) x = a.use_scale ? m_canon<F_R>(m_mul<F_R>(x, a.scale)) : m_to_int<F_R>(x);
+        if (a.last) {
+            if (i >= a.n_out) continue;
+            if (a.post) x = m_canon<F_R>(m_mul<F_R>(x, load256(a.post + 4 * i)));
+            else x = a.use_scale ? m_canon<F_R>(m_mul<F_R>(x, a.scale)) : m_to_int<F_R>(x);
+        }
         store256(a.out + 4 * i, x);
     }
 }
@@ -741,42 +761,53 @@ u256 to_u256(const H256& a) {
 
 extern "C" {
 
-int32_t gl355_bn254_fr_ntt(gl355_ctx* h, uint64_t* data, uint32_t log_n, int32_t inverse) {
-    Ctx* ctx = ctx_of(h);
-    if (!ctx) return GL355_E_INVALID_ARG;
-    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
-    if (!data) return ctx->fail(GL355_E_INVALID_ARG, "bn254_fr_ntt: null data");
-    if (log_n > 26) return ctx->fail(GL355_E_UNSUPPORTED, "bn254_fr_ntt: log_n > 26 unsupported (Fr has 2-adicity 28)");
-    const uint64_t n = 1ull << log_n;
-    if (log_n == 0) return GL355_OK;
+// in: n_in = 2^log_in values, out: n_out values of the 2^log_n-point transform; shift == nullptr: the plain transform
+static int32_t fr_ntt_run(Ctx* ctx, const uint64_t* in, uint32_t log_in, uint64_t* out, uint64_t n_out, uint32_t log_n, int32_t inverse,
+                          const uint64_t* shift) {
+    const uint64_t n = 1ull << log_n, n_in = 1ull << log_in;
     // omega_n = ROOT^(2^(28 - log_n)) (or its inverse), as a plain integer, then to Montgomery form: * R mod r
     H256 w = inverse ? H256{{BN254C_FR_ROOT_INV_64[0], BN254C_FR_ROOT_INV_64[1], BN254C_FR_ROOT_INV_64[2], BN254C_FR_ROOT_INV_64[3]}}
                      : H256{{BN254C_FR_ROOT_64[0], BN254C_FR_ROOT_64[1], BN254C_FR_ROOT_64[2], BN254C_FR_ROOT_64[3]}};
     for (uint32_t k = log_n; k < BN254C_FR_S; k++) w = h_mulmod(w, w);
     const H256 Rm = {{BN254C_FR_ONE_64[0], BN254C_FR_ONE_64[1], BN254C_FR_ONE_64[2], BN254C_FR_ONE_64[3]}};      // R mod r
     const u256 w_mont = to_u256(h_mulmod(w, Rm));
-    u256 scale = to_u256(H256{{0, 0, 0, 0}});
-    if (inverse) {
-        H256 e = {{HR[0] - 2, HR[1], HR[2], HR[3]}};
-        scale = to_u256(h_powmod(H256{{n, 0, 0, 0}}, e));                  // n^-1 mod r, plain
+    const H256 e_inv = {{HR[0] - 2, HR[1], HR[2], HR[3]}};
+    H256 scale_h = {{1, 0, 0, 0}};
+    if (inverse) scale_h = h_powmod(H256{{n, 0, 0, 0}}, e_inv);              // n^-1 mod r, plain
+    const u256 scale = to_u256(scale_h);
+    // coset: powers of the shift multiply the inputs of the forward form, powers of its inverse (and 1/n) the outputs of the inverse form
+    u256 pow_base = to_u256(H256{{0, 0, 0, 0}});
+    if (shift) {
+        H256 sh = {{shift[0], shift[1], shift[2], shift[3]}};
+        while (h_geq(sh)) { unsigned __int128 br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 dd = (unsigned __int128)sh.l[i] - HR[i] - (uint64_t)br; sh.l[i] = (uint64_t)dd; br = (dd >> 64) & 1; } }
+        if ((sh.l[0] | sh.l[1] | sh.l[2] | sh.l[3]) == 0) return ctx->fail(GL355_E_INVALID_ARG, "bn254_fr_coset_ntt: the shift must not be zero");
+        if (inverse) sh = h_powmod(sh, e_inv);
+        pow_base = to_u256(h_mulmod(sh, Rm));
     }
-    Staged sd(ctx);
-    GL355_TRY(sd.open(data, n * 32, 3));
+    const uint64_t n_pow = shift ? (inverse ? n_out : n_in) : 0;
     Scratch tw(ctx);
-    const uint64_t n_hi = (n / 2 + 1023) / 1024;
-    GL355_TRY(tw.get((n / 2) * 32 + 32 + n * 32 + (1024 + n_hi) * 32));
-    uint64_t* d = sd.as<uint64_t>();
+    const uint64_t n_hi = (std::max(n / 2, n_pow) + 1023) / 1024;
+    GL355_TRY(tw.get((n / 2) * 32 + 32 + n * 32 + 2 * (1024 + n_hi) * 32 + n_pow * 32));
     uint64_t* twp = tw.as<uint64_t>();
     uint64_t* work = twp + 4 * (n / 2) + 4;                 // the first pass reads the data bit-reversed: it cannot run in place
     uint64_t* tw_lo = work + 4 * n;
     uint64_t* tw_hi = tw_lo + 4 * 1024;
+    uint64_t* pw_lo = tw_hi + 4 * n_hi;
+    uint64_t* pw_hi = pw_lo + 4 * 1024;
+    uint64_t* pw = pw_hi + 4 * n_hi;
     const uint32_t hblk = (uint32_t)((n / 2 + 255) / 256);
     static const bool staged = getenv("GL355_EXP_FR_NTT_STAGES") != nullptr;      // A/B: one global pass per stage (the first slice)
     {
-        ProfScope ps(ctx, "bn254_fr_ntt", n * 64);
+        ProfScope ps(ctx, "bn254_fr_ntt", (n_in + n_out) * 32);
         hipLaunchKernelGGL(fr_twiddle_seed_kernel, dim3((uint32_t)((1024 + n_hi + 255) / 256)), dim3(256), 0, ctx->stream, tw_lo, tw_hi, n_hi, w_mont);
         hipLaunchKernelGGL(fr_twiddle_kernel, dim3(hblk ? hblk : 1), dim3(256), 0, ctx->stream, twp, n / 2, tw_lo, tw_hi);
-        if (staged) {
+        if (n_pow) {
+            hipLaunchKernelGGL(fr_twiddle_seed_kernel, dim3((uint32_t)((1024 + n_hi + 255) / 256)), dim3(256), 0, ctx->stream, pw_lo, pw_hi, n_hi, pow_base);
+            if (inverse) hipLaunchKernelGGL(fr_power_plain_kernel, dim3((uint32_t)((n_pow + 255) / 256)), dim3(256), 0, ctx->stream, pw, n_pow, pw_lo, pw_hi, scale);
+            else hipLaunchKernelGGL(fr_twiddle_kernel, dim3((uint32_t)((n_pow + 255) / 256)), dim3(256), 0, ctx->stream, pw, n_pow, pw_lo, pw_hi);
+        }
+        if (staged && !shift && in == out && n_in == n && n_out == n) {
+            uint64_t* d = out;
             const uint32_t blk = (uint32_t)((n + 255) / 256);
             hipLaunchKernelGGL(fr_to_mont_kernel, dim3(blk), dim3(256), 0, ctx->stream, d, n);
             hipLaunchKernelGGL(fr_bitrev_kernel, dim3(blk), dim3(256), 0, ctx->stream, d, log_n);
@@ -793,20 +824,60 @@ int32_t gl355_bn254_fr_ntt(gl355_ctx* h, uint64_t* data, uint32_t log_n, int32_t
             const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, n / 1024);
             for (size_t k = 0; k < ns.size(); k++) {
                 FrPass pa;
+                memset(&pa, 0, sizeof pa);
                 pa.first = k == 0; pa.last = k + 1 == ns.size();
-                pa.in = pa.first ? d : work;
-                pa.out = pa.last ? d : work;
-                if (pa.first && pa.last) pa.out = work;          // a single pass (n <= 1024) still reads bit-reversed: copy back below
+                pa.in = pa.first ? in : work;
+                // the last pass may write straight to `out` unless it is also the first one and out aliases in (bit-reversed reads)
+                pa.out = (pa.last && !(pa.first && in == out)) ? out : work;
                 pa.tw = twp; pa.log_n = log_n; pa.s0 = s0; pa.ns = ns[k];
                 pa.use_scale = inverse ? 1 : 0; pa.scale = scale;
+                pa.n_in = n_in; pa.n_out = pa.out == out ? n_out : n;
+                pa.pre = (shift && !inverse) ? pw : nullptr;
+                pa.post = (shift && inverse && pa.out == out) ? pw : nullptr;
                 hipLaunchKernelGGL(fr_fft_pass_kernel, dim3(tiles), dim3(256), 0, ctx->stream, pa);
                 s0 += ns[k];
             }
-            if (ns.size() == 1) GL355_HIP(ctx, hipMemcpyAsync(d, work, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+            if (ns.size() == 1 && in == out) {
+                if (shift && inverse) return ctx->fail(GL355_E_UNSUPPORTED, "bn254_fr_coset_ntt: in-place inverse coset transform of <= 1024 points");
+                GL355_HIP(ctx, hipMemcpyAsync(out, work, n_out * 32, hipMemcpyDeviceToDevice, ctx->stream));
+            }
         }
         GL355_HIP(ctx, hipGetLastError());
     }
+    return GL355_OK;
+}
+
+int32_t gl355_bn254_fr_ntt(gl355_ctx* h, uint64_t* data, uint32_t log_n, int32_t inverse) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+    if (!data) return ctx->fail(GL355_E_INVALID_ARG, "bn254_fr_ntt: null data");
+    if (log_n > 26) return ctx->fail(GL355_E_UNSUPPORTED, "bn254_fr_ntt: log_n > 26 unsupported (Fr has 2-adicity 28)");
+    const uint64_t n = 1ull << log_n;
+    if (log_n == 0) return GL355_OK;
+    Staged sd(ctx);
+    GL355_TRY(sd.open(data, n * 32, 3));
+    GL355_TRY(fr_ntt_run(ctx, sd.as<uint64_t>(), log_n, sd.as<uint64_t>(), n, log_n, inverse, nullptr));
     return sd.finish();
+}
+
+int32_t gl355_bn254_fr_coset_ntt(gl355_ctx* h, const uint64_t* in, uint32_t log_small, uint32_t log_n, const uint64_t shift[4], int32_t inverse,
+                                 uint64_t* out) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+    if (!in || !out || !shift) return ctx->fail(GL355_E_INVALID_ARG, "bn254_fr_coset_ntt: null argument");
+    if (in == out) return ctx->fail(GL355_E_INVALID_ARG, "bn254_fr_coset_ntt: in and out must differ");
+    if (log_n > 26 || log_small > log_n) return ctx->fail(GL355_E_UNSUPPORTED, "bn254_fr_coset_ntt: needs log_small <= log_n <= 26");
+    if (log_n == 0) return ctx->fail(GL355_E_UNSUPPORTED, "bn254_fr_coset_ntt: log_n == 0");
+    const uint64_t n = 1ull << log_n, ns = 1ull << log_small;
+    // forward: 2^log_small coefficients -> 2^log_n evaluations on shift * <omega_n>; inverse: 2^log_n evaluations -> 2^log_small coefficients
+    const uint64_t n_in = inverse ? n : ns, n_out = inverse ? ns : n;
+    Staged si(ctx), so(ctx);
+    GL355_TRY(si.open(in, n_in * 32, 1));
+    GL355_TRY(so.open(out, n_out * 32, 2));
+    GL355_TRY(fr_ntt_run(ctx, si.as<uint64_t>(), inverse ? log_n : log_small, so.as<uint64_t>(), n_out, log_n, inverse, shift));
+    return so.finish();
 }
 
 static int32_t msm_run(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t m, uint64_t* result) {

@@ -191,3 +191,32 @@ def test_g1_msm_batch_equals_single_msms(ctx, orc):
             ref = cv.msm_arrays(pts, sc[j]) if n == 300 else gpu_msm(ctx, pts, sc[j])
             assert np.array_equal(out[j], ref), (n, j)
     assert ctx.lib.gl355_bn254_g1_msm_batch(ctx.h, pts.ctypes.data, sc.ctypes.data, 4, 65, out.ctypes.data) == -5       # GL355_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("log_small,log_n", [(3, 3), (6, 9), (9, 11), (10, 13), (12, 14)])
+def test_fr_coset_ntt_vs_oracle(ctx, orc, log_small, log_n):
+    """coeff_to_extended / extended_to_coeff of halo2's EvaluationDomain: c_i shift^i zero-padded, transformed -- against the oracle's FFT of
+    the shifted coefficients (Python integers for the powers); the inverse form gives the coefficients back"""
+    cv = Bn254Curve(orc)
+    rng = np.random.default_rng(0x4E8 + log_n)
+    ns, n = 1 << log_small, 1 << log_n
+    shift = 0x1D4C7A2B5E6F8091A2B3C4D5E6F708192A3B4C5D6E7F8091A2B3C4D5E6F7081 % pm.R
+    c = rand_scalars(rng, ns, below_r=False)
+    ci = [v % pm.R for v in cv.ints(c)]
+    padded = cv.scalars([ci[i] * pow(shift, i, pm.R) % pm.R if i < ns else 0 for i in range(n)])
+    want = cv.ntt_array(padded)
+    sh = cv.scalars([shift])[0]
+    out = np.full((n, 4), 0xAA, dtype=np.uint64)
+    ctx.check(ctx.lib.gl355_bn254_fr_coset_ntt(ctx.h, np.ascontiguousarray(c).ctypes.data, log_small, log_n, sh.ctypes.data, 0, out.ctypes.data))
+    assert np.array_equal(out, want)
+    back = np.full((ns, 4), 0xAA, dtype=np.uint64)
+    ctx.check(ctx.lib.gl355_bn254_fr_coset_ntt(ctx.h, out.ctypes.data, log_small, log_n, sh.ctypes.data, 1, back.ctypes.data))
+    assert cv.ints(back) == ci
+    # the inverse form on arbitrary evaluations: ifft, divide by shift^i, keep the first 2^log_small
+    ev = rand_scalars(rng, n)
+    inv = cv.ints(cv.ntt_array(ev, inverse=True))
+    sinv = pow(shift, pm.R - 2, pm.R)
+    ctx.check(ctx.lib.gl355_bn254_fr_coset_ntt(ctx.h, ev.ctypes.data, log_small, log_n, sh.ctypes.data, 1, back.ctypes.data))
+    assert cv.ints(back) == [inv[i] * pow(sinv, i, pm.R) % pm.R for i in range(ns)]
+    zero = np.zeros(4, dtype=np.uint64)
+    assert ctx.lib.gl355_bn254_fr_coset_ntt(ctx.h, ev.ctypes.data, log_small, log_n, zero.ctypes.data, 0, out.ctypes.data) == -1
