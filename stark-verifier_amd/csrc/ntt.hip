@@ -291,14 +291,21 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
     if (!p.in_bitrev) {
         // natural in -> (cols over N1, twiddle at store) -> (rows over N2) -> bit-reversed out
         split_two_pass(p.log_n, true, &l1, &l2);
+        // From 2^22 points on, THREE passes over 4096-element tiles beat two with 16384-point rows (one block per CU, 4 waves per SIMD):
+        // after the column pass over N1 = N / 2^17 the rows are independent 2^17-point transforms, each the usual column + row pair.
+        // Forward, single coset, contiguous output columns, no pre-multiplier (plain forward NTT: cfg-2 (C)); 2^22 x 16: 1.44 -> see DESIGN 4.1
+        static const bool no3 = getenv("GL355_EXP_NTT_NO_3PASS") != nullptr;
+        const bool three = !no3 && !ntt_r16_only() && !inv && p.log_n >= 22 && p.n_cosets == 1 && !p.pre_lo && !p.post_lo && p.scale == 1 &&
+                           p.out_col_stride == (1ull << p.log_n) && p.coset_slot[0] == 0;
+        if (three) { l2 = 17; l1 = p.log_n - l2; }
         a.in = p.in; a.out = p.out;
         a.in_col_stride = p.in_col_stride; a.out_col_stride = p.out_col_stride;
         a.log_rows = l2;  // log2(N2): row stride of the N1 x N2 matrix
         a.pre_lo = p.pre_lo; a.pre_hi = p.pre_hi;
         a.step_lo = step_lo; a.step_hi = step_hi;
-        if (p.log_n <= 20) {
-            // full-size tables (<= 8 MiB each): 1 load + 1 modmul per element instead of 2 + 2 (beyond 2^20 measured a wash: 2^21
-            // slower, 2^22 / 2^23 +2-3 %)
+        if (p.log_n <= 20 || three) {
+            // full-size tables (<= 8 MiB each; the three-pass form: up to 128 MiB of 288 GiB): 1 load + 1 modmul per element instead
+            // of 2 + 2 (beyond 2^20 measured a wash for the radix-16 kernels: 2^21 slower, 2^22 / 2^23 +2-3 %)
             if (p.pre_lo && ((uint64_t)p.n_cosets << p.log_n) <= (1ull << 21)) {
                 GL355_TRY(ctx->full_pow_table(p.pre_lo, p.pre_hi, p.n_cosets, p.log_n, &a.pre_full));
                 a.pre_full_stride = 1ull << p.log_n;
@@ -312,6 +319,16 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         }
         a.in_bitrev = 0; a.out_natural = 0; a.canon = 0;
         { ProfScope ps(ctx, "ntt_cols_pass1", ((uint64_t)p.batch << p.log_n) * 8); GL355_HIP(ctx, launch_cols(a, l1, inv, ctx->stream)); }
+        if (three) {
+            NttPlan sub;
+            sub.in = p.out; sub.out = p.out;
+            sub.in_col_stride = sub.out_col_stride = 1ull << l2;
+            sub.log_n = l2; sub.batch = p.batch << l1;
+            sub.inverse = false; sub.in_bitrev = false; sub.out_bitrev = true;
+            GL355_TRY(ntt_run(ctx, sub));
+            if (!p.out_bitrev) GL355_TRY(bitrev_permute(ctx, p.out, p.out, p.log_n, 1, p.out_col_stride, p.out_col_stride, p.batch));
+            return GL355_OK;
+        }
         PassArgs b = a;
         b.in = p.out; b.in_col_stride = p.out_col_stride;
         // each coset's intermediate lives in its own output block: rows pass runs per coset slot
