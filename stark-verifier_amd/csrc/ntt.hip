@@ -182,8 +182,11 @@ static hipError_t launch_rows(const PassArgs& a, uint32_t log_t, bool inv, hipSt
         (a.pre_full || !a.pre_lo || !a.pre_hi)) {
         PassArgs b = a;
         if (!b.pre_full && b.pre_lo) { b.pre_full = b.pre_lo; b.pre_full_stride = 4096; }   // n <= 2^12: the one-level table is the full one
-        return launch_rows_r8(b, log_t, s);
+        return launch_rows_r8(b, log_t, false, s);
     }
+    // ... and so do the inverse forms without multiplier tables (values -> coefficients: natural order within the row and the 1/n at the store)
+    if (!ntt_r16_only() && inv && log_t >= 12 && log_t <= 14 && !a.post_lo && !a.pre_lo && !a.pre_full && a.canon && !a.in_bitrev)
+        return launch_rows_r8(a, log_t, true, s);
     const uint64_t total_rows = ((uint64_t)a.batch) << a.log_rows;
     const int lt = log_t <= 12 ? 12 : (int)log_t;
     const uint64_t rpt = 1ull << (lt - log_t);
@@ -204,10 +207,11 @@ template <int LOG_T>
 static hipError_t launch_cols_t(const PassArgs& a, bool inv, uint64_t blocks, hipStream_t s) {
     const size_t shmem = (4096 + 256) * sizeof(uint64_t);
     const bool fast = !inv && a.pre_full && a.step_full && !a.in_bitrev && !a.out_natural && !a.post_lo && a.scale == 1 && !a.canon;
-    const bool r8 = !inv && a.step_full && (a.pre_full || !a.pre_lo) && !a.in_bitrev && !a.out_natural && !a.post_lo && a.scale == 1 && !a.canon;
+    const bool r8 = a.step_full && (inv ? !a.pre_lo && !a.pre_full : (a.pre_full || !a.pre_lo)) && !a.in_bitrev && !a.out_natural && !a.post_lo &&
+                    a.scale == 1 && !a.canon;
     static const bool per_coset = getenv("GL355_EXP_NTT_PER_COSET") != nullptr;     // A/B: one block per (tile, coset) as before
-    if (r8 && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset) return launch_cols_r8_cosets(a, LOG_T, s);
-    if (r8 && !ntt_r16_only()) return launch_cols_r8(a, LOG_T, s);
+    if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset) return launch_cols_r8_cosets(a, LOG_T, s);
+    if (r8 && !ntt_r16_only()) return launch_cols_r8(a, LOG_T, inv, s);
     if (fast) hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, false, true>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
     else if (inv) hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, true>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
     else hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, false>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);

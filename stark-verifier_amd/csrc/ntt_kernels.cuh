@@ -250,8 +250,8 @@ struct PassArgs {
 };
 
 // radix-8 commit-path kernels, compiled in ntt_r8.hip
-hipError_t launch_rows_r8(const PassArgs& a, uint32_t log_t, hipStream_t s);
-hipError_t launch_cols_r8(const PassArgs& a, uint32_t log_t, hipStream_t s);
+hipError_t launch_rows_r8(const PassArgs& a, uint32_t log_t, bool inv, hipStream_t s);
+hipError_t launch_cols_r8(const PassArgs& a, uint32_t log_t, bool inv, hipStream_t s);
 hipError_t launch_cols_r8_cosets(const PassArgs& a, uint32_t log_t, hipStream_t s);
 
 // Row pass: each row = 2^LOG_T contiguous elements; a tile packs 2^(LT-LOG_T) rows.
@@ -336,7 +336,9 @@ GL_DEV void dif_tile_r8(uint64_t* lds, const uint64_t* __restrict__ tw, int LO, 
 }
 // Row pass / single pass: one 2^LT-point row per tile; PRE = multiply by the full table a.pre_full (coset powers) at the load.
 // blockIdx = tile * n_cosets + coset like the radix-16 kernel (each XCD keeps one coset's table in its L2).
-template <int LT, bool PRE, int WPE>
+// INV: the inverse transform (omega^-1 twiddles and shifts); it also honours a.out_natural (natural order within the row: the single-pass
+// ifft) and a.scale (the 1/n), both wave-uniform tests at the store.
+template <int LT, bool PRE, int WPE, bool INV = false>
 __global__ void __launch_bounds__(LT >= 13 ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_rows_r8_kernel(PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     constexpr int NT = LT >= 13 ? 1024 : 512, EPT = (1 << LT) / NT;
@@ -355,11 +357,15 @@ __global__ void __launch_bounds__(LT >= 13 ? 1024 : 512) __attribute__((amdgpu_w
         lds[lds_phys(g)] = v;
     }
     __syncthreads();
-    dif_tile_r8<LT, LT, false>(lds, a.tw_r8, 0, tid, NT);
+    dif_tile_r8<LT, LT, INV>(lds, a.tw_r8, 0, tid, NT);
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
         const uint32_t g = tid + i * NT;
-        out[g] = gl_canon(lds[lds_phys(g)]);
+        if constexpr (INV) {
+            uint64_t v = lds[lds_phys(a.out_natural ? brev(g, LT) : g)];
+            if (a.scale != 1) v = gl_mul(v, a.scale);
+            out[g] = gl_canon(v);
+        } else out[g] = gl_canon(lds[lds_phys(g)]);
     }
 }
 
@@ -427,7 +433,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) n
 }
 
 // Column pass of the commit path (full step table, PRE = full pre table, nothing else) with radix-8 rounds: 8 elements per thread, 512 threads per tile.
-template <int LOG_T, bool PRE, int WPE>
+template <int LOG_T, bool PRE, int WPE, bool INV = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_cols_r8_kernel(PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     constexpr int LT = 12, NT = 512;
@@ -453,7 +459,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
         lds[lds_phys(g)] = v;
     }
     __syncthreads();
-    dif_tile_r8<LT, LOG_T, false>(lds, a.tw_r8, LOG_TC, tid, NT);
+    dif_tile_r8<LT, LOG_T, INV>(lds, a.tw_r8, LOG_TC, tid, NT);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint32_t g = tid + i * NT;

@@ -10,6 +10,16 @@
 namespace gl355 {
 
 template <int LT>
+static hipError_t launch_rows8_inv(const PassArgs& a, uint64_t blocks, hipStream_t s) {       // inverse: no pre table
+    constexpr int NT = LT >= 13 ? 1024 : 512;
+    constexpr int WPE = LT <= 13 ? 8 : 4;
+    const size_t shmem = ((1u << LT) + (1u << (LT - 4))) * sizeof(uint64_t);
+    auto k = ntt_rows_r8_kernel<LT, false, WPE, true>;
+    if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
+    return hipGetLastError();
+}
+template <int LT>
 static hipError_t launch_rows8_lt(const PassArgs& a, uint64_t blocks, hipStream_t s) {
     constexpr int NT = LT >= 13 ? 1024 : 512;
     // 8192-point tiles: two 1024-thread blocks per CU need <= 64 VGPRs (0.65 -> 0.53 ms
@@ -29,8 +39,16 @@ static hipError_t launch_rows8_lt(const PassArgs& a, uint64_t blocks, hipStream_
 }
 
 // rows of 2^log_t points (log_t = 12, 13, 14), a.batch << a.log_rows of them, times a.n_cosets
-hipError_t launch_rows_r8(const PassArgs& a, uint32_t log_t, hipStream_t s) {
+hipError_t launch_rows_r8(const PassArgs& a, uint32_t log_t, bool inv, hipStream_t s) {
     const uint64_t blocks = (((uint64_t)a.batch) << a.log_rows) * a.n_cosets;
+    if (inv) {
+        switch (log_t) {
+            case 12: return launch_rows8_inv<12>(a, blocks, s);
+            case 13: return launch_rows8_inv<13>(a, blocks, s);
+            case 14: return launch_rows8_inv<14>(a, blocks, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (log_t) {
         case 12: return launch_rows8_lt<12>(a, blocks, s);
         case 13: return launch_rows8_lt<13>(a, blocks, s);
@@ -52,14 +70,15 @@ hipError_t launch_rows_r8(const PassArgs& a, uint32_t log_t, hipStream_t s) {
     }
 }
 
-hipError_t launch_cols_r8(const PassArgs& a, uint32_t log_t, hipStream_t s) {
+hipError_t launch_cols_r8(const PassArgs& a, uint32_t log_t, bool inv, hipStream_t s) {
     const uint64_t n2 = 1ull << a.log_rows;
     const uint64_t tc = 1ull << (12 - log_t);
     const uint64_t blocks = (n2 / tc) * a.batch * a.n_cosets;
     const size_t shmem = (4096 + 256) * sizeof(uint64_t);
     switch (log_t) {
 #define GL355_COL8_CASE(L) case L:                                                                                            \
-        if (a.pre_full) hipLaunchKernelGGL((ntt_cols_r8_kernel<L, true, 4>), dim3((uint32_t)blocks), dim3(512), shmem, s, a);  \
+        if (inv) hipLaunchKernelGGL((ntt_cols_r8_kernel<L, false, 4, true>), dim3((uint32_t)blocks), dim3(512), shmem, s, a);  \
+        else if (a.pre_full) hipLaunchKernelGGL((ntt_cols_r8_kernel<L, true, 4>), dim3((uint32_t)blocks), dim3(512), shmem, s, a);  \
         else hipLaunchKernelGGL((ntt_cols_r8_kernel<L, false, 4>), dim3((uint32_t)blocks), dim3(512), shmem, s, a);            \
         break;
         GL355_COL8_CASE(1) GL355_COL8_CASE(2) GL355_COL8_CASE(3) GL355_COL8_CASE(4) GL355_COL8_CASE(5) GL355_COL8_CASE(6)

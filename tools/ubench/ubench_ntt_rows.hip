@@ -15,8 +15,8 @@
 #include <vector>
 using namespace gl355;
 namespace gl355 {   // declared by the header for the library build; not used here
-hipError_t launch_rows_r8(const PassArgs&, uint32_t, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_cols_r8(const PassArgs&, uint32_t, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_rows_r8(const PassArgs&, uint32_t, bool, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_cols_r8(const PassArgs&, uint32_t, bool, hipStream_t) { return hipErrorNotSupported; }
 }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
