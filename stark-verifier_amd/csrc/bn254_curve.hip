@@ -975,9 +975,12 @@ static int32_t msm_run(gl355_ctx* h, const uint64_t* points, const uint64_t* sca
     }
     // per window S (and Wt when there was at least one level): 2 x W Jacobian points to the host, which combines the windows
     std::vector<uint32_t> hs(W * 24), hw(W * 24, 0);
+    uint32_t big_used[2] = {0, 0};
+    GL355_HIP(ctx, ctx->d2h(big_used, a.big_counters, 8));
     GL355_HIP(ctx, ctx->d2h(hs.data(), fin_s, W * 96));
     if (fin_w) GL355_HIP(ctx, ctx->d2h(hw.data(), fin_w, W * 96));
     GL355_HIP(ctx, ctx->wait());
+    if (big_used[0] > a.max_items || big_used[1] > a.max_big) return ctx->fail(GL355_E_HIP, "bn254_g1_msm: big-bucket work list overflow (internal bound)");
     std::vector<uint64_t> res(8ull * m);
     for (uint32_t set = 0; set < m; set++)
         bn254_g1_horner_host(hs.data() + 24ull * set * a.wps, fin_w ? hw.data() + 24ull * set * a.wps : nullptr, a.wps, a.c, res.data() + 8 * set);
