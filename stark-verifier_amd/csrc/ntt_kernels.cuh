@@ -334,6 +334,76 @@ GL_DEV void dif_tile_r8(uint64_t* lds, const uint64_t* __restrict__ tw, int LO, 
     if constexpr (REM == 1) dif_round<LT, 1, INV>(lds, tw, 1, LO, tid, nthreads);
     if constexpr (REM != 0) __syncthreads();
 }
+// The first radix-8 round straight from the registers that loaded the tile, and the last round straight to its consumer: a thread that
+// loaded tile elements tid + q * NT (q < 8, NT = 2^(LT-3) threads) holds exactly the operands of its own first-round butterfly (the first
+// DIF round pairs elements 2^(LT-3) apart), so the load -> LDS -> barrier -> LDS -> registers detour is skipped; and the last round's
+// results (no twiddles follow) can go to `sink(tile index, value)` instead of back to LDS.  GL355_NTT_R8_DIRECT=0 keeps the staged form (A/B).
+#ifndef GL355_NTT_R8_DIRECT
+#define GL355_NTT_R8_DIRECT 1
+#endif
+template <int LT, int LOG_T, bool INV>
+GL_DEV void dif_first_round_regs(uint64_t (&x)[16], uint64_t* lds, const uint64_t* __restrict__ tw, int LO, int tid) {
+    static_assert(LOG_T >= 3, "needs a radix-8 first round");
+    constexpr int fbit = LT - 3;
+    if constexpr (!(GL355_NTT_KO & 8)) {
+        if constexpr (GL355_NTT_R8_LAZY != 0) dif8_lazy<INV>(x);
+        else dif_regs<3, INV>(x);
+    }
+    if constexpr (LOG_T > 3 && (GL355_NTT_KO & 4) == 0) {
+        const uint32_t r = ((uint32_t)tid >> LO) & ((1u << (LOG_T - 3)) - 1);
+        const uint64_t* __restrict__ twm = tw + (1u << LOG_T) + r;
+#pragma unroll
+        for (int q = 1; q < 8; q++) {
+            if constexpr (GL355_NTT_KO & 1) x[q] = gl_mul(x[q], x[0] + r * brev(q, 3));
+            else x[q] = gl_mul(x[q], twm[brev(q, 3) << (LOG_T - 3)]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) lds[lds_phys((uint32_t)tid + ((uint32_t)q << fbit))] = x[q];
+}
+// last round of radix 2^RHO (m == RHO: no twiddles): LDS -> network -> sink(tile index, value)
+template <int LT, int RHO, bool INV, class Sink>
+GL_DEV void dif_last_round_sink(const uint64_t* lds, int LO, int tid, int nthreads, Sink sink) {
+    constexpr int R = 1 << RHO;
+    const int tasks = (1 << LT) >> RHO;
+    const int fbit = LO;
+    for (int t = tid; t < tasks; t += nthreads) {
+        const uint32_t low = t & ((1u << fbit) - 1), high = t >> fbit;
+        const uint32_t idx0 = (high << (fbit + RHO)) | low;
+        uint64_t x[16];
+#pragma unroll
+        for (int q = 0; q < R; q++) x[q] = lds[lds_phys(idx0 + ((uint32_t)q << fbit))];
+        if constexpr (!(GL355_NTT_KO & 8)) {
+            if constexpr (GL355_NTT_R8_LAZY != 0 && RHO == 3) dif8_lazy<INV>(x);
+            else dif_regs<RHO, INV>(x);
+        }
+#pragma unroll
+        for (int q = 0; q < R; q++) sink(idx0 + ((uint32_t)q << fbit), x[q]);
+    }
+}
+// rounds between a register-fed first round and (KEEP_LAST) a sunk last round; x holds the thread's 8 loaded elements
+template <int LT, int LOG_T, bool INV, bool KEEP_LAST>
+GL_DEV void dif_tile_r8_regs(uint64_t (&x)[16], uint64_t* lds, const uint64_t* __restrict__ tw, int LO, int tid, int nthreads) {
+    constexpr int FULL = LOG_T / 3, REM = LOG_T % 3;
+    static_assert(!KEEP_LAST || LOG_T >= 4, "the last round must not be the first");
+    dif_first_round_regs<LT, LOG_T, INV>(x, lds, tw, LO, tid);
+    __syncthreads();
+    int m = LOG_T - 3;
+    constexpr int MID = FULL - 1 - ((KEEP_LAST && REM == 0) ? 1 : 0);       // radix-8 rounds done here after the first
+#pragma unroll
+    for (int round = 0; round < MID; round++) {
+        dif_round<LT, 3, INV, GL355_NTT_R8_LAZY != 0>(lds, tw, m, LO, tid, nthreads);
+        m -= 3;
+        __syncthreads();
+    }
+    if constexpr (!KEEP_LAST) {
+        if constexpr (REM == 2) dif_round<LT, 2, INV>(lds, tw, 2, LO, tid, nthreads);
+        if constexpr (REM == 1) dif_round<LT, 1, INV>(lds, tw, 1, LO, tid, nthreads);
+        if constexpr (REM != 0) __syncthreads();
+    }
+}
+template <int LOG_T> struct R8Last { static constexpr int RHO = (LOG_T % 3) ? (LOG_T % 3) : 3; };
+
 // Row pass / single pass: one 2^LT-point row per tile; PRE = multiply by the full table a.pre_full (coset powers) at the load.
 // blockIdx = tile * n_cosets + coset like the radix-16 kernel (each XCD keeps one coset's table in its L2).
 // INV: the inverse transform (omega^-1 twiddles and shifts); it also honours a.out_natural (natural order within the row: the single-pass
@@ -349,15 +419,27 @@ __global__ void __launch_bounds__(LT >= 13 ? 1024 : 512) __attribute__((amdgpu_w
     const uint64_t* in = a.in + col * a.in_col_stride + (rin << LT);
     const uint64_t* pre = PRE ? a.pre_full + (uint64_t)coset * a.pre_full_stride + (rin << LT) : nullptr;
     uint64_t* out = a.out + (uint64_t)a.coset_slot[coset] * a.coset_out_stride + col * a.out_col_stride + (rin << LT);
+    // measured: 8192-point tiles gain 5 % from the register-fed first round, 4096-point tiles at 64 VGPRs lose 4 % (more spilled registers)
+    if constexpr (EPT == 8 && LT == 13 && GL355_NTT_R8_DIRECT != 0) {
+        uint64_t x[16];
 #pragma unroll
-    for (int i = 0; i < EPT; i++) {
-        const uint32_t g = tid + i * NT;
-        uint64_t v = (GL355_NTT_KO & 2) ? (uint64_t)g + row : in[g];
-        if constexpr (PRE) v = gl_mul(v, pre[g]);
-        lds[lds_phys(g)] = v;
+        for (int i = 0; i < 8; i++) {
+            const uint32_t g = tid + i * NT;
+            x[i] = (GL355_NTT_KO & 2) ? (uint64_t)g + row : in[g];
+            if constexpr (PRE) x[i] = gl_mul(x[i], pre[g]);
+        }
+        dif_tile_r8_regs<LT, LT, INV, false>(x, lds, a.tw_r8, 0, tid, NT);
+    } else {
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            const uint32_t g = tid + i * NT;
+            uint64_t v = (GL355_NTT_KO & 2) ? (uint64_t)g + row : in[g];
+            if constexpr (PRE) v = gl_mul(v, pre[g]);
+            lds[lds_phys(g)] = v;
+        }
+        __syncthreads();
+        dif_tile_r8<LT, LT, INV>(lds, a.tw_r8, 0, tid, NT);
     }
-    __syncthreads();
-    dif_tile_r8<LT, LT, INV>(lds, a.tw_r8, 0, tid, NT);
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
         const uint32_t g = tid + i * NT;
@@ -449,26 +531,38 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
     const uint64_t* in = a.in + col * a.in_col_stride;
     const uint64_t* pre = PRE ? a.pre_full + (uint64_t)coset * a.pre_full_stride : nullptr;
     uint64_t* out = a.out + (uint64_t)a.coset_slot[coset] * a.coset_out_stride + col * a.out_col_stride;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t g = tid + i * NT;
-        const uint32_t r = g >> LOG_TC, cc = g & (TC - 1);
-        const uint64_t gi = ((uint64_t)r << log_n2) + c0 + cc;
-        uint64_t v = (GL355_NTT_KO & 2) ? gi : in[gi];
-        if constexpr (PRE && !(GL355_NTT_KO & 32)) v = gl_mul(v, (GL355_NTT_KO & 16) ? gi + 3 : pre[gi]);
-        lds[lds_phys(g)] = v;
-    }
-    __syncthreads();
-    dif_tile_r8<LT, LOG_T, INV>(lds, a.tw_r8, LOG_TC, tid, NT);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t g = tid + i * NT;
+    auto store = [&](uint32_t g, uint64_t v) {
         const uint32_t r = g >> LOG_TC, cc = g & (TC - 1);
         const uint64_t go = ((uint64_t)r << log_n2) + c0 + cc;
-        uint64_t v = lds[lds_phys(g)];
         if constexpr (!(GL355_NTT_KO & 32)) v = gl_mul(v, (GL355_NTT_KO & 16) ? go + 5 : a.step_full[go]);
         if constexpr (GL355_NTT_KO & 64) out[go + r * 16] = v;      // padded row stride (timing experiment: channel camping?)
         else out[go] = v;
+    };
+    if constexpr (LOG_T >= 4 && GL355_NTT_R8_DIRECT != 0) {
+        uint64_t x[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t g = tid + i * NT;
+            const uint64_t gi = ((uint64_t)(g >> LOG_TC) << log_n2) + c0 + (g & (TC - 1));
+            x[i] = (GL355_NTT_KO & 2) ? gi : in[gi];
+            if constexpr (PRE && !(GL355_NTT_KO & 32)) x[i] = gl_mul(x[i], (GL355_NTT_KO & 16) ? gi + 3 : pre[gi]);
+        }
+        dif_tile_r8_regs<LT, LOG_T, INV, true>(x, lds, a.tw_r8, LOG_TC, tid, NT);
+        dif_last_round_sink<LT, R8Last<LOG_T>::RHO, INV>(lds, LOG_TC, tid, NT, store);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t g = tid + i * NT;
+            const uint32_t r = g >> LOG_TC, cc = g & (TC - 1);
+            const uint64_t gi = ((uint64_t)r << log_n2) + c0 + cc;
+            uint64_t v = (GL355_NTT_KO & 2) ? gi : in[gi];
+            if constexpr (PRE && !(GL355_NTT_KO & 32)) v = gl_mul(v, (GL355_NTT_KO & 16) ? gi + 3 : pre[gi]);
+            lds[lds_phys(g)] = v;
+        }
+        __syncthreads();
+        dif_tile_r8<LT, LOG_T, INV>(lds, a.tw_r8, LOG_TC, tid, NT);
+#pragma unroll
+        for (int i = 0; i < 8; i++) store(tid + i * NT, lds[lds_phys(tid + i * NT)]);
     }
 }
 
@@ -503,16 +597,24 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
                 v[i] = gl_mul(v[i], a.ratio_full[((uint64_t)(g >> LOG_TC) << log_n2) + c0 + (g & (TC - 1))]);
             }
         }
-#pragma unroll
-        for (int i = 0; i < 8; i++) lds[lds_phys(tid + i * NT)] = v[i];
-        __syncthreads();
-        dif_tile_r8<LT, LOG_T, false>(lds, a.tw_r8, LOG_TC, tid, NT);
         uint64_t* out = a.out + (uint64_t)a.coset_slot[c] * a.coset_out_stride + col * a.out_col_stride;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint32_t g = tid + i * NT;
+        auto store = [&](uint32_t g, uint64_t val) {
             const uint64_t go = ((uint64_t)(g >> LOG_TC) << log_n2) + c0 + (g & (TC - 1));
-            out[go] = gl_mul(lds[lds_phys(g)], a.step_full[go]);
+            out[go] = gl_mul(val, a.step_full[go]);
+        };
+        if constexpr (LOG_T >= 4 && GL355_NTT_R8_DIRECT != 0) {
+            uint64_t x[16];
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = v[i];
+            dif_tile_r8_regs<LT, LOG_T, false, true>(x, lds, a.tw_r8, LOG_TC, tid, NT);
+            dif_last_round_sink<LT, R8Last<LOG_T>::RHO, false>(lds, LOG_TC, tid, NT, store);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) lds[lds_phys(tid + i * NT)] = v[i];
+            __syncthreads();
+            dif_tile_r8<LT, LOG_T, false>(lds, a.tw_r8, LOG_TC, tid, NT);
+#pragma unroll
+            for (int i = 0; i < 8; i++) store(tid + i * NT, lds[lds_phys(tid + i * NT)]);
         }
         __syncthreads();
     }
