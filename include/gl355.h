@@ -352,7 +352,8 @@ int32_t gl355_prove(gl355_ctx* ctx, const gl355_prover_data* pd, const uint64_t*
 /* the same proof from a SPARSE witness: only the n_rows non-trivial circuit rows are given (rows[r] = all
  * num_wires values of circuit row row_idx[r]; all other rows are zero Noop rows), and the zero-knowledge
  * blinding rows are filled on the device from stream 4 of `blinding_key`: rows [blind_start, blind_start + n_blind) random on
- * every wire, n_z_pairs consecutive row pairs from z_start sharing one random value on wire 0. */
+ * every wire, n_z_pairs consecutive row pairs from z_start carrying one random value per routed wire, shared by the two rows of
+ * the pair (plonky2 `blind`; the circuit must copy-constrain every routed column between the rows of a pair). */
 int32_t gl355_prove_sparse(gl355_ctx* ctx, const gl355_prover_data* pd, const uint32_t* row_idx, const uint64_t* rows,
                            uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
                            const uint64_t* public_inputs, uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof,
@@ -490,7 +491,11 @@ int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx, const gl35
  *                    communicator is created from a unique id the caller distributes: rank 0 calls gl355_comm_unique_id and
  *                    hands the 128 bytes to the other ranks by the host's own means (launcher, file, socket).
  *   GL355_COMM_HOST  the same calls over TCP between the host processes, rank 0 listening on the address named by
- *                    gl355_comm_host_id (hosts without RCCL; CPU tests).  Selected explicitly, never a fallback.
+ *                    gl355_comm_host_id (hosts without RCCL; CPU tests).  Selected explicitly, never a fallback.  Like an
+ *                    ncclUniqueId the id is minted ONCE (rank 0) and handed to the other ranks: it carries a 128-bit random token
+ *                    that every rank presents in its handshake; connections without it are closed and ignored, rank 0 keeps
+ *                    accepting until all ranks have arrived (120 s), and the data sockets time out (GL355_COMM_TIMEOUT_S, 600 s)
+ *                    instead of hanging on a dead peer.
  * gl355_gather_digests: every rank contributes words_per_rank u64 (host or device memory); `all` receives world * words_per_rank
  * words in rank order on every rank.  gl355_comm_barrier / gl355_comm_max_f64: what a benchmark or a driver needs around it. */
 #define GL355_COMM_ID_BYTES 128

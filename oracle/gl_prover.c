@@ -545,10 +545,16 @@ int orc_prove_sparse(const orc_prover_data *pd, const uint32_t *row_idx, const u
     for (uint32_t r = 0; r < n_rows; r++)
         for (uint32_t cidx = 0; cidx < nw; cidx++) wires[(size_t)cidx * n + row_idx[r]] = canon(rows[(size_t)r * nw + cidx]);
     const size_t n_a = (size_t)n_blind * nw;
-    uint64_t *bl = (uint64_t *)malloc((n_a + n_z_pairs + 1) * 8);
-    orc_blinding_elements(key, 4, n_a + n_z_pairs, bl);
+    /* plonky2 `blind`: every routed column of a Z-blinding pair has its own random value, the same on both rows of the pair
+     * (stream order: column-major over the pairs, after the n_blind x num_wires block) */
+    const uint32_t routed = pd->circuit->num_routed_wires;
+    const size_t n_z = (size_t)n_z_pairs * routed;
+    uint64_t *bl = (uint64_t *)malloc((n_a + n_z + 1) * 8);
+    orc_blinding_elements(key, 4, n_a + n_z, bl);
     for (size_t gidx = 0; gidx < n_a; gidx++) wires[(gidx / n_blind) * n + blind_start + gidx % n_blind] = bl[gidx];
-    for (size_t k = 0; k < n_z_pairs; k++) wires[z_start + 2 * k] = wires[z_start + 2 * k + 1] = bl[n_a + k];
+    for (uint32_t cidx = 0; cidx < routed; cidx++)
+        for (size_t k = 0; k < n_z_pairs; k++)
+            wires[(size_t)cidx * n + z_start + 2 * k] = wires[(size_t)cidx * n + z_start + 2 * k + 1] = bl[n_a + (size_t)cidx * n_z_pairs + k];
     free(bl);
     int rc = orc_prove(pd, wires, public_inputs, n_pi, key, proof);
     free(wires);

@@ -35,6 +35,7 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
     for (uint32_t j = 0; j < count; j++)
         if (member_indices[j] >= n_members) return ctx_of(ctxs[0])->fail(GL355_E_INVALID_ARG, "semaphore_units: member index out of range");
     const uint64_t out_words = rec ? rec_words : sem_words;
+    if (units_per_ctx) for (uint32_t t = 0; t < n_ctx; t++) units_per_ctx[t] = 0;       // written on every exit path from here on
     std::atomic<int32_t> first_error{GL355_OK};
     std::atomic<uint32_t> next_unit{0};     // units are handed out a batch at a time: a context that finishes early takes the next batch
     // One context's loop is software-pipelined over its batches: while the tapes of batch k are replayed on host threads (the
@@ -86,17 +87,20 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
             const uint64_t* result = s.flat.data();
             const uint64_t* opis = s.pis.data();
             if (rec) {
-                int32_t rc = s.replay.get();
+                // the future is consumed here: on every failure below the slot is emptied (nb = 0), so neither a later iteration nor
+                // the drain path can call get() a second time on an invalid future
+                int32_t rc = s.replay.valid() ? s.replay.get() : GL355_E_INVALID_ARG;
                 if (rc != GL355_OK) {
                     char msg[128];
                     snprintf(msg, sizeof msg, "semaphore_units: witness generation of unit %llu failed at tape entry %llu",
                              (unsigned long long)(s.j0 + s.failed_unit), (unsigned long long)s.failed_op);
                     cx->fail(rc, msg);
                     fail(rc);
+                    s.nb = 0;
                     return false;
                 }
                 rc = gl355_circuit_prove_rows_units(ctxs[t], rec, s.nb, s.d_rows, s.rpis.data(), 12, key_base ? s.k_rec.data() : nullptr, s.outer.data());
-                if (rc != GL355_OK) { fail(rc); return false; }
+                if (rc != GL355_OK) { fail(rc); s.nb = 0; return false; }
                 result = s.outer.data(); opis = s.rpis.data();
             }
             for (uint32_t b = 0; b < s.nb; b++) {
@@ -104,6 +108,7 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
                 if (proofs_out) memcpy(proofs_out + (uint64_t)(s.j0 + b) * out_words, result + (uint64_t)b * out_words, out_words * 8);
             }
             done += s.nb;
+            if (units_per_ctx) units_per_ctx[t] = done;       // kept current, so it is written on every exit path (incl. an exception)
             s.nb = 0;
             return true;
         };
@@ -166,7 +171,7 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
             }
             if (prev.nb) { if (!finish(prev)) ok = false; }
             if (j0 >= count) {                       // nothing new was started: drain the current slot and stop
-                if (s.nb) { if (rec && !ok) { (void)s.replay.get(); s.nb = 0; } else finish(s); }
+                if (s.nb) { if (rec && !ok) { if (s.replay.valid()) (void)s.replay.get(); s.nb = 0; } else finish(s); }
                 break;
             }
             cur ^= 1;

@@ -100,9 +100,14 @@ int32_t gl355_circuit_load(gl355_ctx* h, const uint64_t* blob, uint64_t words, g
     ch->seg_lens.assign(p, p + n_segs);
     ch->n_seq = n_seq;
     {
+        // no entry may exceed n_ops, so the running sum (checked after every step) cannot wrap around to n_ops
         uint64_t tot = n_seq;
-        for (uint64_t v : ch->seg_lens) tot += v;
-        if (tot != n_ops) { delete ch; return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: tape segments do not add up"); }
+        bool fits = n_seq <= n_ops;
+        for (uint64_t v : ch->seg_lens) {
+            if (v > n_ops || tot + v > n_ops) { fits = false; break; }
+            tot += v;
+        }
+        if (!fits || tot != n_ops) { delete ch; return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: tape segments do not add up"); }
     }
     if ((uint64_t)ch->blind_start + ch->n_blind > n || (uint64_t)ch->z_start + 2ull * ch->n_z_pairs > n) {
         delete ch; return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: blinding rows out of range");

@@ -19,11 +19,14 @@
 #include <dlfcn.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
+#include <sys/random.h>
 #include <rccl/rccl.h>
 #include <sys/socket.h>
 #include <sys/time.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <thread>
 
@@ -86,6 +89,19 @@ bool recv_all(int fd, void* p, size_t n) {
 }
 
 constexpr char HOST_ID_MAGIC[8] = {'g', 'l', '3', '5', '5', 't', 'c', 'p'};
+constexpr size_t HOST_TOKEN_OFFSET = 16, HOST_TOKEN_BYTES = 16;       // id bytes [16, 32): the handshake token
+
+// seconds a data-socket send / receive may block before the call fails (a dead peer must not hang every rank for ever)
+int comm_timeout_s() {
+    const char* e = getenv("GL355_COMM_TIMEOUT_S");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 600;
+}
+void set_io_timeouts(int fd, int seconds) {
+    const timeval t{seconds, 0};
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &t, sizeof t);
+    setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &t, sizeof t);
+}
 
 }  // namespace
 
@@ -127,6 +143,14 @@ int32_t gl355_comm_host_id(const char* ipv4, uint16_t port, uint8_t id[GL355_COM
     memcpy(id, HOST_ID_MAGIC, 8);
     memcpy(id + 8, &a, 4);
     id[12] = (uint8_t)(port & 0xFF); id[13] = (uint8_t)(port >> 8);
+    // a random token every rank must present in its handshake: the id is minted ONCE (by rank 0) and handed to the other ranks by
+    // the host's launcher, like an ncclUniqueId -- a process that merely reaches the port cannot claim a rank
+    size_t got = 0;
+    while (got < HOST_TOKEN_BYTES) {
+        const ssize_t r = getrandom(id + HOST_TOKEN_OFFSET + got, HOST_TOKEN_BYTES - got, 0);
+        if (r < 0) { if (errno == EINTR) continue; g_comm_error = "comm_host_id: getrandom failed"; return GL355_E_UNSUPPORTED; }
+        got += (size_t)r;
+    }
     return GL355_OK;
 }
 
@@ -174,21 +198,36 @@ int32_t gl355_comm_create(gl355_ctx* h, int32_t backend, const uint8_t id[GL355_
             ::close(c->listen_fd); delete c;
             return GL355_E_UNSUPPORTED;
         }
-        timeval tmo{120, 0};                              // a rank that never arrives must not hang the others for ever
-        setsockopt(c->listen_fd, SOL_SOCKET, SO_RCVTIMEO, &tmo, sizeof tmo);
-        for (int k = 1; k < world; k++) {
+        // Accept until every rank has arrived or the deadline passes.  A connection that does not present (rank, token) within a few
+        // seconds -- a port scan, a stray client, a duplicate or out-of-range rank -- is closed and IGNORED; it neither claims a
+        // rank nor tears the communicator down.
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+        int have = 1;
+        while (have < world) {
+            const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+            if (left <= 0) break;
+            pollfd pf{c->listen_fd, POLLIN, 0};
+            const int pr = ::poll(&pf, 1, (int)std::min<long long>(left, 1000));
+            if (pr < 0 && errno != EINTR) break;
+            if (pr <= 0) continue;
             const int fd = ::accept(c->listen_fd, nullptr, nullptr);
-            int32_t peer = -1;
-            if (fd < 0 || !recv_all(fd, &peer, sizeof peer) || peer <= 0 || peer >= world || c->peers[peer] >= 0) {
-                if (fd >= 0) ::close(fd);
-                gl355_comm_destroy(c);
-                g_comm_error = "comm_create: bad handshake from a peer";
-                return GL355_E_INVALID_ARG;
+            if (fd < 0) continue;
+            set_io_timeouts(fd, 5);                       // the handshake itself must arrive promptly
+            struct { int32_t rank; uint8_t token[HOST_TOKEN_BYTES]; } hs;
+            if (!recv_all(fd, &hs, sizeof hs) || hs.rank <= 0 || hs.rank >= world || c->peers[hs.rank] >= 0 ||
+                memcmp(hs.token, id + HOST_TOKEN_OFFSET, HOST_TOKEN_BYTES) != 0) {
+                ::close(fd);
+                continue;
             }
             setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-            const timeval none{0, 0};                      // the accept time-out must not carry over to the data sockets
-            setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &none, sizeof none);
-            c->peers[peer] = fd;
+            set_io_timeouts(fd, comm_timeout_s());
+            c->peers[hs.rank] = fd;
+            have++;
+        }
+        if (have < world) {
+            gl355_comm_destroy(c);
+            g_comm_error = "comm_create: not every rank presented a valid handshake before the deadline";
+            return GL355_E_UNSUPPORTED;
         }
     } else {
         int fd = -1;
@@ -199,14 +238,17 @@ int32_t gl355_comm_create(gl355_ctx* h, int32_t backend, const uint8_t id[GL355_
             fd = -1;
             std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
-        const int32_t me = rank;
-        if (fd < 0 || !send_all(fd, &me, sizeof me)) {
+        struct { int32_t rank; uint8_t token[HOST_TOKEN_BYTES]; } hs;
+        hs.rank = rank;
+        memcpy(hs.token, id + HOST_TOKEN_OFFSET, HOST_TOKEN_BYTES);
+        if (fd < 0 || !send_all(fd, &hs, sizeof hs)) {
             if (fd >= 0) ::close(fd);
             delete c;
             g_comm_error = "comm_create: cannot reach rank 0";
             return GL355_E_UNSUPPORTED;
         }
         setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+        set_io_timeouts(fd, comm_timeout_s());
         c->peers.assign(1, fd);
     }
     *out = c;
@@ -250,6 +292,7 @@ int32_t gl355_gather_digests(gl355_comm* c, const uint64_t* local, uint64_t word
     if (!c) return GL355_E_INVALID_ARG;
     if (words_per_rank == 0) return GL355_OK;
     if (!local || !all) return c->fail(GL355_E_INVALID_ARG, "gather_digests: null buffer");
+    if (words_per_rank > (UINT64_MAX / 8) / (uint64_t)c->world) return c->fail(GL355_E_INVALID_ARG, "gather_digests: words_per_rank * world overflows");
     const size_t bytes = (size_t)words_per_rank * 8;
     if (c->backend == GL355_COMM_HOST) {
         const bool ld = ptr_is_device(local), ad = ptr_is_device(all);

@@ -163,22 +163,15 @@ int32_t deep_batch_dev(Ctx* ctx, const uint64_t* const* poly_ptrs_host, uint32_t
 }
 
 // ---- openings: p_i(z) for base-field coefficient columns, z in F_p^2 ---------------------------
-// one workgroup per polynomial; lane t Horner-evaluates its contiguous chunk, partials are combined
-// with z^(chunk * t) in LDS.
+// one workgroup per polynomial; lane t Horner-evaluates the coefficients k = t (mod 256) in z^256 (coalesced loads) and scales
+// by z^t; the partials are summed in LDS.
 __global__ void __launch_bounds__(256) eval_polys_kernel(const uint64_t* const* polys, uint64_t n, const uint64_t* z,
                                                         uint64_t* out) {
     __shared__ uint64_t sh[512];
     const int tid = threadIdx.x;
     const uint64_t* p = polys[blockIdx.x];
     const gl2 zz = gl2_make(z[0], z[1]);
-    const uint64_t chunk = (n + 255) / 256;
-    const uint64_t lo = tid * chunk, hi = min(n, lo + chunk);
-    gl2 acc = gl2_make(0, 0);
-    for (uint64_t k = hi; k-- > lo;) {
-        acc = gl2_mul(acc, zz);
-        acc.c0 = gl_add(acc.c0, p[k]);
-    }
-    acc = gl2_mul(acc, gl2_pow(zz, lo));
+    const gl2 acc = gl2_horner_strided256(p, n, zz, (uint32_t)tid);
     sh[2 * tid] = acc.c0; sh[2 * tid + 1] = acc.c1;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {

@@ -251,3 +251,23 @@ GL_HD gl2 gl2_pow(gl2 a, uint64_t e) {
     }
     return r;
 }
+
+// sum over k = t (mod 256), k < n, of p[k] z^k for base-field coefficients p and an extension point z: the share of lane t of a
+// 256-lane workgroup in p(z).  Lane t strides through the coefficients, so the 64 lanes of a wave read 64 CONSECUTIVE words per step
+// (one 512-byte segment) -- with a contiguous chunk per lane every wave load touched 64 cache lines (round 2: 6x the algorithmic
+// bytes through the fabric).  Two interleaved Horner chains in z^512 give the lane some ILP.
+GL_HD gl2 gl2_horner_strided256(const uint64_t* __restrict__ p, uint64_t n, gl2 z, uint32_t t) {
+    if (t >= n) return gl2_make(0, 0);
+    gl2 z256 = z;
+    for (int i = 0; i < 8; i++) z256 = gl2_mul(z256, z256);
+    const gl2 z512 = gl2_mul(z256, z256);
+    uint64_t j = (n - t + 255) >> 8;                 // terms of this lane
+    gl2 a0 = gl2_make(0, 0), a1 = gl2_make(0, 0);
+    if (j & 1) { j--; a0.c0 = p[t + (j << 8)]; }     // odd count: the top term has an even index
+    while (j) {
+        j -= 2;
+        a0 = gl2_mul(a0, z512); a0.c0 = gl_add(a0.c0, p[t + (j << 8)]);
+        a1 = gl2_mul(a1, z512); a1.c0 = gl_add(a1.c0, p[t + ((j + 1) << 8)]);
+    }
+    return gl2_mul(gl2_add(a0, gl2_mul(a1, z256)), gl2_pow(z, t));
+}

@@ -212,7 +212,8 @@ extern "C" int32_t gl355_prove(gl355_ctx* h, const gl355_prover_data* pd, const 
 // Witness given as its non-zero rows only (the rest of the 2^degree_bits rows are Noop rows): rows[r] lists
 // all num_wires values of circuit row row_idx[r].  The zero-knowledge blinding rows are filled on the device:
 // rows [blind_start, blind_start+n_blind) get random values on every wire, and n_z_pairs consecutive row
-// pairs starting at z_start share one random value on routed wire 0 (the builder copy-constrains them).
+// pairs starting at z_start carry, on every routed wire, one random value shared by the two rows of the pair (the builder
+// copy-constrains each column between them: plonky2 `blind`).
 extern "C" int32_t gl355_prove_sparse(gl355_ctx* h, const gl355_prover_data* pd, const uint32_t* row_idx, const uint64_t* rows,
                                       uint32_t n_rows, uint32_t blind_start, uint32_t n_blind, uint32_t z_start, uint32_t n_z_pairs,
                                       const uint64_t* public_inputs, uint32_t n_public_inputs, const uint8_t* blinding_key, uint64_t* proof,

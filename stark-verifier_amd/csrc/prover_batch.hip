@@ -83,13 +83,15 @@ __global__ void witness_rows_units_kernel(uint64_t* wires, uint64_t n, uint32_t 
     const uint32_t u = blockIdx.y, r = g / num_wires, c = g % num_wires;
     wires[((uint64_t)u * num_wires + c) * n + row_idx[r]] = gl_canon(row_vals[(uint64_t)u * per + g]);
 }
-// element g of unit u's witness-blinding stream: g < n_blind * num_wires fills wire g / n_blind of blinding row g % n_blind,
-// the next n_z_pairs elements are the shared routed value of the Z-blinding row pairs
-__global__ void witness_blind_units_kernel(uint64_t* wires, uint64_t n, uint32_t num_wires, uint32_t blind_start, uint32_t n_blind,
+// element g of unit u's witness-blinding stream: g < n_blind * num_wires fills wire g / n_blind of blinding row g % n_blind; the next
+// n_z_pairs * num_routed elements are the Z-blinding pairs: element c * n_z_pairs + k is the value of routed column c on BOTH rows of
+// pair k (plonky2 `blind`: every routed wire of a pair is random and copy-constrained between its two rows -- one value per pair on
+// column 0 only, as in round 2, left Z_0 and Z_1 at a blinding row functions of the same value)
+__global__ void witness_blind_units_kernel(uint64_t* wires, uint64_t n, uint32_t num_wires, uint32_t num_routed, uint32_t blind_start, uint32_t n_blind,
                                            uint32_t z_start, uint32_t n_z_pairs, UnitKeys keys) {
     const uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    const uint64_t n_a = (uint64_t)n_blind * num_wires;
-    if (4 * b >= n_a + n_z_pairs) return;
+    const uint64_t n_a = (uint64_t)n_blind * num_wires, n_z = (uint64_t)n_z_pairs * num_routed;
+    if (4 * b >= n_a + n_z) return;
     const uint32_t u = blockIdx.y;
     uint64_t* w = wires + (uint64_t)u * num_wires * n;
     uint64_t e[4];
@@ -100,10 +102,10 @@ __global__ void witness_blind_units_kernel(uint64_t* wires, uint64_t n, uint32_t
         if (g < n_a) {
             const uint32_t c = g / n_blind, r = g % n_blind;
             w[(uint64_t)c * n + blind_start + r] = e[j];
-        } else if (g < n_a + n_z_pairs) {
-            const uint64_t k = g - n_a;
-            w[z_start + 2 * k] = e[j];
-            w[z_start + 2 * k + 1] = e[j];
+        } else if (g < n_a + n_z) {
+            const uint64_t h = g - n_a, c = h / n_z_pairs, k = h % n_z_pairs;
+            w[c * n + z_start + 2 * k] = e[j];
+            w[c * n + z_start + 2 * k + 1] = e[j];
         }
     }
 }
@@ -238,7 +240,7 @@ GL_DEV const uint64_t* poly_ptr(const PolySet& s, uint32_t u, uint32_t i) {
 }
 
 // OpeningSet::new: block (i, u) evaluates polynomial i of unit u at zeta_u (i < n_all) or Z polynomial i - n_all at g * zeta_u;
-// lane t Horner-evaluates its contiguous chunk, partials are combined with z^(chunk * t) in LDS.  out[u][i] (extension)
+// lane t Horner-evaluates the coefficients k = t (mod 256) in z^256 (coalesced loads) and scales by z^t; the partials are summed in LDS.  out[u][i] (extension)
 struct EvalArgs { PolySet all, zs; uint32_t n_all; UnitVals zeta /* [u*4+0..1] = zeta, [u*4+2..3] = g * zeta */; uint64_t* out; uint32_t out_us; };
 __global__ void __launch_bounds__(256) eval_polys_units_kernel(EvalArgs a) {
     __shared__ uint64_t sh[512];
@@ -248,14 +250,7 @@ __global__ void __launch_bounds__(256) eval_polys_units_kernel(EvalArgs a) {
     const uint64_t* p = at_next ? poly_ptr(a.zs, u, i - a.n_all) : poly_ptr(a.all, u, i);
     const gl2 zz = at_next ? gl2_make(a.zeta.v[u * 4 + 2], a.zeta.v[u * 4 + 3]) : gl2_make(a.zeta.v[u * 4], a.zeta.v[u * 4 + 1]);
     const uint64_t n = 1ull << a.all.log_n;
-    const uint64_t chunk = (n + 255) / 256;
-    const uint64_t lo = tid * chunk, hi = min(n, lo + chunk);
-    gl2 acc = gl2_make(0, 0);
-    for (uint64_t k = hi; k-- > lo;) {
-        acc = gl2_mul(acc, zz);
-        acc.c0 = gl_add(acc.c0, p[k]);
-    }
-    acc = gl2_mul(acc, gl2_pow(zz, lo));
+    const gl2 acc = gl2_horner_strided256(p, n, zz, (uint32_t)tid);
     sh[2 * tid] = acc.c0; sh[2 * tid + 1] = acc.c1;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -594,10 +589,10 @@ int32_t prove_units(Ctx* ctx, const gl355_prover_data* pd, uint32_t B, const uin
             hipLaunchKernelGGL(witness_rows_units_kernel, dim3((uint32_t)((per + 255) / 256), B), dim3(256), 0, ctx->stream, wires, n, nw, d_idx, d_vals, n_rows);
             LAUNCH_CHECK(ctx);
         }
-        const uint64_t cnt_b = (uint64_t)n_blind * nw + n_z_pairs;
+        const uint64_t cnt_b = (uint64_t)n_blind * nw + (uint64_t)n_z_pairs * routed;
         if (cnt_b) {
             ProfScope ps(ctx, "witness_blind", (uint64_t)B * cnt_b * 8);
-            hipLaunchKernelGGL(witness_blind_units_kernel, dim3((uint32_t)((cnt_b / 4 + 256) / 256), B), dim3(256), 0, ctx->stream, wires, n, nw, blind_start,
+            hipLaunchKernelGGL(witness_blind_units_kernel, dim3((uint32_t)((cnt_b / 4 + 256) / 256), B), dim3(256), 0, ctx->stream, wires, n, nw, routed, blind_start,
                                n_blind, z_start, n_z_pairs, keys);
             LAUNCH_CHECK(ctx);
         }

@@ -61,7 +61,10 @@ inline Alg alg_sub(Alg a, Alg b) { return Alg{gl2_sub(a.a0, b.a0), gl2_sub(a.a1,
 inline Alg alg_scal(E c, Alg a) { return Alg{gl2_mul(c, a.a0), gl2_mul(c, a.a1)}; }
 
 // constraints of one gate at the opened point: consts = the gate constants (after the selectors), w = the wires
-bool eval_gate(const gl355_gate& gt, const E* consts, const E* w, const uint64_t pi_hash[4], uint32_t num_wires, std::vector<E>& c) {
+// (num_constants = gate constants present in the opening; every read of consts[] / w[] is bounded against the verifier data here,
+// which may come from an untrusted artifact)
+bool eval_gate(const gl355_gate& gt, const E* consts, const E* w, const uint64_t pi_hash[4], uint32_t num_wires, uint32_t num_constants,
+               std::vector<E>& c) {
     c.clear();
     auto alg = [&](uint32_t j) { return Alg{w[j], w[j + 1]}; };
     auto push_alg = [&](Alg v) { c.push_back(v.a0); c.push_back(v.a1); };
@@ -69,9 +72,11 @@ bool eval_gate(const gl355_gate& gt, const E* consts, const E* w, const uint64_t
     switch (gt.type) {
     case GL355_GATE_NOOP: return true;
     case GL355_GATE_CONSTANT:
+        if (p > num_constants || p > num_wires) return false;
         for (uint32_t i = 0; i < p; i++) c.push_back(gl2_sub(consts[i], w[i]));
         return true;
     case GL355_GATE_PUBLIC_INPUT:
+        if (num_wires < 4) return false;
         for (int i = 0; i < 4; i++) c.push_back(gl2_sub(w[i], e_base(pi_hash[i])));
         return true;
     case GL355_GATE_BASE_SUM: {
@@ -81,7 +86,7 @@ bool eval_gate(const gl355_gate& gt, const E* consts, const E* w, const uint64_t
         return true;
     }
     case GL355_GATE_ARITHMETIC:
-        if (4 * p > num_wires) return false;
+        if (4 * p > num_wires || num_constants < 2) return false;
         for (uint32_t i = 0; i < p; i++)
             c.push_back(gl2_sub(w[4 * i + 3], gl2_add(gl2_mul(gl2_mul(w[4 * i], w[4 * i + 1]), consts[0]), gl2_mul(w[4 * i + 2], consts[1]))));
         return true;
@@ -119,12 +124,12 @@ bool eval_gate(const gl355_gate& gt, const E* consts, const E* w, const uint64_t
         return true;
     }
     case GL355_GATE_ARITHMETIC_EXT:
-        if (8 * p > num_wires) return false;
+        if (8 * p > num_wires || num_constants < 2) return false;
         for (uint32_t i = 0; i < p; i++)
             push_alg(alg_sub(alg(8 * i + 6), alg_add(alg_scal(consts[0], alg_mul(alg(8 * i), alg(8 * i + 2))), alg_scal(consts[1], alg(8 * i + 4)))));
         return true;
     case GL355_GATE_MUL_EXT:
-        if (6 * p > num_wires) return false;
+        if (6 * p > num_wires || num_constants < 1) return false;
         for (uint32_t i = 0; i < p; i++) push_alg(alg_sub(alg(6 * i + 4), alg_scal(consts[0], alg_mul(alg(6 * i), alg(6 * i + 2)))));
         return true;
     case GL355_GATE_POSEIDON_MDS:
@@ -139,7 +144,7 @@ bool eval_gate(const gl355_gate& gt, const E* consts, const E* w, const uint64_t
     case GL355_GATE_RANDOM_ACCESS: {
         const uint32_t bits = p & 0xFF, copies = (p >> 8) & 0xFF, extra = (p >> 16) & 0xFF;
         const uint32_t vec = 1u << bits, routed = (2 + vec) * copies + extra;
-        if (bits > 8 || routed + copies * bits > num_wires) return false;
+        if (bits > 8 || routed + copies * bits > num_wires || extra > num_constants) return false;
         for (uint32_t cp = 0; cp < copies; cp++) {
             const uint32_t b0 = (2 + vec) * cp;
             const E* bl = w + routed + cp * bits;
@@ -225,6 +230,7 @@ static int32_t verify_impl(const gl355_verifier_data* vd, const uint64_t* proof,
     const uint32_t cap_h = vd->cap_height, L = vd->n_fri_layers, nq = vd->num_queries, lde_bits = c.degree_bits + c.rate_bits;
     const int32_t hasher = vd->hasher;
     if (nch == 0 || nch > 4 || L > 32 || lde_bits > 40 || c.num_gates > GL355_MAX_GATES || qdf == 0 || c.num_selectors == 0 ||
+        L > lde_bits || cap_h > lde_bits - L ||        // every FRI layer tree (2^(lde_bits - l) leaves... the last has lde_bits - L path bits) must reach its cap
         (hasher != GL355_HASH_POSEIDON && hasher != GL355_HASH_BN254_POSEIDON)) { g_verify_error = "verify: unsupported verifier data"; return GL355_E_INVALID_ARG; }
     const bool zk = vd->zero_knowledge != 0;
     const uint64_t n_cap = 1ull << cap_h;
@@ -249,6 +255,10 @@ static int32_t verify_impl(const gl355_verifier_data* vd, const uint64_t* proof,
     const uint64_t* final_poly = p; p += 2 * final_len;
     const uint64_t pow_witness = *p++;
     const uint64_t* queries = p;
+    // public inputs are field elements too: v and v + p hash alike (gl355_host_hash_no_pad canonicalises), so a consumer comparing
+    // or de-duplicating them as raw u64 (nullifiers, topics) could be aliased -- only the canonical encoding is accepted
+    for (uint32_t i = 0; i < n_public_inputs; i++)
+        if (public_inputs[i] >= GL_P) return fail("non-canonical public input");
     // every field element of the proof must be canonical (plonky2 deserialisation rejects anything else)
     for (const uint64_t* q = proof + 8; q < proof + need; q++)
         if (*q >= GL_P) return fail("non-canonical field element in the proof");
@@ -304,7 +314,7 @@ static int32_t verify_impl(const gl355_verifier_data* vd, const uint64_t* proof,
             const gl355_gate& gt = c.gates[gi];
             if (gt.type > GL355_GATE_TYPE_MAX || gt.selector_index >= c.num_selectors || gt.group_end > c.num_gates || gt.group_start > gt.group_end)
                 { g_verify_error = "verify: bad gate table"; return GL355_E_INVALID_ARG; }
-            if (!eval_gate(gt, o_consts + c.num_selectors, o_wires, pi_hash, c.num_wires, gc)) { g_verify_error = "verify: gate does not fit the wire count"; return GL355_E_INVALID_ARG; }
+            if (!eval_gate(gt, o_consts + c.num_selectors, o_wires, pi_hash, c.num_wires, c.num_constants, gc)) { g_verify_error = "verify: gate does not fit the wire / constant count"; return GL355_E_INVALID_ARG; }
             const E sel = o_consts[gt.selector_index];
             E filt = one;
             for (uint32_t k = gt.group_start; k < gt.group_end; k++)

@@ -108,19 +108,21 @@ def aggregation_root(ctx, leaves, cap_height=0):
     return MerkleTree(ctx, pad_pow2(lv), cap_height).cap
 
 
-def aggregate_distributed(aggregator, local_signals, dist=None, device=None, ctxs=None, seed=1, rng=None, comm=None):
+def aggregate_distributed(aggregator, local_signals, dist=None, device=None, ctxs=None, seed=None, rng=None, comm=None):
     """recursion.rs:187-247 across GPUs: every rank aggregates its own block of signals into one proof (the lower
     log2(len(local_signals)) levels of the tree, no communication), the per-rank proofs -- flat words | public inputs, the wire
     format of SURVEY N3 -- are exchanged with ONE all-gather (about 0.2 MB per rank: gl355_gather_digests over RCCL / xGMI when
     `comm` is a Comm; a torch.distributed group `dist` is accepted for the gloo tests), and rank 0 aggregates them through the
     upper log2(world) levels.  Every rank builds the same level circuits (deterministic builder), so a proof made on one GPU is an
-    input of a circuit loaded on another.  Returns (proof, public inputs, common data) on rank 0, None elsewhere."""
-    proof, pis, cd = aggregator.aggregate(local_signals, seed=seed, rng=rng, ctxs=ctxs)
+    input of a circuit loaded on another.  Returns (proof, public inputs, common data) on rank 0, None elsewhere.
+    seed: None = a fresh OS-random blinding key per proof; otherwise every proof's key is derived from (seed, rank, level, node)
+    -- ranks never share a blinding stream (Aggregator.aggregate, `key_domain`)."""
     if comm is not None:
         world, rank = comm.world, comm.rank
     else:
         world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
         rank = dist.get_rank() if world > 1 else 0
+    proof, pis, cd = aggregator.aggregate(local_signals, seed=seed, rng=rng, ctxs=ctxs, key_domain=1 + rank)
     if world == 1:
         return proof, pis, cd
     assert world & (world - 1) == 0, "the aggregation tree is binary: a power-of-two number of ranks"
@@ -138,4 +140,4 @@ def aggregate_distributed(aggregator, local_signals, dist=None, device=None, ctx
         return None
     n_words = proof.size
     signals = [(allp[r, :n_words].copy(), allp[r, n_words:].copy()) for r in range(world)]
-    return aggregator.aggregate(signals, seed=seed + 1000003, rng=rng, ctxs=ctxs, start_level=local_levels)
+    return aggregator.aggregate(signals, seed=seed, rng=rng, ctxs=ctxs, start_level=local_levels, key_domain=0)

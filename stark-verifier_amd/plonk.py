@@ -141,8 +141,9 @@ class CircuitBuilder:
         cfg = self.config
         noop = self.gate_type(GATE_NOOP)
         n_real = len(self.rows)
-        # zero-knowledge blinding: random unconstrained rows hide the wire openings,
-        # and pairs of rows sharing one random routed value randomise the Z polynomials
+        # zero-knowledge blinding (plonky2 `CircuitBuilder::blind`): random unconstrained rows hide the wire
+        # openings, and pairs of rows whose EVERY routed column carries its own random value, copy-constrained between the two
+        # rows of the pair, randomise the Z and partial-product polynomials
         n_blind_wires = n_blind_z = 0
         if cfg.zero_knowledge:
             arities = cfg.fri_reduction_arity_bits(max(min_degree_bits, 13))
@@ -155,7 +156,8 @@ class CircuitBuilder:
         z_pairs = []
         for k in range(n_blind_z // 2):
             r0 = blind_start + n_blind_wires + 2 * k
-            self.connect((r0, 0), (r0 + 1, 0))
+            for c in range(cfg.num_routed_wires):
+                self.connect((r0, c), (r0 + 1, c))
             z_pairs.append((r0, r0 + 1))
         degree_bits = max(min_degree_bits, 2, int(len(self.rows) - 1).bit_length())
         n = 1 << degree_bits
@@ -392,14 +394,16 @@ class CircuitData:
 
 
 def fill_blinding(data, wires, rng):
-    """Random values on the blinding rows (all wires) and on the Z-blinding pairs (one shared value)."""
+    """Random values on the blinding rows (all wires) and on the Z-blinding pairs (one value per routed column, shared by the
+    two rows of a pair: plonky2 `blind`)."""
     start, n_wires_rows, z_pairs, _ = data.blind_rows
     if n_wires_rows:
         wires[:, start:start + n_wires_rows] = rng.integers(0, P, size=(wires.shape[0], n_wires_rows), dtype=np.uint64)
+    routed = data.config.num_routed_wires
     for r0, r1 in z_pairs:
-        v = np.uint64(rng.integers(0, P, dtype=np.uint64))
-        wires[0, r0] = v
-        wires[0, r1] = v
+        v = rng.integers(0, P, size=routed, dtype=np.uint64)
+        wires[:routed, r0] = v
+        wires[:routed, r1] = v
 
 
 def check_copy_constraints(data, wires):

@@ -15,7 +15,7 @@ import numpy as np
 from ._lib import (GATE_ARITHMETIC, GATE_ARITHMETIC_EXT, GATE_BASE_SUM, GATE_CONSTANT, GATE_NOOP, GATE_POSEIDON,
                    GATE_POSEIDON_MDS, GATE_PUBLIC_INPUT, GATE_RANDOM_ACCESS, GATE_REDUCING, GATE_REDUCING_EXT)
 from .gadgets import CIRC, GadgetBuilder, T
-from .plonk import CircuitConfig, P, _ptr, _u64, parse_proof_tagged, prove_sparse
+from .plonk import CircuitConfig, P, _ptr, _u64, derive_key, parse_proof_tagged, prove_sparse
 
 UNUSED_SELECTOR = 0xFFFFFFFF
 _RC = None
@@ -520,9 +520,13 @@ class Aggregator:
         self.levels = []            # RecursiveCircuit per level
         self.commons = [signal_common]
 
-    def aggregate(self, signals, seed=1, rng=None, ctxs=None, start_level=0):
+    def aggregate(self, signals, seed=None, rng=None, ctxs=None, start_level=0, key_domain=0):
         """signals: list of (flat proof, public inputs), power-of-two many, all of the level-0 circuit and the
         same Merkle root.  Returns (flat proof, public inputs, common data of the final circuit).
+        seed: None (the default) lets the library draw a fresh 256-bit blinding key from the OS CSPRNG for every proof (the
+        zero-knowledge setting of recursion.rs:32-48).  A seed (integer or 32 bytes) makes the run reproducible: the key of node j of
+        tree level l is gl355_derive_key(seed, key_domain << 48 | l << 32 | j), so no two proofs of a tree -- or, with a distinct
+        `key_domain` per rank, of a distributed tree -- share a blinding stream.
         ctxs: prover contexts of the same device; the nodes of a level are independent and are proven on them in parallel
         (the reference's `par_chunks_exact(2)`, recursion.rs:211-227), one host thread per context.
         start_level: the signals are proofs of tree level `start_level` already (continuing a tree whose lower part was aggregated
@@ -549,13 +553,14 @@ class Aggregator:
             # (gl355_circuit_prove_tape_units: one launch per stage for up to `units` nodes)
             units = max(1, min(8, -(-n_nodes // len(ctxs))))
 
-            def worker(t, cur=cur, nxt=nxt, nat=nat, n_nodes=n_nodes, units=units):
+            def worker(t, cur=cur, nxt=nxt, nat=nat, n_nodes=n_nodes, units=units, lvl=level):
                 try:
                     mine = list(range(t, n_nodes, len(ctxs)))
                     for b in range(0, len(mine), units):
                         js = mine[b:b + units]
                         inputs = np.stack([np.concatenate([np.concatenate([_u64(f), _u64(p)]) for f, p in cur[2 * j:2 * j + 2]]) for j in js])
-                        flats, pis = nat.prove_tape_units(ctxs[t], inputs, [seed + 2 * j for j in js])
+                        keys = None if seed is None else [derive_key(seed, (int(key_domain) << 48) | (lvl << 32) | j) for j in js]
+                        flats, pis = nat.prove_tape_units(ctxs[t], inputs, keys)
                         for k, j in enumerate(js):
                             nxt[j] = (flats[k], pis[k])
                 except Exception as exc:

@@ -21,12 +21,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total, q):
+def _worker(rank, world, cid, total, q):
     sys.path.insert(0, ROOT)
     import time
     par = importlib.import_module("stark-verifier_amd.parallel")
     lib = importlib.import_module("stark-verifier_amd._lib").load()
-    cid = par.Comm.unique_id(lib, par.COMM_HOST, "127.0.0.1", port)
     if rank == 0:
         time.sleep(0.3)                      # the other ranks retry until rank 0 listens
     comm = par.Comm(None, par.COMM_HOST, cid, rank, world, lib=lib)
@@ -52,9 +51,34 @@ def test_host_comm_three_ranks():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    par = importlib.import_module("stark-verifier_amd.parallel")
+    lib = importlib.import_module("stark-verifier_amd._lib").load()
+    cid = par.Comm.unique_id(lib, par.COMM_HOST, "127.0.0.1", port)      # minted once (token inside), handed to every rank
+    assert cid != par.Comm.unique_id(lib, par.COMM_HOST, "127.0.0.1", port)
+    procs = [ctx.Process(target=_worker, args=(r, world, cid, total, q)) for r in range(world)]
     for p in procs:
         p.start()
+    # strangers on the port while the ranks assemble: a silent connection, garbage, and a well-formed rank claim with the
+    # wrong token -- none of them may claim a rank or tear the communicator down
+    import struct
+    import threading
+    import time
+    strangers = []
+
+    def intrude():
+        for payload in (struct.pack("<i", 1) + b"\0" * 16, b"\xff" * 20, b""):
+            for _ in range(200):                 # until rank 0 listens
+                try:
+                    s = socket.create_connection(("127.0.0.1", port), timeout=2)
+                except OSError:
+                    time.sleep(0.05)
+                    continue
+                if payload:
+                    s.sendall(payload)
+                strangers.append(s)
+                break
+    th = threading.Thread(target=intrude)
+    th.start()
     res = {}
     for _ in range(world):
         r, allv, m, tiny = q.get(timeout=90)
@@ -62,6 +86,10 @@ def test_host_comm_three_ranks():
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
+    th.join(30)
+    assert len(strangers) >= 1                 # at least the wrong-token claim of rank 1 reached the listener
+    for s in strangers:
+        s.close()
     want = np.array([[i * 8 + j for j in range(8)] for i in range(total)], dtype=np.uint64)
     for r in range(world):
         allv, m, tiny = res[r]

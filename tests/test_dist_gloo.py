@@ -84,8 +84,8 @@ class _FakeAggregator:
     def __init__(self):
         self.calls = []
 
-    def aggregate(self, signals, seed=1, rng=None, ctxs=None, start_level=0):
-        self.calls.append((len(signals), start_level))
+    def aggregate(self, signals, seed=None, rng=None, ctxs=None, start_level=0, key_domain=0):
+        self.calls.append((len(signals), start_level, key_domain))
         proof = np.concatenate([np.asarray(s[0], dtype=np.uint64) for s in signals])[:6]
         proof = np.concatenate([proof, np.zeros(6 - proof.size, dtype=np.uint64)])          # fixed "proof" size
         pis = np.concatenate([np.asarray(s[1], dtype=np.uint64) for s in signals])
@@ -125,9 +125,9 @@ def test_aggregate_distributed_exchange_gloo():
         res[rank] = (calls, out)
     for p in procs:
         p.join(timeout=30)
-    assert res[1] == ([(4, 0)], None)
+    assert res[1] == ([(4, 0, 2)], None)                   # blinding-key domain 1 + rank: ranks never share a key stream
     calls0, out0 = res[0]
-    assert calls0 == [(4, 0), (2, 2)]                      # 4 local signals = 2 levels, then the 2 rank proofs from level 2
+    assert calls0 == [(4, 0, 1), (2, 2, 0)]                # 4 local signals = 2 levels, then the 2 rank proofs from level 2 (domain 0)
     proof, pis, cd = out0
     assert pis == [0, 1, 2, 3, 1000, 1001, 1002, 1003] and cd == {"level": 3}
     assert proof[:4] == [0, 1, 2, 3]                       # rank 0's proof words first, then rank 1's

@@ -184,6 +184,17 @@ def test_aggregate_four_signals(gl, ctx, orc):
     proof_p, pis_p, _ = agg.aggregate(sigs, seed=100, ctxs=[ctx, ctx2])
     assert np.array_equal(proof_p, proof) and np.array_equal(pis_p, pis)
     ctx2.close()
+    # the default (seed=None): every proof of the tree is blinded under a fresh OS-random key -- two runs differ, both verify
+    # (small public integers as keys, shared between levels and ranks, are gone; a seed now derives per-(domain, level, node) keys)
+    fresh_a, pis_a, _ = agg.aggregate(sigs)
+    fresh_b, pis_b, _ = agg.aggregate(sigs)
+    assert not np.array_equal(fresh_a, fresh_b) and np.array_equal(pis_a, pis) and np.array_equal(pis_b, pis)
+    for fresh in (fresh_a, fresh_b):
+        o = plonk.parse_proof(cd, fresh)
+        o["public_inputs"] = pis
+        pv.verify(orc, cd, o)
+    other_domain, _, _ = agg.aggregate(sigs, seed=100, key_domain=3)
+    assert not np.array_equal(other_domain, proof)
     outer = plonk.parse_proof(cd, proof)
     outer["public_inputs"] = pis
     pv.verify(orc, cd, outer)

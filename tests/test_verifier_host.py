@@ -62,6 +62,19 @@ def test_semaphore_proof_accept_and_reject(orc):
             case["data"].verify(f, pi)
     with pytest.raises(Exception):
         case["data"].verify(flat[:-1], pi)
+    # ... and so is a non-canonical PUBLIC INPUT: v + p hashes like v, but a consumer comparing nullifiers / topics as raw u64 would
+    # see two different values.  Topic words are user-chosen and small here, so v + p still fits 64 bits.
+    topic2 = np.array([7, 0, 123456, 1], dtype=np.uint64)
+    idx2, vals2, pi2 = cs.witness(orc, case, 1, topic2)
+    flat2 = case["cpu"].prove_sparse(idx2, vals2, pi2, 5)
+    case["data"].verify(flat2, pi2)
+    gl = importlib.import_module("stark-verifier_amd")
+    for k in range(8, 12):
+        alias = pi2.copy()
+        alias[k] = pi2[k] + np.uint64(0xFFFFFFFF00000001)
+        with pytest.raises(gl.Gl355Error) as ei:
+            case["data"].verify(flat2, alias)
+        assert ei.value.code == -7
 
 
 def test_recursive_proof_accept_and_reject(orc):
