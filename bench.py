@@ -206,9 +206,11 @@ class RecursiveProvers:
         return agg, sum(self.units_done[t] - self.units_mark[t] for t in self.prof_ctx)
 
 
-def cpu_baseline_recursive(pr, units=1):
+def cpu_baseline_recursive(pr, units=3):
     """The CPU restatement of prove() (oracle/gl_prover.c, OpenMP) on the same two circuits and witnesses: `units` signals +
-    recursive proofs, proofs only (the witnesses are handed over ready-made)."""
+    recursive proofs on every usable host core, proofs only (the witnesses are handed over ready-made); then the per-core figure
+    BASELINE.md 3 asks for: one Semaphore proof (n = 2^13) on ONE thread and on all threads (a whole unit on one thread is ~1 min,
+    outside the bench's budget)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import CpuProver, Oracle
     orc = Oracle()
@@ -223,29 +225,51 @@ def cpu_baseline_recursive(pr, units=1):
     inner = pr.last[0]
     wrows, wpis = pr.rc.witness([inner])
     t0 = time.perf_counter()
+    t_inner_all = 0.0
     for u in range(units):
+        ti = time.perf_counter()
         flat_in = cpu_in.prove_sparse(idx, vals, pi, 7 + u)
+        t_inner_all += time.perf_counter() - ti
         flat_out = cpu_out.prove_sparse(pr.rc.row_idx, wrows, wpis, 9 + u)
     dt = time.perf_counter() - t0
     # bit-exactness of the product against this baseline on the very same inputs (seed of the last unit)
     g_in = pr.sem.prove_rows(ctx, vals, pi, 7 + units - 1)
     g_out, _ = pr.nat.prove_tape(ctx, np.concatenate([inner[0], inner[1]]), 9 + units - 1)
     same = bool(np.array_equal(g_in, flat_in) and np.array_equal(g_out, flat_out))
+    # one thread: the Semaphore proof alone (bounded sample)
+    orc.L.orc_set_num_threads(1)
+    t1 = time.perf_counter()
+    flat_1 = cpu_in.prove_sparse(idx, vals, pi, 7 + units - 1)
+    t1 = time.perf_counter() - t1
+    orc.L.orc_set_num_threads(threads)
+    same = same and bool(np.array_equal(flat_1, flat_in))
     return {"value": round(units / dt, 4), "unit": "recursive proofs/s", "cores": int(threads), "kind": "port",
             "byte_identical_to_gpu_proofs": same,
+            "one_thread": {"value": round(1.0 / t1, 4), "unit": "Semaphore proofs/s (n=2^13, no recursive proof)", "cores": 1,
+                           "same_proof_all_threads_per_s": round(units / t_inner_all, 4),
+                           "parallel_speedup": round(t1 / (t_inner_all / units), 2),
+                           "sample": "1 Semaphore proof, %.1f s on one thread; the same proof on %d threads: %.2f s" % (t1, threads, t_inner_all / units)},
             "sample": "%d unit(s): Semaphore proof (n=2^13) + recursive proof (n=2^%d) by the C restatement of plonky2's prove() "
                       "(oracle/gl_prover.c, OpenMP, %d threads), witnesses given, preprocessed commitments prebuilt (%.1f s, untimed); "
                       "%.2f s wall.  Not the Rust binary (no Rust toolchain here); reference README: ~0.14 recursive proofs/s "
                       "on 16 vCPU" % (units, pr.rc.data.degree_bits, threads, t_build, dt)}
 
 
+def latest_profile(suffix):
+    """profiles/rNN<suffix> of the latest round that has one (bench.py cannot collect PMC counters itself: they come from the
+    committed rocprofv3 --pmc passes)"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]" + suffix)))
+    return c[-1] if c else None
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (bench.py cannot collect PMC counters
     itself); None when no pass covers the kernel."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = latest_profile("_pmc_traffic.json")
     try:
         d = json.load(open(path))
-        return d["kernels"][kernel]["bytes_per_launch_corrected"], "profiles/r02_pmc_traffic.json: " + d["_source"]
+        return d["kernels"][kernel]["bytes_per_launch_corrected"], "profiles/%s: %s" % (os.path.basename(path), d["_source"])
     except Exception:
         return None, None
 
@@ -255,7 +279,7 @@ def pmc_valu(kernel, avg_launch_ms):
     committed --pmc pass) over the launch duration measured here, against the chip's issue rate (1 024 SIMDs, one instruction per
     ~4.2 clk for this instruction mix (tools/ubench), ~2.05 GHz sustained under this load)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        d = json.load(open(latest_profile("_pmc_traffic.json")))
         insts = d["kernels"][kernel]["valu_insts_per_launch"]
     except Exception:
         return None
@@ -300,12 +324,65 @@ def lde_figure(gl, device, steps=8):
     ach = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     del coeffs, out
     ctx.close()
+    traffic, tsrc, valu = lde_pmc()
     return {"value": round(alg * steps / dt / 1e9, 2), "unit": "GB/s", "steps": steps,
             "workload": "lde n=2^17 -> N=2^20, 135 columns, bit-reversed output, resident operands",
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": 3563000000, "traffic_source": "profiles/r02_lde_pmc.txt (FETCH_SIZE x 2 + WRITE_SIZE of both passes, separate --pmc runs)",
-                         "hbm_moved_GBps": round(3.563e9 / (kern_ms * 1e-3) / 1e9, 1) if kern_ms > 0 else None,
+                         "traffic": traffic, "traffic_source": tsrc,
+                         "hbm_moved_GBps": round(traffic / (kern_ms * 1e-3) / 1e9, 1) if kern_ms > 0 and traffic else None,
+                         "valu_insts_per_lde": valu,
                          "kernels_ms_per_launch": {k: round(v[1] / max(1, v[0]), 4) for k, v in prof.items()}}}
+
+
+def lde_pmc():
+    """(HBM-side bytes per LDE, source, wave-level VALU instructions per LDE) from the latest committed --pmc passes over the LDE"""
+    path = latest_profile("_lde_pmc.json")
+    try:
+        d = json.load(open(path))
+        return int(d["hbm_bytes_per_lde"]), "profiles/%s: %s" % (os.path.basename(path), d["_source"]), d.get("valu_insts_per_lde")
+    except Exception:
+        return None, None, None
+
+
+def merkle_figures(gl, device):
+    """BASELINE configs[2] / SURVEY cfg-3: MerkleTree::new over 2^22 leaves -- (L = 4, cap 4) the FRI-layer shape, (L = 135, cap 4)
+    the wires-like shape (4.5 GB of leaves) -- and the Semaphore group tree (2^20 leaves, L = 4, cap 0, signal.rs:40); row-major leaves
+    resident in HBM, gl355_merkle_build, HIP-event time per build.  The kernels are integer-VALU work (a permutation is 17.6 k VALU
+    instructions): `valu_frac` prices the build's permutations at that count against the chip's issue rate."""
+    import torch
+    ctx = gl.Context(device)
+    lib = ctx.lib
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x356)
+    out = {"what": "gl355_merkle_build (leaf sponge + compression levels + cap, plonky2 digest layout), leaves resident, HIP events"}
+    issue_peak = 1024 * 2.05e9 / 4.2           # wave-level VALU instructions per second (tools/ubench: ~4.2 clk per multiply-add at ~2.05 GHz)
+    for log_n, L, cap in ((22, 4, 4), (22, 135, 4), (20, 4, 0)):
+        n = 1 << log_n
+        leaves = torch.randint(0, (1 << 63) - 1, (n, L), dtype=torch.int64, device="cuda", generator=g)
+        dig = torch.empty((2 * (n - (1 << cap)), 4), dtype=torch.int64, device="cuda")
+        capb = torch.empty((1 << cap, 4), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+
+        def build():
+            ctx.check(lib.gl355_merkle_build(ctx.h, C.c_void_p(leaves.data_ptr()), n, L, cap, C.c_void_p(dig.data_ptr()), C.c_void_p(capb.data_ptr())))
+        build()
+        ctx.sync()
+        reps = 2 if L > 8 else 4
+        ctx.timer_start()
+        for _ in range(reps):
+            build()
+        ms = ctx.timer_stop() / reps
+        perms = n * ((L + 7) // 8 if L > 4 else 0) + (n - (1 << cap))
+        alg = 8.0 * n * L + 64.0 * (n - (1 << cap)) + 32.0 * (1 << cap)
+        out["N=2^%d L=%d cap=%d" % (log_n, L, cap)] = {
+            "ms": round(ms, 3), "permutations": perms, "Gperm_per_s": round(perms / ms / 1e6, 3),
+            "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes": int(alg)},
+            "valu_frac": round(perms * 17600 / 64.0 / (ms * 1e-3) / issue_peak, 3)}
+        del leaves, dig, capb
+        torch.cuda.empty_cache()
+    ctx.close()
+    return out
 
 
 class _TorchComm:
@@ -576,6 +653,22 @@ def main_recursive(args):
         iso_units //= 2
         iso = {k: (v[0] // 2, v[1] / 2, v[2] // 2) for k, v in iso.items()}      # two 8-unit batches, the second one timed on the host
         pr.profile(False)
+        # BASELINE configs[3] as stated: ONE proof end to end.  One context, one unit per call (no lock-step partners, no pipelining):
+        # gl355_semaphore_prove (witness + proof, n = 2^13) then gl355_circuit_prove_tape (tape replay + proof), host-visible wall time
+        lat = []
+        for k in range(6):
+            t_l = time.perf_counter()
+            pr.unit(0, 9200 + k)
+            lat.append(time.perf_counter() - t_l)
+        lat = sorted(lat[1:])
+        t_b1 = time.perf_counter()
+        pr.prove_batch(9300, 1)                                                  # the same through the batch runtime (one unit)
+        t_b1 = time.perf_counter() - t_b1
+        latency = {"what": "configs[3]: one depth-20 Semaphore signal + the recursive proof verifying it, one prover context, one unit, "
+                           "host-visible wall time (witness generation, transcript, downloads included)",
+                   "median_ms": round(1e3 * lat[len(lat) // 2], 2), "min_ms": round(1e3 * lat[0], 2), "max_ms": round(1e3 * lat[-1], 2),
+                   "runs": len(lat), "through_batch_runtime_ms": round(1e3 * t_b1, 2),
+                   "lockstep_8_units_ms_per_unit": round(1e3 * t_iso / 8, 2)}
         pr.sets = all_sets
         # host/device split of one context: wall time in Ctx::wait() ("host:stream_wait" pseudo-scope) against the wall time per unit
         iso_wait = iso.pop("host:stream_wait", (0, 0.0, 0))
@@ -628,6 +721,7 @@ def main_recursive(args):
                                                          "(includes queueing behind the other streams)" % n_threads,
                                                  "units": local_units, "kernel_groups": groups(prof, local_units, 6)}},
             "aggregation_root": ["%016x" % int(x) for x in root[0]],
+            "latency_single_unit_ms": latency,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -656,6 +750,10 @@ def main_recursive(args):
                 line["ntt_lde"] = lde_figure(gl, local_rank)
             except Exception as exc:
                 line["ntt_lde"] = {"error": repr(exc)}
+            try:
+                line["merkle_2p22"] = merkle_figures(gl, local_rank)
+            except Exception as exc:
+                line["merkle_2p22"] = {"error": repr(exc)}
             try:
                 line["bn254_finalisation_kernels"] = bn254_figures(gl, local_rank)
             except Exception as exc:
@@ -782,10 +880,8 @@ def main_lde(args):
                                    "bit-reversed (commitment) output order, operands resident in HBM",
                        "algorithmic_bytes_per_step_per_gpu": alg_bytes_step, "parallelism": "independent batches per GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": 3563000000,
-                         "traffic_source": "profiles/r02_lde_pmc.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes over tools/prof_lde.py), "
-                                           "FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, both kernels of one LDE summed: 0.17 + 1.13 GB (pass 1) "
-                                           "+ 1.13 + 1.13 GB (pass 2); the intermediate of the two-pass split is the excess over the algorithmic 1.27 GB",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": lde_pmc()[0],
+                         "traffic_source": "%s; both kernels of one LDE summed -- the intermediate of the two-pass split is the excess over the algorithmic 1.27 GB" % lde_pmc()[1],
                          "kernel": "lde = ntt_cols_r8_cosets_kernel<5> (pass 1: 32-point transforms over 128-column tiles, all 8 cosets per block) + "
                                    "ntt_rows_r8_kernel<12> (pass 2: 4096-point rows)",
                          "dominant_kernel": dom_name,
@@ -797,8 +893,9 @@ def main_lde(args):
         }
         # the other bound: wave-level VALU instructions of the two passes (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r02_lde_pmc.txt:
         # 2.19e8 + 3.58e8 per LDE; 1.082e9 in round 1) against the chip's issue rate
-        line["roofline"]["valu_issue"] = {"unit": "G wave-instructions/s", "insts_per_lde": 5.76e8,
-                                          "achieved": round(5.76e8 / (lde_ms * 1e-3) / 1e9, 1) if lde_ms > 0 else None,
+        insts_lde = lde_pmc()[2] or 0.0
+        line["roofline"]["valu_issue"] = {"unit": "G wave-instructions/s", "insts_per_lde": insts_lde,
+                                          "achieved": round(insts_lde / (lde_ms * 1e-3) / 1e9, 1) if lde_ms > 0 else None,
                                           "peak": round(1024 * 2.05e9 / 4.2 / 1e9, 1),
                                           "note": "peak = 1024 SIMDs x 2.05 GHz / 4.2 clk per multiply-add-heavy instruction (tools/ubench); the row pass's mix "
                                                   "(adds, selects, moves) issues at 3.7 clk, so `achieved` can pass it: the row pass is instruction-bound at "
