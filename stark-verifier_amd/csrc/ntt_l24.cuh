@@ -1,0 +1,269 @@
+// The LDE passes of the commit path on CARRY-FREE 24-BIT LIMBS (round 3; a2 / a3 of SURVEY.md 8; conventions as in ntt.hip:
+// omega_N = 7^((p-1)/N) chip/fri_chip.rs:162-163, bit-reversed evaluation order chip/fri_chip.rs:245-264).
+//
+// Why.  gfx950's SIMD-32 issues plain 32-bit add / sub / and / shift-right at twice the rate of everything that carries, multiplies
+// or is 64 bits wide (tools/ubench/ubench_alu2.hip, profiles/r03_ubench_alu2.txt), and in Goldilocks 2^96 = -1.  A value held as four
+// signed 32-bit limbs  v = l0 + l1 X + l2 X^2 + l3 X^3,  X = 2^24  (so X^4 = -1, arithmetic mod 2^96 + 1 = (2^32 + 1) p), with ~7 bits of
+// headroom per limb, makes
+//   * a radix-2 butterfly 4 + 4 full-rate instructions and NO carries (9 half-rate instructions on the 3 x 32-bit lazily reduced
+//     form of round 2: measured 2.07x per butterfly),
+//   * every twiddle inside a radix-8 network (omega_8 = -2^24, omega_4 = 2^48) a RENAMING of limbs (with signs folded into the
+//     subtraction that produces them): free,
+//   * the twiddles between the two radix-8 rounds of a 64-point transform (omega_64 = 2^39: shifts by multiples of 3 bits) a limb
+//     rotation plus a bit shift that doubles as the carry normalisation: ~13 cheap instructions, no multiplication,
+// so a 4096-point row is two radix-64 "super-rounds" with ONE general twiddle product per element between them (three in round 2),
+// and the 32-point column pass has none inside.  The general products (the 4-step twiddle at the column pass's store, the one between the
+// super-rounds, and the final reduction to a canonical u64) take the limbs directly: with W_i = w X^i mod p tabulated,
+//   a w = sum_i (l_i + beta_i) W_i  (beta = a multiple of p with all limbs ~1.5 * 2^28, so the operands are non-negative)
+// is 8 multiply-adds into two 64-bit accumulators that cannot overflow, one 128-bit reduction, no conversion of the limbs first.
+// Magnitudes: split limbs < 2^24; a radix-8 network multiplies the bound by 8 (2^27); the shift step renormalises to < 2^25; the second
+// network gives < 2^28; l + beta < 2^29.4, four products < 2^61.4 each.  (static_asserts and the GPU parity tests hold this up.)
+#pragma once
+#include "gl355_internal.h"
+#include "ntt_kernels.cuh"
+
+namespace gl355 {
+
+struct L24 { int32_t l[4]; };
+constexpr uint32_t L24_MASK = 0xFFFFFFu;
+// beta: sum_i beta_i 2^(24 i) = 0 mod p, every limb within [2^28, 2^29) (LLL + nearest plane on the lattice of multiples of p in limb
+// form, tools/l24_bias.py; checked there and by tests/test_l24_model.py)
+constexpr uint32_t L24_BETA[4] = {402653208u, 402653160u, 402653160u, 402653160u};
+
+GL_DEV L24 l24_split(uint64_t x) {
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    L24 r;
+    r.l[0] = (int32_t)(lo & L24_MASK);
+    r.l[1] = (int32_t)(__builtin_amdgcn_alignbit(hi, lo, 24) & L24_MASK);
+    r.l[2] = (int32_t)(hi >> 16);
+    r.l[3] = 0;
+    return r;
+}
+
+// (a, b) <- (a + b, +-(a - b) * X^RHO): the limb rotation and both signs are folded into which operand each subtraction takes from
+template <int RHO, bool NEG>
+GL_DEV void l24_bfly(L24& a, L24& b) {
+    L24 s, d;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s.l[i] = a.l[i] + b.l[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = (i - RHO) & 3;
+        const bool wrap = i < RHO;                      // X^4 = -1
+        d.l[i] = (NEG != wrap) ? b.l[j] - a.l[j] : a.l[j] - b.l[j];
+    }
+    a = s; b = d;
+}
+// twiddle omega_16^(+-E), E even, as (limb rotation, sign): forward -2^24, 2^48, -2^72; inverse 2^72, -2^48, 2^24 (ntt_kernels.cuh l96_bfly)
+template <bool INV, int E>
+GL_DEV void l24_bfly_w(L24& a, L24& b) {
+    constexpr int FWD_R[4] = {0, 1, 2, 3};
+    constexpr bool FWD_NEG[4] = {false, true, false, true};
+    constexpr int INV_R[4] = {0, 3, 2, 1};
+    constexpr bool INV_NEG[4] = {false, false, true, false};
+    l24_bfly<INV ? INV_R[E / 2] : FWD_R[E / 2], INV ? INV_NEG[E / 2] : FWD_NEG[E / 2]>(a, b);
+}
+// radix-8 DIF network, y[pos] <- Y[bitrev(pos)] (the data flow of dif8_lazy)
+template <bool INV>
+GL_DEV void dif8_l24(L24 (&y)[8]) {
+    l24_bfly_w<INV, 0>(y[0], y[4]); l24_bfly_w<INV, 2>(y[1], y[5]); l24_bfly_w<INV, 4>(y[2], y[6]); l24_bfly_w<INV, 6>(y[3], y[7]);
+    l24_bfly_w<INV, 0>(y[0], y[2]); l24_bfly_w<INV, 4>(y[1], y[3]); l24_bfly_w<INV, 0>(y[4], y[6]); l24_bfly_w<INV, 4>(y[5], y[7]);
+    l24_bfly_w<INV, 0>(y[0], y[1]); l24_bfly_w<INV, 0>(y[2], y[3]); l24_bfly_w<INV, 0>(y[4], y[5]); l24_bfly_w<INV, 0>(y[6], y[7]);
+}
+// radix-4 DIF network on y[0..3]
+template <bool INV>
+GL_DEV void dif4_l24(L24 (&y)[4]) {
+    l24_bfly_w<INV, 0>(y[0], y[2]); l24_bfly_w<INV, 4>(y[1], y[3]);
+    l24_bfly_w<INV, 0>(y[0], y[1]); l24_bfly_w<INV, 0>(y[2], y[3]);
+}
+
+// e * 2^S for a compile-time 0 <= S < 192, renormalised: S = 96 s + 24 a + b.  Limb i splits at bit 24 - b into g (kept, shifted up by
+// b) and h (carried into limb i + 1; out of limb 3 it wraps to limb 0 negated), then the limbs rotate by a; |out| < 2^24 + |e| 2^(b - 24).
+// With S = 0 it is the plain carry normalisation.
+template <int S>
+GL_DEV L24 l24_shift(const L24& e) {
+    static_assert(S >= 0 && S < 192, "shift out of range");
+    constexpr bool SG = S >= 96;
+    constexpr int A = (S % 96) / 24, B = (S % 96) % 24;
+    int32_t g[4], h[4], y[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { g[i] = e.l[i] & (int32_t)((1u << (24 - B)) - 1); h[i] = e.l[i] >> (24 - B); }
+    y[0] = (g[0] << B) - h[3];
+#pragma unroll
+    for (int i = 1; i < 4; i++) y[i] = (g[i] << B) + h[i - 1];
+    L24 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool neg = SG != (i + A >= 4);
+        r.l[(i + A) & 3] = neg ? -y[i] : y[i];
+    }
+    return r;
+}
+// the twiddles after the FIRST radix-8 round of a 2^M-point transform (M = 6: omega_64 = 2^39; M = 5: omega_32 = 2^78): slot q holds
+// output k0 = bitrev3(q) of butterfly R, multiplied by omega^(R k0); every slot is renormalised (slot 0 / R = 0: shift 0)
+template <int M, int R, bool INV>
+GL_DEV void l24_twiddles(L24 (&y)[8]) {
+    constexpr int MULT = M == 6 ? 39 : 78;
+#define GL355_L24_TW(Q, K0) { constexpr int S0 = (MULT * R * K0) % 192; y[Q] = l24_shift<INV ? (192 - S0) % 192 : S0>(y[Q]); }
+    GL355_L24_TW(0, 0) GL355_L24_TW(1, 4) GL355_L24_TW(2, 2) GL355_L24_TW(3, 6) GL355_L24_TW(4, 1) GL355_L24_TW(5, 5) GL355_L24_TW(6, 3) GL355_L24_TW(7, 7)
+#undef GL355_L24_TW
+}
+// r is wave-uniform: one scalar branch, then straight-line code with compile-time shifts and limb renamings
+template <int M, bool INV>
+GL_DEV void l24_twiddles_r(L24 (&y)[8], uint32_t r) {
+    switch (r) {
+        case 0: l24_twiddles<M, 0, INV>(y); break;
+        case 1: l24_twiddles<M, 1, INV>(y); break;
+        case 2: l24_twiddles<M, 2, INV>(y); break;
+        case 3: l24_twiddles<M, 3, INV>(y); break;
+        case 4: if constexpr (M == 6) l24_twiddles<M, 4, INV>(y); break;
+        case 5: if constexpr (M == 6) l24_twiddles<M, 5, INV>(y); break;
+        case 6: if constexpr (M == 6) l24_twiddles<M, 6, INV>(y); break;
+        default: if constexpr (M == 6) l24_twiddles<M, 7, INV>(y); break;
+    }
+}
+
+// a * w mod p (any u64 representative) for limbs |l_i| < 2^28 and w given as the four words W_i = w X^i mod p
+GL_DEV uint64_t l24_mul4(const L24& a, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3) {
+    const uint32_t b0 = (uint32_t)a.l[0] + L24_BETA[0], b1 = (uint32_t)a.l[1] + L24_BETA[1], b2 = (uint32_t)a.l[2] + L24_BETA[2],
+                   b3 = (uint32_t)a.l[3] + L24_BETA[3];
+    uint64_t slo = (uint64_t)b0 * (uint32_t)w0;
+    slo += (uint64_t)b1 * (uint32_t)w1; slo += (uint64_t)b2 * (uint32_t)w2; slo += (uint64_t)b3 * (uint32_t)w3;
+    uint64_t shi = (uint64_t)b0 * (uint32_t)(w0 >> 32);
+    shi += (uint64_t)b1 * (uint32_t)(w1 >> 32); shi += (uint64_t)b2 * (uint32_t)(w2 >> 32); shi += (uint64_t)b3 * (uint32_t)(w3 >> 32);
+    // slo + shi 2^32 as (lo, hi): only the middle word adds
+    uint32_t mid;
+    const bool c = __builtin_uadd_overflow((uint32_t)(slo >> 32), (uint32_t)shi, &mid);
+    const uint64_t lo = ((uint64_t)mid << 32) | (uint32_t)slo, hi = (shi >> 32) + (c ? 1u : 0u);
+    return gl_reduce128(lo, hi);
+}
+GL_DEV uint64_t l24_mul4(const L24& a, const uint64_t* __restrict__ w) {
+    const ulonglong2 p0 = *reinterpret_cast<const ulonglong2*>(w), p1 = *reinterpret_cast<const ulonglong2*>(w + 2);
+    return l24_mul4(a, p0.x, p0.y, p1.x, p1.y);
+}
+// the limbs as a u64 (any representative): the same sum with W_i = 2^(24 i) mod p (2^72 = 2^40 - 2^8); the compiler folds the zero words
+GL_DEV uint64_t l24_value(const L24& a) { return l24_mul4(a, 1ull, 1ull << 24, 1ull << 48, (1ull << 40) - (1ull << 8)); }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Row pass: one 4096-point row per 512-thread block = two radix-64 super-rounds on a 64 x 64 view (index = 64 u + v): A over u (stride
+// 64), the general twiddle omega_4096^(v kA) from a.mid4, B over v.  Wave w is butterfly r = w of every first round, so the shift
+// twiddles are compile-time per branch; the tile lives in LDS as 16-byte limb quads at index + (index >> 6) (row stride 65 quads: the
+// B rounds walk a lane stride of 65 x 16 bytes, conflict-free per 16-lane group).  Output order: plain bit reversal (identical to
+// ntt_rows_r8_kernel<12>), canonical.
+// ------------------------------------------------------------------------------------------------------------------------------
+GL_DEV uint32_t l24_phys(uint32_t idx) { return idx + (idx >> 6); }
+constexpr size_t L24_ROWS_LDS_BYTES = (4096 + 64) * 16;
+
+template <int WPE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_rows_l24_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_raw[];
+    int4* lq = reinterpret_cast<int4*>(lds_raw);
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const uint64_t row = blockIdx.x;
+    const uint64_t col = row >> a.log_rows, rin = row & ((1ull << a.log_rows) - 1);
+    const uint64_t* in = a.in + col * a.in_col_stride + (rin << 12);
+    uint64_t* out = a.out + col * a.out_col_stride + (rin << 12);
+    auto put = [&](uint32_t idx, const L24& v) { lq[l24_phys(idx)] = make_int4(v.l[0], v.l[1], v.l[2], v.l[3]); };
+    auto get = [&](uint32_t idx) { const int4 q = lq[l24_phys(idx)]; L24 v; v.l[0] = q.x; v.l[1] = q.y; v.l[2] = q.z; v.l[3] = q.w; return v; };
+    L24 y[8];
+    // A1: the thread that loaded elements tid + 512 q holds u = 8 q + w, v = lane: its own first-round butterfly (r = w)
+#pragma unroll
+    for (int q = 0; q < 8; q++) y[q] = l24_split(in[tid + 512 * q]);
+    dif8_l24<false>(y);
+    l24_twiddles_r<6, false>(y, w);
+#pragma unroll
+    for (int q = 0; q < 8; q++) put(64 * (8 * q + w) + lane, y[q]);
+    __syncthreads();
+    // A2: u = 8 w + r over r, then the general twiddle of the 64 x 64 split; a thread reads and writes the same eight cells
+#pragma unroll
+    for (int r = 0; r < 8; r++) y[r] = get(64 * (8 * w + r) + lane);
+    dif8_l24<false>(y);
+#pragma unroll
+    for (int s = 0; s < 8; s++) y[s] = l24_split(l24_mul4(y[s], a.mid4 + 4ull * (64 * (8 * w + s) + lane)));
+#pragma unroll
+    for (int s = 0; s < 8; s++) put(64 * (8 * w + s) + lane, y[s]);
+    __syncthreads();
+    // B1: u-slot = lane, v = 8 q + w
+#pragma unroll
+    for (int q = 0; q < 8; q++) y[q] = get(64 * lane + 8 * q + w);
+    dif8_l24<false>(y);
+    l24_twiddles_r<6, false>(y, w);
+#pragma unroll
+    for (int q = 0; q < 8; q++) put(64 * lane + 8 * q + w, y[q]);
+    __syncthreads();
+    // B2: v = 8 w + r over r; results leave the limb form
+#pragma unroll
+    for (int r = 0; r < 8; r++) y[r] = get(64 * lane + 8 * w + r);
+    dif8_l24<false>(y);
+    uint64_t o[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) o[s] = gl_canon(l24_value(y[s]));
+    __syncthreads();                                        // every quad has been read: the tile is reused for the 8-byte results
+#pragma unroll
+    for (int s = 0; s < 8; s++) lds_raw[l24_phys(64 * lane + 8 * w + s)] = o[s];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; q++) out[tid + 512 * q] = lds_raw[l24_phys(tid + 512 * q)];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Column pass of the LDE over all cosets (the shape of ntt_cols_r8_cosets_kernel<5>): 32 rows x 128 columns per tile, 32 = 8 x 4 with
+// omega_32 = 2^78 shift twiddles between the radix-8 and the radix-4 round, the 4-step twiddle (a.step4: four words per element) as
+// the limbs' exit product at the store.  Threads tid >> 7 = r are wave-uniform.  blockIdx is mapped so that an XCD (blockIdx % 8)
+// only ever touches 4 of the 32 column tiles: its L2 holds those slices of the step / pre / ratio tables.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr size_t L24_COLS_LDS_BYTES = 4096 * 16;
+template <int WPE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_cols_l24_cosets_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_raw[];
+    int4* lq = reinterpret_cast<int4*>(lds_raw);
+    constexpr uint32_t LOG_TC = 7, TC = 128;
+    const uint32_t tid = threadIdx.x, r = tid >> 7, cc = tid & (TC - 1);
+    const uint32_t log_n2 = a.log_rows;                     // 12
+    const uint32_t tiles_per_col = (1u << log_n2) >> LOG_TC; // 32
+    uint32_t tile, colu;
+    if (tiles_per_col == 32) { tile = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) & 3); colu = blockIdx.x >> 5; }
+    else { tile = blockIdx.x % tiles_per_col; colu = blockIdx.x / tiles_per_col; }
+    const uint64_t col = colu, c0 = (uint64_t)tile << LOG_TC;
+    const uint64_t* in = a.in + col * a.in_col_stride;
+    uint64_t v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const uint64_t gi = ((uint64_t)(r + 4 * q) << log_n2) + c0 + cc;
+        v[q] = gl_mul(in[gi], a.pre_full[gi]);
+    }
+    for (uint32_t c = 0; c < a.n_cosets; c++) {
+        if (c) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = gl_mul(v[q], a.ratio_full[((uint64_t)(r + 4 * q) << log_n2) + c0 + cc]);
+        }
+        uint64_t* out = a.out + (uint64_t)a.coset_slot[c] * a.coset_out_stride + col * a.out_col_stride;
+        L24 y[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) y[q] = l24_split(v[q]);
+        dif8_l24<false>(y);
+        l24_twiddles_r<5, false>(y, r);
+#pragma unroll
+        for (int q = 0; q < 8; q++) lq[TC * (4 * q + r) + cc] = make_int4(y[q].l[0], y[q].l[1], y[q].l[2], y[q].l[3]);
+        __syncthreads();
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++) {                    // two radix-4 tasks: rows 4 q' + {0..3}, q' = r and r + 4
+            const uint32_t qp = r + 4 * t2;
+            L24 z[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int4 qd = lq[TC * (4 * qp + k) + cc]; z[k].l[0] = qd.x; z[k].l[1] = qd.y; z[k].l[2] = qd.z; z[k].l[3] = qd.w; }
+            dif4_l24<false>(z);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t go = ((uint64_t)(4 * qp + k) << log_n2) + c0 + cc;
+                out[go] = l24_mul4(z[k], a.step4 + 4 * go);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_rows_l24(const PassArgs& a, hipStream_t s);
+hipError_t launch_cols_l24_cosets(const PassArgs& a, hipStream_t s);
+
+}  // namespace gl355

@@ -1,0 +1,78 @@
+// The 24-bit-limb LDE passes (csrc/ntt_l24.cuh): launchers and the two table builders.  Compiled with the 15-instruction inline-asm field
+// product like ntt_r8.hip (the coset-ratio products of the column pass and the 128-bit reductions of the limb products use it).
+// a2 / a3 of SURVEY.md 8; reference call sites as in ntt.hip (plonky2 coset_fft_with_options inside CircuitData::prove, access_set.rs:94).
+#define GL_MUL_VARIANT 1
+#include "gl355_internal.h"
+#include "ntt_l24.cuh"
+
+namespace gl355 {
+
+// mid4[(64 u + v) * 4 + i] = omega_4096^(bitrev6(u) v) 2^(24 i): cell (u, v) of the row tile holds output kA = bitrev6(u) of the first
+// radix-64 super-round (ntt_rows_l24_kernel)
+__global__ void build_mid4_kernel(uint64_t root4096, uint64_t* out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 4096) return;
+    const uint32_t u = g >> 6, v = g & 63;
+    const uint64_t w = gl_canon(gl_pow(root4096, (uint64_t)(__brev(u) >> 26) * v));
+    out[4 * g] = w;
+    out[4 * g + 1] = gl_canon(gl_mul_2exp<24>(w));
+    out[4 * g + 2] = gl_canon(gl_mul_2exp<48>(w));
+    out[4 * g + 3] = gl_canon(gl_mul_2exp<72>(w));
+}
+// step4[4 g + i] = step_full[g] 2^(24 i)
+__global__ void build_step4_kernel(const uint64_t* step_full, uint64_t n, uint64_t* out) {
+    const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const uint64_t w = gl_canon(step_full[g]);
+    out[4 * g] = w;
+    out[4 * g + 1] = gl_canon(gl_mul_2exp<24>(w));
+    out[4 * g + 2] = gl_canon(gl_mul_2exp<48>(w));
+    out[4 * g + 3] = gl_canon(gl_mul_2exp<72>(w));
+}
+
+int32_t Ctx::l24_mid_table(const uint64_t** out) {
+    const std::vector<uint64_t> key{3, 12};
+    auto it = full_cache.find(key);
+    if (it != full_cache.end()) { *out = it->second; return GL355_OK; }
+    uint64_t* d = nullptr;
+    GL355_HIP(this, hipMalloc((void**)&d, 4096 * 4 * 8));
+    hipLaunchKernelGGL(build_mid4_kernel, dim3(16), dim3(256), 0, stream, gl_root_of_unity(12), d);
+    GL355_HIP(this, hipGetLastError());
+    full_cache[key] = d;
+    *out = d;
+    return GL355_OK;
+}
+int32_t Ctx::l24_step_table(const uint64_t* step_full, uint32_t log_n, const uint64_t** out) {
+    const std::vector<uint64_t> key{4, (uint64_t)(uintptr_t)step_full, log_n};
+    auto it = full_cache.find(key);
+    if (it != full_cache.end()) { *out = it->second; return GL355_OK; }
+    const uint64_t n = 1ull << log_n;
+    uint64_t* d = nullptr;
+    GL355_HIP(this, hipMalloc((void**)&d, n * 4 * 8));
+    hipLaunchKernelGGL(build_step4_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, step_full, n, d);
+    GL355_HIP(this, hipGetLastError());
+    full_cache[key] = d;
+    *out = d;
+    return GL355_OK;
+}
+
+// rows of 4096 points: a.batch << a.log_rows of them (forward, natural order in, bit-reversed canonical out, no multiplier tables)
+hipError_t launch_rows_l24(const PassArgs& a, hipStream_t s) {
+    const uint64_t blocks = ((uint64_t)a.batch) << a.log_rows;
+    auto k = ntt_rows_l24_kernel<4>;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L24_ROWS_LDS_BYTES);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(512), L24_ROWS_LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+// 32-point column pass over all cosets: blocks over (column, 128-column tile)
+hipError_t launch_cols_l24_cosets(const PassArgs& a, hipStream_t s) {
+    const uint64_t blocks = ((1ull << a.log_rows) >> 7) * a.batch;
+    auto k = ntt_cols_l24_cosets_kernel<4>;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L24_COLS_LDS_BYTES);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(512), L24_COLS_LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace gl355
