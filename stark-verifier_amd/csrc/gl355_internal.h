@@ -62,9 +62,8 @@ struct Ctx {
     std::map<std::vector<uint64_t>, uint64_t*> full_cache;   // full-size multiplier tables (ntt.hip)
     int32_t full_pow_table(const uint64_t* lo, const uint64_t* hi, uint32_t n_cosets, uint32_t log_n, const uint64_t** out);
     int32_t full_step_table(const uint64_t* lo, const uint64_t* hi, uint32_t l1, uint32_t l2, bool inv, const uint64_t** out);
-    // tables of the 24-bit-limb passes (ntt_l24.hip): four words w 2^(24 i) mod p per twiddle
+    // table of the 24-bit-limb row pass (ntt_l24.hip): the twiddles between its two radix-64 super-rounds
     int32_t l24_mid_table(const uint64_t** out);
-    int32_t l24_step_table(const uint64_t* step_full, uint32_t log_n, const uint64_t** out);
 
     // trivial caching device allocator (per context => per stream, so reuse is stream-ordered)
     struct Block { void* p; size_t size; bool used; };

@@ -37,9 +37,14 @@ namespace gl355 {
 // the 24-bit-limb passes of the LDE (ntt_l24.hip)
 hipError_t launch_rows_l24(const PassArgs& a, hipStream_t s);
 hipError_t launch_cols_l24_cosets(const PassArgs& a, hipStream_t s);
-// GL355_EXP_NTT_NO_L24=1 keeps the LDE on the radix-8 kernels of round 2 (A/B)
+// GL355_EXP_NTT_NO_L24=1 keeps the LDE's column pass on the radix-8 kernel of round 2 (A/B); GL355_EXP_NTT_L24_ROWS=1 also runs the
+// 4096-point rows on limbs (measured slower than the radix-8 row kernel: its 65-KB tile allows two blocks per CU)
 static bool ntt_l24_on() {
     static const bool v = getenv("GL355_EXP_NTT_NO_L24") == nullptr;
+    return v;
+}
+static bool ntt_l24_rows_on() {
+    static const bool v = getenv("GL355_EXP_NTT_L24_ROWS") != nullptr;
     return v;
 }
 
@@ -185,8 +190,8 @@ static bool ntt_r16_only() {
 }
 
 static hipError_t launch_rows(const PassArgs& a, uint32_t log_t, bool inv, hipStream_t s) {
-    // 4096-point rows of the two-pass LDE / forward transform on 24-bit limbs (a.mid4 is set by ntt_run for exactly that shape)
-    if (a.mid4 && !inv && log_t == 12 && a.n_cosets == 1 && !a.pre_full && !a.pre_lo && !a.post_lo && a.scale == 1 && a.canon && !a.in_bitrev &&
+    // 4096-point rows of the two-pass LDE / forward transform on 24-bit limbs (a.mid is set by ntt_run for exactly that shape)
+    if (a.mid && !inv && log_t == 12 && a.n_cosets == 1 && !a.pre_full && !a.pre_lo && !a.post_lo && a.scale == 1 && a.canon && !a.in_bitrev &&
         !a.out_natural && !ntt_r16_only())
         return launch_rows_l24(a, s);
     // the commit-path shape (forward, whole rows of 2^12..2^14 points in natural order, at most a full pre table) runs the
@@ -223,7 +228,7 @@ static hipError_t launch_cols_t(const PassArgs& a, bool inv, uint64_t blocks, hi
     const bool r8 = a.step_full && (inv ? !a.pre_lo && !a.pre_full : (a.pre_full || !a.pre_lo)) && !a.in_bitrev && !a.out_natural && !a.post_lo &&
                     a.scale == 1 && !a.canon;
     static const bool per_coset = getenv("GL355_EXP_NTT_PER_COSET") != nullptr;     // A/B: one block per (tile, coset) as before
-    if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset && LOG_T == 5 && a.log_rows == 12 && a.step4) return launch_cols_l24_cosets(a, s);
+    if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset && LOG_T == 5 && a.log_rows == 12 && ntt_l24_on()) return launch_cols_l24_cosets(a, s);
     if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset) return launch_cols_r8_cosets(a, LOG_T, s);
     if (r8 && !ntt_r16_only()) return launch_cols_r8(a, LOG_T, inv, s);
     if (fast) hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, false, true>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
@@ -333,7 +338,6 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
                 const uint64_t *rlo, *rhi;
                 GL355_TRY(ctx->pow_tables(p.coset_ratio, &rlo, &rhi));
                 GL355_TRY(ctx->full_pow_table(rlo, rhi, 1, p.log_n, &a.ratio_full));
-                if (ntt_l24_on() && !inv && l1 == 5 && l2 == 12) GL355_TRY(ctx->l24_step_table(a.step_full, p.log_n, &a.step4));
             }
         }
         a.in_bitrev = 0; a.out_natural = 0; a.canon = 0;
@@ -351,8 +355,8 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         PassArgs b = a;
         b.in = p.out; b.in_col_stride = p.out_col_stride;
         // each coset's intermediate lives in its own output block: rows pass runs per coset slot
-        b.pre_lo = b.pre_hi = nullptr; b.step_lo = b.step_hi = nullptr; b.pre_full = nullptr; b.step_full = nullptr; b.ratio_full = nullptr; b.step4 = nullptr;
-        if (ntt_l24_on() && !inv && l2 == 12 && p.scale == 1) GL355_TRY(ctx->l24_mid_table(&b.mid4));
+        b.pre_lo = b.pre_hi = nullptr; b.step_lo = b.step_hi = nullptr; b.pre_full = nullptr; b.step_full = nullptr; b.ratio_full = nullptr;
+        if (ntt_l24_on() && ntt_l24_rows_on() && !inv && l2 == 12 && p.scale == 1) GL355_TRY(ctx->l24_mid_table(&b.mid));
         b.log_rows = l1;  // rows per column = N1
         b.scale = p.scale; b.canon = 1;
         if (p.n_cosets == 1) {

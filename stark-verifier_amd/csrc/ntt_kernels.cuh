@@ -243,8 +243,7 @@ struct PassArgs {
     uint64_t pre_full_stride;
     const uint64_t* step_full; // optional full 4-step twiddle table in STORE order (col kernel, first pass)
     const uint64_t* ratio_full; // LDE column pass over all cosets in one block: (base[c+1] / base[c])^i, constant over c (Ctx::full_pow_table)
-    const uint64_t* step4;     // 24-bit-limb kernels (ntt_l24.cuh): step_full as four words per element, w 2^(24 i) mod p
-    const uint64_t* mid4;      //   and the twiddles between the two radix-64 super-rounds of a 4096-point row, same form, LDS-cell order
+    const uint64_t* mid;       // 24-bit-limb row kernel (ntt_l24.cuh): the twiddles between the two radix-64 super-rounds of a 4096-point row, LDS-cell order
     uint64_t scale;            // constant multiplier at store (1 = none)
     uint32_t in_bitrev;        // input transform index is bit-reversed in memory
     uint32_t out_natural;      // write natural order (else DIF-native bit-reversed order)

@@ -12,15 +12,22 @@
 //   * the twiddles between the two radix-8 rounds of a 64-point transform (omega_64 = 2^39: shifts by multiples of 3 bits) a limb
 //     rotation plus a bit shift that doubles as the carry normalisation: ~13 cheap instructions, no multiplication,
 // so a 4096-point row is two radix-64 "super-rounds" with ONE general twiddle product per element between them (three in round 2),
-// and the 32-point column pass has none inside.  The general products (the 4-step twiddle at the column pass's store, the one between the
-// super-rounds, and the final reduction to a canonical u64) take the limbs directly: with W_i = w X^i mod p tabulated,
-//   a w = sum_i (l_i + beta_i) W_i  (beta = a multiple of p with all limbs ~1.5 * 2^28, so the operands are non-negative)
-// is 8 multiply-adds into two 64-bit accumulators that cannot overflow, one 128-bit reduction, no conversion of the limbs first.
+// and the 32-point column pass has none inside.  Leaving the limb form (before a general product, and at the end) is
+//   value = sum_i (l_i + beta_i) 2^(24 i) mod p  (beta = a multiple of p with all limbs ~1.5 * 2^28, so the operands are non-negative):
+// multiply-adds into two 64-bit accumulators that cannot overflow and one 128-bit reduction.  (The same sum with tabulated words
+// W_i = w X^i mod p is the product a w itself, l24_mul4 -- 8 multiply-adds, no conversion first; measured and not used: its 32 bytes
+// of table per element made the passes bound by the CU's vector-memory path, profiles/r03_ubench_ntt_l24.txt.)
 // Magnitudes: split limbs < 2^24; a radix-8 network multiplies the bound by 8 (2^27); the shift step renormalises to < 2^25; the second
 // network gives < 2^28; l + beta < 2^29.4, four products < 2^61.4 each.  (static_asserts and the GPU parity tests hold this up.)
 #pragma once
 #include "gl355_internal.h"
 #include "ntt_kernels.cuh"
+
+// experiments (tools/ubench/ubench_ntt_l24.hip; results are wrong with a KO bit set): 1 = no global loads, 2 = no global stores,
+// 4 = mid twiddles from constants instead of the table
+#ifndef GL355_L24_KO
+#define GL355_L24_KO 0
+#endif
 
 namespace gl355 {
 
@@ -145,11 +152,15 @@ GL_DEV uint64_t l24_mul4(const L24& a, const uint64_t* __restrict__ w) {
 GL_DEV uint64_t l24_value(const L24& a) { return l24_mul4(a, 1ull, 1ull << 24, 1ull << 48, (1ull << 40) - (1ull << 8)); }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Row pass: one 4096-point row per 512-thread block = two radix-64 super-rounds on a 64 x 64 view (index = 64 u + v): A over u (stride
-// 64), the general twiddle omega_4096^(v kA) from a.mid4, B over v.  Wave w is butterfly r = w of every first round, so the shift
-// twiddles are compile-time per branch; the tile lives in LDS as 16-byte limb quads at index + (index >> 6) (row stride 65 quads: the
-// B rounds walk a lane stride of 65 x 16 bytes, conflict-free per 16-lane group).  Output order: plain bit reversal (identical to
-// ntt_rows_r8_kernel<12>), canonical.
+// Row pass: 4096-point rows, 512-thread blocks = two radix-64 super-rounds on a 64 x 64 view (index = 64 u + v): A over u (stride 64),
+// the general twiddle omega_4096^(v kA) (a.mid: one word per cell), B over v.  Wave w is butterfly r = w of every first round, so the
+// shift twiddles are compile-time per branch.  The tile lives in LDS as 16-byte limb quads at index + (index >> 6) (row stride 65
+// quads: the B rounds walk a lane stride of 65 x 16 bytes, conflict-free per 16-lane group); the two exchanges that carry reduced
+// 8-byte values (between the super-rounds, and the transposition to store order) use the low half of a thread's OWN cells, so no
+// barrier is needed before writing them.  Blocks are PERSISTENT (grid = 2 per CU): a block's eight mid twiddles per thread stay in
+// registers for all its rows -- fetched per row they were 128 KB of L2 reads per 64 KB of data and, through the CU's 64-B/clk vector
+// memory path, a fifth of the pass (profiles/r03_ubench_ntt_l24.txt) -- and the next row's elements are fetched while this one is
+// transformed.  Output order: plain bit reversal (identical to ntt_rows_r8_kernel<12>), canonical.
 // ------------------------------------------------------------------------------------------------------------------------------
 GL_DEV uint32_t l24_phys(uint32_t idx) { return idx + (idx >> 6); }
 constexpr size_t L24_ROWS_LDS_BYTES = (4096 + 64) * 16;
@@ -159,58 +170,80 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_raw[];
     int4* lq = reinterpret_cast<int4*>(lds_raw);
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const uint64_t row = blockIdx.x;
-    const uint64_t col = row >> a.log_rows, rin = row & ((1ull << a.log_rows) - 1);
-    const uint64_t* in = a.in + col * a.in_col_stride + (rin << 12);
-    uint64_t* out = a.out + col * a.out_col_stride + (rin << 12);
+    const uint64_t total_rows = ((uint64_t)a.batch) << a.log_rows;
     auto put = [&](uint32_t idx, const L24& v) { lq[l24_phys(idx)] = make_int4(v.l[0], v.l[1], v.l[2], v.l[3]); };
     auto get = [&](uint32_t idx) { const int4 q = lq[l24_phys(idx)]; L24 v; v.l[0] = q.x; v.l[1] = q.y; v.l[2] = q.z; v.l[3] = q.w; return v; };
-    L24 y[8];
-    // A1: the thread that loaded elements tid + 512 q holds u = 8 q + w, v = lane: its own first-round butterfly (r = w)
+    auto put8 = [&](uint32_t idx, uint64_t v) { lds_raw[2 * l24_phys(idx)] = v; };      // the low 8 bytes of a quad cell
+    auto get8 = [&](uint32_t idx) { return lds_raw[2 * l24_phys(idx)]; };
+    auto row_ptr = [&](uint64_t row, const uint64_t* base, uint64_t stride) {
+        const uint64_t col = row >> a.log_rows, rin = row & ((1ull << a.log_rows) - 1);
+        return base + col * stride + (rin << 12);
+    };
+    uint64_t tw[8];                                         // cell (8 w + s, lane) of the mid table, s < 8: the same for every row
 #pragma unroll
-    for (int q = 0; q < 8; q++) y[q] = l24_split(in[tid + 512 * q]);
-    dif8_l24<false>(y);
-    l24_twiddles_r<6, false>(y, w);
+    for (int s = 0; s < 8; s++) tw[s] = (GL355_L24_KO & 4) ? 3 + s + w : a.mid[64 * (8 * w + s) + lane];
+    uint64_t row = blockIdx.x;
+    uint64_t x[8];
+    if (row < total_rows) {
+        const uint64_t* in = row_ptr(row, a.in, a.in_col_stride);
 #pragma unroll
-    for (int q = 0; q < 8; q++) put(64 * (8 * q + w) + lane, y[q]);
-    __syncthreads();
-    // A2: u = 8 w + r over r, then the general twiddle of the 64 x 64 split; a thread reads and writes the same eight cells
+        for (int q = 0; q < 8; q++) x[q] = (GL355_L24_KO & 1) ? (uint64_t)tid * 0x9E3779B97F4A7C15ull + q : in[tid + 512 * q];
+    }
+    while (row < total_rows) {
+        L24 y[8];
+        // A1: the thread that loaded elements tid + 512 q holds u = 8 q + w, v = lane: its own first-round butterfly (r = w)
 #pragma unroll
-    for (int r = 0; r < 8; r++) y[r] = get(64 * (8 * w + r) + lane);
-    dif8_l24<false>(y);
+        for (int q = 0; q < 8; q++) y[q] = l24_split(x[q]);
+        const uint64_t next = row + gridDim.x;
+        if (next < total_rows) {
+            const uint64_t* in = row_ptr(next, a.in, a.in_col_stride);
 #pragma unroll
-    for (int s = 0; s < 8; s++) y[s] = l24_split(l24_mul4(y[s], a.mid4 + 4ull * (64 * (8 * w + s) + lane)));
+            for (int q = 0; q < 8; q++) x[q] = (GL355_L24_KO & 1) ? x[q] + next : in[tid + 512 * q];
+        }
+        dif8_l24<false>(y);
+        l24_twiddles_r<6, false>(y, w);
 #pragma unroll
-    for (int s = 0; s < 8; s++) put(64 * (8 * w + s) + lane, y[s]);
-    __syncthreads();
-    // B1: u-slot = lane, v = 8 q + w
+        for (int q = 0; q < 8; q++) put(64 * (8 * q + w) + lane, y[q]);
+        __syncthreads();
+        // A2: u = 8 w + r over r, then the general twiddle of the 64 x 64 split; 8-byte products into the thread's own cells
 #pragma unroll
-    for (int q = 0; q < 8; q++) y[q] = get(64 * lane + 8 * q + w);
-    dif8_l24<false>(y);
-    l24_twiddles_r<6, false>(y, w);
+        for (int r = 0; r < 8; r++) y[r] = get(64 * (8 * w + r) + lane);
+        dif8_l24<false>(y);
 #pragma unroll
-    for (int q = 0; q < 8; q++) put(64 * lane + 8 * q + w, y[q]);
-    __syncthreads();
-    // B2: v = 8 w + r over r; results leave the limb form
+        for (int s = 0; s < 8; s++) put8(64 * (8 * w + s) + lane, gl_mul(l24_value(y[s]), tw[s]));
+        __syncthreads();
+        // B1: u-slot = lane, v = 8 q + w; reads and writes the same eight cells
 #pragma unroll
-    for (int r = 0; r < 8; r++) y[r] = get(64 * lane + 8 * w + r);
-    dif8_l24<false>(y);
-    uint64_t o[8];
+        for (int q = 0; q < 8; q++) y[q] = l24_split(get8(64 * lane + 8 * q + w));
+        dif8_l24<false>(y);
+        l24_twiddles_r<6, false>(y, w);
 #pragma unroll
-    for (int s = 0; s < 8; s++) o[s] = gl_canon(l24_value(y[s]));
-    __syncthreads();                                        // every quad has been read: the tile is reused for the 8-byte results
+        for (int q = 0; q < 8; q++) put(64 * lane + 8 * q + w, y[q]);
+        __syncthreads();
+        // B2: v = 8 w + r over r; results leave the limb form (own cells again), then the transposition to store order
 #pragma unroll
-    for (int s = 0; s < 8; s++) lds_raw[l24_phys(64 * lane + 8 * w + s)] = o[s];
-    __syncthreads();
+        for (int r = 0; r < 8; r++) y[r] = get(64 * lane + 8 * w + r);
+        dif8_l24<false>(y);
 #pragma unroll
-    for (int q = 0; q < 8; q++) out[tid + 512 * q] = lds_raw[l24_phys(tid + 512 * q)];
+        for (int s = 0; s < 8; s++) put8(64 * lane + 8 * w + s, gl_canon(l24_value(y[s])));
+        __syncthreads();
+        uint64_t* out = const_cast<uint64_t*>(row_ptr(row, a.out, a.out_col_stride));
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint64_t v = get8(tid + 512 * q);
+            if (!(GL355_L24_KO & 2) || v == 0x123456789ull) out[tid + 512 * q] = v;
+        }
+        __syncthreads();                                    // the tile is free for the next row's quads
+        row = next;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Column pass of the LDE over all cosets (the shape of ntt_cols_r8_cosets_kernel<5>): 32 rows x 128 columns per tile, 32 = 8 x 4 with
-// omega_32 = 2^78 shift twiddles between the radix-8 and the radix-4 round, the 4-step twiddle (a.step4: four words per element) as
-// the limbs' exit product at the store.  Threads tid >> 7 = r are wave-uniform.  blockIdx is mapped so that an XCD (blockIdx % 8)
-// only ever touches 4 of the 32 column tiles: its L2 holds those slices of the step / pre / ratio tables.
+// omega_32 = 2^78 shift twiddles between the radix-8 and the radix-4 round, the 4-step twiddle (a.step_full) at the store.  Threads
+// tid >> 7 = r are wave-uniform.  A thread stores to the same eight places with the same step twiddles for every coset: they are loaded
+// once per tile.  blockIdx is mapped so that an XCD
+// (blockIdx % 8) only ever touches 4 of the 32 column tiles: its L2 holds those slices of the step / pre / ratio tables.
 // ------------------------------------------------------------------------------------------------------------------------------
 constexpr size_t L24_COLS_LDS_BYTES = 4096 * 16;
 template <int WPE>
@@ -226,14 +259,18 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
     else { tile = blockIdx.x % tiles_per_col; colu = blockIdx.x / tiles_per_col; }
     const uint64_t col = colu, c0 = (uint64_t)tile << LOG_TC;
     const uint64_t* in = a.in + col * a.in_col_stride;
-    uint64_t v[8];
+    uint64_t v[8], step[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const uint64_t gi = ((uint64_t)(r + 4 * q) << log_n2) + c0 + cc;
-        v[q] = gl_mul(in[gi], a.pre_full[gi]);
+        v[q] = gl_mul((GL355_L24_KO & 1) ? gi : in[gi], a.pre_full[gi]);
     }
+#pragma unroll
+    for (int t2 = 0; t2 < 2; t2++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) step[4 * t2 + k] = a.step_full[((uint64_t)(4 * (r + 4 * t2) + k) << log_n2) + c0 + cc];
     for (uint32_t c = 0; c < a.n_cosets; c++) {
-        if (c) {
+        if (c) {        // the ratio table is re-read per coset (L2-resident, coalesced) rather than held: 16 VGPRs less, no spills
 #pragma unroll
             for (int q = 0; q < 8; q++) v[q] = gl_mul(v[q], a.ratio_full[((uint64_t)(r + 4 * q) << log_n2) + c0 + cc]);
         }
@@ -256,7 +293,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint64_t go = ((uint64_t)(4 * qp + k) << log_n2) + c0 + cc;
-                out[go] = l24_mul4(z[k], a.step4 + 4 * go);
+                const uint64_t val = gl_mul(l24_value(z[k]), step[4 * t2 + k]);
+                if (!(GL355_L24_KO & 2) || val == 0x123456789ull) out[go] = val;
             }
         }
         __syncthreads();

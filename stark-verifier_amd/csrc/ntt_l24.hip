@@ -4,30 +4,17 @@
 #define GL_MUL_VARIANT 1
 #include "gl355_internal.h"
 #include "ntt_l24.cuh"
+#include <algorithm>
 
 namespace gl355 {
 
-// mid4[(64 u + v) * 4 + i] = omega_4096^(bitrev6(u) v) 2^(24 i): cell (u, v) of the row tile holds output kA = bitrev6(u) of the first
-// radix-64 super-round (ntt_rows_l24_kernel)
-__global__ void build_mid4_kernel(uint64_t root4096, uint64_t* out) {
+// mid[64 u + v] = omega_4096^(bitrev6(u) v): cell (u, v) of the row tile holds output kA = bitrev6(u) of the first radix-64
+// super-round (ntt_rows_l24_kernel)
+__global__ void build_mid_kernel(uint64_t root4096, uint64_t* out) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= 4096) return;
     const uint32_t u = g >> 6, v = g & 63;
-    const uint64_t w = gl_canon(gl_pow(root4096, (uint64_t)(__brev(u) >> 26) * v));
-    out[4 * g] = w;
-    out[4 * g + 1] = gl_canon(gl_mul_2exp<24>(w));
-    out[4 * g + 2] = gl_canon(gl_mul_2exp<48>(w));
-    out[4 * g + 3] = gl_canon(gl_mul_2exp<72>(w));
-}
-// step4[4 g + i] = step_full[g] 2^(24 i)
-__global__ void build_step4_kernel(const uint64_t* step_full, uint64_t n, uint64_t* out) {
-    const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (g >= n) return;
-    const uint64_t w = gl_canon(step_full[g]);
-    out[4 * g] = w;
-    out[4 * g + 1] = gl_canon(gl_mul_2exp<24>(w));
-    out[4 * g + 2] = gl_canon(gl_mul_2exp<48>(w));
-    out[4 * g + 3] = gl_canon(gl_mul_2exp<72>(w));
+    out[g] = gl_canon(gl_pow(root4096, (uint64_t)(__brev(u) >> 26) * v));
 }
 
 int32_t Ctx::l24_mid_table(const uint64_t** out) {
@@ -35,21 +22,8 @@ int32_t Ctx::l24_mid_table(const uint64_t** out) {
     auto it = full_cache.find(key);
     if (it != full_cache.end()) { *out = it->second; return GL355_OK; }
     uint64_t* d = nullptr;
-    GL355_HIP(this, hipMalloc((void**)&d, 4096 * 4 * 8));
-    hipLaunchKernelGGL(build_mid4_kernel, dim3(16), dim3(256), 0, stream, gl_root_of_unity(12), d);
-    GL355_HIP(this, hipGetLastError());
-    full_cache[key] = d;
-    *out = d;
-    return GL355_OK;
-}
-int32_t Ctx::l24_step_table(const uint64_t* step_full, uint32_t log_n, const uint64_t** out) {
-    const std::vector<uint64_t> key{4, (uint64_t)(uintptr_t)step_full, log_n};
-    auto it = full_cache.find(key);
-    if (it != full_cache.end()) { *out = it->second; return GL355_OK; }
-    const uint64_t n = 1ull << log_n;
-    uint64_t* d = nullptr;
-    GL355_HIP(this, hipMalloc((void**)&d, n * 4 * 8));
-    hipLaunchKernelGGL(build_step4_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, step_full, n, d);
+    GL355_HIP(this, hipMalloc((void**)&d, 4096 * 8));
+    hipLaunchKernelGGL(build_mid_kernel, dim3(16), dim3(256), 0, stream, gl_root_of_unity(12), d);
     GL355_HIP(this, hipGetLastError());
     full_cache[key] = d;
     *out = d;
@@ -58,7 +32,10 @@ int32_t Ctx::l24_step_table(const uint64_t* step_full, uint32_t log_n, const uin
 
 // rows of 4096 points: a.batch << a.log_rows of them (forward, natural order in, bit-reversed canonical out, no multiplier tables)
 hipError_t launch_rows_l24(const PassArgs& a, hipStream_t s) {
-    const uint64_t blocks = ((uint64_t)a.batch) << a.log_rows;
+    // persistent blocks: two per CU (the 65-KB tile allows no more), each walks rows blockIdx, blockIdx + grid, ...
+    static const int n_cu = [] { int dev = 0, cu = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); return cu; }();
+    const uint64_t total = ((uint64_t)a.batch) << a.log_rows;
+    const uint64_t blocks = std::min<uint64_t>(total, 2ull * (uint64_t)n_cu);
     auto k = ntt_rows_l24_kernel<4>;
     static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L24_ROWS_LDS_BYTES);
     if (attr != hipSuccess) return attr;
