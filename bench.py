@@ -500,6 +500,51 @@ def bn254_figures(gl, device):
     ctx.check(lib.gl355_bn254_g1_msm_batch(ctx.h, C.c_void_p(pts.data_ptr()), C.c_void_p(scb.data_ptr()), n, m_sets, C.c_void_p(resb.data_ptr())))
     ms = ctx.timer_stop()
     out["g1_msm_batch_8x2p20"] = {"ms": round(ms, 2), "ms_per_msm": round(ms / m_sets, 2), "points_per_s": round(m_sets * n / ms * 1e3 / 1e6, 2), "unit": "M points/s"}
+    # the reference's circuit size (README.md:171-177: k = 23): SRS on the device, FFT, extended-domain FFT, commit (= MSM over 2^23 distinct
+    # bases), single-point opening (synthetic division + MSM); parity of these entries: tests/test_gpu_kzg.py
+    try:
+        k = 23
+        n = 1 << k
+        del pts, sc, scb, s_i
+        torch.cuda.empty_cache()
+        tau = np.array([0x5E3F50617283940A, 0x1B2C3D4E5F607182, 0x93A4B5C6D7E8F901, 0x0203040506070809], dtype=np.uint64)
+        srs = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+        t0 = time.perf_counter()
+        ctx.check(lib.gl355_kzg_setup(ctx.h, tau.ctypes.data, k, C.c_void_p(srs.data_ptr()), None))
+        ctx.sync()
+        kz = {"setup_powers_of_tau_ms": round(1e3 * (time.perf_counter() - t0), 1)}
+        poly = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+        poly[:, 3] &= (1 << 61) - 1
+        x = poly.clone()
+        ctx.check(lib.gl355_bn254_fr_ntt(ctx.h, C.c_void_p(x.data_ptr()), k, 0))
+        ctx.sync()
+        ctx.timer_start()
+        ctx.check(lib.gl355_bn254_fr_ntt(ctx.h, C.c_void_p(x.data_ptr()), k, 0))
+        kz["fr_ntt_k23_ms"] = round(ctx.timer_stop(), 2)
+        ext = torch.empty((1 << 25, 4), dtype=torch.int64, device="cuda")
+        sh = np.array([7, 0, 0, 0], dtype=np.uint64)
+        ctx.check(lib.gl355_bn254_fr_coset_ntt(ctx.h, C.c_void_p(poly.data_ptr()), k, 25, sh.ctypes.data, 0, C.c_void_p(ext.data_ptr())))
+        ctx.sync()
+        ctx.timer_start()
+        ctx.check(lib.gl355_bn254_fr_coset_ntt(ctx.h, C.c_void_p(poly.data_ptr()), k, 25, sh.ctypes.data, 0, C.c_void_p(ext.data_ptr())))
+        kz["coeff_to_extended_23_to_25_ms"] = round(ctx.timer_stop(), 2)
+        del ext, x
+        cm = np.zeros(8, dtype=np.uint64)
+        ctx.check(lib.gl355_kzg_commit(ctx.h, C.c_void_p(srs.data_ptr()), C.c_void_p(poly.data_ptr()), k, 0, cm.ctypes.data))
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.check(lib.gl355_kzg_commit(ctx.h, C.c_void_p(srs.data_ptr()), C.c_void_p(poly.data_ptr()), k, 0, cm.ctypes.data))
+        kz["commit_msm_2p23_ms"] = round(1e3 * (time.perf_counter() - t0) / 3, 2)
+        kz["commit_points_per_s"] = round(n / kz["commit_msm_2p23_ms"] * 1e3 / 1e6, 1)
+        ev, wit = np.zeros(4, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        z = np.array([0x8899AABBCCDDEEFF, 0x0011223344556677, 0x8796A5B4C3D2E1F0, 0x0F1E2D3C4B5A6978 >> 4], dtype=np.uint64)
+        t0 = time.perf_counter()
+        ctx.check(lib.gl355_kzg_open(ctx.h, C.c_void_p(srs.data_ptr()), C.c_void_p(poly.data_ptr()), k, z.ctypes.data, ev.ctypes.data, wit.ctypes.data, None))
+        kz["open_division_plus_msm_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+        kz["what"] = "k = 23 (the reference's Halo2 circuit size): ParamsKZG::setup's powers of tau, best_fft, coeff_to_extended, commit, single-point opening; operands resident; host-side window combination included in the MSM figures"
+        out["kzg_k23"] = kz
+    except Exception as exc:
+        out["kzg_k23"] = {"error": repr(exc)}
     ctx.close()
     return out
 

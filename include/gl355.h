@@ -538,6 +538,23 @@ int32_t gl355_bn254_g1_msm_batch(gl355_ctx* ctx, const uint64_t* points /* n x 8
                                  uint32_t n_sets, uint64_t* results /* n_sets x 8 */);
 int32_t gl355_bn254_g1_fixed_base_mul(gl355_ctx* ctx, const uint64_t base[8], const uint64_t* scalars /* n x 4 */, uint64_t n, uint64_t* out /* n x 8 */);
 
+/* ---- KZG composites over those kernels: what halo2_proofs' ParamsKZG / create_proof do with them at the reference's
+ * k = 23 (verifier_api.rs:77-92 `ParamsKZG::<Bn256>::setup`, `create_proof_checked`; chip/native_chip/test_utils.rs:57-95; README.md:171-177).
+ * Scalars are plain 256-bit integers (4 x u64, reduced mod r on load), points affine (x | y, 8 x u64; all zero = the identity); every
+ * array may be host or device memory.
+ *   gl355_kzg_setup    ParamsKZG::setup with the secret handed in: g[i] = [tau^i] G1, g_lagrange[i] = [L_i(tau)] G1 (NULL to skip), G1 = (1, 2),
+ *                      L_i the Lagrange basis of the 2^log_n domain.  GL355_E_INVALID_ARG if tau lies in the domain.
+ *   gl355_kzg_commit   ParamsKZG::commit / commit_lagrange: sum_i poly[i] g[i].  values_form 0: poly goes with the bases as given (coefficients
+ *                      with g, evaluations with g_lagrange); 1: poly are evaluations over the domain and g the MONOMIAL bases (inverse FFT, then MSM)
+ *   gl355_kzg_open     eval = p(z) and witness = commit((p - p(z)) / (X - z)) for the coefficients of p: the single-point opening halo2's
+ *                      multi-open provers reduce to.  quotient (optional, 2^log_n x 4) receives the quotient's coefficients.
+ * A verifier with the pairing checks e(C - [eval] G1, G2) = e(witness, [tau - z] G2); with a known tau: C - [eval] G1 = [tau - z] witness. */
+int32_t gl355_kzg_setup(gl355_ctx* ctx, const uint64_t tau[4], uint32_t log_n, uint64_t* g /* 2^log_n x 8 */, uint64_t* g_lagrange /* or NULL */);
+int32_t gl355_kzg_commit(gl355_ctx* ctx, const uint64_t* g /* 2^log_n x 8 */, const uint64_t* poly /* 2^log_n x 4 */, uint32_t log_n, int32_t values_form,
+                         uint64_t result[8]);
+int32_t gl355_kzg_open(gl355_ctx* ctx, const uint64_t* g, const uint64_t* coeffs, uint32_t log_n, const uint64_t z[4], uint64_t eval[4],
+                       uint64_t witness[8], uint64_t* quotient /* or NULL */);
+
 /* ---- a9: wires_permutation_partial_products_and_zs (vanishing_poly.rs:54-108,183-218) --------- */
 int32_t gl355_zs_partial_products(gl355_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas,
                                   const uint64_t* k_is, uint32_t log_n, uint32_t n_routed,

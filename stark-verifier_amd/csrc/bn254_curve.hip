@@ -721,6 +721,86 @@ __global__ void __launch_bounds__(256) fb_mul_kernel(FbArgs a) {
 
 using namespace gl355;
 
+// ================================================================ KZG composites ====================
+// ParamsKZG::setup / commit / commit_lagrange and the single-point opening the SHPLONK prover reduces to, as the reference reaches them
+// through verify_inside_snark (src/plonky2_verifier/verifier_api.rs:77-92, chip/native_chip/test_utils.rs:57-95; k = 23 in README.md:171-177).
+// Scalars cross the ABI as plain 256-bit integers (4 x u64, any value: reduced on load); kernels work in Montgomery form.
+
+// out[i] = tau^i (plain integers), i < n: the scalars of the powers-of-tau loop
+__global__ void kzg_tau_powers_kernel(u256 tau_mont, uint64_t n, uint64_t* out) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    store256(out + 4 * i, m_to_int<F_R>(m_pow_u64<F_R>(tau_mont, i)));
+}
+// out[i] = L_i(tau) = (tau^n - 1) / n * w^i / (tau - w^i) (plain integers): the Lagrange basis of the 2^k domain at tau.  A lane takes KZG_LG_CHUNK
+// consecutive i: one inversion per chunk (Montgomery's trick).  *bad is set if tau lies in the domain.
+constexpr int KZG_LG_CHUNK = 16;
+__global__ void __launch_bounds__(64) kzg_lagrange_kernel(u256 tau_mont, u256 w_mont, u256 w_inv_mont, u256 c_mont /* (tau^n - 1) / n */, uint64_t n,
+                                                          uint64_t* out, uint64_t* pre /* n x 4 scratch */, uint32_t* bad) {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t i0 = t * KZG_LG_CHUNK;
+    if (i0 >= n) return;
+    const uint64_t i1 = min(n, i0 + KZG_LG_CHUNK);
+    u256 wi = m_pow_u64<F_R>(w_mont, i0);
+    u256 acc = u_const(f_one<F_R>());
+#pragma unroll 1
+    for (uint64_t i = i0; i < i1; i++) {                 // forward: denominators (kept in out[]) and their running products
+        const u256 d = m_sub<F_R>(tau_mont, wi);
+        if (m_is_zero<F_R>(d)) atomicOr(bad, 1u);
+        store256(pre + 4 * i, acc);
+        store256(out + 4 * i, d);
+        acc = m_mul<F_R>(acc, d);
+        if (i + 1 < i1) wi = m_mul<F_R>(wi, w_mont);
+    }
+    u256 inv = m_inv<F_R>(acc);
+#pragma unroll 1
+    for (uint64_t i = i1; i-- > i0;) {                   // backward: 1 / d_i = inv * pre_i, then inv *= d_i; w^i steps down with w^-1
+        const u256 d = load256(out + 4 * i);
+        const u256 dinv = m_mul<F_R>(inv, load256(pre + 4 * i));
+        inv = m_mul<F_R>(inv, d);
+        store256(out + 4 * i, m_to_int<F_R>(m_mul<F_R>(m_mul<F_R>(c_mont, wi), dinv)));
+        wi = m_mul<F_R>(wi, w_inv_mont);
+    }
+}
+// Synthetic division by (X - z) as a blocked suffix Horner scan.  For an array A of m field elements and a point Z:
+//     Q[i] = sum_{j > i} A[j] Z^(j - i - 1)  (i < m; Q[m-1] = 0),      E = sum_j A[j] Z^j.
+// With A = the coefficients of p and Z = z: Q[0 .. n-2] are the coefficients of (p - p(z)) / (X - z) and E = p(z).
+// Level kernels: (1) a lane's chunk value H_t = sum_{j in chunk t} A[j] Z^(j - start_t); the carries C_t = Q_H[t] of the array H at the
+// point Z^chunk come from the next level (same problem, m / chunk elements); (3) a lane walks its chunk downwards from its carry.
+constexpr uint32_t KZG_DIV_CHUNK = 64;
+__global__ void kzg_div_chunk_kernel(const uint64_t* A, uint64_t m, u256 z_mont, int a_is_mont, uint64_t* H /* Montgomery */) {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t s0 = t * KZG_DIV_CHUNK;
+    if (s0 >= m) return;
+    const uint64_t e0 = min(m, s0 + KZG_DIV_CHUNK);
+    u256 h = u_zero();
+#pragma unroll 1
+    for (uint64_t j = e0; j-- > s0;) {
+        const u256 a = a_is_mont ? load256(A + 4 * j) : m_from_int<F_R>(load256(A + 4 * j));
+        h = m_add<F_R>(m_mul<F_R>(h, z_mont), a);
+    }
+    store256(H + 4 * t, h);
+}
+// carry == nullptr: the whole array is one chunk (m <= KZG_DIV_CHUNK), lane 0 only.  q_plain: write Q as plain integers (the top level)
+__global__ void kzg_div_walk_kernel(const uint64_t* A, uint64_t m, u256 z_mont, int a_is_mont, const uint64_t* carry /* Montgomery, per chunk */,
+                                    uint64_t* Q, int q_plain, uint64_t* E /* Montgomery; written by the lane of chunk 0 */) {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t s0 = t * KZG_DIV_CHUNK;
+    if (s0 >= m) return;
+    const uint64_t e0 = min(m, s0 + KZG_DIV_CHUNK);
+    u256 sacc = carry ? load256(carry + 4 * t) : u_zero();
+#pragma unroll 1
+    for (uint64_t j = e0; j-- > s0;) {
+        store256(Q + 4 * j, q_plain ? m_to_int<F_R>(sacc) : sacc);         // Q[j] = the running suffix value before A[j] enters
+        const u256 a = a_is_mont ? load256(A + 4 * j) : m_from_int<F_R>(load256(A + 4 * j));
+        sacc = m_add<F_R>(m_mul<F_R>(sacc, z_mont), a);
+    }
+    if (t == 0 && E) store256(E, sacc);
+}
+__global__ void kzg_from_mont1_kernel(const uint64_t* in, uint64_t* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) store256(out, m_to_int<F_R>(load256(in)));
+}
+
 // host-side Fr helpers for the few constants a call needs (omega_n, n^-1): plain 256-bit integers with __int128
 namespace {
 typedef unsigned __int128 u128;
@@ -1021,6 +1101,149 @@ int32_t gl355_bn254_g1_fixed_base_mul(gl355_ctx* h, const uint64_t base[8], cons
         GL355_HIP(ctx, hipGetLastError());
     }
     return so.finish();
+}
+
+
+// ---- KZG composites ------------------------------------------------------------------------------------------------------------
+static H256 h_from_words(const uint64_t w[4]) {
+    H256 a = {{w[0], w[1], w[2], w[3]}};
+    while (h_geq(a)) { u128 br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)a.l[i] - HR[i] - (uint64_t)br; a.l[i] = (uint64_t)d; br = (d >> 64) & 1; } }
+    return a;
+}
+static H256 h_submod(const H256& a, const H256& b) {
+    H256 nb; u128 br = 0;
+    for (int i = 0; i < 4; i++) { u128 d = (u128)HR[i] - b.l[i] - (uint64_t)br; nb.l[i] = (uint64_t)d; br = (d >> 64) & 1; }
+    if ((b.l[0] | b.l[1] | b.l[2] | b.l[3]) == 0) nb = H256{{0, 0, 0, 0}};
+    return h_addmod(a, nb);
+}
+static u256 h_to_mont(const H256& a) {
+    const H256 Rm = {{BN254C_FR_ONE_64[0], BN254C_FR_ONE_64[1], BN254C_FR_ONE_64[2], BN254C_FR_ONE_64[3]}};      // R mod r
+    return to_u256(h_mulmod(a, Rm));
+}
+static H256 h_root_of_unity(uint32_t log_n) {
+    H256 w = {{BN254C_FR_ROOT_64[0], BN254C_FR_ROOT_64[1], BN254C_FR_ROOT_64[2], BN254C_FR_ROOT_64[3]}};
+    for (uint32_t k = log_n; k < BN254C_FR_S; k++) w = h_mulmod(w, w);
+    return w;
+}
+
+// ParamsKZG::setup(k, rng) with the secret handed in (verifier_api.rs:77): g[i] = [tau^i] G1, g_lagrange[i] = [L_i(tau)] G1, G1 = (1, 2).
+// halo2 computes g_lagrange by an inverse FFT over the GROUP; here the Lagrange scalars are evaluated in Fr (one batched inversion per 16
+// points) and go through the same fixed-base kernel as the powers.  g_lagrange may be NULL.  Outputs are affine points (n x 8 words).
+int32_t gl355_kzg_setup(gl355_ctx* h, const uint64_t tau[4], uint32_t log_n, uint64_t* g, uint64_t* g_lagrange) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+    if (!tau || !g) return ctx->fail(GL355_E_INVALID_ARG, "kzg_setup: null argument");
+    if (log_n > 26) return ctx->fail(GL355_E_UNSUPPORTED, "kzg_setup: log_n > 26");
+    const uint64_t n = 1ull << log_n;
+    const H256 t = h_from_words(tau);
+    const u256 tau_mont = h_to_mont(t);
+    Scratch sc(ctx);
+    GL355_TRY(sc.get((g_lagrange ? 2 : 1) * n * 32 + 64));
+    uint64_t* d_s = sc.as<uint64_t>();
+    uint64_t* d_pre = d_s + 4 * n;                          // Lagrange pass only
+    uint32_t* d_bad = reinterpret_cast<uint32_t*>(d_s + 4 * n * (g_lagrange ? 2 : 1));
+    const uint64_t gen[8] = {1, 0, 0, 0, 2, 0, 0, 0};
+    {
+        ProfScope ps(ctx, "kzg_setup_scalars", n * 32);
+        hipLaunchKernelGGL(kzg_tau_powers_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, tau_mont, n, d_s);
+        GL355_HIP(ctx, hipGetLastError());
+    }
+    GL355_TRY(gl355_bn254_g1_fixed_base_mul(h, gen, d_s, n, g));
+    if (g_lagrange) {
+        // c = (tau^n - 1) / n
+        H256 tn = t;
+        for (uint32_t k = 0; k < log_n; k++) tn = h_mulmod(tn, tn);
+        const H256 e_inv = {{HR[0] - 2, HR[1], HR[2], HR[3]}};
+        const H256 c = h_mulmod(h_submod(tn, H256{{1, 0, 0, 0}}), h_powmod(H256{{n, 0, 0, 0}}, e_inv));
+        GL355_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+        {
+            ProfScope ps(ctx, "kzg_setup_scalars", n * 32);
+            const uint64_t lanes = (n + KZG_LG_CHUNK - 1) / KZG_LG_CHUNK;
+            const H256 w = h_root_of_unity(log_n);
+            hipLaunchKernelGGL(kzg_lagrange_kernel, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, ctx->stream, tau_mont, h_to_mont(w),
+                               h_to_mont(h_powmod(w, e_inv)), h_to_mont(c), n, d_s, d_pre, d_bad);
+            GL355_HIP(ctx, hipGetLastError());
+        }
+        uint32_t bad = 0;
+        GL355_HIP(ctx, ctx->d2h(&bad, d_bad, 4));
+        GL355_HIP(ctx, ctx->wait());
+        if (bad) return ctx->fail(GL355_E_INVALID_ARG, "kzg_setup: tau lies in the evaluation domain");
+        GL355_TRY(gl355_bn254_g1_fixed_base_mul(h, gen, d_s, n, g_lagrange));
+    }
+    return GL355_OK;
+}
+
+// ParamsKZG::commit / commit_lagrange: result = sum_i poly[i] * g[i] over 2^log_n bases.  values_form = 0: `poly` are the scalars that go
+// with the given bases as they are (coefficients with the monomial bases g, or evaluations with g_lagrange -- an MSM does not care);
+// values_form = 1: `poly` are EVALUATIONS over the 2^log_n domain but `g` are the monomial bases: inverse FFT on a scratch copy, then the MSM.
+int32_t gl355_kzg_commit(gl355_ctx* h, const uint64_t* g, const uint64_t* poly, uint32_t log_n, int32_t values_form, uint64_t result[8]) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+    if (!g || !poly || !result) return ctx->fail(GL355_E_INVALID_ARG, "kzg_commit: null argument");
+    if (log_n > 26) return ctx->fail(GL355_E_UNSUPPORTED, "kzg_commit: log_n > 26");
+    const uint64_t n = 1ull << log_n;
+    if (!values_form) return gl355_bn254_g1_msm(h, g, poly, n, result);
+    Scratch sc(ctx);
+    GL355_TRY(sc.get(n * 32));
+    uint64_t* d_c = sc.as<uint64_t>();
+    GL355_HIP(ctx, hipMemcpyAsync(d_c, poly, n * 32, ptr_is_device(poly) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    if (log_n) GL355_TRY(fr_ntt_run(ctx, d_c, log_n, d_c, n, log_n, 1, nullptr));
+    return gl355_bn254_g1_msm(h, g, d_c, n, result);
+}
+
+// Q and E of the comment above the division kernels, levels chained on the stream; A and Q are device arrays (Q plain at the top level)
+static int32_t kzg_divide(Ctx* ctx, const uint64_t* A, uint64_t m, const H256& z, int a_is_mont, uint64_t* Q, int q_plain, uint64_t* E_mont) {
+    const u256 z_mont = h_to_mont(z);
+    if (m <= KZG_DIV_CHUNK) {
+        hipLaunchKernelGGL(kzg_div_walk_kernel, dim3(1), dim3(64), 0, ctx->stream, A, m, z_mont, a_is_mont, (const uint64_t*)nullptr, Q, q_plain, E_mont);
+        GL355_HIP(ctx, hipGetLastError());
+        return GL355_OK;
+    }
+    const uint64_t chunks = (m + KZG_DIV_CHUNK - 1) / KZG_DIV_CHUNK;
+    Scratch sc(ctx);
+    GL355_TRY(sc.get(chunks * 64));
+    uint64_t* H = sc.as<uint64_t>();
+    uint64_t* C = H + 4 * chunks;
+    hipLaunchKernelGGL(kzg_div_chunk_kernel, dim3((uint32_t)((chunks + 63) / 64)), dim3(64), 0, ctx->stream, A, m, z_mont, a_is_mont, H);
+    GL355_HIP(ctx, hipGetLastError());
+    H256 zc = z;                                             // Z = z^chunk
+    for (uint32_t k = 1; k < KZG_DIV_CHUNK; k <<= 1) zc = h_mulmod(zc, zc);
+    GL355_TRY(kzg_divide(ctx, H, chunks, zc, 1, C, 0, nullptr));
+    hipLaunchKernelGGL(kzg_div_walk_kernel, dim3((uint32_t)((chunks + 63) / 64)), dim3(64), 0, ctx->stream, A, m, z_mont, a_is_mont, (const uint64_t*)C, Q, q_plain, E_mont);
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+
+// The single-point KZG opening (what halo2's multiopen provers reduce to per rotation set): eval = p(z), witness = commit((p - p(z)) / (X - z)).
+// `coeffs` are the 2^log_n coefficients of p, `g` the monomial bases.  quotient (optional, 2^log_n x 4 words, device or host) receives the
+// quotient's coefficients (the last one is 0).
+int32_t gl355_kzg_open(gl355_ctx* h, const uint64_t* g, const uint64_t* coeffs, uint32_t log_n, const uint64_t z[4], uint64_t eval[4],
+                       uint64_t witness[8], uint64_t* quotient) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+    if (!g || !coeffs || !z || !eval || !witness) return ctx->fail(GL355_E_INVALID_ARG, "kzg_open: null argument");
+    if (log_n > 26) return ctx->fail(GL355_E_UNSUPPORTED, "kzg_open: log_n > 26");
+    const uint64_t n = 1ull << log_n;
+    Staged sp(ctx);
+    GL355_TRY(sp.open(coeffs, n * 32, 1));
+    Scratch sq(ctx);
+    GL355_TRY(sq.get(n * 32 + 64));
+    uint64_t* d_q = sq.as<uint64_t>();
+    uint64_t* d_e = d_q + 4 * n;
+    {
+        ProfScope ps(ctx, "kzg_divide", n * 64);
+        GL355_TRY(kzg_divide(ctx, sp.as<uint64_t>(), n, h_from_words(z), 0, d_q, 1, d_e));
+        hipLaunchKernelGGL(kzg_from_mont1_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t*)d_e, d_e + 4);
+        GL355_HIP(ctx, hipGetLastError());
+    }
+    if (ptr_is_device(eval)) GL355_HIP(ctx, hipMemcpyAsync(eval, d_e + 4, 32, hipMemcpyDeviceToDevice, ctx->stream));
+    else GL355_HIP(ctx, ctx->d2h(eval, d_e + 4, 32));
+    if (quotient) GL355_HIP(ctx, hipMemcpyAsync(quotient, d_q, n * 32, ptr_is_device(quotient) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    GL355_HIP(ctx, ctx->wait());
+    return gl355_bn254_g1_msm(h, g, d_q, n, witness);
 }
 
 }  // extern "C"
