@@ -162,34 +162,38 @@ __global__ void __launch_bounds__(64) merkle_level_lanes_kernel(uint64_t* digest
     }
 }
 
-// The top of every cap subtree in ONE launch: one block per subtree takes its 2^TOP_LOG nodes of layer `layer0` and climbs to
-// the cap entry (2^TOP_LOG, ..., 2, 1 nodes), the digests of a level staying in LDS for the next one (and going to the plonky2
-// layout in HBM).  Each of those levels is a single lane-parallel permutation deep; as separate launches they cost ~20 us
-// apiece, mostly launch latency.  Waves whose groups have no node on a level skip its permutation.
-#define MERKLE_TOP_LOG 5
-__global__ void __launch_bounds__(512) merkle_top_kernel(uint64_t* digests, uint64_t* cap, uint32_t sub_bits, uint32_t layer0) {
-    __shared__ uint64_t rings[32][24];
-    __shared__ uint64_t lvl[2][(1 << MERKLE_TOP_LOG) * 4];
+// The top of every cap subtree in ONE launch: one 1024-thread block per subtree takes its 2^(n_levels - 1) nodes of layer `layer0` (at most
+// 128) and climbs n_levels levels to the cap entry, the digests of a level staying in LDS for the next one (and going to the plonky2
+// layout in HBM).  Each of those levels is one lane-parallel permutation deep (two for the 128-node level: 64 groups of 16 lanes); as
+// separate launches they cost ~20 us apiece, mostly launch latency -- round 2 ran the last six levels here and two more as separate
+// lane-parallel launches (12.7 % of the kernel time of the 8-context profile between them); with eight levels a tree is leaf hashing,
+// its wide levels, and this.  Trees of at most 2^8 leaves per cap entry are built whole.  Waves whose groups have no node on a level skip it.
+#define MERKLE_TOP_LEVELS 8
+__global__ void __launch_bounds__(1024) merkle_top_kernel(uint64_t* digests, uint64_t* cap, uint32_t sub_bits, uint32_t layer0, uint32_t n_levels) {
+    __shared__ uint64_t rings[64][24];
+    __shared__ uint64_t lvl[2][(1 << (MERKLE_TOP_LEVELS - 1)) * 4];
     const int li = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int wave_first_grp = (threadIdx.x >> 6) << 2;
     const uint64_t sub_leaves = 1ull << sub_bits;
     const uint64_t t = blockIdx.x;
     uint64_t* tree = digests + t * 2 * (sub_leaves - 1) * 4;
     int cur = 0;
-    for (uint32_t l = 0; l <= MERKLE_TOP_LOG; l++) {
+    for (uint32_t l = 0; l < n_levels; l++) {
         const uint32_t layer = layer0 + l;
-        const int cnt = 1 << (MERKLE_TOP_LOG - l);
-        if (wave_first_grp < cnt) {                       // wave-uniform: this wave owns at least one node of the level
-            const bool valid = grp < cnt;
-            const int j = valid ? grp : 0;
-            uint64_t s = 0;
-            if (li < 8) s = (l == 0) ? tree[digest_slot(layer - 1, 2 * (uint64_t)j) * 4 + li] : lvl[cur][(2 * j) * 4 + li];
-            s = psd_permute_lanes(s, li, rings[grp]);
-            if (valid && li < 4) {
-                const uint64_t v = gl_canon(s);
-                lvl[cur ^ 1][j * 4 + li] = v;
-                uint64_t* dst = (layer == sub_bits) ? cap + t * 4 : tree + digest_slot(layer, (uint64_t)j) * 4;
-                dst[li] = v;
+        const int cnt = 1 << (n_levels - 1 - l);
+        for (int base = 0; base < cnt; base += 64) {
+            if (base + wave_first_grp < cnt) {                // wave-uniform: this wave owns at least one node of the round
+                const bool valid = base + grp < cnt;
+                const int j = valid ? base + grp : 0;
+                uint64_t s = 0;
+                if (li < 8) s = (l == 0) ? tree[digest_slot(layer - 1, 2 * (uint64_t)j) * 4 + li] : lvl[cur][(2 * j) * 4 + li];
+                s = psd_permute_lanes(s, li, rings[grp]);
+                if (valid && li < 4) {
+                    const uint64_t v = gl_canon(s);
+                    lvl[cur ^ 1][j * 4 + li] = v;
+                    uint64_t* dst = (layer == sub_bits) ? cap + t * 4 : tree + digest_slot(layer, (uint64_t)j) * 4;
+                    dst[li] = v;
+                }
             }
         }
         __syncthreads();
@@ -325,14 +329,23 @@ int32_t merkle_build_args(Ctx* ctx, LeafArgs a, uint32_t sub_bits, uint64_t* dig
     a.out = digests; a.cap = cap; a.sub_bits = sub_bits; a.linear = 0;
     { ProfScope ps(ctx, "hash_leaves_kernel", n_leaves * ((uint64_t)a.leaf_len * 8 + 32)); GL355_TRY(launch_leaves(ctx, a)); }
     const uint64_t lanes_max = 1ull << ctx->merkle_lanes_log;
-    // the last MERKLE_TOP_LOG + 1 levels of every cap subtree go to merkle_top_kernel (when they are lane-parallel levels anyway)
+    // the last MERKLE_TOP_LEVELS levels of every cap subtree go to merkle_top_kernel (when they are lane-parallel levels anyway: at most
+    // lanes_max nodes enter it over the whole forest); GL355_EXP_MERKLE_TOP6=1: six levels as in round 2 (A/B)
+    // Eight levels per block cost three dependent permutations more than six levels behind two forest-wide lane-parallel launches: with
+    // few subtrees (one proof: 16) the separate launches spread over the whole chip and the tree is done sooner (single-unit latency 17.0 vs
+    // 17.6 ms); with a lock-step batch (>= 64 subtrees) the chip is full either way and four launches fewer per unit win
+    // (profiles/r03_merkle_top_ab.txt).
+    static const bool top6 = getenv("GL355_EXP_MERKLE_TOP6") != nullptr;
+    const uint32_t top_levels_max = (top6 || (n_leaves >> sub_bits) < 64) ? 6 : MERKLE_TOP_LEVELS;
+    uint32_t top_levels = std::min<uint32_t>(top_levels_max, sub_bits);
+    while (top_levels > 1 && ((n_leaves >> (sub_bits - top_levels + 1)) > lanes_max)) top_levels--;      // a forest of many subtrees: fewer levels each
     uint32_t top_from = sub_bits + 1;
-    if (sub_bits > MERKLE_TOP_LOG && ((n_leaves >> (sub_bits - MERKLE_TOP_LOG)) <= lanes_max)) top_from = sub_bits - MERKLE_TOP_LOG;
+    if (top_levels >= 1 && ((n_leaves >> (sub_bits - top_levels + 1)) <= lanes_max)) top_from = sub_bits - top_levels + 1;
     for (uint32_t layer = 1; layer <= sub_bits; layer++) {
         const uint64_t n_nodes = n_leaves >> layer;
         if (layer == top_from) {
             ProfScope ps(ctx, "merkle_top_kernel", (2 * n_nodes - (n_leaves >> sub_bits)) * 96);
-            hipLaunchKernelGGL(merkle_top_kernel, dim3((uint32_t)(n_leaves >> sub_bits)), dim3(512), 0, ctx->stream, digests, cap, sub_bits, layer);
+            hipLaunchKernelGGL(merkle_top_kernel, dim3((uint32_t)(n_leaves >> sub_bits)), dim3(1024), 0, ctx->stream, digests, cap, sub_bits, layer, top_levels);
             GL355_HIP(ctx, hipGetLastError());
             break;
         }
