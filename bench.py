@@ -619,6 +619,22 @@ def main_recursive(args):
     # (lowest latency); with fewer usable cores per rank (cgroup quota / ranks) than contexts every device wait sleeps instead,
     # so the contexts still keep the GPU fed (host work is ~10-12 ms of ~90 ms per unit and context)
     cores_per_rank = max(1, host_cores() // max(1, world))
+    # N > 1: every rank pins itself to its own contiguous slice of the CPUs the job may use (rank r of the node -> slice r), before any
+    # thread exists, so the 8 x (prover contexts + replay threads + the HIP runtime's own thread) of a node do not migrate over each other's
+    # cores; contiguous CPU numbers share a socket on the usual numbering, i.e. GPU r's slice sits on the socket of GPUs 4 (r // 4) .. + 3.
+    # GL355_BENCH_NO_PIN=1 leaves the affinity alone.
+    pinned = None
+    if world > 1 and os.environ.get("GL355_BENCH_NO_PIN") != "1":
+        cpus = sorted(os.sched_getaffinity(0))
+        k = len(cpus) // world
+        if k >= 1:
+            mine = cpus[local_rank * k:(local_rank + 1) * k]
+            try:
+                os.sched_setaffinity(0, mine)
+                pinned = "%d-%d" % (mine[0], mine[-1])
+                cores_per_rank = min(cores_per_rank, len(mine))
+            except OSError:
+                pinned = None
     n_threads = max(1, int(os.environ.get("GL355_BENCH_CONTEXTS", args.threads)))
     # how a context's host thread waits for its stream: "spin" (hipStreamSynchronize, a core per context), "poll" (GL355_OPT_BLOCKING_SYNC
     # = 2: hipStreamQuery + 30-us sleeps, a few percent of a core per context), "sleep" (hipDeviceScheduleBlockingSync for the device)
@@ -749,7 +765,8 @@ def main_recursive(args):
                        "exchange": getattr(comm, "backend_name", "none (one rank): gl355_aggregation_root over the local leaves"),
                        "host": "%d usable host cores per rank, %s device waits, %d tape-replay thread(s) per context" % (
                            cores_per_rank, {"sleep": "sleeping (hipDeviceScheduleBlockingSync)", "poll": "polling (hipStreamQuery + 30-us sleeps)", "spin": "spinning"}[wait_mode], replay_threads) +
-                               ("; witness tape replayed on the device" if os.environ.get("GL355_BENCH_DEVICE_REPLAY") == "1" else "; witness tape replayed on host threads"),
+                               ("; witness tape replayed on the device" if os.environ.get("GL355_BENCH_DEVICE_REPLAY") == "1" else "; witness tape replayed on host threads") +
+                               ("; rank pinned to CPUs %s (ranks take contiguous slices)" % pinned if pinned else ("; no CPU pinning (one rank)" if world == 1 else "; CPU pinning off / unavailable")),
                        "host_cpu_ms_per_unit": round(1e3 * host_cpu_s / max(1, (hi - lo) * args.steps), 2),
                        "host_split": host_split},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),

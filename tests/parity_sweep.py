@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 
-def run_sweep(M=256, K=6, contexts=22, log_members=20, blocking_sync=False, out=print):
+def run_sweep(M=256, K=6, contexts=22, log_members=20, blocking_sync=False, out=print, check_root=False):
     import bench
     gl = importlib.import_module("stark-verifier_amd")
     plonk = importlib.import_module("stark-verifier_amd.plonk")
@@ -30,6 +30,24 @@ def run_sweep(M=256, K=6, contexts=22, log_members=20, blocking_sync=False, out=
     out("1 context: %.2f s; recursive proofs and leaves identical to the concurrent run: %s" % (t2 - t1, same))
     out("sha256 of the %d recursive proofs: %s" % (M, hashlib.sha256(np.ascontiguousarray(proofs).tobytes()).hexdigest()))
     assert same
+    if check_root:
+        # BASELINE configs[4], one GPU's share: the (nullifier | topic) leaves of the step and the aggregation root over them (rank 0's
+        # gl355_aggregation_root) against the oracle: nullifier = hash_no_pad(sk | topic) (signal.rs / circuit.rs:53), root = the
+        # Poseidon Merkle cap of height 0 over the leaves padded to a power of two
+        par = importlib.import_module("stark-verifier_amd.parallel")
+        from oracle_lib import Oracle as _O
+        o = _O()
+        want_null = np.stack([o.hash_no_pad(np.concatenate([pr.sks[int(m)], pr.topic])) for m in members])
+        assert np.array_equal(leaves[:, :4], want_null), "nullifiers differ from hash(sk | topic)"
+        assert np.array_equal(leaves[:, 4:], np.tile(pr.topic, (M, 1)))
+        root = par.aggregation_root(pr.sets[0], leaves)
+        want_root = o.merkle_build(par.pad_pow2(leaves), 0)[1]
+        assert np.array_equal(root, want_root), "aggregation root differs from the oracle"
+        # every recursive proof of the step passes the product-side verifier (CircuitData::verify) with its own public inputs
+        for j in range(M):
+            opis = np.concatenate([pr.root, leaves[j]])
+            pr.rc.data.verify(proofs[j], opis)
+        out("aggregation root over %d leaves == oracle; %d recursive proofs verified" % (M, M))
     # ---- CPU restatement on K sampled units ----------------------------------------------------------------------------
     orc = Oracle()
     orc.L.orc_set_num_threads(bench.host_cores())

@@ -99,6 +99,39 @@ def test_host_comm_three_ranks():
         assert m == 12.0 and list(tiny.reshape(-1)) == [0, 1, 2]
 
 
+@pytest.mark.timeout(180)
+def test_host_comm_eight_ranks_cfg5_shape(orc):
+    """BASELINE configs[4] without GPUs: 8 ranks (one process each, TCP back-end of the communicator) x 128 units -- the flow of
+    examples/native_units --ranks 8 / bench.py --gpus 8 with stub leaves: block partition, one gl355_gather_digests of 64 B per unit,
+    every rank sees the 1024 leaves in unit order, and the aggregation root over the gathered leaves == the single-process root"""
+    import multiprocessing as mp
+    total, world = 1024, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    par = importlib.import_module("stark-verifier_amd.parallel")
+    lib = importlib.import_module("stark-verifier_amd._lib").load()
+    cid = par.Comm.unique_id(lib, par.COMM_HOST, "127.0.0.1", port)
+    procs = [ctx.Process(target=_worker, args=(r, world, cid, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, allv, m, tiny = q.get(timeout=150)
+        res[r] = (allv, m, tiny)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    want = np.array([[i * 8 + j for j in range(8)] for i in range(total)], dtype=np.uint64)
+    single_root = orc.merkle_build(par.pad_pow2(want), 0)[1]
+    for r in range(world):
+        allv, m, tiny = res[r]
+        assert np.array_equal(allv, want), r                    # 128 units per rank, rank (= unit) order, no padding rows
+        assert m == 10.0 + world - 1 and list(tiny.reshape(-1)) == list(range(world))
+    assert np.array_equal(orc.merkle_build(par.pad_pow2(res[0][0]), 0)[1], single_root)
+    assert [par.shard_range(total, r, world) for r in (0, 7)] == [(0, 128), (896, 1024)]
+
+
 def test_comm_argument_errors(gl):
     lib = gl._lib.load()
     par = importlib.import_module("stark-verifier_amd.parallel")
