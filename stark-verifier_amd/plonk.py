@@ -104,8 +104,13 @@ def poseidon_gate_witness(inputs, swap):
 class CircuitBuilder:
     """Minimal gate-level builder: rows of gates, copy constraints between routed wires."""
 
-    def __init__(self, config=None):
+    def __init__(self, config=None, gate_order="own"):
         self.config = config or CircuitConfig()
+        # "own": gate indices by decreasing degree (this framework's choice); "plonky2": the order and selector groups upstream's
+        # CircuitBuilder::build / selector_polynomials give (by degree, ties by the gate's id string, groups grown greedily from the
+        # cheapest gate) -- the tables a plonky2-side exporter would hand over (INTEGRATION.md 3c).  Prover, loader and verifier take the
+        # indices / groups from the artifact, whatever the order.
+        self.gate_order = gate_order
         self.gate_types = []          # [(type, param)] in registration order
         self.rows = []                # [(gate_type_index, [gate constants])]
         self.copies = []              # [((row, col), (row, col))]
@@ -166,14 +171,29 @@ class CircuitBuilder:
         # selector groups (plonky2's selector_polynomials): a group of g gates sharing one selector column gets the
         # filter prod_{k != i}(k - s) * (UNUSED - s) of degree g, so every member needs g + degree <= qdf + 1 = 9
         max_deg = cfg.max_quotient_degree_factor + 1
-        order = sorted(range(len(self.gate_types)), key=lambda i: -_GATE_DEGREE[self.gate_types[i][0]](self.gate_types[i][1]))
+        deg = lambda tp: _GATE_DEGREE[tp[0]](tp[1])
+        if self.gate_order == "plonky2":
+            order = sorted(range(len(self.gate_types)), key=lambda i: (deg(self.gate_types[i]), gate_id_string(*self.gate_types[i])))
+        else:
+            order = sorted(range(len(self.gate_types)), key=lambda i: -deg(self.gate_types[i]))
         remap = {old: new for new, old in enumerate(order)}
         gates = [self.gate_types[i] for i in order]
         groups, sel_index = [], []
         start = 0
+        if self.gate_order == "plonky2":
+            if deg(gates[-1]) + len(gates) - 1 <= max_deg:          # upstream's special case: one selector polynomial for everything
+                groups.append((0, len(gates)))
+                start = len(gates)
+            while start < len(gates):
+                size = 0
+                while start + size < len(gates) and size + deg(gates[start + size]) < max_deg:
+                    size += 1
+                assert size >= 1, "a gate of degree >= max_quotient_degree_factor + 1 has no selector group"
+                groups.append((start, start + size))
+                start += size
         while start < len(gates):
             end = start + 1
-            top = _GATE_DEGREE[gates[start][0]](gates[start][1])       # sorted: the first member has the largest degree
+            top = deg(gates[start])       # sorted: the first member has the largest degree
             while end < len(gates) and (end - start + 1) + top <= max_deg:
                 end += 1
             groups.append((start, end))
@@ -248,6 +268,38 @@ class CircuitBuilder:
             cc.gates[i].group_start, cc.gates[i].group_end = groups[sel_index[i]]
         data.c_circuit = cc
         return data
+
+
+def gate_id_string(gtype, param):
+    """`Gate::id()` of the reference's gate set (the strings chip/plonk/gates/mod.rs:141-196 matches on; BaseSumGate{20} is the Semaphore
+    circuit's, circuit.rs:42): plonky2 orders gates of equal degree by it"""
+    f = "plonky2_field::goldilocks_field::GoldilocksField"
+    if gtype == GATE_ARITHMETIC:
+        return "ArithmeticGate { num_ops: %d }" % param
+    if gtype == GATE_PUBLIC_INPUT:
+        return "PublicInputGate"
+    if gtype == GATE_NOOP:
+        return "NoopGate"
+    if gtype == GATE_CONSTANT:
+        return "ConstantGate { num_consts: %d }" % param
+    if gtype == GATE_BASE_SUM:
+        return "BaseSumGate { num_limbs: %d } + Base: 2" % param
+    if gtype == GATE_POSEIDON:
+        return "PoseidonGate(PhantomData<%s>)<WIDTH=12>" % f
+    if gtype == GATE_POSEIDON_MDS:
+        return "PoseidonMdsGate(PhantomData<%s>)<WIDTH=12>" % f
+    if gtype == GATE_RANDOM_ACCESS:
+        return "RandomAccessGate { bits: %d, num_copies: %d, num_extra_constants: %d, _phantom: PhantomData<%s> }<D=2>" % (
+            param & 0xFF, (param >> 8) & 0xFF, (param >> 16) & 0xFF, f)
+    if gtype == GATE_REDUCING_EXT:
+        return "ReducingExtensionGate { num_coeffs: %d }" % param
+    if gtype == GATE_REDUCING:
+        return "ReducingGate { num_coeffs: %d }" % param
+    if gtype == GATE_ARITHMETIC_EXT:
+        return "ArithmeticExtensionGate { num_ops: %d }" % param
+    if gtype == GATE_MUL_EXT:
+        return "MulExtensionGate { num_ops: %d }" % param
+    raise ValueError("unknown gate type %r" % (gtype,))
 
 
 _GATE_DEGREE = {

@@ -136,9 +136,9 @@ class AccessSet:
                        dtype=np.uint32)
         return idx, vals, pi
 
-    def build(self, rng, config=None):
+    def build(self, rng, config=None, gate_order="own"):
         if self._circuit is None:
-            builder = CircuitBuilder(config or CircuitConfig())
+            builder = CircuitBuilder(config or CircuitConfig(), gate_order=gate_order)
             rows = self.semaphore_circuit(builder)
             data = builder.build(self.ctx, rng)
             self._circuit = (data, rows)

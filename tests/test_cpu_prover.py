@@ -58,3 +58,28 @@ def test_cpu_prover_rejects_bad_witness(orc):
     proof["public_inputs"] = pi_bad
     with pytest.raises(pv.VerifyError):
         pv.verify(orc, data.common(), proof)
+
+
+def test_plonky2_gate_order_tables_prove_and_verify(orc):
+    """The gate indices, selector values and selector groups are DATA of the artifact, not conventions of the prover: the same Semaphore
+    circuit laid out the way upstream's CircuitBuilder::build orders gates (by degree, ties by Gate::id(); groups grown greedily from the
+    cheapest gate -- what a plonky2-side exporter hands over) has different tables and a different commitment, and the
+    CPU prover's proof over them passes the restated reference verifier and the product's gl355_verify"""
+    import importlib
+    own = cs.build_case(orc, 2, 0x7E57)
+    up = cs.build_case(orc, 2, 0x7E57, gate_order="plonky2")
+    d_own, d_up = own["data"], up["data"]
+    assert sorted(d_own.gates) == sorted(d_up.gates) and d_own.gates != d_up.gates          # same gate set, another order
+    degs = [importlib.import_module("stark-verifier_amd.plonk")._GATE_DEGREE[t](p) for t, p in d_up.gates]
+    assert degs == sorted(degs)                                                             # ascending degree, as upstream sorts
+    assert not np.array_equal(d_own.constants[:d_own.num_selectors], d_up.constants[:d_up.num_selectors]) or d_own.groups != d_up.groups
+    assert not np.array_equal(own["cpu"].cap(), up["cpu"].cap())
+    topic = rand_field(np.random.default_rng(5), 4)
+    idx, vals, pi = cs.witness(orc, up, 1, topic)
+    flat = up["cpu"].prove_sparse(idx, vals, pi, 31)
+    proof = up["plonk"].parse_proof(d_up, flat)
+    proof["public_inputs"] = pi
+    pv.verify(orc, d_up.common(), proof)
+    d_up.verify(flat, pi)                                  # gl355_verify (product, host only) on the upstream-ordered verifier data
+    with pytest.raises(Exception):
+        d_own.verify(flat, pi)                             # another circuit digest, other selector tables

@@ -200,3 +200,32 @@ def test_artifact_with_an_external_digest(gl, ctx, orc):
     bad[-1] ^= np.uint64(1)                                           # the carried cap itself
     with pytest.raises(gl.Gl355Error):
         plonk.NativeCircuit(ctx, bad)
+
+
+def test_artifact_in_plonky2_gate_order_with_an_external_digest(gl, ctx, orc):
+    """What a plonky2-side exporter hands over: tables in upstream's gate order and selector grouping, and upstream's
+    own circuit digest.  The loader ties the tables to the digest through the constants_sigmas cap, the GPU proves from the artifact alone,
+    and the proof passes gl355_circuit_verify and the restated reference verifier run on the same verifier data"""
+    import plonk_verifier as pv
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    aset, sks, rng = make_access_set(gl, ctx, 3, 0x905)
+    topic = rand_field(rng, 4)
+    data, rows = aset.build(None, gate_order="plonky2")
+    degs = [plonk._GATE_DEGREE[t](p) for t, p in data.gates]
+    assert degs == sorted(degs) and len(data.groups) >= 2
+    idx, vals, pi = aset.witness_rows(rows, sks[5], topic, 5)
+    ext = rand_field(rng, 4)                                             # stands for plonky2's circuit_digest (covers its domain separator too)
+    nat = plonk.NativeCircuit(ctx, data.export_blob(idx, external_digest=ext))
+    flat, pis = nat.semaphore_prove(ctx, sks[5], topic, 5, aset.tree.prove_host(5), 9)
+    p = np.ascontiguousarray(pis, dtype=np.uint64)
+    assert np.array_equal(p, pi)
+    assert ctx.lib.gl355_circuit_verify(nat.h, flat.ctypes.data, flat.size, p.ctypes.data, p.size) == 0
+    data.circuit_digest = ext                                            # the verifier data of the exported circuit
+    proof = plonk.parse_proof(data, flat)
+    proof["public_inputs"] = p
+    pv.verify(orc, data.common(), proof)
+    # the same circuit in this framework's own order is another artifact: its verifier refuses the proof
+    aset2, _, _ = make_access_set(gl, ctx, 3, 0x905)
+    d2, _ = aset2.build(None)
+    own = plonk.NativeCircuit(ctx, d2.export_blob(idx))
+    assert ctx.lib.gl355_circuit_verify(own.h, flat.ctypes.data, flat.size, p.ctypes.data, p.size) == -7
