@@ -62,6 +62,7 @@ struct Ctx {
     std::map<std::vector<uint64_t>, uint64_t*> full_cache;   // full-size multiplier tables (ntt.hip)
     int32_t full_pow_table(const uint64_t* lo, const uint64_t* hi, uint32_t n_cosets, uint32_t log_n, const uint64_t** out);
     int32_t full_step_table(const uint64_t* lo, const uint64_t* hi, uint32_t l1, uint32_t l2, bool inv, const uint64_t** out);
+    int32_t nat_step_table(const uint64_t* lo, const uint64_t* hi, uint32_t l1, uint32_t l2, const uint64_t** out);   // natural -> natural flow
     // table of the 24-bit-limb row pass (ntt_l24.hip): the twiddles between its two radix-64 super-rounds
     int32_t l24_mid_table(const uint64_t** out);
 

@@ -150,6 +150,15 @@ __global__ void build_step_table_kernel(const uint64_t* lo, const uint64_t* hi, 
     out[g] = gl_canon(gl_mul(lo[e & 4095], hi[e >> 12]));
 }
 
+// step_t[i2 * N1 + k1] = omega^(k1 * i2): the 4-step twiddles in the store order of pass A of the natural -> natural flow
+__global__ void build_nat_step_table_kernel(const uint64_t* lo, const uint64_t* hi, uint32_t l1, uint32_t l2, uint64_t* out) {
+    const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (g >= (1ull << (l1 + l2))) return;
+    const uint64_t i2 = g >> l1, k1 = g & ((1ull << l1) - 1);
+    const uint64_t e = k1 * i2;
+    out[g] = gl_canon(gl_mul(lo[e & 4095], hi[e >> 12]));
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -311,6 +320,28 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
     int32_t rc = ctx->pow_tables(inv ? gl_inv(gl_root_of_unity(p.log_n)) : gl_root_of_unity(p.log_n), &step_lo, &step_hi);
     if (rc) return rc;
     uint32_t l1, l2;
+    // natural order in AND out, plain forward transform of 2^12 < n <= 2^20 points: two column-type passes with the transposition in LDS
+    // (ntt_cols_r8_nat_kernel) instead of two passes + the bit-reversal pass.  GL355_EXP_NTT_NO_NAT2=1: the three-pass form (A/B)
+    static const bool no_nat2 = getenv("GL355_EXP_NTT_NO_NAT2") != nullptr;
+    if (!no_nat2 && !ntt_r16_only() && !inv && !p.in_bitrev && !p.out_bitrev && p.n_cosets == 1 && !p.pre_lo && !p.post_lo && p.scale == 1 &&
+        p.log_n <= 20 && p.coset_slot[0] == 0) {
+        l2 = p.log_n / 2; l1 = p.log_n - l2;               // l1 >= l2; both <= 10
+        Scratch mid(ctx);
+        GL355_TRY(mid.get(((uint64_t)p.batch << p.log_n) * 8));
+        const uint64_t n = 1ull << p.log_n;
+        a.in = p.in; a.in_col_stride = p.in_col_stride;
+        a.out = mid.as<uint64_t>(); a.out_col_stride = n;
+        a.log_rows = l2;                                   // pass A walks the [N1][N2] matrix: row stride N2
+        GL355_TRY(ctx->nat_step_table(step_lo, step_hi, l1, l2, &a.step_full));
+        { ProfScope ps(ctx, "ntt_cols_pass1", ((uint64_t)p.batch << p.log_n) * 8); GL355_HIP(ctx, launch_cols_r8_nat(a, l1, 0, ctx->stream)); }
+        PassArgs b = a;
+        b.in = mid.as<uint64_t>(); b.in_col_stride = n;
+        b.out = p.out; b.out_col_stride = p.out_col_stride;
+        b.log_rows = l1;                                   // pass B walks the [N2][N1] matrix: row stride N1
+        b.step_full = nullptr;
+        { ProfScope ps(ctx, "ntt_cols_pass2", ((uint64_t)p.batch << p.log_n) * 8); GL355_HIP(ctx, launch_cols_r8_nat(b, l2, 1, ctx->stream)); }
+        return GL355_OK;
+    }
     if (!p.in_bitrev) {
         // natural in -> (cols over N1, twiddle at store) -> (rows over N2) -> bit-reversed out
         split_two_pass(p.log_n, true, &l1, &l2);
@@ -454,6 +485,20 @@ int32_t Ctx::full_step_table(const uint64_t* lo, const uint64_t* hi, uint32_t l1
     uint64_t* d = nullptr;
     GL355_HIP(this, hipMalloc((void**)&d, total * 8));
     hipLaunchKernelGGL(build_step_table_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, lo, hi, l1, l2, d);
+    GL355_HIP(this, hipGetLastError());
+    full_cache[key] = d;
+    *out = d;
+    return GL355_OK;
+}
+
+int32_t Ctx::nat_step_table(const uint64_t* lo, const uint64_t* hi, uint32_t l1, uint32_t l2, const uint64_t** out) {
+    const std::vector<uint64_t> key{5, l1, l2};
+    auto it = full_cache.find(key);
+    if (it != full_cache.end()) { *out = it->second; return GL355_OK; }
+    const uint64_t total = 1ull << (l1 + l2);
+    uint64_t* d = nullptr;
+    GL355_HIP(this, hipMalloc((void**)&d, total * 8));
+    hipLaunchKernelGGL(build_nat_step_table_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, lo, hi, l1, l2, d);
     GL355_HIP(this, hipGetLastError());
     full_cache[key] = d;
     *out = d;

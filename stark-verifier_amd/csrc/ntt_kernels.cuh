@@ -24,6 +24,9 @@ GL_DEV uint32_t brev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (3
 // LDS index padding: one extra element every 16 keeps the stride-16 / stride-256 register rounds
 // conflict-free for ds_read_b64 (NTT section)
 GL_DEV uint32_t lds_phys(uint32_t idx) { return idx + (idx >> 4); }
+// PAD = 1 adds one element every 256 as well: the transposing read of the natural -> natural flow (lanes over bit-reversed rows:
+// strides of 128 / 256 elements) is then conflict-free too; LDS elements: 2^LT + 2^(LT-4) + 2^(LT-8)
+template <int PAD> GL_DEV uint32_t lds_phys_t(uint32_t idx) { return PAD ? idx + (idx >> 4) + (idx >> 8) : idx + (idx >> 4); }
 
 // g^e from a two-level table: lo[j] = g^j (j < 4096), hi[j] = g^(4096 j)
 GL_DEV uint64_t pow2lvl(const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi, uint64_t e) {
@@ -169,7 +172,7 @@ GL_DEV void dif8_lazy(uint64_t (&x)[16]) {
 // (consecutive r) read 64 consecutive words per register q.  With the plain omega_{2^14}^e table the same loads were gathers
 // at a stride of k0 * 2^(14-m) words -- up to 64 cache lines per wave instruction, and a third of the row pass's time
 // (tools/ubench/ubench_ntt_rows.hip, knock-out 1).
-template <int LT, int RHO, bool INV, bool LAZY = false>
+template <int LT, int RHO, bool INV, bool LAZY = false, int PAD = 0>
 GL_DEV void dif_round(uint64_t* lds, const uint64_t* __restrict__ tw, int m, int LO, int tid, int nthreads) {
     constexpr int R = 1 << RHO;
     const int tasks = (1 << LT) >> RHO;
@@ -179,7 +182,7 @@ GL_DEV void dif_round(uint64_t* lds, const uint64_t* __restrict__ tw, int m, int
         const uint32_t idx0 = (high << (fbit + RHO)) | low;
         uint64_t x[16];
 #pragma unroll
-        for (int q = 0; q < R; q++) x[q] = lds[lds_phys(idx0 + ((uint32_t)q << fbit))];
+        for (int q = 0; q < R; q++) x[q] = lds[lds_phys_t<PAD>(idx0 + ((uint32_t)q << fbit))];
         if constexpr (!(GL355_NTT_KO & 8)) {
             if constexpr (LAZY && RHO == 3) dif8_lazy<INV>(x);
             else dif_regs<RHO, INV>(x);
@@ -196,7 +199,7 @@ GL_DEV void dif_round(uint64_t* lds, const uint64_t* __restrict__ tw, int m, int
             }
         }
 #pragma unroll
-        for (int q = 0; q < R; q++) lds[lds_phys(idx0 + ((uint32_t)q << fbit))] = x[q];
+        for (int q = 0; q < R; q++) lds[lds_phys_t<PAD>(idx0 + ((uint32_t)q << fbit))] = x[q];
     }
 }
 
@@ -321,18 +324,18 @@ __global__ void __launch_bounds__(1 << (LT - 4)) __attribute__((amdgpu_waves_per
 // many waves the 15-instruction inline-asm product (GL_MUL_VARIANT 1, ntt_r8.hip) pays: measured in tools/ubench/ubench_ntt_rows.hip
 // 1.25 -> 0.83 ms for the row pass and 0.75 -> 0.58 ms for the column pass of the 2^17 -> 2^20 x 135 LDE.
 // ------------------------------------------------------------------------------------------------
-template <int LT, int LOG_T, bool INV>
+template <int LT, int LOG_T, bool INV, int PAD = 0>
 GL_DEV void dif_tile_r8(uint64_t* lds, const uint64_t* __restrict__ tw, int LO, int tid, int nthreads) {
     int m = LOG_T;
 #pragma unroll
     for (int round = 0; round < LOG_T / 3; round++) {
-        dif_round<LT, 3, INV, GL355_NTT_R8_LAZY != 0>(lds, tw, m, LO, tid, nthreads);
+        dif_round<LT, 3, INV, GL355_NTT_R8_LAZY != 0, PAD>(lds, tw, m, LO, tid, nthreads);
         m -= 3;
         __syncthreads();
     }
     constexpr int REM = LOG_T % 3;
-    if constexpr (REM == 2) dif_round<LT, 2, INV>(lds, tw, 2, LO, tid, nthreads);
-    if constexpr (REM == 1) dif_round<LT, 1, INV>(lds, tw, 1, LO, tid, nthreads);
+    if constexpr (REM == 2) dif_round<LT, 2, INV, false, PAD>(lds, tw, 2, LO, tid, nthreads);
+    if constexpr (REM == 1) dif_round<LT, 1, INV, false, PAD>(lds, tw, 1, LO, tid, nthreads);
     if constexpr (REM != 0) __syncthreads();
 }
 // The first radix-8 round straight from the registers that loaded the tile, and the last round straight to its consumer: a thread that
@@ -342,7 +345,7 @@ GL_DEV void dif_tile_r8(uint64_t* lds, const uint64_t* __restrict__ tw, int LO, 
 #ifndef GL355_NTT_R8_DIRECT
 #define GL355_NTT_R8_DIRECT 1
 #endif
-template <int LT, int LOG_T, bool INV>
+template <int LT, int LOG_T, bool INV, int PAD = 0>
 GL_DEV void dif_first_round_regs(uint64_t (&x)[16], uint64_t* lds, const uint64_t* __restrict__ tw, int LO, int tid) {
     static_assert(LOG_T >= 3, "needs a radix-8 first round");
     constexpr int fbit = LT - 3;
@@ -360,10 +363,10 @@ GL_DEV void dif_first_round_regs(uint64_t (&x)[16], uint64_t* lds, const uint64_
         }
     }
 #pragma unroll
-    for (int q = 0; q < 8; q++) lds[lds_phys((uint32_t)tid + ((uint32_t)q << fbit))] = x[q];
+    for (int q = 0; q < 8; q++) lds[lds_phys_t<PAD>((uint32_t)tid + ((uint32_t)q << fbit))] = x[q];
 }
 // last round of radix 2^RHO (m == RHO: no twiddles): LDS -> network -> sink(tile index, value)
-template <int LT, int RHO, bool INV, class Sink>
+template <int LT, int RHO, bool INV, class Sink, int PAD = 0>
 GL_DEV void dif_last_round_sink(const uint64_t* lds, int LO, int tid, int nthreads, Sink sink) {
     constexpr int R = 1 << RHO;
     const int tasks = (1 << LT) >> RHO;
@@ -373,7 +376,7 @@ GL_DEV void dif_last_round_sink(const uint64_t* lds, int LO, int tid, int nthrea
         const uint32_t idx0 = (high << (fbit + RHO)) | low;
         uint64_t x[16];
 #pragma unroll
-        for (int q = 0; q < R; q++) x[q] = lds[lds_phys(idx0 + ((uint32_t)q << fbit))];
+        for (int q = 0; q < R; q++) x[q] = lds[lds_phys_t<PAD>(idx0 + ((uint32_t)q << fbit))];
         if constexpr (!(GL355_NTT_KO & 8)) {
             if constexpr (GL355_NTT_R8_LAZY != 0 && RHO == 3) dif8_lazy<INV>(x);
             else dif_regs<RHO, INV>(x);
@@ -383,23 +386,23 @@ GL_DEV void dif_last_round_sink(const uint64_t* lds, int LO, int tid, int nthrea
     }
 }
 // rounds between a register-fed first round and (KEEP_LAST) a sunk last round; x holds the thread's 8 loaded elements
-template <int LT, int LOG_T, bool INV, bool KEEP_LAST>
+template <int LT, int LOG_T, bool INV, bool KEEP_LAST, int PAD = 0>
 GL_DEV void dif_tile_r8_regs(uint64_t (&x)[16], uint64_t* lds, const uint64_t* __restrict__ tw, int LO, int tid, int nthreads) {
     constexpr int FULL = LOG_T / 3, REM = LOG_T % 3;
     static_assert(!KEEP_LAST || LOG_T >= 4, "the last round must not be the first");
-    dif_first_round_regs<LT, LOG_T, INV>(x, lds, tw, LO, tid);
+    dif_first_round_regs<LT, LOG_T, INV, PAD>(x, lds, tw, LO, tid);
     __syncthreads();
     int m = LOG_T - 3;
     constexpr int MID = FULL - 1 - ((KEEP_LAST && REM == 0) ? 1 : 0);       // radix-8 rounds done here after the first
 #pragma unroll
     for (int round = 0; round < MID; round++) {
-        dif_round<LT, 3, INV, GL355_NTT_R8_LAZY != 0>(lds, tw, m, LO, tid, nthreads);
+        dif_round<LT, 3, INV, GL355_NTT_R8_LAZY != 0, PAD>(lds, tw, m, LO, tid, nthreads);
         m -= 3;
         __syncthreads();
     }
     if constexpr (!KEEP_LAST) {
-        if constexpr (REM == 2) dif_round<LT, 2, INV>(lds, tw, 2, LO, tid, nthreads);
-        if constexpr (REM == 1) dif_round<LT, 1, INV>(lds, tw, 1, LO, tid, nthreads);
+        if constexpr (REM == 2) dif_round<LT, 2, INV, false, PAD>(lds, tw, 2, LO, tid, nthreads);
+        if constexpr (REM == 1) dif_round<LT, 1, INV, false, PAD>(lds, tw, 1, LO, tid, nthreads);
         if constexpr (REM != 0) __syncthreads();
     }
 }
@@ -566,6 +569,63 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
         for (int i = 0; i < 8; i++) store(tid + i * NT, lds[lds_phys(tid + i * NT)]);
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Natural order in, natural order out in TWO passes (round 3): N = N1 * N2, input index i = i1 * N2 + i2, output k = k1 + N1 * k2.
+//   pass A  column pass over i1 (tile = all N1 rows x TC adjacent i2), the 4-step twiddle omega_N^(k1 i2), and the tile leaves
+//           TRANSPOSED: element (k1, i2) goes to intermediate position i2 * N1 + k1 -- runs of N1 contiguous words, read from LDS with the
+//           row index bit-reversed, so the bit reversal of this dimension costs nothing in HBM;
+//   pass B  column pass over i2 on that [N2][N1] matrix (tile = all N2 rows x TC adjacent k1), rows written at bitrev: position
+//           k2 * N1 + k1 = the natural index.
+// The DIF-DIF flow above leaves bit-reversed order (what the commitment wants) and needed a third pass (bitrev_tiled_kernel, 0.59 of
+// 1.99 ms at 2^20 x 135) for natural order.  Both tiles are 2^LT elements with TC >= 8 (64-byte segments): N1, N2 <= 2^(LT - 3).
+// step_t: the 4-step twiddles in pass A's STORE order, step_t[i2 * N1 + k1] = omega^(k1 i2) (Ctx::nat_step_table).
+// ------------------------------------------------------------------------------------------------
+template <int LT, int LOG_T, int PASS, int WPE>
+__global__ void __launch_bounds__(1 << (LT - 3)) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_cols_r8_nat_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    constexpr int NT = 1 << (LT - 3);
+    constexpr int LOG_TC = LT - LOG_T, TC = 1 << LOG_TC;
+    static_assert(LOG_TC >= 3, "tiles of at least 8 adjacent columns");
+    const int tid = threadIdx.x;
+    const uint32_t log_n2 = a.log_rows;                     // log2 of the row stride of the matrix this pass walks
+    const uint64_t tiles_per_col = (1ull << log_n2) >> LOG_TC;
+    // A tile of 8 columns reads / writes 64-byte halves of 128-byte lines; the tile with the other halves must run on the SAME XCD (its
+    // L2), soon after: blocks are dealt to the XCDs round-robin, so block 8 q + x takes tile 2 (8 (q >> 1) + x) + (q & 1)
+    uint64_t bt = blockIdx.x;
+    if constexpr (TC * 8 < 128) {
+        if ((gridDim.x & 15) == 0) { const uint64_t q = bt >> 3, xcd = bt & 7; bt = ((((q >> 1) << 3) + xcd) << 1) + (q & 1); }
+    }
+    const uint64_t col = bt / tiles_per_col;
+    const uint64_t c0 = (bt % tiles_per_col) << LOG_TC;
+    const uint64_t* in = a.in + col * a.in_col_stride;
+    uint64_t* out = a.out + col * a.out_col_stride;
+    uint64_t x[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t g = tid + i * NT;
+        x[i] = in[((uint64_t)(g >> LOG_TC) << log_n2) + c0 + (g & (TC - 1))];
+    }
+    if constexpr (PASS == 0) {
+        dif_tile_r8_regs<LT, LOG_T, false, false, 1>(x, lds, a.tw_r8, LOG_TC, tid, NT);
+        // out[(c0 + cc) * N1 + k1] = tile[bitrev(k1)][cc] * omega^(k1 (c0 + cc)): lanes run over k1
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t g = tid + i * NT;
+            const uint32_t k1 = g & ((1u << LOG_T) - 1), cc = g >> LOG_T;
+            const uint64_t go = ((c0 + cc) << LOG_T) + k1;
+            out[go] = gl_mul(lds[lds_phys_t<1>((brev(k1, LOG_T) << LOG_TC) | cc)], a.step_full[go]);
+        }
+    } else {
+        auto store = [&](uint32_t g, uint64_t v) {
+            const uint32_t r = g >> LOG_TC, cc = g & (TC - 1);
+            out[((uint64_t)brev(r, LOG_T) << log_n2) + c0 + cc] = gl_canon(v);
+        };
+        dif_tile_r8_regs<LT, LOG_T, false, true, 1>(x, lds, a.tw_r8, LOG_TC, tid, NT);
+        dif_last_round_sink<LT, R8Last<LOG_T>::RHO, false, decltype(store), 1>(lds, LOG_TC, tid, NT, store);
+    }
+}
+hipError_t launch_cols_r8_nat(const PassArgs& a, uint32_t log_t, int pass, hipStream_t s);
 
 // Column pass of an LDE whose coset bases form a geometric sequence (base[c] = shift * w^c: PolynomialCoeffs::lde): ONE block takes a
 // tile through ALL cosets.  The per-coset kernel above reads the coefficients once per coset (8 x 141 MB through the fabric at

@@ -89,6 +89,35 @@ hipError_t launch_cols_r8(const PassArgs& a, uint32_t log_t, bool inv, hipStream
     return hipGetLastError();
 }
 
+// natural -> natural in two passes (ntt_kernels.cuh): pass 0 over a.log_n - a.log_rows... the caller sets a.log_rows = log2 of the row stride;
+// tiles of 4096 elements while 8 adjacent columns fit (log_t <= 9), 8192 elements for log_t = 10
+template <int LT, int LOG_T, int PASS>
+static hipError_t launch_nat_t(const PassArgs& a, hipStream_t s) {
+    constexpr int NT = 1 << (LT - 3);
+    constexpr int WPE = LT == 12 ? 4 : 8;                  // 8192-element tiles: two 1024-thread blocks per CU need <= 64 VGPRs
+    const size_t shmem = ((1u << LT) + (1u << (LT - 4)) + (1u << (LT - 8))) * sizeof(uint64_t);
+    const uint64_t blocks = ((1ull << a.log_rows) >> (LT - LOG_T)) * a.batch;
+    auto k = ntt_cols_r8_nat_kernel<LT, LOG_T, PASS, WPE>;
+    if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_cols_r8_nat(const PassArgs& a, uint32_t log_t, int pass, hipStream_t s) {
+    switch (log_t * 2 + (pass ? 1 : 0)) {
+        case 6 * 2: return launch_nat_t<12, 6, 0>(a, s);
+        case 6 * 2 + 1: return launch_nat_t<12, 6, 1>(a, s);
+        case 7 * 2: return launch_nat_t<12, 7, 0>(a, s);
+        case 7 * 2 + 1: return launch_nat_t<12, 7, 1>(a, s);
+        case 8 * 2: return launch_nat_t<12, 8, 0>(a, s);
+        case 8 * 2 + 1: return launch_nat_t<12, 8, 1>(a, s);
+        case 9 * 2: return launch_nat_t<12, 9, 0>(a, s);
+        case 9 * 2 + 1: return launch_nat_t<12, 9, 1>(a, s);
+        case 10 * 2: return launch_nat_t<13, 10, 0>(a, s);
+        case 10 * 2 + 1: return launch_nat_t<13, 10, 1>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 // all cosets of a tile in one block (a.ratio_full set): blocks over (column, tile)
 hipError_t launch_cols_r8_cosets(const PassArgs& a, uint32_t log_t, hipStream_t s) {
     const uint64_t n2 = 1ull << a.log_rows;
