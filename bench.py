@@ -355,7 +355,9 @@ def merkle_figures(gl, device):
     g = torch.Generator(device="cuda")
     g.manual_seed(0x356)
     out = {"what": "gl355_merkle_build (leaf sponge + compression levels + cap, plonky2 digest layout), leaves resident, HIP events"}
-    issue_peak = 1024 * 2.05e9 / 4.2           # wave-level VALU instructions per second (tools/ubench: ~4.2 clk per multiply-add at ~2.05 GHz)
+    # wave-level VALU instructions per second at the issue rate: 1024 SIMDs x 2.4 GHz (the clock these kernels hold when they run alone) / 4.0 clk
+    # per instruction of this mix (rocprofv3 --pmc, profiles/r03_pmc_traffic.json: hash_leaves_kernel 4.0 clk per VALU instruction per SIMD)
+    issue_peak = 1024 * 2.4e9 / 4.0
     for log_n, L, cap in ((22, 4, 4), (22, 135, 4), (20, 4, 0)):
         n = 1 << log_n
         leaves = torch.randint(0, (1 << 63) - 1, (n, L), dtype=torch.int64, device="cuda", generator=g)
