@@ -287,9 +287,13 @@ def pmc_valu(kernel, avg_launch_ms):
     ach = insts / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     return {"unit": "G wave-instructions/s", "insts_per_launch": insts, "achieved": round(ach, 1), "peak": round(peak, 1),
             "frac": round(ach / peak, 3),
-            "note": "instructions per launch averaged over the launches of the committed --pmc pass (lock-step batches of 8: leaf hashing of "
-                    "2^19-2^20 rows and the tiny FRI-layer launches alike), duration from this run's one-context pass; in the timed region "
-                    "the device has a kernel resident 99.5 % of the time (profiles/r02_timeline.txt) and the job runs at the VALU issue rate"}
+            "source": "profiles/" + os.path.basename(latest_profile("_pmc_traffic.json")),
+            "clk_per_valu_inst_in_the_pmc_pass": d["kernels"][kernel].get("clk_per_valu_inst_per_simd"),
+            "note": "two sources (bench.py cannot collect PMC counters): instructions per launch averaged over the launches of the committed --pmc "
+                    "pass (lock-step batches of 8: leaf hashing of 2^19-2^20 rows and the tiny FRI-layer launches alike), duration from this "
+                    "run's one-context pass.  The same-run figure is clk_per_valu_inst_in_the_pmc_pass (SQ_BUSY_CYCLES / SQ_INSTS_VALU of ONE "
+                    "rocprofv3 pass): at the issue rate.  In the timed region the device has a kernel resident 99.5 % of the time "
+                    "(profiles/r02_timeline.txt) and the job runs at the VALU issue rate"}
 
 
 def lde_figure(gl, device, steps=8):
