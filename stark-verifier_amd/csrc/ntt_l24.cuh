@@ -28,6 +28,10 @@
 #ifndef GL355_L24_KO
 #define GL355_L24_KO 0
 #endif
+// 1: a persistent row block keeps its eight mid twiddles in registers for all its rows (128 VGPRs + scratch); 0: re-read per row
+#ifndef GL355_L24_TW_REGS
+#define GL355_L24_TW_REGS 0
+#endif
 
 namespace gl355 {
 
@@ -112,7 +116,11 @@ template <int M, int R, bool INV>
 GL_DEV void l24_twiddles(L24 (&y)[8]) {
     constexpr int MULT = M == 6 ? 39 : 78;
 #define GL355_L24_TW(Q, K0) { constexpr int S0 = (MULT * R * K0) % 192; y[Q] = l24_shift<INV ? (192 - S0) % 192 : S0>(y[Q]); }
-    GL355_L24_TW(0, 0) GL355_L24_TW(1, 4) GL355_L24_TW(2, 2) GL355_L24_TW(3, 6) GL355_L24_TW(4, 1) GL355_L24_TW(5, 5) GL355_L24_TW(6, 3) GL355_L24_TW(7, 7)
+    // (scheduling fences every two elements: with all eight in flight the g / h / y temporaries alone are ~100 registers)
+    GL355_L24_TW(0, 0) GL355_L24_TW(1, 4) __builtin_amdgcn_sched_barrier(0);
+    GL355_L24_TW(2, 2) GL355_L24_TW(3, 6) __builtin_amdgcn_sched_barrier(0);
+    GL355_L24_TW(4, 1) GL355_L24_TW(5, 5) __builtin_amdgcn_sched_barrier(0);
+    GL355_L24_TW(6, 3) GL355_L24_TW(7, 7)
 #undef GL355_L24_TW
 }
 // r is wave-uniform: one scalar branch, then straight-line code with compile-time shifts and limb renamings
@@ -163,6 +171,18 @@ GL_DEV uint64_t l24_value(const L24& a) { return l24_mul4(a, 1ull, 1ull << 24, 1
 // transformed.  Output order: plain bit reversal (identical to ntt_rows_r8_kernel<12>), canonical.
 // ------------------------------------------------------------------------------------------------------------------------------
 GL_DEV uint32_t l24_phys(uint32_t idx) { return idx + (idx >> 6); }
+// A 4096-element row through buffer instructions: resource descriptor and the 4096 q byte offsets in scalar registers, ONE vector register
+// (8 tid) of address per thread -- the flat-address form keeps eight 64-bit pointers per direction alive (32 VGPRs the persistent loop does not have)
+typedef uint32_t l24_u32x2 __attribute__((ext_vector_type(2)));
+GL_DEV __amdgpu_buffer_rsrc_t l24_row_rsrc(const uint64_t* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 4096 * 8, 0x00020000); }
+GL_DEV uint64_t l24_row_load(__amdgpu_buffer_rsrc_t r, uint32_t tid8, int q) {
+    const l24_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)tid8, q * 4096, 0);
+    return ((uint64_t)v.y << 32) | v.x;
+}
+GL_DEV void l24_row_store(__amdgpu_buffer_rsrc_t r, uint32_t tid8, int q, uint64_t x) {
+    l24_u32x2 v; v.x = (uint32_t)x; v.y = (uint32_t)(x >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)tid8, q * 4096, 0);
+}
 constexpr size_t L24_ROWS_LDS_BYTES = (4096 + 64) * 16;
 
 template <int WPE>
@@ -171,23 +191,33 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
     int4* lq = reinterpret_cast<int4*>(lds_raw);
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const uint64_t total_rows = ((uint64_t)a.batch) << a.log_rows;
-    auto put = [&](uint32_t idx, const L24& v) { lq[l24_phys(idx)] = make_int4(v.l[0], v.l[1], v.l[2], v.l[3]); };
-    auto get = [&](uint32_t idx) { const int4 q = lq[l24_phys(idx)]; L24 v; v.l[0] = q.x; v.l[1] = q.y; v.l[2] = q.z; v.l[3] = q.w; return v; };
-    auto put8 = [&](uint32_t idx, uint64_t v) { lds_raw[2 * l24_phys(idx)] = v; };      // the low 8 bytes of a quad cell
-    auto get8 = [&](uint32_t idx) { return lds_raw[2 * l24_phys(idx)]; };
+    // cell addresses written out as base + compile-time offset (the padding idx + (idx >> 6) is linear inside each access pattern), so the
+    // compiler issues ds instructions with immediate offsets from five base registers instead of keeping ~40 precomputed addresses alive
+    auto put = [&](uint32_t cell, const L24& v) { lq[cell] = make_int4(v.l[0], v.l[1], v.l[2], v.l[3]); };
+    auto get = [&](uint32_t cell) { const int4 q = lq[cell]; L24 v; v.l[0] = q.x; v.l[1] = q.y; v.l[2] = q.z; v.l[3] = q.w; return v; };
+    auto put8 = [&](uint32_t cell, uint64_t v) { lds_raw[2 * cell] = v; };      // the low 8 bytes of a quad cell
+    auto get8 = [&](uint32_t cell) { return lds_raw[2 * cell]; };
+    const uint32_t cA1 = 65 * w + lane;          // idx = 64 (8 q + w) + lane      -> cell cA1 + 520 q
+    const uint32_t cA2 = 520 * w + lane;         // idx = 64 (8 w + r) + lane      -> cell cA2 + 65 r
+    const uint32_t cB1 = 65 * lane + w;          // idx = 64 lane + 8 q + w        -> cell cB1 + 8 q
+    const uint32_t cB2 = 65 * lane + 8 * w;      // idx = 64 lane + 8 w + r        -> cell cB2 + r
+    const uint32_t cST = tid + w;                // idx = tid + 512 q              -> cell cST + 520 q
     auto row_ptr = [&](uint64_t row, const uint64_t* base, uint64_t stride) {
         const uint64_t col = row >> a.log_rows, rin = row & ((1ull << a.log_rows) - 1);
         return base + col * stride + (rin << 12);
     };
+#if GL355_L24_TW_REGS
     uint64_t tw[8];                                         // cell (8 w + s, lane) of the mid table, s < 8: the same for every row
 #pragma unroll
     for (int s = 0; s < 8; s++) tw[s] = (GL355_L24_KO & 4) ? 3 + s + w : a.mid[64 * (8 * w + s) + lane];
+#endif
     uint64_t row = blockIdx.x;
+    const uint32_t tid8 = tid * 8;
     uint64_t x[8];
     if (row < total_rows) {
-        const uint64_t* in = row_ptr(row, a.in, a.in_col_stride);
+        const __amdgpu_buffer_rsrc_t rin = l24_row_rsrc(row_ptr(row, a.in, a.in_col_stride));
 #pragma unroll
-        for (int q = 0; q < 8; q++) x[q] = (GL355_L24_KO & 1) ? (uint64_t)tid * 0x9E3779B97F4A7C15ull + q : in[tid + 512 * q];
+        for (int q = 0; q < 8; q++) x[q] = (GL355_L24_KO & 1) ? (uint64_t)tid * 0x9E3779B97F4A7C15ull + q : l24_row_load(rin, tid8, q);
     }
     while (row < total_rows) {
         L24 y[8];
@@ -196,42 +226,53 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
         for (int q = 0; q < 8; q++) y[q] = l24_split(x[q]);
         const uint64_t next = row + gridDim.x;
         if (next < total_rows) {
-            const uint64_t* in = row_ptr(next, a.in, a.in_col_stride);
+            const __amdgpu_buffer_rsrc_t rin = l24_row_rsrc(row_ptr(next, a.in, a.in_col_stride));
 #pragma unroll
-            for (int q = 0; q < 8; q++) x[q] = (GL355_L24_KO & 1) ? x[q] + next : in[tid + 512 * q];
+            for (int q = 0; q < 8; q++) x[q] = (GL355_L24_KO & 1) ? x[q] + next : l24_row_load(rin, tid8, q);
         }
         dif8_l24<false>(y);
         l24_twiddles_r<6, false>(y, w);
 #pragma unroll
-        for (int q = 0; q < 8; q++) put(64 * (8 * q + w) + lane, y[q]);
+        for (int q = 0; q < 8; q++) put(cA1 + 520 * q, y[q]);
+#if !GL355_L24_TW_REGS
+        uint64_t tw[8];                                     // fetched per row (32 KB per tile, L2-resident), issued before the barrier: held
+#pragma unroll                                              // across rows they cost 16 VGPRs and pushed the kernel into scratch
+        for (int s = 0; s < 8; s++) tw[s] = (GL355_L24_KO & 4) ? 3 + s + w : a.mid[64 * (8 * w + s) + lane];
+#endif
         __syncthreads();
         // A2: u = 8 w + r over r, then the general twiddle of the 64 x 64 split; 8-byte products into the thread's own cells
 #pragma unroll
-        for (int r = 0; r < 8; r++) y[r] = get(64 * (8 * w + r) + lane);
+        for (int r = 0; r < 8; r++) y[r] = get(cA2 + 65 * r);
         dif8_l24<false>(y);
 #pragma unroll
-        for (int s = 0; s < 8; s++) put8(64 * (8 * w + s) + lane, gl_mul(l24_value(y[s]), tw[s]));
+        for (int s = 0; s < 8; s++) {
+            put8(cA2 + 65 * s, gl_mul(l24_value(y[s]), tw[s]));
+            if (s & 1) __builtin_amdgcn_sched_barrier(0);   // two elements in flight, not eight: their temporaries would not fit 128 VGPRs
+        }
         __syncthreads();
         // B1: u-slot = lane, v = 8 q + w; reads and writes the same eight cells
 #pragma unroll
-        for (int q = 0; q < 8; q++) y[q] = l24_split(get8(64 * lane + 8 * q + w));
+        for (int q = 0; q < 8; q++) y[q] = l24_split(get8(cB1 + 8 * q));
         dif8_l24<false>(y);
         l24_twiddles_r<6, false>(y, w);
 #pragma unroll
-        for (int q = 0; q < 8; q++) put(64 * lane + 8 * q + w, y[q]);
+        for (int q = 0; q < 8; q++) put(cB1 + 8 * q, y[q]);
         __syncthreads();
         // B2: v = 8 w + r over r; results leave the limb form (own cells again), then the transposition to store order
 #pragma unroll
-        for (int r = 0; r < 8; r++) y[r] = get(64 * lane + 8 * w + r);
+        for (int r = 0; r < 8; r++) y[r] = get(cB2 + r);
         dif8_l24<false>(y);
 #pragma unroll
-        for (int s = 0; s < 8; s++) put8(64 * lane + 8 * w + s, gl_canon(l24_value(y[s])));
+        for (int s = 0; s < 8; s++) {
+            put8(cB2 + s, gl_canon(l24_value(y[s])));
+            if (s & 1) __builtin_amdgcn_sched_barrier(0);
+        }
         __syncthreads();
-        uint64_t* out = const_cast<uint64_t*>(row_ptr(row, a.out, a.out_col_stride));
+        const __amdgpu_buffer_rsrc_t rout = l24_row_rsrc(row_ptr(row, a.out, a.out_col_stride));
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            const uint64_t v = get8(tid + 512 * q);
-            if (!(GL355_L24_KO & 2) || v == 0x123456789ull) out[tid + 512 * q] = v;
+            const uint64_t v = get8(cST + 520 * q);
+            if (!(GL355_L24_KO & 2) || v == 0x123456789ull) l24_row_store(rout, tid8, q, v);
         }
         __syncthreads();                                    // the tile is free for the next row's quads
         row = next;
