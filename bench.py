@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LOG_N, RATE_BITS, BATCH = 17, 3, 135
+LDE_PER_STEP = 8      # --workload lde: LDEs of BATCH columns per step
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -296,8 +297,10 @@ def pmc_valu(kernel, avg_launch_ms):
                     "(profiles/r02_timeline.txt) and the job runs at the VALU issue rate"}
 
 
-def lde_figure(gl, device, steps=8):
-    """BASELINE configs[1] on this GPU, a few steps: the metric's 'NTT HBM GB/s' half (full treatment: --workload lde)."""
+def lde_figure(gl, device, steps=40, warm=12):
+    """BASELINE configs[1] on this GPU: the metric's 'NTT HBM GB/s' half (full treatment: --workload lde).  The first ~10 launches
+    after the device did something else run 15-20 % slower (memory-side clocks settling, profiles/r03_ubench_ntt_l24s.txt), so the
+    figure is taken after `warm` untimed steps over `steps` steps (~50 ms in all)."""
     import torch
     ctx = gl.Context(device)
     lib = ctx.lib
@@ -311,7 +314,7 @@ def lde_figure(gl, device, steps=8):
 
     def step():
         ctx.check(lib.gl355_lde_bitrev(ctx.h, C.c_void_p(coeffs.data_ptr()), LOG_N, RATE_BITS, 7, BATCH, C.c_void_p(out.data_ptr())))
-    for _ in range(2):
+    for _ in range(warm):
         step()
     ctx.sync()
     ctx.profile_enable(True)
@@ -883,9 +886,13 @@ def main_lde(args):
     out = torch.empty((BATCH, N), dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
+    # one step = LDE_PER_STEP LDEs of 135 columns, back to back (the lock-step prover transforms the wires of 8 units per launch
+    # sequence); with the default 3 warm-up steps the device's memory-side clocks have settled when the timed region starts
+    # (the first ~10 LDEs after something else ran are 15-20 % slower, profiles/r03_ubench_ntt_l24s.txt)
     def step():
-        ctx.check(lib.gl355_lde_bitrev(ctx.h, C.c_void_p(coeffs.data_ptr()), LOG_N, RATE_BITS, 7, BATCH,
-                                       C.c_void_p(out.data_ptr())))
+        for _ in range(LDE_PER_STEP):
+            ctx.check(lib.gl355_lde_bitrev(ctx.h, C.c_void_p(coeffs.data_ptr()), LOG_N, RATE_BITS, 7, BATCH,
+                                           C.c_void_p(out.data_ptr())))
 
     for _ in range(args.warmup):
         step()
@@ -923,7 +930,8 @@ def main_lde(args):
         elapsed = comm.max(elapsed)
 
     if rank == 0:
-        alg_bytes_step = 8.0 * BATCH * (n + N)
+        alg_bytes_lde = 8.0 * BATCH * (n + N)
+        alg_bytes_step = alg_bytes_lde * LDE_PER_STEP
         value = alg_bytes_step * args.steps * world / elapsed / 1e9
         # dominant kernel = the kernel group with the largest HIP-event time in the timed region
         dom_name, (dom_cnt, dom_ms, _) = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, 0.0, 0))
@@ -933,28 +941,29 @@ def main_lde(args):
         # pass is charged the FULL algorithmic traffic of the LDE it belongs to divided between the two
         # passes in proportion to what each must move at minimum: pass1 = 8*B*n, pass2 = 8*B*N.
         alg_by_kernel = {"ntt_cols_pass1": 8.0 * BATCH * n, "ntt_rows_pass2": 8.0 * BATCH * N,
-                         "ntt_rows_single_pass": alg_bytes_step}
+                         "ntt_rows_single_pass": alg_bytes_lde}
         per_launch_ms = dom_ms / max(1, dom_cnt)
         # roofline of the whole LDE (both passes are needed to produce one unit of output): algorithmic
         # bytes of one LDE over the summed average launch durations of its kernels
         lde_ms = sum(v[1] / max(1, v[0]) for k, v in prof.items() if k.startswith("ntt_"))
-        achieved = alg_bytes_step / (lde_ms * 1e-3) / 1e9 if lde_ms > 0 else 0.0
+        achieved = alg_bytes_lde / (lde_ms * 1e-3) / 1e9 if lde_ms > 0 else 0.0
         line = {
             "metric": "NTT HBM GB/s (2^20-point Goldilocks LDE, blowup 8, bit-exact)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
             "config": {"workload": "lde n=2^17 -> N=2^20 (rate_bits 3, coset 7), batch 135 columns per GPU, "
-                                   "bit-reversed (commitment) output order, operands resident in HBM",
+                                   "bit-reversed (commitment) output order, operands resident in HBM; one step = %d such LDEs back to back" % LDE_PER_STEP,
+                       "ldes_per_step": LDE_PER_STEP, "algorithmic_bytes_per_lde": alg_bytes_lde,
                        "algorithmic_bytes_per_step_per_gpu": alg_bytes_step, "parallelism": "independent batches per GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": lde_pmc()[0],
                          "traffic_source": "%s; both kernels of one LDE summed -- the intermediate of the two-pass split is the excess over the algorithmic 1.27 GB" % lde_pmc()[1],
-                         "kernel": "lde = ntt_cols_r8_cosets_kernel<5> (pass 1: 32-point transforms over 128-column tiles, all 8 cosets per block) + "
-                                   "ntt_rows_r8_kernel<12> (pass 2: 4096-point rows)",
+                         "kernel": "lde = ntt_cols_l24s_cosets_kernel<6> (pass 1: 32-point transforms over 64-column tiles on 24-bit limbs, all 8 cosets per block) + "
+                                   "ntt_rows_l24s_kernel (pass 2: 4096-point rows as two radix-64 super-rounds on 24-bit limbs)",
                          "dominant_kernel": dom_name,
                          "dominant_avg_launch_ms": round(per_launch_ms, 4),
-                         "dominant_alg_GBps": round(alg_by_kernel.get(dom_name, alg_bytes_step) / (per_launch_ms * 1e-3) / 1e9, 2)
+                         "dominant_alg_GBps": round(alg_by_kernel.get(dom_name, alg_bytes_lde) / (per_launch_ms * 1e-3) / 1e9, 2)
                          if per_launch_ms > 0 else None,
                          "kernels_ms_per_launch": {k: round(v[1] / max(1, v[0]), 4) for k, v in prof.items()},
                          "kernel_time_fraction_of_wall": round(total_kernel_ms * 1e-3 / elapsed, 3)},

@@ -37,14 +37,15 @@ namespace gl355 {
 // the 24-bit-limb passes of the LDE (ntt_l24.hip)
 hipError_t launch_rows_l24(const PassArgs& a, hipStream_t s);
 hipError_t launch_cols_l24_cosets(const PassArgs& a, hipStream_t s);
-// GL355_EXP_NTT_NO_L24=1 keeps the LDE's column pass on the radix-8 kernel of round 2 (A/B); GL355_EXP_NTT_L24_ROWS=1 also runs the
-// 4096-point rows on limbs (measured slower than the radix-8 row kernel: its 65-KB tile allows two blocks per CU)
+// GL355_EXP_NTT_NO_L24=1 keeps both passes of the two-pass LDE / forward transform on the radix-8 kernels of round 2 (A/B);
+// GL355_EXP_NTT_L24_ROWS=0 only the 4096-point rows (1 = the first, limb-quad version of the limb row kernel, 2 = default: the
+// split-exchange version; ntt_l24.hip reads the same variable)
 static bool ntt_l24_on() {
     static const bool v = getenv("GL355_EXP_NTT_NO_L24") == nullptr;
     return v;
 }
 static bool ntt_l24_rows_on() {
-    static const bool v = getenv("GL355_EXP_NTT_L24_ROWS") != nullptr;
+    static const bool v = [] { const char* e = getenv("GL355_EXP_NTT_L24_ROWS"); return !(e && e[0] == '0'); }();
     return v;
 }
 

@@ -280,6 +280,114 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// The same row pass with the limb quads exchanged in TWO SUB-STEPS (limbs 0, 1 of every element, then limbs 2, 3) through 8-byte
+// cells: the tile is 33 KB of LDS instead of 65, so a CU holds 3-4 tiles = 6-8 waves per SIMD instead of 4 -- the limb kernels were
+// never short of issue slots, they were short of waves to cover their global loads and LDS round trips.  Same cells,
+// same padding, same output as ntt_rows_l24_kernel; 8 barriers per row instead of 5.  A hi-pair sub-step is read only by the thread
+// that later overwrites those cells, so the 8-byte exchanges still start without a barrier.  grid = rows: one row per block; a
+// smaller grid walks rows blockIdx, blockIdx + grid, ... (PREFETCH: the next row's elements are fetched under this row's transform).
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr size_t L24S_ROWS_LDS_BYTES = (4096 + 64) * 8;
+template <int WPE, bool PREFETCH>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_rows_l24s_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_raw[];
+    int2* lp = reinterpret_cast<int2*>(lds_raw);
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const uint64_t total_rows = ((uint64_t)a.batch) << a.log_rows;
+    const uint32_t cA1 = 65 * w + lane;          // idx = 64 (8 q + w) + lane      -> cell cA1 + 520 q
+    const uint32_t cA2 = 520 * w + lane;         // idx = 64 (8 w + r) + lane      -> cell cA2 + 65 r
+    const uint32_t cB1 = 65 * lane + w;          // idx = 64 lane + 8 q + w        -> cell cB1 + 8 q
+    const uint32_t cB2 = 65 * lane + 8 * w;      // idx = 64 lane + 8 w + r        -> cell cB2 + r
+    const uint32_t cST = tid + w;                // idx = tid + 512 q              -> cell cST + 520 q
+    auto row_ptr = [&](uint64_t row, const uint64_t* base, uint64_t stride) {
+        const uint64_t col = row >> a.log_rows, rin = row & ((1ull << a.log_rows) - 1);
+        return base + col * stride + (rin << 12);
+    };
+    uint64_t row = blockIdx.x;
+    const uint32_t tid8 = tid * 8;
+    uint64_t x[8];
+    if (PREFETCH && row < total_rows) {
+        const __amdgpu_buffer_rsrc_t rin = l24_row_rsrc(row_ptr(row, a.in, a.in_col_stride));
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[q] = l24_row_load(rin, tid8, q);
+    }
+    while (row < total_rows) {
+        L24 y[8];
+        const uint64_t next = row + gridDim.x;
+        if (!PREFETCH) {
+            const __amdgpu_buffer_rsrc_t rin = l24_row_rsrc(row_ptr(row, a.in, a.in_col_stride));
+#pragma unroll
+            for (int q = 0; q < 8; q++) x[q] = (GL355_L24_KO & 1) ? (uint64_t)tid * 0x9E3779B97F4A7C15ull + q : l24_row_load(rin, tid8, q);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) y[q] = l24_split(x[q]);
+        if (PREFETCH && next < total_rows) {
+            const __amdgpu_buffer_rsrc_t rin = l24_row_rsrc(row_ptr(next, a.in, a.in_col_stride));
+#pragma unroll
+            for (int q = 0; q < 8; q++) x[q] = l24_row_load(rin, tid8, q);
+        }
+        // A1 (own butterfly r = w of the loaded elements), exchange to A2 in two sub-steps
+        dif8_l24<false>(y);
+        l24_twiddles_r<6, false>(y, w);
+#pragma unroll
+        for (int q = 0; q < 8; q++) lp[cA1 + 520 * q] = make_int2(y[q].l[0], y[q].l[1]);
+        uint64_t tw[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) tw[s] = (GL355_L24_KO & 4) ? 3 + s + w : a.mid[64 * (8 * w + s) + lane];
+        __syncthreads();
+        L24 z[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const int2 t = lp[cA2 + 65 * r]; z[r].l[0] = t.x; z[r].l[1] = t.y; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; q++) lp[cA1 + 520 * q] = make_int2(y[q].l[2], y[q].l[3]);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const int2 t = lp[cA2 + 65 * r]; z[r].l[2] = t.x; z[r].l[3] = t.y; }
+        // A2, the general twiddle; 8-byte products into the cells whose hi pairs only this thread has read
+        dif8_l24<false>(z);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            lds_raw[cA2 + 65 * s] = gl_mul(l24_value(z[s]), tw[s]);
+            if (s & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        // B1 reads and writes the same eight cells
+#pragma unroll
+        for (int q = 0; q < 8; q++) y[q] = l24_split(lds_raw[cB1 + 8 * q]);
+        dif8_l24<false>(y);
+        l24_twiddles_r<6, false>(y, w);
+#pragma unroll
+        for (int q = 0; q < 8; q++) lp[cB1 + 8 * q] = make_int2(y[q].l[0], y[q].l[1]);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const int2 t = lp[cB2 + r]; z[r].l[0] = t.x; z[r].l[1] = t.y; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; q++) lp[cB1 + 8 * q] = make_int2(y[q].l[2], y[q].l[3]);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const int2 t = lp[cB2 + r]; z[r].l[2] = t.x; z[r].l[3] = t.y; }
+        // B2: results leave the limb form (own cells), then the transposition to store order
+        dif8_l24<false>(z);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            lds_raw[cB2 + s] = gl_canon(l24_value(z[s]));
+            if (s & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t rout = l24_row_rsrc(row_ptr(row, a.out, a.out_col_stride));
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint64_t v = lds_raw[cST + 520 * q];
+            if (!(GL355_L24_KO & 2) || v == 0x123456789ull) l24_row_store(rout, tid8, q, v);
+        }
+        row = next;
+        if (row < total_rows) __syncthreads();               // the tile is free for the next row
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Column pass of the LDE over all cosets (the shape of ntt_cols_r8_cosets_kernel<5>): 32 rows x 128 columns per tile, 32 = 8 x 4 with
 // omega_32 = 2^78 shift twiddles between the radix-8 and the radix-4 round, the 4-step twiddle (a.step_full) at the store.  Threads
 // tid >> 7 = r are wave-uniform.  A thread stores to the same eight places with the same step twiddles for every coset: they are loaded
@@ -339,6 +447,88 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
             }
         }
         __syncthreads();
+    }
+}
+
+// The column pass with the limb quads exchanged in two sub-steps (8-byte cells; see ntt_rows_l24s_kernel): a tile of 32 rows x 2^LOG_TC
+// columns on 4 * 2^LOG_TC threads is 32 KB (LOG_TC = 7) or 16 KB (6) of LDS, so the CU holds as many tiles as the registers allow.
+GL_DEV __amdgpu_buffer_rsrc_t l24_buf_rsrc(const uint64_t* p, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000); }
+GL_DEV uint64_t l24_buf_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const l24_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+    return ((uint64_t)v.y << 32) | v.x;
+}
+GL_DEV void l24_buf_store(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, uint64_t x) {
+    l24_u32x2 v; v.x = (uint32_t)x; v.y = (uint32_t)(x >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, 0);
+}
+// (all global accesses through buffer instructions: two vector registers of byte offsets -- one for the load pattern, one for the store
+// pattern -- and scalar row offsets, instead of ~30 registers of flat addresses)
+template <int LOG_TC, int WPE>
+__global__ void __launch_bounds__(4 << LOG_TC) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_cols_l24s_cosets_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_raw[];
+    int2* lp = reinterpret_cast<int2*>(lds_raw);
+    constexpr uint32_t TC = 1u << LOG_TC;
+    const uint32_t tid = threadIdx.x, r = tid >> LOG_TC, cc = tid & (TC - 1);
+    const uint32_t log_n2 = a.log_rows;                     // 12
+    const uint32_t tiles_per_col = (1u << log_n2) >> LOG_TC; // 32 or 64
+    uint32_t tile, colu;
+    if (tiles_per_col == 32) { tile = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) & 3); colu = blockIdx.x >> 5; }
+    else if (tiles_per_col == 64) { tile = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) & 7); colu = blockIdx.x >> 6; }
+    else { tile = blockIdx.x % tiles_per_col; colu = blockIdx.x / tiles_per_col; }
+    const uint64_t col = colu;
+    const uint32_t c0 = tile << LOG_TC;
+    const uint32_t n_bytes = 8u << (log_n2 + 5);            // one coset block / one table: 32 rows of 2^log_n2 words
+    const uint32_t row_bytes = 8u << log_n2;
+    const uint32_t vld = ((r << log_n2) + c0 + cc) * 8;      // row r + 4 q: + 4 q row_bytes
+    const uint32_t vst = (((4 * r) << log_n2) + c0 + cc) * 8; // row 4 (r + 4 t2) + k: + (16 t2 + k) row_bytes
+    const __amdgpu_buffer_rsrc_t rs_in = l24_buf_rsrc(a.in + col * a.in_col_stride, n_bytes), rs_pre = l24_buf_rsrc(a.pre_full, n_bytes),
+                                 rs_ratio = l24_buf_rsrc(a.ratio_full, n_bytes), rs_step = l24_buf_rsrc(a.step_full, n_bytes);
+    uint64_t v[8], step[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+        v[q] = gl_mul((GL355_L24_KO & 1) ? vld + q : l24_buf_load(rs_in, vld, 4 * q * row_bytes), l24_buf_load(rs_pre, vld, 4 * q * row_bytes));
+#pragma unroll
+    for (int t2 = 0; t2 < 2; t2++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) step[4 * t2 + k] = l24_buf_load(rs_step, vst, (16 * t2 + k) * row_bytes);
+    for (uint32_t c = 0; c < a.n_cosets; c++) {
+        if (c) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = gl_mul(v[q], l24_buf_load(rs_ratio, vld, 4 * q * row_bytes));
+            __syncthreads();                                // the previous coset's hi pairs have been read
+        }
+        const __amdgpu_buffer_rsrc_t rs_out = l24_buf_rsrc(a.out + (uint64_t)a.coset_slot[c] * a.coset_out_stride + col * a.out_col_stride, n_bytes);
+        L24 y[8], z[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) y[q] = l24_split(v[q]);
+        dif8_l24<false>(y);
+        l24_twiddles_r<5, false>(y, r);
+#pragma unroll
+        for (int q = 0; q < 8; q++) lp[TC * (4 * q + r) + cc] = make_int2(y[q].l[0], y[q].l[1]);
+        __syncthreads();
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int2 t = lp[TC * (4 * (r + 4 * t2) + k) + cc]; z[4 * t2 + k].l[0] = t.x; z[4 * t2 + k].l[1] = t.y; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; q++) lp[TC * (4 * q + r) + cc] = make_int2(y[q].l[2], y[q].l[3]);
+        __syncthreads();
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int2 t = lp[TC * (4 * (r + 4 * t2) + k) + cc]; z[4 * t2 + k].l[2] = t.x; z[4 * t2 + k].l[3] = t.y; }
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++) {                    // two radix-4 tasks: rows 4 q' + {0..3}, q' = r and r + 4
+            L24 t4[4] = {z[4 * t2], z[4 * t2 + 1], z[4 * t2 + 2], z[4 * t2 + 3]};
+            dif4_l24<false>(t4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t val = gl_mul(l24_value(t4[k]), step[4 * t2 + k]);
+                if (!(GL355_L24_KO & 2) || val == 0x123456789ull) l24_buf_store(rs_out, vst, (16 * t2 + k) * row_bytes, val);
+                if (k & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 }
 

@@ -118,6 +118,9 @@ def bench_commit(ctx, log_n, batch, rate_bits=3, cap=4, salted=True, reps=3):
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     ctx = gl.Context(0)
+    if what == "lde17":     # the cfg-2 (B) shape alone, short and long: the device's clock settles over tens of milliseconds
+        for reps in (5, 50, 200):
+            bench_lde(ctx, 17, 3, 135, reps=reps)
     if what in ("lde", "all"):
         bench_lde(ctx, 17, 3, 135)
         bench_lde(ctx, 17, 3, 16)

@@ -42,6 +42,12 @@ template <int WPE> static void rows(const PassArgs& a, uint32_t blocks, double g
     char name[64]; snprintf(name, sizeof name, "rows 2^12 l24 wpe%d", WPE);
     report(name, timeit([&] { hipLaunchKernelGGL(k, dim3(512), dim3(512), L24_ROWS_LDS_BYTES, 0, a); }, 10), gb);   // persistent: 2 blocks per CU
 }
+template <int WPE, bool PF> static void rows_s(const PassArgs& a, uint32_t grid, double gb) {
+    auto k = ntt_rows_l24s_kernel<WPE, PF>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L24S_ROWS_LDS_BYTES));
+    char name[64]; snprintf(name, sizeof name, "rows 2^12 l24s wpe%d pf%d g%u", WPE, (int)PF, grid);
+    report(name, timeit([&] { hipLaunchKernelGGL(k, dim3(grid), dim3(512), L24S_ROWS_LDS_BYTES, 0, a); }, 10), gb);
+}
 template <int WPE> static void cols(const PassArgs& c, uint32_t blocks, double gb) {
     auto k = ntt_cols_l24_cosets_kernel<WPE>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L24_COLS_LDS_BYTES));
@@ -49,6 +55,35 @@ template <int WPE> static void cols(const PassArgs& c, uint32_t blocks, double g
     report(name, timeit([&] { hipLaunchKernelGGL(k, dim3(blocks), dim3(512), L24_COLS_LDS_BYTES, 0, c); }, 10), gb);
 }
 
+template <int LOG_TC, int WPE> static void cols_s(const PassArgs& c, uint32_t batch, double gb) {
+    auto k = ntt_cols_l24s_cosets_kernel<LOG_TC, WPE>;
+    const size_t lds = (size_t)32 * 8 << LOG_TC;
+    const uint32_t blocks = (4096u >> LOG_TC) * batch;
+    char name[64]; snprintf(name, sizeof name, "cols 2^5 l24s tc%d wpe%d", 1 << LOG_TC, WPE);
+    report(name, timeit([&] { hipLaunchKernelGGL(k, dim3(blocks), dim3(4 << LOG_TC), lds, 0, c); }, 10), gb);
+}
+// shader clock under load: a one-wave kernel on a second stream spins for ~ticks of the 100-MHz real-time counter and reports the
+// shader-clock cycles (s_memtime) that passed meanwhile
+__global__ void clock_probe_kernel(uint64_t ticks, uint64_t* out) {
+    const uint64_t w0 = wall_clock64(), c0 = clock64();
+    uint64_t w1 = w0;
+    while (w1 - w0 < ticks) { __builtin_amdgcn_s_sleep(8); w1 = wall_clock64(); }
+    const uint64_t c1 = clock64();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+}
+template <typename F> static void clocked(const char* what, F f, int reps) {
+    hipStream_t s2; CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    uint64_t* d; CK(hipMalloc(&d, 16)); uint64_t h[2];
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; i++) { f(); if (i == reps / 2) hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s2, 40000, d); }
+    CK(hipEventRecord(b)); CK(hipDeviceSynchronize());
+    float t; CK(hipEventElapsedTime(&t, a, b));
+    CK(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
+    printf("%-40s %4d reps  %.3f ms each   shader clock %.0f MHz (probe window %.2f ms)\n", what, reps, t / reps, h[0] / (h[1] / 100.0), h[1] / 1e5);
+    CK(hipFree(d)); CK(hipStreamDestroy(s2));
+}
 int main(int argc, char** argv) {
     const uint32_t batch = argc > 1 ? atoi(argv[1]) : 135;
     const uint64_t N = 1ull << 20, n = 1ull << 17;
@@ -69,12 +104,36 @@ int main(int argc, char** argv) {
     a.scale = 1; a.canon = 1; a.mid = mid;
     const double gb = 2.0 * batch * N * 8 / 1e9;
     rows<2>(a, batch * 256, gb); rows<3>(a, batch * 256, gb); rows<4>(a, batch * 256, gb);
+    rows_s<4, false>(a, batch * 256, gb); rows_s<5, false>(a, batch * 256, gb); rows_s<6, false>(a, batch * 256, gb); rows_s<8, false>(a, batch * 256, gb);
+    rows_s<6, false>(a, 768, gb); rows_s<8, false>(a, 1024, gb);
+    rows_s<4, true>(a, 512, gb); rows_s<5, true>(a, 512, gb); rows_s<6, true>(a, 768, gb); rows_s<8, true>(a, 1024, gb);
     PassArgs c; memset(&c, 0, sizeof c);
     c.in = cin; c.out = buf; c.in_col_stride = n; c.out_col_stride = N; c.batch = batch; c.n_cosets = 8; c.coset_out_stride = n;
     for (int i = 0; i < 8; i++) c.coset_slot[i] = i;
     c.log_n = 17; c.log_rows = 12; c.pre_full = pre; c.pre_full_stride = n; c.ratio_full = ratio; c.step_full = step; c.scale = 1;
     const double cgb = (batch * n + batch * N) * 8.0 / 1e9;
     cols<2>(c, 32 * batch, cgb); cols<3>(c, 32 * batch, cgb); cols<4>(c, 32 * batch, cgb);
+    cols_s<7, 4>(c, batch, cgb); cols_s<7, 5>(c, batch, cgb); cols_s<7, 6>(c, batch, cgb);
+    cols_s<6, 4>(c, batch, cgb); cols_s<6, 5>(c, batch, cgb); cols_s<6, 6>(c, batch, cgb); cols_s<6, 8>(c, batch, cgb);
     CK(hipDeviceSynchronize());
+    {   // the shipped pair alone and alternating, short and long: what the device's clock does under each
+        auto kr = ntt_rows_l24s_kernel<5, false>; auto kc = ntt_cols_l24s_cosets_kernel<6, 5>;
+        auto fr = [&] { hipLaunchKernelGGL(kr, dim3(batch * 256), dim3(512), L24S_ROWS_LDS_BYTES, 0, a); };
+        auto fc = [&] { hipLaunchKernelGGL(kc, dim3(64 * batch), dim3(256), 32 * 64 * 8, 0, c); };
+        for (int reps : {10, 200}) {
+            clocked("rows l24s alone", fr, reps);
+            clocked("cols l24s alone", fc, reps);
+            clocked("cols + rows alternating (per pair)", [&] { fc(); fr(); }, reps);
+        }
+        // per-kernel times inside the alternating sequence
+        hipEvent_t e[3]; for (auto& x : e) CK(hipEventCreate(&x));
+        float tc = 0, tr = 0;
+        for (int i = 0; i < 50; i++) {
+            CK(hipEventRecord(e[0])); fc(); CK(hipEventRecord(e[1])); fr(); CK(hipEventRecord(e[2])); CK(hipEventSynchronize(e[2]));
+            float x, y; CK(hipEventElapsedTime(&x, e[0], e[1])); CK(hipEventElapsedTime(&y, e[1], e[2]));
+            if (i >= 10) { tc += x; tr += y; }
+        }
+        printf("alternating, per kernel: cols %.3f ms  rows %.3f ms\n", tc / 40, tr / 40);
+    }
     return 0;
 }
