@@ -463,7 +463,10 @@ GL_DEV void l24_buf_store(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff
 }
 // (all global accesses through buffer instructions: two vector registers of byte offsets -- one for the load pattern, one for the store
 // pattern -- and scalar row offsets, instead of ~30 registers of flat addresses)
-template <int LOG_TC, int WPE>
+// MODE 0: the ratio table re-read per coset; 1: held in registers (no load follows a store inside the loop: on this ISA one counter tracks
+// loads and stores in order, so waiting for a load issued after stores waits for their acknowledgements too); 2: one coset per block
+// (blockIdx.y), the input and that coset's pre table re-read through L2, no loop at all
+template <int LOG_TC, int WPE, int MODE = 0>
 __global__ void __launch_bounds__(4 << LOG_TC) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_cols_l24s_cosets_kernel(PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_raw[];
     int2* lp = reinterpret_cast<int2*>(lds_raw);
@@ -483,18 +486,24 @@ __global__ void __launch_bounds__(4 << LOG_TC) __attribute__((amdgpu_waves_per_e
     const uint32_t vst = (((4 * r) << log_n2) + c0 + cc) * 8; // row 4 (r + 4 t2) + k: + (16 t2 + k) row_bytes
     const __amdgpu_buffer_rsrc_t rs_in = l24_buf_rsrc(a.in + col * a.in_col_stride, n_bytes), rs_pre = l24_buf_rsrc(a.pre_full, n_bytes),
                                  rs_ratio = l24_buf_rsrc(a.ratio_full, n_bytes), rs_step = l24_buf_rsrc(a.step_full, n_bytes);
-    uint64_t v[8], step[8];
+    uint64_t v[8], step[8], ratio[MODE == 1 ? 8 : 1];
+    const __amdgpu_buffer_rsrc_t rs_pre_c = MODE == 2 ? l24_buf_rsrc(a.pre_full + (uint64_t)blockIdx.y * a.pre_full_stride, n_bytes) : rs_pre;
 #pragma unroll
     for (int q = 0; q < 8; q++)
-        v[q] = gl_mul((GL355_L24_KO & 1) ? vld + q : l24_buf_load(rs_in, vld, 4 * q * row_bytes), l24_buf_load(rs_pre, vld, 4 * q * row_bytes));
+        v[q] = gl_mul((GL355_L24_KO & 1) ? vld + q : l24_buf_load(rs_in, vld, 4 * q * row_bytes), l24_buf_load(rs_pre_c, vld, 4 * q * row_bytes));
+    if (MODE == 1) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) ratio[q] = l24_buf_load(rs_ratio, vld, 4 * q * row_bytes);
+    }
 #pragma unroll
     for (int t2 = 0; t2 < 2; t2++)
 #pragma unroll
         for (int k = 0; k < 4; k++) step[4 * t2 + k] = l24_buf_load(rs_step, vst, (16 * t2 + k) * row_bytes);
-    for (uint32_t c = 0; c < a.n_cosets; c++) {
-        if (c) {
+    const uint32_t c_begin = MODE == 2 ? blockIdx.y : 0, c_end = MODE == 2 ? blockIdx.y + 1 : a.n_cosets;
+    for (uint32_t c = c_begin; c < c_end; c++) {
+        if (c != c_begin) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = gl_mul(v[q], l24_buf_load(rs_ratio, vld, 4 * q * row_bytes));
+            for (int q = 0; q < 8; q++) v[q] = gl_mul(v[q], MODE == 1 ? ratio[q] : l24_buf_load(rs_ratio, vld, 4 * q * row_bytes));
             __syncthreads();                                // the previous coset's hi pairs have been read
         }
         const __amdgpu_buffer_rsrc_t rs_out = l24_buf_rsrc(a.out + (uint64_t)a.coset_slot[c] * a.coset_out_stride + col * a.out_col_stride, n_bytes);

@@ -64,7 +64,9 @@ hipError_t launch_cols_l24_cosets(const PassArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
     const uint64_t blocks = ((1ull << a.log_rows) >> 6) * a.batch;
-    hipLaunchKernelGGL((ntt_cols_l24s_cosets_kernel<6, 5>), dim3((uint32_t)blocks), dim3(256), 32 * 64 * 8, s, a);
+    // ratio table held in registers (116 VGPRs, 4 tiles per CU): no load follows a store inside the coset loop; mode 2 = re-read per coset (84 VGPRs, 5 tiles)
+    if (mode == 2) hipLaunchKernelGGL((ntt_cols_l24s_cosets_kernel<6, 4, 1>), dim3((uint32_t)blocks), dim3(256), 32 * 64 * 8, s, a);
+    else hipLaunchKernelGGL((ntt_cols_l24s_cosets_kernel<6, 5, 0>), dim3((uint32_t)blocks), dim3(256), 32 * 64 * 8, s, a);
     return hipGetLastError();
 }
 

@@ -20,7 +20,15 @@ def dev_rand(shape, seed=1):
     return torch.randint(0, (1 << 63) - 1, shape, dtype=torch.int64, device="cuda", generator=g)
 
 
-def timed(ctx, fn, reps=5, warm=1):
+# KBENCH_WARM / KBENCH_REPS_X: untimed warm-up calls and a multiplier on every repetition count -- the first ~10 launches after the device
+# did something else run 15-20 % slow (profiles/r03_ubench_ntt_l24s.txt); steady state: KBENCH_WARM=20 KBENCH_REPS_X=10
+WARM = int(os.environ.get("KBENCH_WARM", "1"))
+REPS_X = int(os.environ.get("KBENCH_REPS_X", "1"))
+
+
+def timed(ctx, fn, reps=5, warm=None):
+    warm = WARM if warm is None else warm
+    reps *= REPS_X
     for _ in range(warm):
         fn()
     ctx.sync()

@@ -55,12 +55,12 @@ template <int WPE> static void cols(const PassArgs& c, uint32_t blocks, double g
     report(name, timeit([&] { hipLaunchKernelGGL(k, dim3(blocks), dim3(512), L24_COLS_LDS_BYTES, 0, c); }, 10), gb);
 }
 
-template <int LOG_TC, int WPE> static void cols_s(const PassArgs& c, uint32_t batch, double gb) {
-    auto k = ntt_cols_l24s_cosets_kernel<LOG_TC, WPE>;
+template <int LOG_TC, int WPE, int MODE = 0> static void cols_s(const PassArgs& c, uint32_t batch, double gb) {
+    auto k = ntt_cols_l24s_cosets_kernel<LOG_TC, WPE, MODE>;
     const size_t lds = (size_t)32 * 8 << LOG_TC;
     const uint32_t blocks = (4096u >> LOG_TC) * batch;
-    char name[64]; snprintf(name, sizeof name, "cols 2^5 l24s tc%d wpe%d", 1 << LOG_TC, WPE);
-    report(name, timeit([&] { hipLaunchKernelGGL(k, dim3(blocks), dim3(4 << LOG_TC), lds, 0, c); }, 10), gb);
+    char name[64]; snprintf(name, sizeof name, "cols 2^5 l24s tc%d wpe%d mode%d", 1 << LOG_TC, WPE, MODE);
+    report(name, timeit([&] { hipLaunchKernelGGL(k, dim3(blocks, MODE == 2 ? c.n_cosets : 1), dim3(4 << LOG_TC), lds, 0, c); }, 30), gb);
 }
 // shader clock under load: a one-wave kernel on a second stream spins for ~ticks of the 100-MHz real-time counter and reports the
 // shader-clock cycles (s_memtime) that passed meanwhile
@@ -90,11 +90,11 @@ int main(int argc, char** argv) {
     uint64_t *buf, *cin, *pre, *ratio, *step, *mid;
     CK(hipMalloc(&buf, (batch * N + (1 << 20)) * 8));
     CK(hipMalloc(&cin, batch * n * 8));
-    CK(hipMalloc(&pre, n * 8)); CK(hipMalloc(&ratio, n * 8));
+    CK(hipMalloc(&pre, 8 * n * 8)); CK(hipMalloc(&ratio, n * 8));
     CK(hipMalloc(&step, n * 8)); CK(hipMalloc(&mid, 4096 * 8));
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, buf, batch * N);
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, cin, batch * n);
-    hipLaunchKernelGGL(fill_kernel, dim3(512), dim3(256), 0, 0, pre, n);
+    hipLaunchKernelGGL(fill_kernel, dim3(512), dim3(256), 0, 0, pre, 8 * n);
     hipLaunchKernelGGL(fill_kernel, dim3(512), dim3(256), 0, 0, ratio, n);
     hipLaunchKernelGGL(fill_kernel, dim3(512), dim3(256), 0, 0, step, n);
     hipLaunchKernelGGL(fill_kernel, dim3(16), dim3(256), 0, 0, mid, 4096);
@@ -115,6 +115,8 @@ int main(int argc, char** argv) {
     cols<2>(c, 32 * batch, cgb); cols<3>(c, 32 * batch, cgb); cols<4>(c, 32 * batch, cgb);
     cols_s<7, 4>(c, batch, cgb); cols_s<7, 5>(c, batch, cgb); cols_s<7, 6>(c, batch, cgb);
     cols_s<6, 4>(c, batch, cgb); cols_s<6, 5>(c, batch, cgb); cols_s<6, 6>(c, batch, cgb); cols_s<6, 8>(c, batch, cgb);
+    cols_s<6, 4, 1>(c, batch, cgb); cols_s<6, 5, 1>(c, batch, cgb); cols_s<7, 4, 1>(c, batch, cgb);
+    cols_s<6, 4, 2>(c, batch, cgb); cols_s<6, 6, 2>(c, batch, cgb); cols_s<6, 8, 2>(c, batch, cgb); cols_s<7, 6, 2>(c, batch, cgb); cols_s<7, 8, 2>(c, batch, cgb);
     CK(hipDeviceSynchronize());
     {   // the shipped pair alone and alternating, short and long: what the device's clock does under each
         auto kr = ntt_rows_l24s_kernel<5, false>; auto kc = ntt_cols_l24s_cosets_kernel<6, 5>;
