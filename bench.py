@@ -424,14 +424,20 @@ class _TorchComm:
 def cfg2_sweep(ctx, dev):
     """BASELINE configs[1] / SURVEY cfg-2: (A) forward NTT N = 2^20, natural order in and out, batch 1 / 16 / 135; (B) LDE 2^17 -> 2^20
     (rate_bits 3, coset 7), same batches, bit-reversed (commitment) order; (C) forward NTT N = 2^16 .. 2^23, batch 16.  Operands resident;
-    HIP-event time per call; algorithmic bytes 16 B N (A, C) and 8 B (n + N) (B)."""
+    HIP-event time per call in steady state; algorithmic bytes 16 B N (A, C) and 8 B (n + N) (B)."""
     import torch
     lib = ctx.lib
     g = torch.Generator(device=dev)
     g.manual_seed(0x355)
 
-    def timed(fn, reps=4):
+    def timed(fn):
+        # steady state (see lde_figure): warm up for ~15 ms, then time ~40 ms
         fn(); ctx.sync()
+        ctx.timer_start(); fn(); one = max(ctx.timer_stop(), 1e-3)
+        for _ in range(min(200, int(15.0 / one) + 2)):
+            fn()
+        ctx.sync()
+        reps = min(400, int(40.0 / one) + 4)
         ctx.timer_start()
         for _ in range(reps):
             fn()

@@ -71,8 +71,9 @@ enum { GL355_OPT_MERKLE_LANES_LOG = 1,
                                            (hipStreamQuery, 30-us sleeps): a few percent of a core per waiting context and ~30 us of
                                            wake-up latency -- for ranks with more prover contexts than cores */
        GL355_OPT_REPLAY_THREADS = 3,    /* host threads gl355_circuit_prove_tape uses for a segmented tape (default 1) */
-       GL355_OPT_NTT_SINGLE_PASS_MAX_LOG = 4, /* 12..14 (default 14): commit-path transforms of 2^13 / 2^14 points above this size run
-                                           in two passes of 4096-point tiles instead of one pass that owns a whole CU */
+       GL355_OPT_NTT_SINGLE_PASS_MAX_LOG = 4, /* 12..14 (default 12): commit-path transforms of 2^13 / 2^14 points above this size run
+                                           in two passes (a streaming 2- / 4-row column pass, then 4096-point limb rows, 3 tiles per
+                                           CU) instead of one pass whose 64- / 128-KB tile owns a whole CU */
        GL355_OPT_BATCH_UNITS = 5,       /* 1..GL355_MAX_UNITS (default 8): units gl355_semaphore_units proves in lock-step per context */
        GL355_OPT_DEVICE_REPLAY = 6 };   /* != 0 (default): gl355_semaphore_units generates the recursive circuit's witness rows on the
                                            device (tape interpreter kernel) instead of on host threads; same rows, same failures */

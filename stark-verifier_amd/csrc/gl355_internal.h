@@ -76,7 +76,7 @@ struct Ctx {
     // event wait that leaves the CPU to other prover threads (more host threads than cores)
     uint32_t replay_threads = 1;      // GL355_OPT_REPLAY_THREADS
     uint32_t batch_units = 8;         // GL355_OPT_BATCH_UNITS
-    uint32_t ntt_single_pass_max_log = 14;   // GL355_OPT_NTT_SINGLE_PASS_MAX_LOG (12..14)
+    uint32_t ntt_single_pass_max_log = 12;   // GL355_OPT_NTT_SINGLE_PASS_MAX_LOG (12..14); 12: +1.8 % units/s over 14 (profiles/r03b_single_pass_ab.txt)
     int blocking_sync = 0;            // GL355_OPT_BLOCKING_SYNC: 0 runtime wait, 1 blocking event, 2 poll + back-off
     hipEvent_t sync_ev = nullptr;
     hipError_t wait();

@@ -37,6 +37,7 @@ namespace gl355 {
 // the 24-bit-limb passes of the LDE (ntt_l24.hip)
 hipError_t launch_rows_l24(const PassArgs& a, hipStream_t s);
 hipError_t launch_cols_l24_cosets(const PassArgs& a, hipStream_t s);
+hipError_t launch_cols_small_cosets(const PassArgs& a, uint32_t log_t, hipStream_t s);
 // GL355_EXP_NTT_NO_L24=1 keeps both passes of the two-pass LDE / forward transform on the radix-8 kernels of round 2 (A/B);
 // GL355_EXP_NTT_L24_ROWS=0 only the 4096-point rows (1 = the first, limb-quad version of the limb row kernel, 2 = default: the
 // split-exchange version; ntt_l24.hip reads the same variable)
@@ -239,6 +240,9 @@ static hipError_t launch_cols_t(const PassArgs& a, bool inv, uint64_t blocks, hi
                     a.scale == 1 && !a.canon;
     static const bool per_coset = getenv("GL355_EXP_NTT_PER_COSET") != nullptr;     // A/B: one block per (tile, coset) as before
     if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset && LOG_T == 5 && a.log_rows == 12 && ntt_l24_on()) return launch_cols_l24_cosets(a, s);
+    static const bool no_small = getenv("GL355_EXP_NTT_NO_SMALL_COLS") != nullptr;  // A/B: the tiled radix-8 kernel for 2- / 4-row column passes
+    if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset && LOG_T <= 2 && a.log_rows == 12 && a.batch <= 65535 && ntt_l24_on() && !no_small)
+        return launch_cols_small_cosets(a, LOG_T, s);
     if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset) return launch_cols_r8_cosets(a, LOG_T, s);
     if (r8 && !ntt_r16_only()) return launch_cols_r8(a, LOG_T, inv, s);
     if (fast) hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, false, true>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);

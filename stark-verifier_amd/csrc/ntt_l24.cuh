@@ -541,6 +541,46 @@ __global__ void __launch_bounds__(4 << LOG_TC) __attribute__((amdgpu_waves_per_e
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Column pass of a two-pass LDE whose column dimension is 2 or 4 (n = 2^13 / 2^14, the in-proof sizes, with 4096-point rows): nothing to
+// exchange, so no LDS and no tile -- a thread owns one index i2 < 4096 of one polynomial, loads its 2 / 4 coefficients and table words once
+// and, for every coset, scales (coset ratio), runs the radix-2 / radix-4 network in registers (omega_4 = 2^48), applies the 4-step
+// twiddle and stores.  Same tables, output order and values (mod p) as ntt_cols_r8_cosets_kernel<1 / 2>.  grid = (4096 / 256, columns).
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int LOG_T>
+__global__ void __launch_bounds__(256) ntt_cols_small_cosets_kernel(PassArgs a) {
+    static_assert(LOG_T == 1 || LOG_T == 2, "2 or 4 rows");
+    constexpr int T = 1 << LOG_T;
+    const uint32_t log_n2 = a.log_rows;
+    const uint64_t i2 = blockIdx.x * 256u + threadIdx.x, col = blockIdx.y;
+    const uint64_t* in = a.in + col * a.in_col_stride;
+    uint64_t v[T], ratio[T], step[T];
+#pragma unroll
+    for (int k = 0; k < T; k++) {
+        const uint64_t gi = ((uint64_t)k << log_n2) + i2;
+        v[k] = gl_mul(in[gi], a.pre_full[gi]);
+        ratio[k] = a.ratio_full[gi];
+        step[k] = a.step_full[gi];
+    }
+    for (uint32_t c = 0; c < a.n_cosets; c++) {
+        if (c) {
+#pragma unroll
+            for (int k = 0; k < T; k++) v[k] = gl_mul(v[k], ratio[k]);
+        }
+        uint64_t* out = a.out + (uint64_t)a.coset_slot[c] * a.coset_out_stride + col * a.out_col_stride + i2;
+        uint64_t y[T];
+        if constexpr (LOG_T == 1) {
+            y[0] = gl_add(v[0], v[1]); y[1] = gl_sub(v[0], v[1]);
+        } else {
+            const uint64_t s0 = gl_add(v[0], v[2]), d0 = gl_sub(v[0], v[2]), s1 = gl_add(v[1], v[3]), d1 = gl_mul_2exp<48>(gl_sub(v[1], v[3]));
+            y[0] = gl_add(s0, s1); y[1] = gl_sub(s0, s1); y[2] = gl_add(d0, d1); y[3] = gl_sub(d0, d1);
+        }
+#pragma unroll
+        for (int k = 0; k < T; k++) out[(uint64_t)k << log_n2] = gl_mul(y[k], step[k]);
+    }
+}
+hipError_t launch_cols_small_cosets(const PassArgs& a, uint32_t log_t, hipStream_t s);
+
 hipError_t launch_rows_l24(const PassArgs& a, hipStream_t s);
 hipError_t launch_cols_l24_cosets(const PassArgs& a, hipStream_t s);
 

@@ -117,16 +117,16 @@ def test_lde(ctx, orc, log_n, rate_bits):
     eq(ctx.lde(c, rate_bits, bitrev=True), orc.reverse_index_bits(want.T.copy()).T)
 
 
-@pytest.mark.parametrize("log_n", [13, 14])
-def test_lde_small_sizes_in_two_passes(gl, orc, log_n):
-    """GL355_OPT_NTT_SINGLE_PASS_MAX_LOG = 12: the commit-path shape (natural coefficients in, bit-reversed cosets out) of
-    2^13 / 2^14 points runs as two passes of 4096-point tiles instead of one CU-filling pass; same values, and the proofs that
-    use it stay byte-identical (checked on a whole Semaphore proof below)"""
+@pytest.mark.parametrize("log_n,max_log", [(13, 12), (14, 12), (13, 14), (14, 14), (14, 13)])
+def test_lde_small_sizes_in_one_and_two_passes(gl, orc, log_n, max_log):
+    """GL355_OPT_NTT_SINGLE_PASS_MAX_LOG: the commit-path shape (natural coefficients in, bit-reversed cosets out) of 2^13 / 2^14
+    points runs as two passes (12, the default since round 3: the streaming 2- / 4-row column kernel + 4096-point limb rows) or as
+    one CU-filling pass (14: the radix-8 single-pass kernels); same values either way"""
     c2 = gl.Context(0)
-    c2.set_option(4, 12)
+    c2.set_option(4, max_log)
     rng = np.random.default_rng(0x386 + log_n)
     c = rand_field(rng, (5, 1 << log_n))
-    for rate_bits in (1, 3):
+    for rate_bits in (1, 2, 3):
         want = orc.lde(c, rate_bits)
         eq(c2.lde(c, rate_bits, bitrev=True), orc.reverse_index_bits(want.T.copy()).T)
         eq(c2.lde(c, rate_bits), want)
