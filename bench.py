@@ -974,15 +974,16 @@ def main_lde(args):
                          "kernels_ms_per_launch": {k: round(v[1] / max(1, v[0]), 4) for k, v in prof.items()},
                          "kernel_time_fraction_of_wall": round(total_kernel_ms * 1e-3 / elapsed, 3)},
         }
-        # the other bound: wave-level VALU instructions of the two passes (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r02_lde_pmc.txt:
-        # 2.19e8 + 3.58e8 per LDE; 1.082e9 in round 1) against the chip's issue rate
+        # the other bound: wave-level VALU instructions of the two passes (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r03_lde_pmc.json) against
+        # the chip's issue rate for their instruction mix
         insts_lde = lde_pmc()[2] or 0.0
         line["roofline"]["valu_issue"] = {"unit": "G wave-instructions/s", "insts_per_lde": insts_lde,
                                           "achieved": round(insts_lde / (lde_ms * 1e-3) / 1e9, 1) if lde_ms > 0 else None,
-                                          "peak": round(1024 * 2.05e9 / 4.2 / 1e9, 1),
-                                          "note": "peak = 1024 SIMDs x 2.05 GHz / 4.2 clk per multiply-add-heavy instruction (tools/ubench); the row pass's mix "
-                                                  "(adds, selects, moves) issues at 3.7 clk, so `achieved` can pass it: the row pass is instruction-bound at "
-                                                  "162 lane-instructions per element (225 with radix 16, ~490 per LDE output element in round 1)"}
+                                          "peak": round(1024 * 2.05e9 / 2.95 / 1e9, 1),
+                                          "note": "peak = 1024 SIMDs x 2.05 GHz (measured under load with an s_memtime probe) / 2.95 clk, the cost of the limb kernels' mix: "
+                                                  "~60 % plain 32-bit add / sub / and / shift-right at ~2.3 clk and ~40 % carry / multiply / 64-bit instructions at ~3.9 clk per wave "
+                                                  "instruction (tools/ubench/ubench_alu2.hip read with the real clock); 133 (rows) + 84 (columns) lane-instructions per output "
+                                                  "element (162 + 99 on the radix-8 kernels of round 2, ~490 in round 1)"}
         if root is not None:
             line["aggregation_root"] = ["%016x" % x for x in root]
         if world == 1:

@@ -10,7 +10,7 @@ python bench.py > $O/bench_recursive.json 2> $O/bench_recursive.err
 python bench.py --workload lde > $O/bench_lde.json 2> $O/bench_lde.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python bench.py --steps 1 --warmup 1 --proofs-per-step 16 --threads 1 --no-cpu-baseline > $O/bench_under_rocprof_1stream.json 2> $O/stats1.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_lde -- python tools/prof_lde.py 10 > /dev/null 2> $O/stats_lde.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_lde -- python tools/prof_lde.py 80 > /dev/null 2> $O/stats_lde.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --steps 1 --warmup 0 --proofs-per-step 16 --threads 1 --no-cpu-baseline > /dev/null 2> $O/pmc_$c.err
   rocprofv3 --pmc $c --output-format csv -d $O/ldepmc_$c -- python tools/prof_lde.py > /dev/null 2> $O/ldepmc_$c.err
