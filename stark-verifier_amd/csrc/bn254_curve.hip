@@ -394,7 +394,16 @@ struct MsmArgs {
     uint32_t* big_buckets;      // [max_big][3]  bucket id, first item, items
     uint32_t* big_partial;      // [max_items][24]
     uint32_t max_items, max_big;
+    // two-level sort (msm_digits_kernel ... msm_fine_sort_kernel): signed digits, (index | sign, low digit bits) pairs grouped by the
+    // digit's high bits, and the per-window counters of those coarse bins
+    uint32_t* dig;              // [W][n]     magnitude | sign << 31; 0 = nothing to add
+    uint32_t* pairs;            // [W][n][2]
+    uint32_t* coarse_cnt;       // [W][2^cbits] points per coarse bin
+    uint32_t* coarse_start;     // [W][2^cbits] exclusive scan of the counts
+    uint32_t* coarse_fill;      // [W][2^cbits] reservation cursors of the scatter
+    uint32_t cbits, chunk;      // coarse bits (cb - MSM_FINE_BITS), points per block of the coarse kernels
 };
+#define MSM_FINE_BITS 10u
 #define MSM_SIZE_BINS 128
 #define MSM_BIG 256u            // a lane sums at most this many points; a normal bucket holds 8-64
 #define MSM_BIG_WG_POINTS 4096u // points per workgroup item of a big bucket (16 per lane), more when a bucket would need over 256 items
@@ -508,6 +517,133 @@ __global__ void msm_scatter_kernel(MsmArgs a) {
         }
     }
 }
+// ---- the sort in two levels (round 3).  The histogram and the scatter above pay one DEVICE-scope atomic per point and window each
+// (2 x 109 M at 2^23 points: 4.0 + 6.0 of 36.6 ms -- the L2s of the eight XCDs are not coherent, so those atomics execute at the memory
+// side).  Here the digits are written once (msm_digits_kernel), blocks of `chunk` points count and scatter them by part of the digit's bits
+// with LDS atomics and one global atomic per (block, coarse bin), and one workgroup per (window, coarse bin) sorts its region by the other
+// MSM_FINE_BITS bits in LDS, writing the bucket offsets (hist / cursor) and the final index array.  The coarse bin is the digit's LOW bits:
+// the top window of a 254-bit scalar has only a few significant bits, and binned by the high bits its 2^23 points fell into 8 regions of
+// a million points each, one workgroup per region (5 ms).  Same outputs as msm_prepare /
+// msm_scan / msm_scatter up to the order of the points inside a bucket, which does not matter.  Skewed scalars only make regions large
+// (a workgroup then loops over its region); nothing overflows.
+__global__ void msm_digits_kernel(MsmArgs a) {            // points to Montgomery form + the signed digits of every window
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const u256 x = load256(a.points + 8 * i), y = load256(a.points + 8 * i + 4);
+    const bool ident = u_is_zero(x) && u_is_zero(y);
+    const u256 xm = ident ? u_zero() : m_from_int<F_Q>(x), ym = ident ? u_zero() : m_from_int<F_Q>(y);
+    uint32_t* d = a.pm + 16 * i;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { d[j] = xm.l[j]; d[8 + j] = ym.l[j]; }
+    for (uint32_t set = 0; set < a.n_sets; set++) {
+        const uint64_t* k = a.scalars + 4 * ((uint64_t)set * a.n + i);
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < a.wps; w++) {
+            bool neg;
+            const uint32_t mag = msm_signed_digit(k, w, a.c, carry, neg);
+            a.dig[(uint64_t)(set * a.wps + w) * a.n + i] = ident ? 0u : (mag | (neg && mag ? 0x80000000u : 0u));
+        }
+    }
+}
+__global__ void __launch_bounds__(256) msm_coarse_count_kernel(MsmArgs a) {
+    extern __shared__ uint32_t lh[];
+    const uint32_t w = blockIdx.y, nbin = 1u << a.cbits;
+    const uint64_t lo = (uint64_t)blockIdx.x * a.chunk, hi = min(a.n, lo + a.chunk);
+    for (uint32_t b = threadIdx.x; b < nbin; b += 256) lh[b] = 0;
+    __syncthreads();
+    const uint32_t* dg = a.dig + (uint64_t)w * a.n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const uint32_t mag = dg[i] & 0x7fffffffu;
+        if (mag) atomicAdd(&lh[(mag - 1) & (nbin - 1)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbin; b += 256)
+        if (lh[b]) atomicAdd(a.coarse_cnt + (uint64_t)w * nbin + b, lh[b]);
+}
+__global__ void __launch_bounds__(1024) msm_coarse_scan_kernel(MsmArgs a) {     // per window: exclusive scan of the coarse counts
+    __shared__ uint32_t sh[1024];
+    const uint32_t w = blockIdx.x, nbin = 1u << a.cbits, tid = threadIdx.x;
+    const uint32_t* c = a.coarse_cnt + (uint64_t)w * nbin;
+    uint32_t* st = a.coarse_start + (uint64_t)w * nbin;
+    const uint32_t per = (nbin + 1023) / 1024, lo = min(nbin, tid * per), hi = min(nbin, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; b++) sum += c[b];
+    sh[tid] = sum;
+    __syncthreads();
+    for (int stp = 1; stp < 1024; stp <<= 1) {
+        const uint32_t o = tid >= (uint32_t)stp ? sh[tid - stp] : 0;
+        __syncthreads();
+        sh[tid] += o;
+        __syncthreads();
+    }
+    uint32_t run = tid ? sh[tid - 1] : 0;
+    for (uint32_t b = lo; b < hi; b++) { st[b] = run; run += c[b]; }
+}
+__global__ void __launch_bounds__(256) msm_coarse_scatter_kernel(MsmArgs a) {
+    extern __shared__ uint32_t lh[];                       // [2^cbits] counts, then running cursors; [2^cbits] bases
+    const uint32_t w = blockIdx.y, nbin = 1u << a.cbits;
+    uint32_t* lbase = lh + nbin;
+    const uint64_t lo = (uint64_t)blockIdx.x * a.chunk, hi = min(a.n, lo + a.chunk);
+    for (uint32_t b = threadIdx.x; b < nbin; b += 256) lh[b] = 0;
+    __syncthreads();
+    const uint32_t* dg = a.dig + (uint64_t)w * a.n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const uint32_t mag = dg[i] & 0x7fffffffu;
+        if (mag) atomicAdd(&lh[(mag - 1) & (nbin - 1)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbin; b += 256) {
+        const uint32_t cnt = lh[b];
+        lbase[b] = cnt ? a.coarse_start[(uint64_t)w * nbin + b] + atomicAdd(a.coarse_fill + (uint64_t)w * nbin + b, cnt) : 0;
+        lh[b] = 0;
+    }
+    __syncthreads();
+    uint32_t* pr = a.pairs + 2ull * (uint64_t)w * a.n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const uint32_t d = dg[i], mag = d & 0x7fffffffu;
+        if (!mag) continue;
+        const uint32_t bin = (mag - 1) & (nbin - 1);
+        const uint32_t pos = lbase[bin] + atomicAdd(&lh[bin], 1u);
+        *reinterpret_cast<uint2*>(pr + 2ull * pos) = make_uint2((uint32_t)i | (d & 0x80000000u), (mag - 1) >> a.cbits);
+    }
+}
+__global__ void __launch_bounds__(256) msm_fine_sort_kernel(MsmArgs a) {
+    __shared__ uint32_t fh[1u << MSM_FINE_BITS], fbase[1u << MSM_FINE_BITS], part[256];
+    const uint32_t bin = blockIdx.x, w = blockIdx.y, nbin = 1u << a.cbits, tid = threadIdx.x;
+    const uint32_t start = a.coarse_start[(uint64_t)w * nbin + bin], cnt = a.coarse_cnt[(uint64_t)w * nbin + bin];
+    constexpr uint32_t NF = 1u << MSM_FINE_BITS, PER = NF / 256;
+    for (uint32_t f = tid; f < NF; f += 256) fh[f] = 0;
+    __syncthreads();
+    const uint32_t* pr = a.pairs + 2ull * ((uint64_t)w * a.n + start);
+    for (uint32_t k = tid; k < cnt; k += 256) atomicAdd(&fh[pr[2ull * k + 1]], 1u);
+    __syncthreads();
+    uint32_t c[PER], sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) { c[j] = fh[tid * PER + j]; sum += c[j]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (int stp = 1; stp < 256; stp <<= 1) {
+        const uint32_t o = tid >= (uint32_t)stp ? part[tid - stp] : 0;
+        __syncthreads();
+        part[tid] += o;
+        __syncthreads();
+    }
+    uint32_t run = start + (tid ? part[tid - 1] : 0);
+    const uint64_t bucket0 = ((uint64_t)w << a.cb) + bin;            // bucket = digit - 1 = fine << cbits | bin
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+        const uint32_t f = tid * PER + j;
+        a.hist[bucket0 + ((uint64_t)f << a.cbits)] = run; a.cursor[bucket0 + ((uint64_t)f << a.cbits)] = run + c[j];
+        fbase[f] = run; fh[f] = 0;
+        run += c[j];
+    }
+    __syncthreads();
+    uint32_t* out = a.idx + (uint64_t)w * a.n;
+    for (uint32_t k = tid; k < cnt; k += 256) {
+        const uint2 p = *reinterpret_cast<const uint2*>(pr + 2ull * k);
+        out[fbase[p.y] + atomicAdd(&fh[p.y], 1u)] = p.x;
+    }
+}
 // Buckets by decreasing size.  A lane sums one bucket, so a wave takes as long as its largest bucket: with 2^20 points in 2^16
 // buckets per window the sizes are Poisson(16) and the largest of 64 is ~27 -- 40 % of the lanes' time idle.  Sizes are small
 // integers, so a counting sort (per-workgroup LDS histogram, one global atomic per class and workgroup) puts equal sizes side by side.
@@ -563,7 +699,13 @@ __global__ void __launch_bounds__(256) msm_bucket_kernel(MsmArgs a) {
 // ---- big buckets: a work list (bucket, slice) built on the device, one workgroup per slice (lanes stride through the slice, then a
 // tree over the 256 lane sums in LDS), one workgroup per big bucket for the slices' sums.  One lane per bucket made a 2^20-point MSM
 // whose scalars were all equal -- or whose top window held one digit -- a matter of seconds (2^19 dependent additions).
+// Buckets of MSM_BIG < sz <= MSM_MID points (the top window of a uniform 2^23-point MSM: 2^13 buckets of ~1024) are cut into items of
+// MSM_MID_SLICE points summed by ONE LANE each, like ordinary buckets, and their <= 32 partial sums are added by one lane per bucket: a
+// workgroup per 1024-point bucket spent its time in the 8-level tree over 256 lane sums of 4 points each (4.0 of 38.5 ms at 2^23).
+#define MSM_MID 2048u
+#define MSM_MID_SLICE 64u
 GL_DEV uint32_t msm_big_slice(uint32_t sz) {                       // points per item: at most 256 items per bucket
+    if (sz <= MSM_MID) return MSM_MID_SLICE;
     const uint32_t need = (sz + 255) / 256;
     return need > MSM_BIG_WG_POINTS ? ((need + 255) & ~255u) : MSM_BIG_WG_POINTS;
 }
@@ -588,11 +730,36 @@ GL_DEV jac msm_wg_tree(jac acc, uint32_t* sh /* 256 x 24 */) {     // sum of the
     }
     return acc;
 }
+// items of mid-size buckets: one lane per item (a fixed grid strides over the work list)
+__global__ void __launch_bounds__(256) msm_mid_partial_kernel(MsmArgs a) {
+    const uint32_t n_items = *a.big_counters;
+    for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < n_items; it += gridDim.x * blockDim.x) {
+        const uint32_t id = a.big_items[2 * it], off = a.big_items[2 * it + 1], w = id >> a.cb;
+        const uint32_t base = a.hist[id], end = a.cursor[id];
+        if (end - base > MSM_MID) continue;                        // a workgroup item (below)
+        const uint32_t lo = base + off, hi = min(end, lo + MSM_MID_SLICE);
+        jac acc = j_identity();
+        for (uint32_t k = lo; k < hi; k++) acc = msm_add_point(a, acc, a.idx[(uint64_t)w * a.n + k]);
+        j_store(a.big_partial + 24ull * it, acc);
+    }
+}
+// ... and one lane per mid-size bucket for its partial sums
+__global__ void __launch_bounds__(64) msm_mid_final_kernel(MsmArgs a) {
+    const uint32_t n_big = a.big_counters[1];
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_big; b += gridDim.x * blockDim.x) {
+        const uint32_t id = a.big_buckets[3 * b], first = a.big_buckets[3 * b + 1], cnt = a.big_buckets[3 * b + 2];
+        if (a.cursor[id] - a.hist[id] > MSM_MID) continue;
+        jac acc = j_load(a.big_partial + 24ull * first);
+        for (uint32_t k = 1; k < cnt; k++) acc = j_add(acc, j_load(a.big_partial + 24ull * (first + k)));
+        j_store(a.buckets + (uint64_t)id * 24, acc);
+    }
+}
 __global__ void __launch_bounds__(256) msm_big_partial_kernel(MsmArgs a) {      // a fixed grid walks the work list (usually empty)
     __shared__ uint32_t sh[256 * 24];
     const uint32_t n_items = *a.big_counters;
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
         const uint32_t id = a.big_items[2 * it], off = a.big_items[2 * it + 1], w = id >> a.cb;
+        if (a.cursor[id] - a.hist[id] <= MSM_MID) continue;        // a lane item (above); block-uniform
         const uint32_t lo = a.hist[id] + off, end = a.cursor[id];
         const uint32_t hi = min(end, lo + msm_big_slice(end - a.hist[id]));
         jac acc = j_identity();
@@ -607,6 +774,7 @@ __global__ void __launch_bounds__(256) msm_big_final_kernel(MsmArgs a) {
     const uint32_t n_big = a.big_counters[1];
     for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
         const uint32_t id = a.big_buckets[3 * b], first = a.big_buckets[3 * b + 1], cnt = a.big_buckets[3 * b + 2];
+        if (a.cursor[id] - a.hist[id] <= MSM_MID) continue;        // msm_mid_final_kernel's; block-uniform
         jac acc = threadIdx.x < cnt ? j_load(a.big_partial + 24ull * (first + threadIdx.x)) : j_identity();
         acc = msm_wg_tree(acc, sh);
         if (threadIdx.x == 0) j_store(a.buckets + (uint64_t)id * 24, acc);
@@ -645,6 +813,50 @@ __global__ void __launch_bounds__(64) msm_level_kernel(MsmLevel l) {
     }
     j_store(l.out_s + ((uint64_t)w * groups + v) * 24, run);
     j_store(l.out_w + ((uint64_t)w * groups + v) * 24, acc);
+}
+
+// The same level with EIGHT LANES PER GROUP (kbits == 3).  A level is pure latency -- one lane's chain of ~26 dependent additions of ~30 us
+// each, whatever the level's size: 7 levels were 5.7 of 38.5 ms at 2^23 points -- so the chain is cut instead: suffix sums of the eight S_u
+// by a three-step scan across the lanes, sum_{u >= 1} run_u and sum_u Wt_u by three-step trees: 10 dependent additions + the doublings.
+GL_DEV jac j_shfl_down(const jac& p, uint32_t d) {
+    jac r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { r.x.l[j] = __shfl_down(p.x.l[j], d, 8); r.y.l[j] = __shfl_down(p.y.l[j], d, 8); r.z.l[j] = __shfl_down(p.z.l[j], d, 8); }
+    return r;
+}
+__global__ void __launch_bounds__(64) msm_level_coop_kernel(MsmLevel l) {
+    const uint32_t groups = l.t_in >> 3, total = groups * l.n_windows;
+    const uint32_t gq = blockIdx.x * 8 + (threadIdx.x >> 3), u = threadIdx.x & 7;
+    const bool live = gq < total;
+    const uint32_t g = live ? gq : total - 1;                        // idle groups of the last block redo the last one (lanes stay for the shuffles)
+    const uint32_t w = g / groups, v = g % groups;
+    const uint64_t item = (uint64_t)w * l.t_in + (uint64_t)v * 8 + u;
+    jac x = j_load(l.in_s + item * 24);
+#pragma unroll 1
+    for (uint32_t d = 1; d < 8; d <<= 1) {                           // x_u = S_u + ... + S_7
+        const jac y = j_shfl_down(x, d);
+        if (u + d < 8) x = j_add(x, y);
+    }
+    jac acc = u ? x : j_identity();                                  // sum_{u >= 1} run_u = sum_u u S_u
+#pragma unroll 1
+    for (uint32_t d = 4; d >= 1; d >>= 1) {
+        const jac y = j_shfl_down(acc, d);
+        if (u < d) acc = j_add(acc, y);
+    }
+    if (u == 0) for (uint32_t d = 0; d < l.shift; d++) acc = j_double(acc);
+    if (l.in_w) {
+        jac wt = j_load(l.in_w + item * 24);
+#pragma unroll 1
+        for (uint32_t d = 4; d >= 1; d >>= 1) {
+            const jac y = j_shfl_down(wt, d);
+            if (u < d) wt = j_add(wt, y);
+        }
+        if (u == 0) acc = j_add(acc, wt);
+    }
+    if (u == 0 && live) {
+        j_store(l.out_s + ((uint64_t)w * groups + v) * 24, x);
+        j_store(l.out_w + ((uint64_t)w * groups + v) * 24, acc);
+    }
 }
 
 // ================================================================ fixed-base batch multiplication ===================
@@ -1009,10 +1221,17 @@ static int32_t msm_run(gl355_ctx* h, const uint64_t* points, const uint64_t* sca
     // big-bucket work list: a bucket of sz > MSM_BIG points makes ceil(sz / slice) items with slice >= MSM_BIG_WG_POINTS, so over all
     // buckets at most W n / MSM_BIG_WG_POINTS + (number of big buckets) items, and at most W n / MSM_BIG big buckets
     a.max_big = (uint32_t)(W * n / MSM_BIG + 1);
-    a.max_items = (uint32_t)(W * n / MSM_BIG_WG_POINTS + a.max_big + 1);
+    a.max_items = (uint32_t)(W * n / MSM_MID_SLICE + a.max_big + 1);   // (mid-size buckets: items of MSM_MID_SLICE points)
+    // the two-level sort: from 2^11 buckets per window on (below that the histograms are small and the point count with them)
+    static const bool old_sort = getenv("GL355_EXP_MSM_OLD_SORT") != nullptr;    // A/B: device-scope atomics per point and window
+    const bool two_level = !old_sort && a.cb > MSM_FINE_BITS;
+    a.cbits = two_level ? a.cb - MSM_FINE_BITS : 0;
+    const uint64_t nbin = 1ull << a.cbits;
+    a.chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, 32 * nbin), 1ull << 20);
+    const uint64_t sort_words = two_level ? 3 * W * n + 3 * W * nbin + 2 : 0;
     Scratch buf(ctx);
     const uint64_t words32 = n * 16 + 3 * W * nb + W * n + W * nb * 24 + MSM_SIZE_BINS + lvl_words + 64 +
-                             2 + 2ull * a.max_items + 3ull * a.max_big + 24ull * a.max_items;
+                             2 + 2ull * a.max_items + 3ull * a.max_big + 24ull * a.max_items + sort_words;
     GL355_TRY(buf.get(words32 * 4 + 64));
     uint32_t* p = buf.as<uint32_t>();
     a.pm = p; p += n * 16;
@@ -1026,21 +1245,41 @@ static int32_t msm_run(gl355_ctx* h, const uint64_t* points, const uint64_t* sca
     a.big_items = p; p += 2ull * a.max_items;
     a.big_buckets = p; p += 3ull * a.max_big;
     a.big_partial = p; p += 24ull * a.max_items;
-    uint32_t* lvl = p;
+    uint32_t* lvl = p; p += lvl_words;
+    if (two_level) {
+        p += (2 - ((uintptr_t)p / 4) % 2) % 2;                      // 8-byte alignment of the pairs
+        a.pairs = p; p += 2 * W * n;
+        a.dig = p; p += W * n;
+        a.coarse_cnt = p; p += W * nbin;
+        a.coarse_fill = p; p += W * nbin;
+        a.coarse_start = p; p += W * nbin;
+        GL355_HIP(ctx, hipMemsetAsync(a.coarse_cnt, 0, 2 * W * nbin * 4, ctx->stream));
+    }
     GL355_HIP(ctx, hipMemsetAsync(a.hist, 0, (W * nb + MSM_SIZE_BINS + 2) * 4, ctx->stream));
     const uint32_t blk = (uint32_t)((n + 255) / 256), bblk = (uint32_t)((W * nb + 255) / 256);
     const uint32_t *fin_s = a.buckets, *fin_w = nullptr;
     {
         ProfScope ps(ctx, "bn254_g1_msm", n * (64 + 32ull * m));
-        hipLaunchKernelGGL(msm_prepare_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_scan_kernel, dim3((uint32_t)W), dim3(1024), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_scatter_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
+        if (two_level) {
+            const dim3 cgrid((uint32_t)((n + a.chunk - 1) / a.chunk), (uint32_t)W);
+            hipLaunchKernelGGL(msm_digits_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(msm_coarse_count_kernel, cgrid, dim3(256), nbin * 4, ctx->stream, a);
+            hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3((uint32_t)W), dim3(1024), 0, ctx->stream, a);
+            hipLaunchKernelGGL(msm_coarse_scatter_kernel, cgrid, dim3(256), nbin * 8, ctx->stream, a);
+            hipLaunchKernelGGL(msm_fine_sort_kernel, dim3((uint32_t)nbin, (uint32_t)W), dim3(256), 0, ctx->stream, a);
+        } else {
+            hipLaunchKernelGGL(msm_prepare_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(msm_scan_kernel, dim3((uint32_t)W), dim3(1024), 0, ctx->stream, a);
+            hipLaunchKernelGGL(msm_scatter_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
+        }
         hipLaunchKernelGGL(msm_size_hist_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
         hipLaunchKernelGGL(msm_order_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(msm_big_list_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(msm_mid_partial_kernel, dim3(std::min<uint32_t>((a.max_items + 255) / 256, 2048)), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(msm_big_partial_kernel, dim3(std::min<uint32_t>(a.max_items, 1536)), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(msm_mid_final_kernel, dim3(std::min<uint32_t>((a.max_big + 63) / 64, 1024)), dim3(64), 0, ctx->stream, a);
         hipLaunchKernelGGL(msm_big_final_kernel, dim3(std::min<uint32_t>(a.max_big, 512)), dim3(256), 0, ctx->stream, a);
         for (const Lv& lv : levels) {
             MsmLevel l;
@@ -1048,7 +1287,11 @@ static int32_t msm_run(gl355_ctx* h, const uint64_t* points, const uint64_t* sca
             const uint64_t groups = lv.t_in >> lv.kbits;
             l.out_s = lvl; lvl += W * groups * 24;
             l.out_w = lvl; lvl += W * groups * 24;
-            hipLaunchKernelGGL(msm_level_kernel, dim3((uint32_t)((W * groups + 63) / 64)), dim3(64), 0, ctx->stream, l);
+            // eight lanes per group where a level is latency-bound (few groups); the large first levels are throughput-bound and the scan
+            // costs them twice the wave-level additions.  GL355_EXP_MSM_COOP_MAX: largest W x groups that runs the cooperative form (0 = never)
+            static const uint64_t coop_max = getenv("GL355_EXP_MSM_COOP_MAX") ? strtoull(getenv("GL355_EXP_MSM_COOP_MAX"), nullptr, 10) : 16384;
+            if (lv.kbits == 3 && W * groups <= coop_max) hipLaunchKernelGGL(msm_level_coop_kernel, dim3((uint32_t)((W * groups + 7) / 8)), dim3(64), 0, ctx->stream, l);
+            else hipLaunchKernelGGL(msm_level_kernel, dim3((uint32_t)((W * groups + 63) / 64)), dim3(64), 0, ctx->stream, l);
             fin_s = l.out_s; fin_w = l.out_w;
         }
         GL355_HIP(ctx, hipGetLastError());
