@@ -152,7 +152,7 @@ def test_g1_msm_2p20_distinct_bases_linearity(ctx, orc):
     assert cv._unpt(gpu_msm(ctx, pts, ab)) == cv.add(ma, mb)
 
 
-@pytest.mark.parametrize("kind", ["all_equal", "zero_one", "small", "two_values_2p18"])
+@pytest.mark.parametrize("kind", ["all_equal", "zero_one", "small", "two_values_2p18", "mid_buckets", "mid_and_big"])
 def test_g1_msm_skewed_scalars(ctx, orc, kind):
     """scalars that put most points into a handful of buckets (selector columns of 0 / 1, constants, small values): those buckets are
     summed by whole workgroups (one lane per bucket would walk 10^5 dependent additions); bases (i + 1) * 3 G, so the answer is one
@@ -167,6 +167,10 @@ def test_g1_msm_skewed_scalars(ctx, orc, kind):
         vals = [int(v) for v in rng.integers(0, 2, size=n)]
     elif kind == "small":
         vals = [int(v) for v in rng.integers(0, 5, size=n)]
+    elif kind == "mid_buckets":          # 64 buckets of ~1024 points in the lowest window: the lane-item path of mid-size buckets (257 .. 2048 points)
+        vals = [int(v) for v in rng.integers(1, 65, size=n)]
+    elif kind == "mid_and_big":          # bucket sizes from a few points up to ~16 000 in one window, negative digits included
+        vals = [int(v) if v % 3 else pm.R - int(v) for v in np.minimum(rng.geometric(0.25, size=n), 40)]
     else:
         vals = [pm.R - 1 if v else 7 for v in rng.integers(0, 2, size=n)]
     sc = cv.scalars(vals)
