@@ -69,9 +69,74 @@ struct AlphaAcc {
         for (int c = 0; c < NCH; c++) acc[c] = gl_add(acc[c], gl_mul(term, tab[c * stride + k]));
     }
 };
-// per-gate accumulation: sum_k alpha^(base+k) * c_k, later multiplied by the gate's filter
+// per-gate accumulation: sum_k alpha^(base+k) * c_k, later multiplied by the gate's filter.
+//
+// LAZILY REDUCED for two challenges (round 3): about 500 terms are pushed per point of the recursive circuit and a push was a modular
+// product and a modular sum per challenge -- 40 of the kernel's ~76 VALU instructions per term.  Here a gate's sum is kept as three 64-bit
+// columns (weights 1, 2^32, 2^64) with a 32-bit overflow count each; a push is four multiply-adds per challenge whose carry-outs
+// are added into the counts -- 16 instructions for both challenges -- and the field value is formed once per gate (value()).
+// The carry-outs live in scalar register pairs; gfx950 wants two wait states between a VALU write of a scalar register and the VALU read
+// of it and the hazard recogniser does not look inside inline asm, so the two challenges' instructions are interleaved (every carry
+// is consumed four instructions after it was produced).
+#ifndef GL355_QUOT_LAZY
+#define GL355_QUOT_LAZY 1
+#endif
 template <int NCH>
-using GateAccT = AlphaAcc<NCH>;
+struct LazyAcc : AlphaAcc<NCH> {
+    GL_DEV uint64_t value(int c) const { return this->acc[c]; }
+};
+#if GL355_QUOT_LAZY && defined(__HIP_DEVICE_COMPILE__)
+template <>
+struct LazyAcc<2> {
+    uint64_t A0[2], A1[2], A2[2];
+    uint32_t k0[2], k1[2], k2[2];
+    PwTable tab;
+    uint32_t stride, idx;
+    GL_DEV void init(const QuotArgs& a, uint32_t unit, uint32_t first = 0) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) { A0[c] = A1[c] = A2[c] = 0; k0[c] = k1[c] = k2[c] = 0; }
+        tab = (PwTable)(a.alpha_pw + (uint64_t)unit * 2 * a.pw_stride); stride = a.pw_stride; idx = first;
+    }
+    GL_DEV void push(uint64_t term) {
+        const uint64_t ax = tab[idx], ay = tab[stride + idx];
+        const uint32_t t0 = (uint32_t)term, t1 = (uint32_t)(term >> 32);
+        uint64_t c0, c1, c2, c3;
+        asm("v_mad_u64_u32 %0, %12, %16, %18, %0\n\t"
+            "v_mad_u64_u32 %1, %13, %16, %20, %1\n\t"
+            "v_mad_u64_u32 %2, %14, %16, %19, %2\n\t"
+            "v_mad_u64_u32 %3, %15, %16, %21, %3\n\t"
+            "v_addc_co_u32_e64 %6, vcc, 0, %6, %12\n\t"
+            "v_addc_co_u32_e64 %7, vcc, 0, %7, %13\n\t"
+            "v_addc_co_u32_e64 %8, vcc, 0, %8, %14\n\t"
+            "v_addc_co_u32_e64 %9, vcc, 0, %9, %15\n\t"
+            "v_mad_u64_u32 %2, %12, %17, %18, %2\n\t"
+            "v_mad_u64_u32 %3, %13, %17, %20, %3\n\t"
+            "v_mad_u64_u32 %4, %14, %17, %19, %4\n\t"
+            "v_mad_u64_u32 %5, %15, %17, %21, %5\n\t"
+            "v_addc_co_u32_e64 %8, vcc, 0, %8, %12\n\t"
+            "v_addc_co_u32_e64 %9, vcc, 0, %9, %13\n\t"
+            "v_addc_co_u32_e64 %10, vcc, 0, %10, %14\n\t"
+            "v_addc_co_u32_e64 %11, vcc, 0, %11, %15"
+            : "+v"(A0[0]), "+v"(A0[1]), "+v"(A1[0]), "+v"(A1[1]), "+v"(A2[0]), "+v"(A2[1]),          // 0..5
+              "+v"(k0[0]), "+v"(k0[1]), "+v"(k1[0]), "+v"(k1[1]), "+v"(k2[0]), "+v"(k2[1]),          // 6..11
+              "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)                                                // 12..15
+            : "v"(t0), "v"(t1),                                                                          // 16, 17
+              "s"((uint32_t)ax), "s"((uint32_t)(ax >> 32)), "s"((uint32_t)ay), "s"((uint32_t)(ay >> 32)) // 18..21
+            : "vcc");
+        idx++;
+    }
+    // A0 + 2^32 A1 + 2^64 (A2 + k0) + 2^96 k1 + 2^128 k2  with  2^96 = -1, 2^128 = -2^32 (mod p)
+    GL_DEV uint64_t value(int c) const {
+        uint64_t r = gl_reduce128(A0[c], A2[c]);
+        r = gl_add(r, gl_mul_2exp<32>(A1[c]));
+        r = gl_add(r, gl_reduce128(0, k0[c]));
+        r = gl_sub(r, k1[c]);
+        return gl_sub(r, (uint64_t)k2[c] << 32);
+    }
+};
+#endif
+template <int NCH>
+using GateAccT = LazyAcc<NCH>;
 
 // alpha_c^k for k < stride, one thread per entry (square-and-multiply over the bits of k)
 struct AlphaTabArgs { uint64_t alphas[GL355_MAX_UNITS * 4]; uint32_t nch, stride; uint64_t* out; };
@@ -361,7 +426,7 @@ __global__ void __launch_bounds__(STAGE ? 64 : 128) __attribute__((amdgpu_waves_
             if (k != gi) filter = gl_mul(filter, gl_sub(k, sel));
         if (n_sel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFull, sel));  // UNUSED_SELECTOR = u32::MAX
 #pragma unroll
-        for (uint32_t c = 0; c < nch; c++) gate_sum[c] = gl_add(gate_sum[c], gl_mul(filter, g.acc[c]));
+        for (uint32_t c = 0; c < nch; c++) gate_sum[c] = gl_add(gate_sum[c], gl_mul(filter, g.value(c)));
     }
     for (uint32_t c = 0; c < nch; c++) {
         const uint64_t v = gl_mul(gl_add(total.acc[c], gate_sum[c]), zh_inv);
