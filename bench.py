@@ -275,7 +275,7 @@ def pmc_traffic(kernel):
         return None, None
 
 
-def pmc_valu(kernel, avg_launch_ms):
+def pmc_valu(kernel, avg_launch_ms, units_per_s=None):
     """The bound that actually applies to the dominant kernel: wave-level VALU instructions per launch (SQ_INSTS_VALU of the same
     committed --pmc pass) over the launch duration measured here, against the chip's issue rate (1 024 SIMDs, one instruction per
     ~4.2 clk for this instruction mix (tools/ubench), ~2.05 GHz sustained under this load)."""
@@ -284,17 +284,25 @@ def pmc_valu(kernel, avg_launch_ms):
         insts = d["kernels"][kernel]["valu_insts_per_launch"]
     except Exception:
         return None
-    peak = 1024 * 2.05e9 / 4.2 / 1e9
+    peak = 1024 * 2.05e9 / 3.9 / 1e9
     ach = insts / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    return {"unit": "G wave-instructions/s", "insts_per_launch": insts, "achieved": round(ach, 1), "peak": round(peak, 1),
-            "frac": round(ach / peak, 3),
-            "source": "profiles/" + os.path.basename(latest_profile("_pmc_traffic.json")),
-            "clk_per_valu_inst_in_the_pmc_pass": d["kernels"][kernel].get("clk_per_valu_inst_per_simd"),
-            "note": "two sources (bench.py cannot collect PMC counters): instructions per launch averaged over the launches of the committed --pmc "
-                    "pass (lock-step batches of 8: leaf hashing of 2^19-2^20 rows and the tiny FRI-layer launches alike), duration from this "
-                    "run's one-context pass.  The same-run figure is clk_per_valu_inst_in_the_pmc_pass (SQ_BUSY_CYCLES / SQ_INSTS_VALU of ONE "
-                    "rocprofv3 pass): at the issue rate.  In the timed region the device has a kernel resident 99.5 % of the time "
-                    "(profiles/r02_timeline.txt) and the job runs at the VALU issue rate"}
+    clk = d["kernels"][kernel].get("clk_per_valu_inst_per_simd")
+    out = {"unit": "G wave-instructions/s", "issue_floor_clk": 3.9,
+           "clk_per_valu_inst_while_busy": clk, "frac_while_busy": round(3.9 / clk, 3) if clk else None,
+           "one_context_launch": {"insts_per_launch": insts, "achieved": round(ach, 1), "peak": round(peak, 1), "fill": round(ach / peak, 3)},
+           "source": "profiles/" + os.path.basename(latest_profile("_pmc_traffic.json")),
+           "note": "clk_per_valu_inst_while_busy = SQ_BUSY_CYCLES / 32 shader engines over SQ_INSTS_VALU / 1024 SIMDs of ONE rocprofv3 --pmc pass: the "
+                   "kernel issues at the rate of its v_mad_u64_u32 mix (3.9 clk per wave instruction, tools/ubench/ubench_alu2.hip at the measured clock) "
+                   "whenever the shader engines have its waves.  one_context_launch: instructions per launch of that pass over this run's one-context launch "
+                   "duration -- a lock-step batch of 8 units is ~1 800 waves, under two per SIMD, so ONE context leaves the chip partly empty (`fill`); the "
+                   "other seven contexts' kernels run in those slots, which is what `job` measures"}
+    job = d.get("job")
+    if job and units_per_s:
+        j_ach = job["valu_insts_per_unit"] * units_per_s / 1e9
+        out["job"] = {"valu_insts_per_unit": job["valu_insts_per_unit"], "achieved": round(j_ach, 1), "peak": round(peak, 1), "frac": round(j_ach / peak, 3),
+                      "what": "wave-level VALU instructions of ALL kernels per unit (the --pmc pass's total over the units its process proved) x this run's "
+                              "units/s against 1024 SIMDs x 2.05 GHz / 3.9 clk: the whole job against the VALU issue rate"}
+    return out
 
 
 def lde_figure(gl, device, steps=40, warm=12):
@@ -783,6 +791,7 @@ def main_recursive(args):
                                ("; witness tape replayed on the device" if os.environ.get("GL355_BENCH_DEVICE_REPLAY") == "1" else "; witness tape replayed on host threads") +
                                ("; rank pinned to CPUs %s (ranks take contiguous slices)" % pinned if pinned else ("; no CPU pinning (one rank)" if world == 1 else "; CPU pinning off / unavailable")),
                        "host_cpu_ms_per_unit": round(1e3 * host_cpu_s / max(1, (hi - lo) * args.steps), 2),
+                       "units_proven_in_process": int(sum(pr.units_done)),
                        "host_split": host_split},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": dname, "launches_per_unit": round(dcnt / max(1, iso_units), 1),
@@ -791,7 +800,7 @@ def main_recursive(args):
                                 "kernel = the scope group with the largest summed duration" % iso_units,
                          "note": "not an HBM-bound kernel: Poseidon is ~1.1k Goldilocks modmuls per permutation on the integer VALU "
                                  "(no MFMA form, DESIGN.md section 5); its own ceiling is permutations/s, reported per kernel in DESIGN.md",
-                         "valu_issue": pmc_valu(dname, dms / max(1, dcnt)),
+                         "valu_issue": pmc_valu(dname, dms / max(1, dcnt), units / elapsed * 1.0 / max(1, world)),
                          "gpu_ms_per_unit_all_kernels": round(sum(v[1] for v in iso.values()) / max(1, iso_units), 3),
                          "kernel_groups": groups(iso, iso_units, 10),
                          "timed_region_events": {"what": "the same scopes on 1 of the %d concurrent streams during the timed region "

@@ -113,6 +113,23 @@ def test_prove_is_deterministic_in_witness_and_seed(gl, ctx):
     assert np.array_equal(a, b) and not np.array_equal(a, c)
 
 
+def test_proof_bytes_do_not_depend_on_the_ntt_pass_structure(gl):
+    """GL355_OPT_NTT_SINGLE_PASS_MAX_LOG = 12 (default: the 2^13-point LDEs of the Semaphore circuit in two passes, streaming column kernel +
+    limb rows) and = 14 (one pass, radix-8 single-tile kernels) give the same proof, byte for byte"""
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    proofs = []
+    for max_log in (12, 14):
+        c = gl.Context(0)
+        c.set_option(4, max_log)
+        aset, sks, rng = make_access_set(gl, c, 3, 0x35E)
+        data, rows = aset.build(rng)
+        wires, pi = aset.fill_semaphore_targets(data, rows, sks[5], rand_field(rng, 4), 5, np.random.default_rng(6))
+        assert data.degree_bits == 13
+        proofs.append(plonk.prove(c, data, wires, pi, 77, flat_only=True))
+        c.close()
+    assert np.array_equal(proofs[0], proofs[1])
+
+
 def test_wrong_witness_fails_quotient(gl, ctx, orc):
     """a witness that violates a gate constraint yields a 'quotient' of full degree: the proof must not verify."""
     sem = importlib.import_module("stark-verifier_amd.semaphore")

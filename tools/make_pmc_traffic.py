@@ -2,7 +2,9 @@
 """profiles/<round>_pmc_traffic.json from the per-kernel summaries tools/prof_round1c.sh leaves in gpurun_out/<dir>/:
 HBM-side bytes per launch (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as reported; both in KB)
 and cycles per VALU instruction per SIMD (SQ_INSTS_VALU / 1024 SIMDs against SQ_BUSY_CYCLES / 32 shader engines).
-usage: make_pmc_traffic.py gpurun_out/prof_r01c profiles/r01_pmc_traffic.json"""
+usage: make_pmc_traffic.py gpurun_out/prof_r01c profiles/r01_pmc_traffic.json [bench line of the SQ pass]
+With the bench line of the SQ pass (its config.units_proven_in_process) the file also gets job.valu_insts_per_unit: the wave-level VALU
+instructions of every kernel of that process over the units it proved."""
 import json
 import re
 import sys
@@ -43,5 +45,13 @@ doc = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passe
        "_valu_note": "SQ_INSTS_VALU (wave instructions, whole chip) / 1024 SIMDs vs SQ_BUSY_CYCLES / 32 shader engines, same rocprofv3 --pmc run: "
                      "cycles per VALU instruction per SIMD; the issue floor measured by tools/ubench is ~4.2-4.4",
        "kernels": kernels}
+if len(sys.argv) > 3:
+    try:
+        line = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+        n_units = int(line["config"]["units_proven_in_process"])
+        total = sum(v["SQ_INSTS_VALU"][0] * v["SQ_INSTS_VALU"][1] for v in sq.values() if "SQ_INSTS_VALU" in v)
+        doc["job"] = {"units_proven_in_process": n_units, "valu_insts_total": total, "valu_insts_per_unit": round(total / n_units)}
+    except Exception as exc:
+        print("no job figure:", exc)
 json.dump(doc, open(dst, "w"), indent=1)
 print("wrote", dst, len(kernels), "kernels")

@@ -15,7 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --steps 1 --warmup 0 --proofs-per-step 16 --threads 1 --no-cpu-baseline > /dev/null 2> $O/pmc_$c.err
   rocprofv3 --pmc $c --output-format csv -d $O/ldepmc_$c -- python tools/prof_lde.py > /dev/null 2> $O/ldepmc_$c.err
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_sq -- python bench.py --steps 1 --warmup 0 --proofs-per-step 16 --threads 1 --no-cpu-baseline > /dev/null 2> $O/pmc_sq.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_sq -- python bench.py --steps 1 --warmup 0 --proofs-per-step 16 --threads 1 --no-cpu-baseline > $O/bench_under_pmc_sq.json 2> $O/pmc_sq.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/ldepmc_sq -- python tools/prof_lde.py > /dev/null 2> $O/ldepmc_sq.err
 bash tools/prof_lde_pmc.sh > $O/lde_pmc_sets.txt 2>&1
 bash tools/prof_ntt_pmc.sh > $O/ntt_pmc_sets.txt 2>&1
