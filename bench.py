@@ -284,7 +284,7 @@ def pmc_valu(kernel, avg_launch_ms, units_per_s=None):
         insts = d["kernels"][kernel]["valu_insts_per_launch"]
     except Exception:
         return None
-    peak = 1024 * 2.05e9 / 3.9 / 1e9
+    peak = 1024 * 2.3e9 / 3.9 / 1e9          # shader clock under this workload: 2.3 GHz (tools/ubench/clock_probe.hip next to bench.py, profiles/r03b_clock_under_load.txt)
     ach = insts / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     clk = d["kernels"][kernel].get("clk_per_valu_inst_per_simd")
     out = {"unit": "G wave-instructions/s", "issue_floor_clk": 3.9,
@@ -301,7 +301,8 @@ def pmc_valu(kernel, avg_launch_ms, units_per_s=None):
         j_ach = job["valu_insts_per_unit"] * units_per_s / 1e9
         out["job"] = {"valu_insts_per_unit": job["valu_insts_per_unit"], "achieved": round(j_ach, 1), "peak": round(peak, 1), "frac": round(j_ach / peak, 3),
                       "what": "wave-level VALU instructions of ALL kernels per unit (the --pmc pass's total over the units its process proved) x this run's "
-                              "units/s against 1024 SIMDs x 2.05 GHz / 3.9 clk: the whole job against the VALU issue rate"}
+                              "units/s against 1024 SIMDs x 2.3 GHz (measured under this load) / 3.9 clk (v_mad_u64_u32; a fifth of the mix are cheaper moves / adds, so the "
+                              "fraction can pass 1): the whole job against the VALU issue rate"}
     return out
 
 
