@@ -862,11 +862,14 @@ def main():
                          "lde = configs[1]; semaphore = the signals alone")
     ap.add_argument("--proofs-per-step", type=int, default=128,
                     help="units (recursive) / proofs (semaphore) per GPU per step; 128 = BASELINE configs[4] (1024 proofs over 8 GPUs)")
-    ap.add_argument("--threads", type=int, default=8,
+    ap.add_argument("--threads", type=int, default=0,
                     help="concurrent prover contexts per GPU (one HIP stream + one host thread each); every context proves "
-                         "GL355_OPT_BATCH_UNITS = 8 units in lock-step.  Measured flat between 6 and 12 contexts (265-270 units/s)")
+                         "GL355_OPT_BATCH_UNITS = 8 units in lock-step.  Default: 10 with >= 12 usable host cores per rank, else 8 "
+                         "(round 3, final kernels: 8 -> 289.6, 9 -> 291.7, 10 -> 291.4, 11 -> 290.5, 16 -> 249 units/s; profiles/r03b_contexts_sweep.txt)")
     ap.add_argument("--log-members", type=int, default=20, help="log2 of the access-set size (tree depth)")
     args = ap.parse_args()
+    if args.threads <= 0:
+        args.threads = 10 if host_cores() // max(1, int(os.environ.get("WORLD_SIZE", "1"))) >= 12 else 8
     # two hardware queues per prover context (proving stream + side stream): the HIP runtime's default is 4, streams then share queues and a latency-bound
     # Merkle-top kernel on one stream holds up the streams behind it (measured 164 -> 172 proofs/s at 16 contexts).  Read when
     # the HIP runtime initialises, i.e. before torch / libgl355 touch the device (they are imported by the main_* functions).

@@ -105,6 +105,26 @@ def test_g1_msm_2p20_known_multiples(ctx, orc):
     assert cv._unpt(gpu_msm(ctx, pts, sc)) == cv.mul(pm.G, k)
 
 
+@pytest.mark.parametrize("n", [8193, 12345, 16384, 16385, 100003, (1 << 18) + 1])
+def test_g1_msm_two_level_sort_sizes(ctx, orc, n):
+    """sizes around the switch to the two-level sort (more than 2^10 buckets per window: n > 2^13) and away from powers of two, with an
+    identity, a zero scalar, a repeated and an opposite base: bases (i + 1) * 11 G, so the answer is one scalar multiplication"""
+    cv = Bn254Curve(orc)
+    rng = np.random.default_rng(0x4E9 + n)
+    pts = cv.multiples_array(11, 11, n)
+    sc = rand_scalars(rng, n)
+    vals = np.zeros(n, dtype=object)
+    for limb in range(4):
+        vals += sc[:, limb].astype(object) << (64 * limb)
+    mult = [11 * (i + 1) for i in range(n)]
+    pts[2] = 0; mult[2] = 0                                   # the identity among the bases
+    sc[5] = 0; vals[5] = 0                                    # a zero scalar
+    pts[7] = pts[0]; mult[7] = mult[0]                        # a repeated base
+    pts[9, 4:] = cv.scalars([pm.Q - cv.ints(pts[1:2, 4:])[0]])[0]; pts[9, :4] = pts[1, :4]; mult[9] = -mult[1]    # the opposite of base 1
+    k = int(sum(int(v) * m for v, m in zip(vals, mult)) % pm.R)
+    assert cv._unpt(gpu_msm(ctx, pts, sc)) == cv.mul(pm.G, k)
+
+
 def gpu_fixed_base(ctx, base, sc):
     base, sc = np.ascontiguousarray(base, dtype=np.uint64), np.ascontiguousarray(sc, dtype=np.uint64)
     out = np.full((sc.shape[0], 8), 0xAA, dtype=np.uint64)
