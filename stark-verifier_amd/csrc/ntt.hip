@@ -241,7 +241,8 @@ static hipError_t launch_cols_t(const PassArgs& a, bool inv, uint64_t blocks, hi
     static const bool per_coset = getenv("GL355_EXP_NTT_PER_COSET") != nullptr;     // A/B: one block per (tile, coset) as before
     if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset && LOG_T == 5 && a.log_rows == 12 && ntt_l24_on()) return launch_cols_l24_cosets(a, s);
     static const bool no_small = getenv("GL355_EXP_NTT_NO_SMALL_COLS") != nullptr;  // A/B: the tiled radix-8 kernel for 2- / 4-row column passes
-    if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset && LOG_T <= 2 && a.log_rows == 12 && a.batch <= 65535 && ntt_l24_on() && !no_small)
+    static const bool small3 = getenv("GL355_EXP_NTT_NO_SMALL_COLS8") == nullptr;   // A/B: ... and for 8-row column passes (n = 2^15)
+    if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset && LOG_T <= (small3 ? 3 : 2) && a.log_rows == 12 && a.batch <= 65535 && ntt_l24_on() && !no_small)
         return launch_cols_small_cosets(a, LOG_T, s);
     if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset) return launch_cols_r8_cosets(a, LOG_T, s);
     if (r8 && !ntt_r16_only()) return launch_cols_r8(a, LOG_T, inv, s);

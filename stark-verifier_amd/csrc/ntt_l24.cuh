@@ -542,14 +542,15 @@ __global__ void __launch_bounds__(4 << LOG_TC) __attribute__((amdgpu_waves_per_e
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Column pass of a two-pass LDE whose column dimension is 2 or 4 (n = 2^13 / 2^14, the in-proof sizes, with 4096-point rows): nothing to
-// exchange, so no LDS and no tile -- a thread owns one index i2 < 4096 of one polynomial, loads its 2 / 4 coefficients and table words once
-// and, for every coset, scales (coset ratio), runs the radix-2 / radix-4 network in registers (omega_4 = 2^48), applies the 4-step
-// twiddle and stores.  Same tables, output order and values (mod p) as ntt_cols_r8_cosets_kernel<1 / 2>.  grid = (4096 / 256, columns).
+// Column pass of a two-pass LDE whose column dimension is 2, 4 or 8 (n = 2^13 / 2^14, the in-proof sizes, and 2^15, the aggregation
+// nodes, with 4096-point rows): nothing to exchange, so no LDS and no tile -- a thread owns one index i2 < 4096 of one polynomial, loads
+// its 2 / 4 / 8 coefficients and table words once and, for every coset, scales (coset ratio), runs the radix-2 / 4 / 8 network in
+// registers (shift twiddles), applies the 4-step twiddle and stores.  Same tables, output order and values (mod p) as
+// ntt_cols_r8_cosets_kernel<1 / 2 / 3>.  grid = (4096 / 256, columns).
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int LOG_T>
 __global__ void __launch_bounds__(256) ntt_cols_small_cosets_kernel(PassArgs a) {
-    static_assert(LOG_T == 1 || LOG_T == 2, "2 or 4 rows");
+    static_assert(LOG_T >= 1 && LOG_T <= 3, "2, 4 or 8 rows");
     constexpr int T = 1 << LOG_T;
     const uint32_t log_n2 = a.log_rows;
     const uint64_t i2 = blockIdx.x * 256u + threadIdx.x, col = blockIdx.y;
@@ -571,9 +572,24 @@ __global__ void __launch_bounds__(256) ntt_cols_small_cosets_kernel(PassArgs a) 
         uint64_t y[T];
         if constexpr (LOG_T == 1) {
             y[0] = gl_add(v[0], v[1]); y[1] = gl_sub(v[0], v[1]);
-        } else {
+        } else if constexpr (LOG_T == 2) {
             const uint64_t s0 = gl_add(v[0], v[2]), d0 = gl_sub(v[0], v[2]), s1 = gl_add(v[1], v[3]), d1 = gl_mul_2exp<48>(gl_sub(v[1], v[3]));
             y[0] = gl_add(s0, s1); y[1] = gl_sub(s0, s1); y[2] = gl_add(d0, d1); y[3] = gl_sub(d0, d1);
+        } else {
+            // radix-8 DIF network in registers (the data flow of dif8_l24): omega_8 = -2^24, omega_4 = 2^48, omega_8^3 = -2^72, the signs
+            // folded into the order of the subtraction
+            uint64_t t[8];
+            t[0] = gl_add(v[0], v[4]); t[4] = gl_sub(v[0], v[4]);
+            t[1] = gl_add(v[1], v[5]); t[5] = gl_mul_2exp<24>(gl_sub(v[5], v[1]));
+            t[2] = gl_add(v[2], v[6]); t[6] = gl_mul_2exp<48>(gl_sub(v[2], v[6]));
+            t[3] = gl_add(v[3], v[7]); t[7] = gl_mul_2exp<72>(gl_sub(v[7], v[3]));
+            uint64_t u[8];
+            u[0] = gl_add(t[0], t[2]); u[2] = gl_sub(t[0], t[2]);
+            u[1] = gl_add(t[1], t[3]); u[3] = gl_mul_2exp<48>(gl_sub(t[1], t[3]));
+            u[4] = gl_add(t[4], t[6]); u[6] = gl_sub(t[4], t[6]);
+            u[5] = gl_add(t[5], t[7]); u[7] = gl_mul_2exp<48>(gl_sub(t[5], t[7]));
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) { y[k] = gl_add(u[k], u[k + 1]); y[k + 1] = gl_sub(u[k], u[k + 1]); }
         }
 #pragma unroll
         for (int k = 0; k < T; k++) out[(uint64_t)k << log_n2] = gl_mul(y[k], step[k]);

@@ -74,7 +74,8 @@ hipError_t launch_cols_l24_cosets(const PassArgs& a, hipStream_t s) {
 hipError_t launch_cols_small_cosets(const PassArgs& a, uint32_t log_t, hipStream_t s) {
     const dim3 grid((1u << a.log_rows) / 256u, a.batch);
     if (log_t == 1) hipLaunchKernelGGL(ntt_cols_small_cosets_kernel<1>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(ntt_cols_small_cosets_kernel<2>, grid, dim3(256), 0, s, a);
+    else if (log_t == 2) hipLaunchKernelGGL(ntt_cols_small_cosets_kernel<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ntt_cols_small_cosets_kernel<3>, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
