@@ -404,6 +404,7 @@ struct MsmArgs {
     uint32_t cbits, chunk;      // coarse bits (cb - MSM_FINE_BITS), points per block of the coarse kernels
 };
 #define MSM_FINE_BITS 10u
+#define MSM_UNROLL 8
 #define MSM_SIZE_BINS 128
 #define MSM_BIG 256u            // a lane sums at most this many points; a normal bucket holds 8-64
 #define MSM_BIG_WG_POINTS 4096u // points per workgroup item of a big bucket (16 per lane), more when a bucket would need over 256 items
@@ -552,9 +553,16 @@ __global__ void __launch_bounds__(256) msm_coarse_count_kernel(MsmArgs a) {
     for (uint32_t b = threadIdx.x; b < nbin; b += 256) lh[b] = 0;
     __syncthreads();
     const uint32_t* dg = a.dig + (uint64_t)w * a.n;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const uint32_t mag = dg[i] & 0x7fffffffu;
-        if (mag) atomicAdd(&lh[(mag - 1) & (nbin - 1)], 1u);
+    // (MSM_UNROLL loads in flight per thread: with one load per iteration these loops were chains of 64 dependent memory round trips)
+    for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 256 * MSM_UNROLL) {
+        uint32_t d[MSM_UNROLL];
+#pragma unroll
+        for (int k = 0; k < MSM_UNROLL; k++) { const uint64_t i = i0 + 256ull * k; d[k] = i < hi ? dg[i] : 0u; }
+#pragma unroll
+        for (int k = 0; k < MSM_UNROLL; k++) {
+            const uint32_t mag = d[k] & 0x7fffffffu;
+            if (mag) atomicAdd(&lh[(mag - 1) & (nbin - 1)], 1u);
+        }
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nbin; b += 256)
@@ -587,9 +595,15 @@ __global__ void __launch_bounds__(256) msm_coarse_scatter_kernel(MsmArgs a) {
     for (uint32_t b = threadIdx.x; b < nbin; b += 256) lh[b] = 0;
     __syncthreads();
     const uint32_t* dg = a.dig + (uint64_t)w * a.n;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const uint32_t mag = dg[i] & 0x7fffffffu;
-        if (mag) atomicAdd(&lh[(mag - 1) & (nbin - 1)], 1u);
+    for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 256 * MSM_UNROLL) {
+        uint32_t d[MSM_UNROLL];
+#pragma unroll
+        for (int k = 0; k < MSM_UNROLL; k++) { const uint64_t i = i0 + 256ull * k; d[k] = i < hi ? dg[i] : 0u; }
+#pragma unroll
+        for (int k = 0; k < MSM_UNROLL; k++) {
+            const uint32_t mag = d[k] & 0x7fffffffu;
+            if (mag) atomicAdd(&lh[(mag - 1) & (nbin - 1)], 1u);
+        }
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nbin; b += 256) {
@@ -599,12 +613,18 @@ __global__ void __launch_bounds__(256) msm_coarse_scatter_kernel(MsmArgs a) {
     }
     __syncthreads();
     uint32_t* pr = a.pairs + 2ull * (uint64_t)w * a.n;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const uint32_t d = dg[i], mag = d & 0x7fffffffu;
-        if (!mag) continue;
-        const uint32_t bin = (mag - 1) & (nbin - 1);
-        const uint32_t pos = lbase[bin] + atomicAdd(&lh[bin], 1u);
-        *reinterpret_cast<uint2*>(pr + 2ull * pos) = make_uint2((uint32_t)i | (d & 0x80000000u), (mag - 1) >> a.cbits);
+    for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 256 * MSM_UNROLL) {
+        uint32_t dd[MSM_UNROLL];
+#pragma unroll
+        for (int k = 0; k < MSM_UNROLL; k++) { const uint64_t i = i0 + 256ull * k; dd[k] = i < hi ? dg[i] : 0u; }
+#pragma unroll
+        for (int k = 0; k < MSM_UNROLL; k++) {
+            const uint32_t d = dd[k], mag = d & 0x7fffffffu;
+            if (!mag) continue;
+            const uint32_t bin = (mag - 1) & (nbin - 1);
+            const uint32_t pos = lbase[bin] + atomicAdd(&lh[bin], 1u);
+            *reinterpret_cast<uint2*>(pr + 2ull * pos) = make_uint2((uint32_t)(i0 + 256ull * k) | (d & 0x80000000u), (mag - 1) >> a.cbits);
+        }
     }
 }
 __global__ void __launch_bounds__(256) msm_fine_sort_kernel(MsmArgs a) {
@@ -615,7 +635,13 @@ __global__ void __launch_bounds__(256) msm_fine_sort_kernel(MsmArgs a) {
     for (uint32_t f = tid; f < NF; f += 256) fh[f] = 0;
     __syncthreads();
     const uint32_t* pr = a.pairs + 2ull * ((uint64_t)w * a.n + start);
-    for (uint32_t k = tid; k < cnt; k += 256) atomicAdd(&fh[pr[2ull * k + 1]], 1u);
+    for (uint32_t k0 = tid; k0 < cnt; k0 += 256 * MSM_UNROLL) {
+        uint32_t f[MSM_UNROLL];
+#pragma unroll
+        for (int j = 0; j < MSM_UNROLL; j++) { const uint32_t k = k0 + 256u * j; f[j] = k < cnt ? pr[2ull * k + 1] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int j = 0; j < MSM_UNROLL; j++) if (f[j] != 0xFFFFFFFFu) atomicAdd(&fh[f[j]], 1u);
+    }
     __syncthreads();
     uint32_t c[PER], sum = 0;
 #pragma unroll
@@ -639,9 +665,12 @@ __global__ void __launch_bounds__(256) msm_fine_sort_kernel(MsmArgs a) {
     }
     __syncthreads();
     uint32_t* out = a.idx + (uint64_t)w * a.n;
-    for (uint32_t k = tid; k < cnt; k += 256) {
-        const uint2 p = *reinterpret_cast<const uint2*>(pr + 2ull * k);
-        out[fbase[p.y] + atomicAdd(&fh[p.y], 1u)] = p.x;
+    for (uint32_t k0 = tid; k0 < cnt; k0 += 256 * MSM_UNROLL) {
+        uint2 pp[MSM_UNROLL];
+#pragma unroll
+        for (int j = 0; j < MSM_UNROLL; j++) { const uint32_t k = k0 + 256u * j; pp[j] = k < cnt ? *reinterpret_cast<const uint2*>(pr + 2ull * k) : make_uint2(0u, 0xFFFFFFFFu); }
+#pragma unroll
+        for (int j = 0; j < MSM_UNROLL; j++) if (pp[j].y != 0xFFFFFFFFu) out[fbase[pp[j].y] + atomicAdd(&fh[pp[j].y], 1u)] = pp[j].x;
     }
 }
 // Buckets by decreasing size.  A lane sums one bucket, so a wave takes as long as its largest bucket: with 2^20 points in 2^16
