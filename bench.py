@@ -662,7 +662,9 @@ def main_recursive(args):
     n_threads = max(1, int(os.environ.get("GL355_BENCH_CONTEXTS", args.threads)))
     # how a context's host thread waits for its stream: "spin" (hipStreamSynchronize, a core per context), "poll" (GL355_OPT_BLOCKING_SYNC
     # = 2: hipStreamQuery + 30-us sleeps, a few percent of a core per context), "sleep" (hipDeviceScheduleBlockingSync for the device)
-    wait_mode = os.environ.get("GL355_BENCH_WAIT", "sleep" if os.environ.get("GL355_BENCH_SLEEP_WAITS") == "1" else
+    # (round 3, profiles/r03b_wait_modes.txt: host replay + poll 290 units/s at 13.1 ms of host CPU per unit; device replay + poll 282 at 9.2;
+    # device replay + sleeping waits 282 at 6.1 -- the setting of ranks with fewer than 4 cores)
+    wait_mode = os.environ.get("GL355_BENCH_WAIT", "sleep" if (os.environ.get("GL355_BENCH_SLEEP_WAITS") == "1" or cores_per_rank < 4) else
                                "poll")
     sleeping_waits = wait_mode == "sleep"
     # gl355_runtime_config: hardware queues per context (unless GPU_MAX_HW_QUEUES is already set) and, if asked, sleeping waits
