@@ -17,7 +17,7 @@ import pytest
 
 import cpu_semaphore as cs
 import cpu_unit as cu
-from oracle_lib import key_bytes, rand_field
+from oracle_lib import P, key_bytes, rand_field
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -124,6 +124,34 @@ def test_lde_two_pass_coset_shapes(ctx, orc, log_n, rate_bits):
     want = orc.lde(c, rate_bits)
     eq(ctx.lde(c, rate_bits), want)
     eq(ctx.lde(c, rate_bits, bitrev=True), orc.reverse_index_bits(want.T.copy()).T)
+
+
+def test_lde_bench_shape_full_batch(gl, ctx, orc):
+    """BASELINE configs[1] at its full size: 135 columns, 2^17 -> 2^20, bit-reversed output, operands resident (what bench.py times): the
+    columns the tile / XCD mapping of the limb kernels treats differently (first, last, the ones around a multiple of 8) and three random
+    ones against the oracle, every other column through the linearity of the transform (sum of all columns = LDE of the summed column)"""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(0x457)
+    B, log_n, rb = 135, 17, 3
+    c = rand_field(rng, (B, 1 << log_n))
+    cd = torch.from_numpy(c.view(np.int64)).cuda()
+    out = torch.empty((B, 1 << (log_n + rb)), dtype=torch.int64, device="cuda")
+    ctx.check(ctx.lib.gl355_lde_bitrev(ctx.h, C.c_void_p(cd.data_ptr()), log_n, rb, 7, B, C.c_void_p(out.data_ptr())))
+    ctx.sync()
+    got = out.cpu().numpy().view(np.uint64)
+    cols = sorted({0, 7, 8, 63, 64, 134} | {int(v) for v in rng.integers(0, B, size=3)})
+    want = orc.reverse_index_bits(orc.lde(c[cols], rb).T.copy()).T
+    for k, j in enumerate(cols):
+        assert np.array_equal(got[j], want[k]), "column %d" % j
+    tot = np.zeros(1 << log_n, dtype=object)
+    for j in range(B):
+        tot = (tot + c[j].astype(object)) % P
+    want_sum = orc.reverse_index_bits(orc.lde(np.array([tot], dtype=np.uint64), rb).T.copy()).T[0]
+    acc = np.zeros(1 << (log_n + rb), dtype=object)
+    for j in range(B):
+        acc = acc + got[j].astype(object)
+    assert np.array_equal((acc % P).astype(np.uint64), want_sum)
 
 
 # ---- blinding stream -------------------------------------------------------------------------------------------------------
