@@ -617,13 +617,35 @@ def open_comm(lib, par, ctx, rank, world, rehearsal, dev=None):
     if rank == 0 and ok:
         store.set("id", cid)
     flags = [bytes(store.get("ok/%d" % r)) for r in range(world)]
+    created_failed = False
     if all(f == b"1" for f in flags):
-        comm = par.Comm(ctx, backend, bytes(store.get("id")), rank, world, lib=lib)
-        comm.backend_name = "gl355_gather_digests over RCCL (ncclAllGather)" if backend == par.COMM_RCCL else "gl355_gather_digests over TCP (one-device rehearsal)"
-        return comm
+        # phase 2: the communicator itself (ncclCommInitRank is collective).  Every rank reports whether it came up; the job uses it only if
+        # all did -- a communicator that exists on some ranks only would hang the first gather
+        comm, err = None, ""
+        try:
+            if os.environ.get("GL355_BENCH_FORCE_COMM_FAIL") == "1":      # test hook for the fall-back below
+                raise RuntimeError("forced failure (GL355_BENCH_FORCE_COMM_FAIL)")
+            comm = par.Comm(ctx, backend, bytes(store.get("id")), rank, world, lib=lib)
+        except Exception as exc:
+            err = repr(exc)
+        store.set("up/%d" % rank, b"1" if comm is not None else (err.encode()[:200] or b"0"))
+        flags = [bytes(store.get("up/%d" % r)) for r in range(world)]
+        if all(f == b"1" for f in flags):
+            comm.backend_name = "gl355_gather_digests over RCCL (ncclAllGather)" if backend == par.COMM_RCCL else "gl355_gather_digests over TCP (one-device rehearsal)"
+            return comm
+        if comm is not None:
+            comm.close()
+        created_failed = True
     sys.stderr.write("[bench] rank %d: gl355 communicator unavailable (%s); using torch.distributed for the exchange\n" % (rank, [f for f in flags if f != b"1"][:1]))
     import torch.distributed as dist
-    dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world, **({} if rehearsal else {"device_id": dev}))
+    # the exchange is 64 bytes per unit: when the RCCL communicator could not be CREATED (rather than librccl not binding), RCCL itself is
+    # suspect, so the stand-in runs over gloo on host tensors
+    if rehearsal or created_failed:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        c = _TorchComm(dist, "cpu")
+        c.backend_name = "torch.distributed gloo on host tensors (gl355 communicator could not be created on some rank)" if created_failed else c.backend_name
+        return c
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     return _TorchComm(dist, dev)
 
 
