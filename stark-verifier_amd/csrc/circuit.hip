@@ -64,6 +64,11 @@ int32_t gl355_circuit_load(gl355_ctx* h, const uint64_t* blob, uint64_t words, g
         if (g < c.num_gates && (c.gates[g].type > GL355_GATE_TYPE_MAX || c.gates[g].selector_index >= c.num_selectors ||
                                 c.gates[g].group_end > c.num_gates || c.gates[g].group_start > c.gates[g].group_end))
             return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: bad gate table");
+        // gate parameters are counts of per-gate operations (RANDOM_ACCESS: three packed bytes): more of them than wires cannot be laid
+        // out, and a value >= 2^30 would wrap the 32-bit products (4 p, 8 p ...) evaluators form from it
+        if (g < c.num_gates && (p[1] > 0xFFFFFFFFull || (c.gates[g].type != GL355_GATE_RANDOM_ACCESS && p[1] > c.num_wires) ||
+                                (c.gates[g].type == GL355_GATE_RANDOM_ACCESS && p[1] > 0xFFFFFFull)))
+            return ctx->fail(GL355_E_INVALID_ARG, "circuit_load: gate parameter out of range");
     }
     const uint64_t n = 1ull << c.degree_bits;
     const uint64_t n_sc = c.num_selectors + c.num_constants, routed = c.num_routed_wires;

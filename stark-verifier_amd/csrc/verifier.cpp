@@ -69,6 +69,10 @@ bool eval_gate(const gl355_gate& gt, const E* consts, const E* w, const uint64_t
     auto alg = [&](uint32_t j) { return Alg{w[j], w[j + 1]}; };
     auto push_alg = [&](Alg v) { c.push_back(v.a0); c.push_back(v.a1); };
     const uint32_t p = gt.param;
+    // gt.param is untrusted: every bound below is computed in 64 bits (4 * p, 8 * p, 1 + p and 6 + 2 * p wrap in 32), and no gate whose
+    // parameter is a count can have more of them than there are wires (RANDOM_ACCESS packs three byte-sized fields instead)
+    const uint64_t P = p, NW = num_wires;
+    if (gt.type != GL355_GATE_RANDOM_ACCESS && P > NW) return false;
     switch (gt.type) {
     case GL355_GATE_NOOP: return true;
     case GL355_GATE_CONSTANT:
@@ -80,13 +84,13 @@ bool eval_gate(const gl355_gate& gt, const E* consts, const E* w, const uint64_t
         for (int i = 0; i < 4; i++) c.push_back(gl2_sub(w[i], e_base(pi_hash[i])));
         return true;
     case GL355_GATE_BASE_SUM: {
-        if (1 + p > num_wires) return false;
+        if (1 + P > NW) return false;
         c.push_back(gl2_sub(reduce_with_powers(w + 1, p, e_base(2)), w[0]));
         for (uint32_t i = 0; i < p; i++) c.push_back(gl2_sub(gl2_mul(w[1 + i], w[1 + i]), w[1 + i]));
         return true;
     }
     case GL355_GATE_ARITHMETIC:
-        if (4 * p > num_wires || num_constants < 2) return false;
+        if (4 * P > NW || num_constants < 2) return false;
         for (uint32_t i = 0; i < p; i++)
             c.push_back(gl2_sub(w[4 * i + 3], gl2_add(gl2_mul(gl2_mul(w[4 * i], w[4 * i + 1]), consts[0]), gl2_mul(w[4 * i + 2], consts[1]))));
         return true;
@@ -124,12 +128,12 @@ bool eval_gate(const gl355_gate& gt, const E* consts, const E* w, const uint64_t
         return true;
     }
     case GL355_GATE_ARITHMETIC_EXT:
-        if (8 * p > num_wires || num_constants < 2) return false;
+        if (8 * P > NW || num_constants < 2) return false;
         for (uint32_t i = 0; i < p; i++)
             push_alg(alg_sub(alg(8 * i + 6), alg_add(alg_scal(consts[0], alg_mul(alg(8 * i), alg(8 * i + 2))), alg_scal(consts[1], alg(8 * i + 4)))));
         return true;
     case GL355_GATE_MUL_EXT:
-        if (6 * p > num_wires || num_constants < 1) return false;
+        if (6 * P > NW || num_constants < 1) return false;
         for (uint32_t i = 0; i < p; i++) push_alg(alg_sub(alg(6 * i + 4), alg_scal(consts[0], alg_mul(alg(6 * i), alg(6 * i + 2)))));
         return true;
     case GL355_GATE_POSEIDON_MDS:
@@ -144,7 +148,7 @@ bool eval_gate(const gl355_gate& gt, const E* consts, const E* w, const uint64_t
     case GL355_GATE_RANDOM_ACCESS: {
         const uint32_t bits = p & 0xFF, copies = (p >> 8) & 0xFF, extra = (p >> 16) & 0xFF;
         const uint32_t vec = 1u << bits, routed = (2 + vec) * copies + extra;
-        if (bits > 8 || routed + copies * bits > num_wires || extra > num_constants) return false;
+        if (bits > 8 || (uint64_t)routed + (uint64_t)copies * bits > NW || extra > num_constants) return false;
         for (uint32_t cp = 0; cp < copies; cp++) {
             const uint32_t b0 = (2 + vec) * cp;
             const E* bl = w + routed + cp * bits;
@@ -163,8 +167,8 @@ bool eval_gate(const gl355_gate& gt, const E* consts, const E* w, const uint64_t
     case GL355_GATE_REDUCING:
     case GL355_GATE_REDUCING_EXT: {
         const bool isext = gt.type == GL355_GATE_REDUCING_EXT;
+        if (p == 0 || 6 + (isext ? 2 * P : P) + 2 * (P - 1) > NW) return false;
         const uint32_t start_accs = 6 + (isext ? 2 * p : p);
-        if (p == 0 || start_accs + 2 * (p - 1) > num_wires) return false;
         const Alg alpha = alg(2);
         Alg acc = alg(4);
         for (uint32_t i = 0; i < p; i++) {

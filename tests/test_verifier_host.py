@@ -90,3 +90,26 @@ def test_recursive_proof_accept_and_reject(orc):
         c_ok, p_ok = both(orc, rc["data"], case["plonk"], f, p)
         assert c_ok == p_ok, name
         assert c_ok == (name == "untouched"), name
+
+
+def test_wrapped_gate_params_are_refused(orc):
+    """gate data in the verifier comes from an untrusted artifact.  Parameters chosen so that the 32-bit products the
+    evaluators form from them (4 p, 8 p, 6 p, 1 + p, 6 + 2 p + 2 (p - 1)) wrap to small values must be rejected by the bound, not
+    followed into reads far outside the opened wires."""
+    gl = importlib.import_module("stark-verifier_amd")
+    L = importlib.import_module("stark-verifier_amd._lib")
+    case, topic, (idx, vals, pi), flat = cs.golden_proof(orc)
+    data = case["data"]
+    data.verify(flat, pi)
+    cc = data.c_circuit
+    wraps = {L.GATE_ARITHMETIC: 0x40000000, L.GATE_ARITHMETIC_EXT: 0x20000000, L.GATE_MUL_EXT: 0x2AAAAAAB, L.GATE_BASE_SUM: 0xFFFFFFFF,
+             L.GATE_REDUCING: 0x40000000, L.GATE_REDUCING_EXT: 0x40000000, L.GATE_CONSTANT: 0xFFFFFFFF}
+    for g in range(cc.num_gates):
+        old_t, old_p = cc.gates[g].type, cc.gates[g].param
+        for t, p in wraps.items():
+            cc.gates[g].type, cc.gates[g].param = t, p
+            with pytest.raises(gl.Gl355Error) as ei:
+                data.verify(flat, pi)
+            assert ei.value.code == -1 and "does not fit" in str(ei.value), (g, t, hex(p))     # GL355_E_INVALID_ARG: malformed verifier data
+        cc.gates[g].type, cc.gates[g].param = old_t, old_p
+    data.verify(flat, pi)
