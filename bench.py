@@ -636,7 +636,17 @@ def open_comm(lib, par, ctx, rank, world, rehearsal, dev=None):
         if comm is not None:
             comm.close()
         created_failed = True
-    sys.stderr.write("[bench] rank %d: gl355 communicator unavailable (%s); using torch.distributed for the exchange\n" % (rank, [f for f in flags if f != b"1"][:1]))
+    why = [f for f in flags if f != b"1"][:1]
+    # --gpus N > 1 measures the RCCL exchange of SURVEY 8(e): when the RCCL communicator cannot be created on every rank the run FAILS
+    # (every rank sees the same flags, so every rank exits) instead of quietly measuring something else.  GL355_BENCH_ALLOW_STANDIN=1
+    # (never set by the driver) lets the 64-byte-per-unit exchange run over torch.distributed instead; the line then says so in
+    # config.exchange.  The one-device rehearsal never had RCCL to begin with.
+    if not rehearsal and os.environ.get("GL355_BENCH_ALLOW_STANDIN") != "1":
+        sys.stderr.write("[bench] rank %d: the RCCL communicator (gl355_comm_create) is unavailable: %s -- refusing to substitute another "
+                         "exchange (set GL355_BENCH_ALLOW_STANDIN=1 to allow the torch.distributed stand-in)\n" % (rank, why))
+        sys.stderr.flush()
+        os._exit(3)
+    sys.stderr.write("[bench] rank %d: gl355 communicator unavailable (%s); using torch.distributed for the exchange\n" % (rank, why))
     import torch.distributed as dist
     # the exchange is 64 bytes per unit: when the RCCL communicator could not be CREATED (rather than librccl not binding), RCCL itself is
     # suspect, so the stand-in runs over gloo on host tensors
@@ -664,7 +674,9 @@ def main_recursive(args):
     # one prover context = one HIP stream + one host thread.  With a core per context the threads spin in hipStreamSynchronize
     # (lowest latency); with fewer usable cores per rank (cgroup quota / ranks) than contexts every device wait sleeps instead,
     # so the contexts still keep the GPU fed (host work is ~10-12 ms of ~90 ms per unit and context)
-    cores_per_rank = max(1, host_cores() // max(1, world))
+    # ranks of THIS node share its cores (multi-node jobs: LOCAL_WORLD_SIZE ranks per node, not WORLD_SIZE)
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    cores_per_rank = max(1, host_cores() // local_world)
     # N > 1: every rank pins itself to its own contiguous slice of the CPUs the job may use (rank r of the node -> slice r), before any
     # thread exists, so the 8 x (prover contexts + replay threads + the HIP runtime's own thread) of a node do not migrate over each other's
     # cores; contiguous CPU numbers share a socket on the usual numbering, i.e. GPU r's slice sits on the socket of GPUs 4 (r // 4) .. + 3.
@@ -672,7 +684,7 @@ def main_recursive(args):
     pinned = None
     if world > 1 and os.environ.get("GL355_BENCH_NO_PIN") != "1":
         cpus = sorted(os.sched_getaffinity(0))
-        k = len(cpus) // world
+        k = len(cpus) // local_world
         if k >= 1:
             mine = cpus[local_rank * k:(local_rank + 1) * k]
             try:

@@ -53,6 +53,33 @@ def test_rccl_communicator_of_one_rank(gl, ctx):
     comm.close()
 
 
+def test_rccl_two_devices(gl, ctx, orc, tmp_path):
+    """world > 1 over RCCL / xGMI: one process per device, gl355_comm_create(RCCL) + gl355_gather_digests (host and device operands) +
+    barrier + max, and the aggregation root rank 0 computes over the gathered leaves == the root of the same leaves in one process
+    (the oracle's).  Needs two devices: SKIPPED (never passed) on a one-GPU box -- RCCL refuses two ranks on one device."""
+    import ctypes as C
+    n = C.c_int32(0)
+    assert ctx.lib.gl355_device_count(C.byref(n)) == 0
+    if n.value < 2:
+        pytest.skip("needs >= 2 devices (gl355_device_count = %d)" % n.value)
+    par = importlib.import_module("stark-verifier_amd.parallel")
+    world = 8 if n.value >= 8 else (4 if n.value >= 4 else 2)
+    per = 16
+    idf = str(tmp_path / "rccl.id")
+    worker = os.path.join(ROOT, "tests", "rccl_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), idf, str(per)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rccl_worker
+    leaves = np.concatenate([rccl_worker.block(r, per) for r in range(world)])
+    want = orc.merkle_build(par.pad_pow2(leaves), 0)[1][0]
+    got = re.search(r"ROOT ([0-9a-f ]+)", outs[0][0]).group(1).split()
+    assert [int(v, 16) for v in got] == [int(v) for v in want]
+
+
 def test_two_rank_cpp_host_flow(tmp_path):
     art = str(tmp_path / "art")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "export_artifacts.py"), art, "3"], stdout=subprocess.DEVNULL,
