@@ -275,35 +275,120 @@ def pmc_traffic(kernel):
         return None, None
 
 
-def pmc_valu(kernel, avg_launch_ms, units_per_s=None):
-    """The bound that actually applies to the dominant kernel: wave-level VALU instructions per launch (SQ_INSTS_VALU of the same
-    committed --pmc pass) over the launch duration measured here, against the chip's issue rate (1 024 SIMDs, one instruction per
-    ~4.2 clk for this instruction mix (tools/ubench), ~2.05 GHz sustained under this load)."""
+N_SIMD = 1024                     # 256 CUs x 4 SIMDs
+VALU_CLASSES = ("full32", "half32", "mad64")
+
+
+def valu_probe(ctx):
+    """gl355_valu_probe (csrc/valu_probe.hip) on this device, in this run: per instruction class the chip-wide issue rate of a kernel that
+    only issues that class (G wave-instructions/s), the shader clock read inside that kernel, and the cost in shader cycles per wave
+    instruction per SIMD that follows from the two (no assumed frequency anywhere)."""
+    rates = (C.c_double * 3)()
+    mhz = (C.c_double * 3)()
+    ctx.check(ctx.lib.gl355_valu_probe(ctx.h, rates, mhz))
+    return {c: {"rate_ginst_s": round(rates[i], 1), "shader_mhz": round(mhz[i]),
+                "clk_per_wave_inst_per_simd": round(mhz[i] * 1e6 * N_SIMD / (rates[i] * 1e9), 3) if rates[i] > 0 else None}
+            for i, c in enumerate(VALU_CLASSES)}
+
+
+class ClockSampler:
+    """shader clock during the timed region: gl355_clock_probe (one sleeping wave for 2 ms) on a context of its own every ~100 ms"""
+
+    def __init__(self, gl, device):
+        import threading
+        self.ctx = gl.Context(device)
+        self.samples, self.stop = [], threading.Event()
+        self.thread = threading.Thread(target=self.run, daemon=True)
+
+    def run(self):
+        v = C.c_double(0)
+        while not self.stop.is_set():
+            if self.ctx.lib.gl355_clock_probe(self.ctx.h, 2000, C.byref(v)) == 0 and v.value > 0:
+                self.samples.append(v.value)
+            self.stop.wait(0.1)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop.set()
+        self.thread.join()
+        self.ctx.close()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        return {"mean_mhz": round(sum(self.samples) / len(self.samples)), "min_mhz": round(min(self.samples)), "max_mhz": round(max(self.samples)),
+                "samples": len(self.samples)}
+
+
+def valu_mix(kernel=None):
+    """Instruction-class fractions of `kernel` (None: of the whole unit, every kernel weighted by its dynamic instruction count).
+    mad64 share: dynamic, SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU of the committed --pmc pass when it carries those counters; the rest
+    splits into full32 / half32 as the kernel's shipped ISA does (profiles/rNN_isa_mix.json, tools/isa_mix.py).  Without the INT64
+    counters everything comes from the static histogram.  -> (fractions, dynamic VALU instructions per launch or per unit, source)"""
     try:
-        d = json.load(open(latest_profile("_pmc_traffic.json")))
-        insts = d["kernels"][kernel]["valu_insts_per_launch"]
+        pmc = json.load(open(latest_profile("_pmc_traffic.json")))
+        isa = json.load(open(latest_profile("_isa_mix.json")))["kernels"]
     except Exception:
-        return None
-    peak = 1024 * 2.3e9 / 3.9 / 1e9          # shader clock under this workload: 2.3 GHz (tools/ubench/clock_probe.hip next to bench.py, profiles/r03b_clock_under_load.txt)
-    ach = insts / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    clk = d["kernels"][kernel].get("clk_per_valu_inst_per_simd")
-    out = {"unit": "G wave-instructions/s", "issue_floor_clk": 3.9,
-           "clk_per_valu_inst_while_busy": clk, "frac_while_busy": round(3.9 / clk, 3) if clk else None,
-           "one_context_launch": {"insts_per_launch": insts, "achieved": round(ach, 1), "peak": round(peak, 1), "fill": round(ach / peak, 3)},
-           "source": "profiles/" + os.path.basename(latest_profile("_pmc_traffic.json")),
-           "note": "clk_per_valu_inst_while_busy = SQ_BUSY_CYCLES / 32 shader engines over SQ_INSTS_VALU / 1024 SIMDs of ONE rocprofv3 --pmc pass: the "
-                   "kernel issues at the rate of its v_mad_u64_u32 mix (3.9 clk per wave instruction, tools/ubench/ubench_alu2.hip at the measured clock) "
-                   "whenever the shader engines have its waves.  one_context_launch: instructions per launch of that pass over this run's one-context launch "
-                   "duration -- a lock-step batch of 8 units is ~1 800 waves, under two per SIMD, so ONE context leaves the chip partly empty (`fill`); the "
-                   "other seven contexts' kernels run in those slots, which is what `job` measures"}
-    job = d.get("job")
-    if job and units_per_s:
-        j_ach = job["valu_insts_per_unit"] * units_per_s / 1e9
-        out["job"] = {"valu_insts_per_unit": job["valu_insts_per_unit"], "achieved": round(j_ach, 1), "peak": round(peak, 1), "frac": round(j_ach / peak, 3),
-                      "what": "wave-level VALU instructions of ALL kernels per unit (the --pmc pass's total over the units its process proved) x this run's "
-                              "units/s against 1024 SIMDs x 2.3 GHz (measured under this load) / 3.9 clk (v_mad_u64_u32; a fifth of the mix are cheaper moves / adds, so the "
-                              "fraction can pass 1): the whole job against the VALU issue rate"}
-    return out
+        return None, None, None
+    src = "profiles/%s + profiles/%s" % (os.path.basename(latest_profile("_pmc_traffic.json")), os.path.basename(latest_profile("_isa_mix.json")))
+
+    def static_f(name):
+        k = isa.get(name)
+        if k is None:      # template instances: name<...>
+            cands = [v for n, v in isa.items() if n.split("<")[0] == name]
+            if not cands:
+                return None
+            tot = sum(v["valu_static"] for v in cands)
+            return {c: sum(v[c] for v in cands) / tot for c in VALU_CLASSES}
+        return dict(k["f"])
+
+    def one(name, e):
+        f = static_f(name.split("<")[0]) or {"full32": 0.11, "half32": 0.36, "mad64": 0.53}
+        n = e.get("valu_insts_per_launch")
+        i64 = e.get("valu_int64_per_launch")
+        if n and i64 is not None:
+            rest = f["full32"] + f["half32"]
+            m = i64 / n
+            f = {"mad64": m, "full32": (1 - m) * f["full32"] / rest, "half32": (1 - m) * f["half32"] / rest}
+        return f, n
+    if kernel is not None:
+        e = pmc["kernels"].get(kernel)
+        if not e or not e.get("valu_insts_per_launch"):
+            return None, None, None
+        f, n = one(kernel, e)
+        return {c: round(f[c], 4) for c in VALU_CLASSES}, n, src
+    job = pmc.get("job")
+    if not job:
+        return None, None, None
+    tot, acc = 0.0, {c: 0.0 for c in VALU_CLASSES}
+    for name, e in pmc["kernels"].items():
+        if not e.get("valu_insts_per_launch"):
+            continue
+        f, n = one(name, e)
+        w = n * e.get("sq_launches", e.get("launches", 0))
+        tot += w
+        for c in VALU_CLASSES:
+            acc[c] += w * f[c]
+    if tot <= 0:
+        return None, None, None
+    return {c: round(acc[c] / tot, 4) for c in VALU_CLASSES}, job["valu_insts_per_unit"], src
+
+
+def valu_peak(mix, classes, clock_mhz=None):
+    """G wave-instructions/s the chip can issue for instructions that split as `mix`: the harmonic combination of the class rates the probe
+    measured.  clock_mhz: scale every class from the clock its probe ran at to this clock (cost in cycles is what the probe fixes)."""
+    t = 0.0
+    for c in VALU_CLASSES:
+        r = classes[c]["rate_ginst_s"]
+        if clock_mhz and classes[c]["shader_mhz"]:
+            r = r * clock_mhz / classes[c]["shader_mhz"]
+        if r <= 0:
+            return None
+        t += mix[c] / r
+    return 1.0 / t if t > 0 else None
 
 
 def lde_figure(gl, device, steps=40, warm=12):
@@ -733,11 +818,22 @@ def main_recursive(args):
         if comm is not None:
             comm.barrier()
         torch.cuda.synchronize()
+    # the VALU roofline's peak: class issue rates measured on this device now (idle apart from the probe), the clock during the timed
+    # region sampled by a one-wave probe on a context of its own (rank 0)
+    classes = None
+    if rank == 0:
+        try:
+            classes = valu_probe(pr.sets[0])
+        except Exception as exc:
+            sys.stderr.write("[bench] valu probe failed: %r\n" % (exc,))
+    sampler = ClockSampler(gl, local_rank) if rank == 0 and os.environ.get("GL355_BENCH_NO_CLOCK_SAMPLER") != "1" else None
     pr.profile(True)
     barrier()
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     th0 = thread_cpu_snapshot() if os.environ.get("GL355_BENCH_THREAD_CPU") else None
+    if sampler is not None:
+        sampler.__enter__()
     t0 = time.perf_counter()
     root = None
     for step in range(args.steps):
@@ -747,6 +843,10 @@ def main_recursive(args):
             root = par.aggregation_root(pr.sets[0], allv)                   # gl355_aggregation_root
     barrier()
     elapsed = time.perf_counter() - t0
+    job_clock = None
+    if sampler is not None:
+        sampler.__exit__()
+        job_clock = sampler.summary()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)   # rank 0's process, spinning waits included
     if th0 is not None:
@@ -812,6 +912,45 @@ def main_recursive(args):
             return {k: {"launches_per_unit": round(v[0] / max(1, n_units), 1), "ms_per_unit": round(v[1] / max(1, n_units), 4),
                         "alg_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else None} for k, v in items}
         traffic, traffic_src = pmc_traffic(dname)
+        # ---- the roofline block.  Bound: the integer VALU issue rate (Poseidon / Merkle / the constraint kernel are not HBM- or
+        # MFMA-bound).  achieved = wave-level VALU instructions of ALL kernels per unit (SQ_INSTS_VALU of the committed --pmc pass, a property of the
+        # shipped kernels) x the units/s of THIS timed region; peak = 1 / sum_c f_c / rate_c: class rates measured by gl355_valu_probe in this run,
+        # moved from the clock each probe ran at to the clock sampled during the timed region; f_c = the job's dynamic instruction mix
+        # (SQ_INSTS_VALU_INT64 share + the shipped ISA's split of the rest).  The dominant kernel's own launch figures and the HBM-side
+        # figure SURVEY 8(d) also asks for follow as sub-blocks.
+        units_per_s_gpu = units / elapsed / max(1, world)
+        job_mix, insts_per_unit, mix_src = valu_mix(None)
+        k_mix, k_insts, _ = valu_mix(dname)
+        clock_mhz = job_clock["mean_mhz"] if job_clock else None
+        roofline = {"bound": "valu", "unit": "G wave-instructions/s", "kernel": "all kernels of a unit (dominant: %s)" % dname}
+        if classes and job_mix and insts_per_unit:
+            peak = valu_peak(job_mix, classes, clock_mhz)
+            ach_v = insts_per_unit * units_per_s_gpu / 1e9
+            roofline.update({"achieved": round(ach_v, 1), "peak": round(peak, 1), "frac": round(ach_v / peak, 4),
+                             "valu_insts_per_unit": insts_per_unit, "units_per_s_per_gpu": round(units_per_s_gpu, 2), "mix": job_mix, "mix_source": mix_src,
+                             "classes": classes, "clock_during_timed_region": job_clock,
+                             "peak_at_probe_clocks": round(valu_peak(job_mix, classes, None), 1),
+                             "formula": "achieved = valu_insts_per_unit x units_per_s_per_gpu; peak = 1 / sum_c mix[c] / (classes[c].rate_ginst_s x "
+                                        "clock_during_timed_region.mean_mhz / classes[c].shader_mhz)"})
+        else:
+            roofline.update({"achieved": None, "peak": None, "frac": None, "note": "no --pmc pass / ISA histogram under profiles/ or the probe failed"})
+        dom = {"kernel": dname, "launches_per_unit": round(dcnt / max(1, iso_units), 1), "avg_launch_ms": round(dms / max(1, dcnt), 4),
+               "how": "HIP events on the launching stream, ONE prover context (a lock-step batch of 8 units), %d units, straight after the timed region; "
+                      "kernel = the scope group with the largest summed duration.  One context's launch is ~1 800 waves -- under two per SIMD -- so it "
+                      "cannot fill the chip by itself (`fill`); the other contexts' kernels run in those slots, which the job-level figure above measures" % iso_units}
+        if classes and k_mix and k_insts and dms > 0:
+            k_peak = valu_peak(k_mix, classes, None)
+            k_ach = k_insts / (dms / max(1, dcnt) * 1e-3) / 1e9
+            dom.update({"valu_insts_per_launch": k_insts, "mix": k_mix, "achieved": round(k_ach, 1), "peak": round(k_peak, 1), "fill": round(k_ach / k_peak, 4)})
+        roofline["dominant_kernel"] = dom
+        roofline["hbm"] = {"bound": "hbm", "kernel": dname, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                           "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(dbytes / max(1, dcnt)),
+                           "note": "secondary figure (SURVEY 8(d) asks for it): the dominant kernel is not HBM-bound"}
+        roofline["gpu_ms_per_unit_all_kernels"] = round(sum(v[1] for v in iso.values()) / max(1, iso_units), 3)
+        roofline["kernel_groups"] = groups(iso, iso_units, 10)
+        roofline["timed_region_events"] = {"what": "the same scopes on 1 of the %d concurrent streams during the timed region "
+                                                   "(includes queueing behind the other streams)" % n_threads,
+                                           "units": local_units, "kernel_groups": groups(prof, local_units, 6)}
         line = {
             "metric": "recursive plonky2 proofs/sec (Semaphore d=%d)" % args.log_members,
             "value": round(units / elapsed, 2), "unit": "recursive proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -830,19 +969,7 @@ def main_recursive(args):
                        "host_cpu_ms_per_unit": round(1e3 * host_cpu_s / max(1, (hi - lo) * args.steps), 2),
                        "units_proven_in_process": int(sum(pr.units_done)),
                        "host_split": host_split},
-            "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": dname, "launches_per_unit": round(dcnt / max(1, iso_units), 1),
-                         "avg_launch_ms": round(dms / max(1, dcnt), 4), "algorithmic_bytes_per_launch": round(dbytes / max(1, dcnt)),
-                         "how": "HIP events on the launching stream, one prover context, %d units, straight after the timed region; "
-                                "kernel = the scope group with the largest summed duration" % iso_units,
-                         "note": "not an HBM-bound kernel: Poseidon is ~1.1k Goldilocks modmuls per permutation on the integer VALU "
-                                 "(no MFMA form, DESIGN.md section 5); its own ceiling is permutations/s, reported per kernel in DESIGN.md",
-                         "valu_issue": pmc_valu(dname, dms / max(1, dcnt), units / elapsed * 1.0 / max(1, world)),
-                         "gpu_ms_per_unit_all_kernels": round(sum(v[1] for v in iso.values()) / max(1, iso_units), 3),
-                         "kernel_groups": groups(iso, iso_units, 10),
-                         "timed_region_events": {"what": "the same scopes on 1 of the %d concurrent streams during the timed region "
-                                                         "(includes queueing behind the other streams)" % n_threads,
-                                                 "units": local_units, "kernel_groups": groups(prof, local_units, 6)}},
+            "roofline": roofline,
             "aggregation_root": ["%016x" % int(x) for x in root[0]],
             "latency_single_unit_ms": latency,
         }

@@ -82,6 +82,19 @@ const char* gl355_last_error(gl355_ctx* ctx);
 const char* gl355_version(void);
 int32_t gl355_device_count(int32_t* out);
 
+/* ---- the VALU roofline's peak, measured on the device in the run that reports it (csrc/valu_probe.hip).  Poseidon / Merkle /
+ * the constraint kernel are integer-VALU bound ("Roofline: integer VALU issue ... not HBM and not MFMA"); their ceiling is
+ * the chip's issue rate for their instruction mix.
+ *   gl355_valu_probe   per class one kernel that only issues that instruction (8 independent chains per lane, 8 waves per SIMD, all SIMDs):
+ *                      rates[c] = wave-level instructions per second in units of 1e9, shader_mhz[c] = the shader clock read inside that
+ *                      kernel.  A kernel whose instructions split as f_c has the peak 1 / sum_c (f_c / rates[c]).
+ *   gl355_clock_probe  shader clock (MHz) over `micros` microseconds of one sleeping wave on the context's stream: the clock under whatever
+ *                      else the device runs meanwhile */
+enum { GL355_VALU_FULL32 = 0 /* v_add_u32: add / sub / logic / right shift / move */, GL355_VALU_HALF32 = 1 /* v_add_co_u32: carries, left shifts,
+       v_mul_lo, three-operand forms */, GL355_VALU_MAD64 = 2 /* v_mad_u64_u32 and the 64-bit shifts */, GL355_VALU_CLASSES = 3 };
+int32_t gl355_valu_probe(gl355_ctx* ctx, double rates_ginst_per_s[GL355_VALU_CLASSES], double shader_mhz[GL355_VALU_CLASSES]);
+int32_t gl355_clock_probe(gl355_ctx* ctx, uint32_t micros, double* shader_mhz);
+
 /* device memory helpers so a non-torch host (the Rust shim) can keep operands resident */
 int32_t gl355_malloc(gl355_ctx* ctx, size_t bytes, void** dptr);
 int32_t gl355_free(gl355_ctx* ctx, void* dptr);

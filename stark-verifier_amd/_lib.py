@@ -66,6 +66,8 @@ SIGNATURES = {
     "gl355_last_error": (C.c_char_p, [vp]),
     "gl355_version": (C.c_char_p, []),
     "gl355_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
+    "gl355_valu_probe": (C.c_int32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "gl355_clock_probe": (C.c_int32, [vp, C.c_uint32, C.POINTER(C.c_double)]),
     "gl355_malloc": (C.c_int32, [vp, C.c_size_t, C.POINTER(vp)]),
     "gl355_free": (C.c_int32, [vp, vp]),
     "gl355_memcpy_h2d": (C.c_int32, [vp, vp, vp, C.c_size_t]),

@@ -38,6 +38,13 @@ for kern, v in fetch.items():
         e["valu_insts_per_launch"] = s["SQ_INSTS_VALU"][0]
         e["busy_cycles_per_se"] = s["SQ_BUSY_CYCLES"][0] / 32
         e["clk_per_valu_inst_per_simd"] = round((s["SQ_BUSY_CYCLES"][0] / 32) / (s["SQ_INSTS_VALU"][0] / 1024), 2) if s["SQ_INSTS_VALU"][0] else None
+        e["sq_launches"] = s["SQ_INSTS_VALU"][1]
+        # dynamic class counts where the pass carried them (round 4 on): SQ_INSTS_VALU_INT64 = v_mad_u64_u32 and the 64-bit shifts / adds
+        # (calibrated against the probe kernels of csrc/valu_probe.hip in the same pass: profiles/rNN_valu_probe_pmc.txt)
+        if "SQ_INSTS_VALU_INT64" in s:
+            e["valu_int64_per_launch"] = s["SQ_INSTS_VALU_INT64"][0]
+        if "SQ_INSTS_VALU_INT32" in s:
+            e["valu_int32_per_launch"] = s["SQ_INSTS_VALU_INT32"][0]
     kernels[short(kern)] = e
 doc = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over `python bench.py --steps 1 --warmup 0 --proofs-per-step 16 "
                   "--threads 1 --no-cpu-baseline` (one context, lock-step batches of 8 units; tools/prof_round2.sh, tools/make_pmc_traffic.py), per-dispatch averages in KB; FETCH_SIZE doubled "
