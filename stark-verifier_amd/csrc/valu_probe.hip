@@ -18,8 +18,9 @@
 
 namespace gl355 {
 
-constexpr int VP_ILP = 8;
-constexpr int VP_ITERS = 4096;
+constexpr int VP_ILP = 8;           // (GL355_VP_CO8 lists eight carry-out pairs)
+constexpr int VP_ITERS = 512;        // x VP_UNROLL x VP_ILP instructions per lane
+constexpr int VP_UNROLL = 8;         // 64 probe instructions per loop iteration: the loop's scalar compare + branch is < 2 % of the issue slots
 constexpr int VP_BLOCKS = 2048;      // x 256 lanes = 8 waves per SIMD on 1024 SIMDs
 
 struct VpClock { unsigned long long cyc, ticks; };
@@ -37,6 +38,8 @@ __global__ void __launch_bounds__(256) vp_full32_kernel(uint32_t* out, uint32_t 
 #pragma unroll 1
     for (int i = 0; i < VP_ITERS; i++) {
 #pragma unroll
+        for (int r = 0; r < VP_UNROLL; r++)
+#pragma unroll
         for (int j = 0; j < VP_ILP; j++) asm volatile("v_add_u32 %0, %1, %2" : "=v"(acc[j]) : "v"(acc[j]), "v"(b));
     }
     uint32_t s = 0;
@@ -45,27 +48,32 @@ __global__ void __launch_bounds__(256) vp_full32_kernel(uint32_t* out, uint32_t 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     GL355_VP_CLOCK_END
 }
+// one carry-out scalar pair per chain, named in the text: a shared pair (or VCC) makes the assembler pad every instruction with a hazard nop
+#define GL355_VP_CO8(M) M(0, "s[40:41]", "s40", "s41") M(1, "s[42:43]", "s42", "s43") M(2, "s[44:45]", "s44", "s45") M(3, "s[46:47]", "s46", "s47") \
+                        M(4, "s[48:49]", "s48", "s49") M(5, "s[50:51]", "s50", "s51") M(6, "s[52:53]", "s52", "s53") M(7, "s[54:55]", "s54", "s55")
 __global__ void __launch_bounds__(256) vp_half32_kernel(uint32_t* out, uint32_t seed, VpClock* clk) {
     GL355_VP_CLOCK_BEGIN
     uint32_t acc[VP_ILP];
-    uint64_t co[VP_ILP];
     const uint32_t a = threadIdx.x * 2654435761u + seed, b = (blockIdx.x * 40503u + 12345u) | 1u;
 #pragma unroll
     for (int j = 0; j < VP_ILP; j++) acc[j] = a + j;
 #pragma unroll 1
     for (int i = 0; i < VP_ITERS; i++) {
 #pragma unroll
-        for (int j = 0; j < VP_ILP; j++) asm volatile("v_add_co_u32 %0, %1, %2, %3" : "=v"(acc[j]), "=s"(co[j]) : "v"(acc[j]), "v"(b));   // one carry-out pair per chain: no VCC hazard nops
+        for (int r = 0; r < VP_UNROLL; r++) {
+#define GL355_VP_HALF(J, PAIR, LO, HI) asm volatile("v_add_co_u32 %0, " PAIR ", %1, %2" : "=v"(acc[J]) : "v"(acc[J]), "v"(b) : LO, HI);
+            GL355_VP_CO8(GL355_VP_HALF)
+        }
     }
     uint32_t s = 0;
 #pragma unroll
-    for (int j = 0; j < VP_ILP; j++) s ^= acc[j] ^ (uint32_t)co[j];          // the carry-outs stay live: eight distinct scalar pairs
+    for (int j = 0; j < VP_ILP; j++) s ^= acc[j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     GL355_VP_CLOCK_END
 }
 __global__ void __launch_bounds__(256) vp_mad64_kernel(uint32_t* out, uint32_t seed, VpClock* clk) {
     GL355_VP_CLOCK_BEGIN
-    uint64_t acc[VP_ILP], co[VP_ILP];
+    uint64_t acc[VP_ILP];
     const uint64_t a = threadIdx.x * 2654435761ull + seed;
     const uint32_t b = (blockIdx.x * 40503u + 12345u) | 1u, c = seed | 3u;
 #pragma unroll
@@ -73,11 +81,14 @@ __global__ void __launch_bounds__(256) vp_mad64_kernel(uint32_t* out, uint32_t s
 #pragma unroll 1
     for (int i = 0; i < VP_ITERS; i++) {
 #pragma unroll
-        for (int j = 0; j < VP_ILP; j++) asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc[j]), "=s"(co[j]) : "v"(b), "v"(c));
+        for (int r = 0; r < VP_UNROLL; r++) {
+#define GL355_VP_MAD(J, PAIR, LO, HI) asm volatile("v_mad_u64_u32 %0, " PAIR ", %1, %2, %0" : "+v"(acc[J]) : "v"(b), "v"(c) : LO, HI);
+            GL355_VP_CO8(GL355_VP_MAD)
+        }
     }
     uint64_t s = 0;
 #pragma unroll
-    for (int j = 0; j < VP_ILP; j++) s ^= acc[j] ^ co[j];
+    for (int j = 0; j < VP_ILP; j++) s ^= acc[j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(s ^ (s >> 32));
     GL355_VP_CLOCK_END
 }
@@ -105,7 +116,7 @@ int32_t gl355_valu_probe(gl355_ctx* h, double rates_ginst_per_s[GL355_VALU_CLASS
     VpClock* d_clk = reinterpret_cast<VpClock*>(d_out + (size_t)VP_BLOCKS * 256);
     hipEvent_t e0 = ctx->prof_event(), e1 = ctx->prof_event();
     if (!e0 || !e1) return ctx->fail(GL355_E_HIP, "valu_probe: no events");
-    const double insts = (double)VP_BLOCKS * 4 /* waves */ * VP_ITERS * VP_ILP;
+    const double insts = (double)VP_BLOCKS * 4 /* waves */ * VP_ITERS * VP_UNROLL * VP_ILP;
     for (int c = 0; c < GL355_VALU_CLASSES; c++) {
         double best = 0, best_mhz = 0;
         for (int rep = 0; rep < 4; rep++) {                 // rep 0 warms the clocks up
