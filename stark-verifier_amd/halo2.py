@@ -147,6 +147,7 @@ class ConstraintSystem:
         return self.fixed_column()
 
     def enable_equality(self, column):
+        self._query(column, 0)                   # halo2: query_any_index(column, Rotation::cur()) -- the argument reads the column at x
         if column not in self.permutation:
             self.permutation.append(column)
 
