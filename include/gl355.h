@@ -569,6 +569,50 @@ int32_t gl355_kzg_commit(gl355_ctx* ctx, const uint64_t* g /* 2^log_n x 8 */, co
 int32_t gl355_kzg_open(gl355_ctx* ctx, const uint64_t* g, const uint64_t* coeffs, uint32_t log_n, const uint64_t z[4], uint64_t eval[4],
                        uint64_t witness[8], uint64_t* quotient /* or NULL */);
 
+/* ---- SURVEY 8(f) N4, the proving system itself: the data-parallel stages of halo2_proofs' create_proof::<KZGCommitmentScheme<Bn256>,
+ * ProverSHPLONK<_>, _, _, Keccak256Transcript, _> as chip/native_chip/test_utils.rs:57-95 calls it (verifier_api.rs:77-92; README.md:171-177:
+ * 505-511 s at k = 23).  The circuit arrives as a descriptor blob (stark-verifier_amd/halo2.py `export_desc`; the reference's chips
+ * chip/native_chip/arithmetic_chip.rs:44-160 and poseidon_bn254_chip.rs:27-123 in halo2_chips.py): u64 words
+ *   [0] "GL355PLK"  [1] 1  [2] k  [3] advice columns  [4] fixed columns (selectors and table columns included)  [5] instance columns
+ *   [6] permutation columns  [7] lookups  [8] cs.degree()  [9] cs.blinding_factors()  [10..12] advice / fixed / instance queries
+ *   [13] constants  [14] gate-program instructions  [15] gate polynomials  [16..19] the transcript's initial scalar (vk digest)  [20..23] 0
+ *   then: permutation columns (kind << 32 | index; kind 0 advice, 1 fixed, 2 instance), the three query lists (column << 32 | rotation as u32),
+ *   the constant pool (4 words each), the gate program, and per lookup [input instructions, table instructions] + the two programs.
+ *   A program instruction is four u32 (op, dst, a, b): op 0 ADD 1 SUB 2 MUL 3 EMIT 4 NEG 5 MOV; operands kind << 24 | index with kind 0 register
+ *   (< 12), 1 constant, 2 / 3 / 4 advice / fixed / instance QUERY; EMIT a = "a is the next polynomial / expression" (folded with y / theta).
+ * Scalars are 4 x u64 little-endian integers, points affine x | y (8 x u64, zeros = identity), as in the KZG block above.
+ *   gl355_keccak256          Keccak-256 (Ethereum's), the hash of halo2-solidity-verifier's Keccak256Transcript (test_utils.rs:73)
+ *   gl355_kzg_commit_columns n_cols commitments over one resident SRS in batched MSMs: columns = [n_cols][2^log_n] scalars that go with the
+ *                            bases as given (ParamsKZG::commit_lagrange per advice column, plonk/prover.rs)
+ *   gl355_plonk_keygen       keygen_vk / keygen_pk (verifier_api.rs:78-79) as far as proving needs them: fixed_values [fixed columns][2^k]
+ *                            scalars, mapping [permutation columns][2^k][2] u32 = the (column position, row) each cell's sigma points to
+ *                            (permutation::keygen::Assembly); g / g_lagrange = ParamsKZG's two bases (device pointers are used in place and must
+ *                            outlive the key, host arrays are copied).  The key lives on the context's device.
+ *   gl355_plonk_pk_info      [k, extended k, permutation sets, quotient pieces, usable rows, proof bytes, fixed columns, permutation columns]
+ *   gl355_plonk_pk_commitments / _set_digest   the verifying key's commitments; replace the transcript's initial scalar (e.g. by a hash of them)
+ *   gl355_plonk_prove        one proof: advice [advice columns][2^k] scalars (rows >= usable are overwritten by blinding values), instances =
+ *                            the instance columns' values back to back with instance_lens[column] values each, seed = 32 bytes that fix every
+ *                            random scalar (ChaCha20 block (counter = index, nonce = (stream, a, index >> 32)) -> 512-bit little-endian integer
+ *                            mod r; streams 0x11 advice blinding (a = column, index = row), 0x12 permuted lookup columns (a = 2 lookup + {0
+ *                            input, 1 table}), 0x13 permutation products (a = set), 0x14 lookup products (a = lookup), 0x15 the vanishing
+ *                            argument's random polynomial (index = coefficient)).  trace (optional, 32 words): theta beta gamma y x and
+ *                            SHPLONK's y v u.  stage_ms (optional, GL355_PLONK_STAGES doubles): wall milliseconds per stage.
+ * Errors: GL355_E_INVALID_ARG for a malformed descriptor, a lookup input outside its table, or a zero grand-product denominator. */
+typedef struct gl355_plonk_pk gl355_plonk_pk;
+enum { GL355_PLONK_STAGE_ADVICE = 0, GL355_PLONK_STAGE_LOOKUP_PERMUTE = 1, GL355_PLONK_STAGE_PERMUTATION = 2, GL355_PLONK_STAGE_LOOKUP_PRODUCT = 3,
+       GL355_PLONK_STAGE_VANISHING_RANDOM = 4, GL355_PLONK_STAGE_EVALUATE_H = 5, GL355_PLONK_STAGE_QUOTIENT_COMMIT = 6, GL355_PLONK_STAGE_EVALUATIONS = 7,
+       GL355_PLONK_STAGE_SHPLONK = 8, GL355_PLONK_STAGES = 9 };
+int32_t gl355_keccak256(const uint8_t* data, uint64_t len, uint8_t out[32]);
+int32_t gl355_kzg_commit_columns(gl355_ctx* ctx, const uint64_t* g, const uint64_t* columns, uint32_t log_n, uint32_t n_cols, uint64_t* results /* n_cols x 8 */);
+int32_t gl355_plonk_keygen(gl355_ctx* ctx, const uint64_t* desc, uint64_t desc_words, const uint64_t* g, const uint64_t* g_lagrange, const uint64_t* fixed_values,
+                           const uint32_t* mapping, gl355_plonk_pk** out);
+int32_t gl355_plonk_pk_info(const gl355_plonk_pk* pk, uint64_t info[8]);
+int32_t gl355_plonk_pk_commitments(const gl355_plonk_pk* pk, uint64_t* fixed_commitments, uint64_t* sigma_commitments);
+int32_t gl355_plonk_pk_set_digest(gl355_plonk_pk* pk, const uint64_t digest[4]);
+int32_t gl355_plonk_prove(gl355_ctx* ctx, gl355_plonk_pk* pk, const uint64_t* advice, const uint64_t* instances, const uint32_t* instance_lens, const uint8_t seed[32],
+                          uint8_t* proof, uint64_t capacity, uint64_t* proof_len, uint64_t* trace, double* stage_ms);
+int32_t gl355_plonk_pk_destroy(gl355_plonk_pk* pk);
+
 /* ---- a9: wires_permutation_partial_products_and_zs (vanishing_poly.rs:54-108,183-218) --------- */
 int32_t gl355_zs_partial_products(gl355_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas,
                                   const uint64_t* k_is, uint32_t log_n, uint32_t n_routed,

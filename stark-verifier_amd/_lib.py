@@ -66,6 +66,14 @@ SIGNATURES = {
     "gl355_last_error": (C.c_char_p, [vp]),
     "gl355_version": (C.c_char_p, []),
     "gl355_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
+    "gl355_keccak256": (C.c_int32, [vp, C.c_uint64, vp]),
+    "gl355_kzg_commit_columns": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
+    "gl355_plonk_keygen": (C.c_int32, [vp, vp, C.c_uint64, vp, vp, vp, vp, C.POINTER(vp)]),
+    "gl355_plonk_pk_info": (C.c_int32, [vp, vp]),
+    "gl355_plonk_pk_commitments": (C.c_int32, [vp, vp, vp]),
+    "gl355_plonk_pk_set_digest": (C.c_int32, [vp, vp]),
+    "gl355_plonk_prove": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), vp, vp]),
+    "gl355_plonk_pk_destroy": (C.c_int32, [vp]),
     "gl355_valu_probe": (C.c_int32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gl355_clock_probe": (C.c_int32, [vp, C.c_uint32, C.POINTER(C.c_double)]),
     "gl355_malloc": (C.c_int32, [vp, C.c_size_t, C.POINTER(vp)]),

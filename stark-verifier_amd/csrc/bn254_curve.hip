@@ -15,169 +15,13 @@
 // reduction of the buckets of a window, and a Horner combination of the windows.  This is a correct first slice with the right
 // structure for the hardware (integer VALU bound like everything else here), not yet a tuned one: no signed digits, no batched
 // affine additions, FFT stages one global pass each.
-#include "gl355_internal.h"
+#include "bn254_field.cuh"
 #include <vector>
-
-#define BN254C_QUAL __device__ __constant__ const
-#include "bn254_curve_tables.h"
 
 namespace gl355 {
 
 // host_bn254_curve.cpp: sum_w 2^(c w) (S_w + Wt_w) as an affine point (canonical integers; zeros = the identity)
 void bn254_g1_horner_host(const uint32_t* s, const uint32_t* wt, uint32_t n_windows, uint32_t c, uint64_t result[8]);
-
-struct u256 { uint32_t l[8]; };
-enum { F_R = 0, F_Q = 1 };
-
-template <int F> GL_DEV const uint32_t* f_mod() { return F == F_Q ? BN254C_FQ_MOD : BN254C_FR_MOD; }
-template <int F> GL_DEV const uint32_t* f_two_mod() { return F == F_Q ? BN254C_FQ_TWO_MOD : BN254C_FR_TWO_MOD; }
-template <int F> GL_DEV const uint32_t* f_r2() { return F == F_Q ? BN254C_FQ_R2 : BN254C_FR_R2; }
-template <int F> GL_DEV const uint32_t* f_one() { return F == F_Q ? BN254C_FQ_ONE : BN254C_FR_ONE; }
-
-GL_DEV u256 u_const(const uint32_t* p) {
-    u256 r;
-#pragma unroll
-    for (int j = 0; j < 8; j++) r.l[j] = p[j];
-    return r;
-}
-GL_DEV u256 u_zero() {
-    u256 r;
-#pragma unroll
-    for (int j = 0; j < 8; j++) r.l[j] = 0;
-    return r;
-}
-GL_DEV bool u_is_zero(const u256& a) {
-    uint32_t o = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) o |= a.l[j];
-    return o == 0;
-}
-GL_DEV bool u_eq(const u256& a, const u256& b) {
-    uint32_t o = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) o |= a.l[j] ^ b.l[j];
-    return o == 0;
-}
-// a - m if a >= m else a
-GL_DEV u256 u_cond_sub(const u256& a, const uint32_t* m) {
-    uint32_t d[8];
-    uint64_t br = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint64_t v = (uint64_t)a.l[j] - m[j] - br;
-        d[j] = (uint32_t)v;
-        br = (v >> 32) & 1;
-    }
-    u256 r;
-#pragma unroll
-    for (int j = 0; j < 8; j++) r.l[j] = br ? a.l[j] : d[j];
-    return r;
-}
-// a * b * R^-1 (mod m), result < 2m for a, b < 2m
-template <int F>
-__device__ __noinline__ u256 m_mul(u256 a, u256 b) {
-    const uint32_t* M = f_mod<F>();
-    const uint32_t n0 = F == F_Q ? BN254C_FQ_N0INV : BN254C_FR_N0INV;
-    uint32_t t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t t9 = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            c = (uint64_t)a.l[j] * b.l[i] + ((uint64_t)t[j] + c);
-            t[j] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[8] = (uint32_t)c;
-        t9 = (uint32_t)(c >> 32);
-        const uint32_t m = t[0] * n0;
-        c = ((uint64_t)m * M[0] + t[0]) >> 32;
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            c = (uint64_t)m * M[j] + ((uint64_t)t[j] + c);
-            t[j - 1] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[7] = (uint32_t)c;
-        t[8] = t9 + (uint32_t)(c >> 32);
-    }
-    u256 r;
-#pragma unroll
-    for (int j = 0; j < 8; j++) r.l[j] = t[j];
-    return r;
-}
-template <int F> GL_DEV u256 m_add(const u256& a, const u256& b) {
-    u256 s;
-    uint64_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        c += (uint64_t)a.l[j] + b.l[j];
-        s.l[j] = (uint32_t)c;
-        c >>= 32;
-    }
-    return u_cond_sub(s, f_two_mod<F>());
-}
-template <int F> GL_DEV u256 m_sub(const u256& a, const u256& b) {       // a + (2m - b), both < 2m
-    const uint32_t* tm = f_two_mod<F>();
-    u256 nb;
-    uint64_t br = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint64_t v = (uint64_t)tm[j] - b.l[j] - br;
-        nb.l[j] = (uint32_t)v;
-        br = (v >> 32) & 1;
-    }
-    return m_add<F>(a, nb);
-}
-template <int F> GL_DEV u256 m_canon(const u256& a) { return u_cond_sub(a, f_mod<F>()); }       // < 2m -> < m
-template <int F> GL_DEV bool m_is_zero(const u256& a) { return u_is_zero(m_canon<F>(a)); }
-template <int F> GL_DEV bool m_eq(const u256& a, const u256& b) { return u_eq(m_canon<F>(a), m_canon<F>(b)); }
-// any 256-bit integer -> Montgomery form (< 2m): 2^256 < 6m, so five conditional subtractions bring the input below m first
-template <int F> GL_DEV u256 m_from_int(u256 a) {
-#pragma unroll 1
-    for (int k = 0; k < 5; k++) a = u_cond_sub(a, f_mod<F>());
-    return m_mul<F>(a, u_const(f_r2<F>()));
-}
-template <int F> GL_DEV u256 m_to_int(const u256& a) {
-    u256 one = u_zero();
-    one.l[0] = 1;
-    return m_canon<F>(m_mul<F>(a, one));
-}
-GL_DEV u256 load256(const uint64_t* p) {
-    u256 r;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { r.l[2 * i] = (uint32_t)p[i]; r.l[2 * i + 1] = (uint32_t)(p[i] >> 32); }
-    return r;
-}
-GL_DEV void store256(uint64_t* p, const u256& a) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) p[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
-}
-template <int F> GL_DEV u256 m_pow_u64(u256 a, uint64_t e) {
-    u256 r = u_const(f_one<F>());
-    while (e) {
-        if (e & 1) r = m_mul<F>(r, a);
-        a = m_mul<F>(a, a);
-        e >>= 1;
-    }
-    return r;
-}
-// a^(m-2): the inverse
-template <int F> GL_DEV u256 m_inv(const u256& a) {
-    const uint32_t* M = f_mod<F>();
-    u256 r = u_const(f_one<F>());
-#pragma unroll 1
-    for (int i = 255; i >= 0; i--) {
-        r = m_mul<F>(r, r);
-        uint32_t w = M[i >> 5];
-        if ((i >> 5) == 0) w -= 2;               // low limb of both primes is > 2: no borrow
-        if ((w >> (i & 31)) & 1) r = m_mul<F>(r, a);
-    }
-    return r;
-}
 
 // ================================================================ Fr FFT ===========================================
 // values live in Montgomery form between the conversion kernels
@@ -211,6 +55,21 @@ __global__ void fr_power_plain_kernel(uint64_t* tab, uint64_t count, const uint6
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= count) return;
     store256(tab + 4 * i, m_canon<F_R>(m_mul<F_R>(m_mul<F_R>(load256(lo + 4 * (i & 1023)), load256(hi + 4 * (i >> 10))), f)));
+}
+// the same powers in Montgomery form times a Montgomery factor
+__global__ void fr_power_mont_kernel(uint64_t* tab, uint64_t count, const uint64_t* lo, const uint64_t* hi, u256 f_mont) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    store256(tab + 4 * i, m_mul<F_R>(m_mul<F_R>(load256(lo + 4 * (i & 1023)), load256(hi + 4 * (i >> 10))), f_mont));
+}
+// out[i] = in[i] (* post[i]) (* scale): the tail of a one-pass in-place resident transform
+__global__ void fr_scale_copy_kernel(const uint64_t* in, uint64_t* out, uint64_t n, const uint64_t* post, u256 scale, int use_scale) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u256 x = load256(in + 4 * i);
+    if (post) x = m_mul<F_R>(x, load256(post + 4 * i));
+    else if (use_scale) x = m_mul<F_R>(x, scale);
+    store256(out + 4 * i, x);
 }
 __global__ void fr_bitrev_kernel(uint64_t* data, uint32_t log_n) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -253,6 +112,9 @@ struct FrPass {
     uint64_t n_in, n_out;
     const uint64_t* pre;
     const uint64_t* post;
+    // resident form (the PLONK prover, plonk_bn254.hip): inputs already in Montgomery form / outputs left in it (post and scale are then
+    // Montgomery values too)
+    uint32_t in_mont, out_mont;
 };
 __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
     __shared__ uint32_t lds[8][1024];
@@ -269,7 +131,7 @@ __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
         if (a.first) {
             const uint64_t src = __brevll(i) >> (64 - a.log_n);
             if (src < a.n_in) {
-                x = m_from_int<F_R>(load256(a.in + 4 * src));
+                x = a.in_mont ? load256(a.in + 4 * src) : m_from_int<F_R>(load256(a.in + 4 * src));
                 if (a.pre) x = m_mul<F_R>(x, load256(a.pre + 4 * src));
             } else x = u_zero();
         } else x = load256(a.in + 4 * i);
@@ -303,7 +165,10 @@ __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
         for (int l = 0; l < 8; l++) x.l[l] = lds[l][e];
         if (a.last) {
             if (i >= a.n_out) continue;
-            if (a.post) x = m_canon<F_R>(m_mul<F_R>(x, load256(a.post + 4 * i)));
+            if (a.out_mont) {
+                if (a.post) x = m_mul<F_R>(x, load256(a.post + 4 * i));
+                else if (a.use_scale) x = m_mul<F_R>(x, a.scale);
+            } else if (a.post) x = m_canon<F_R>(m_mul<F_R>(x, load256(a.post + 4 * i)));
             else x = a.use_scale ? m_canon<F_R>(m_mul<F_R>(x, a.scale)) : m_to_int<F_R>(x);
         }
         store256(a.out + 4 * i, x);
@@ -1042,43 +907,82 @@ __global__ void kzg_from_mont1_kernel(const uint64_t* in, uint64_t* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) store256(out, m_to_int<F_R>(load256(in)));
 }
 
-// host-side Fr helpers for the few constants a call needs (omega_n, n^-1): plain 256-bit integers with __int128
-namespace {
-typedef unsigned __int128 u128;
-struct H256 { uint64_t l[4]; };
-const uint64_t HR[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};   // r
-bool h_geq(const H256& a) {
-    for (int i = 3; i >= 0; i--) { if (a.l[i] > HR[i]) return true; if (a.l[i] < HR[i]) return false; }
-    return true;
+extern "C" {
+
+}  // extern "C"
+
+namespace gl355 {
+// w_n^i (Montgomery), i < n / 2, for the forward or the inverse transform of 2^log_n points: what every pass of fr_fft_pass_kernel reads.
+// `tw` holds n / 2 + 1 elements; scratch for the two seed tables comes from the context.
+int32_t bn254_fr_twiddles(Ctx* ctx, uint32_t log_n, bool inverse, uint64_t* tw) {
+    const uint64_t n = 1ull << log_n;
+    H256 w = inverse ? H256{{BN254C_FR_ROOT_INV_64[0], BN254C_FR_ROOT_INV_64[1], BN254C_FR_ROOT_INV_64[2], BN254C_FR_ROOT_INV_64[3]}}
+                     : H256{{BN254C_FR_ROOT_64[0], BN254C_FR_ROOT_64[1], BN254C_FR_ROOT_64[2], BN254C_FR_ROOT_64[3]}};
+    for (uint32_t k = log_n; k < BN254C_FR_S; k++) w = h_mulmod(w, w);
+    const uint64_t count = std::max<uint64_t>(1, n / 2), n_hi = (count + 1023) / 1024;
+    Scratch seed(ctx);
+    GL355_TRY(seed.get((1024 + n_hi) * 32));
+    uint64_t* lo = seed.as<uint64_t>();
+    uint64_t* hi = lo + 4 * 1024;
+    hipLaunchKernelGGL(fr_twiddle_seed_kernel, dim3((uint32_t)((1024 + n_hi + 255) / 256)), dim3(256), 0, ctx->stream, lo, hi, n_hi, h_to_mont(w));
+    hipLaunchKernelGGL(fr_twiddle_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, tw, count, lo, hi);
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
 }
-H256 h_addmod(const H256& a, const H256& b) {
-    H256 r; u128 c = 0;
-    for (int i = 0; i < 4; i++) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
-    if (c || h_geq(r)) { u128 br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)r.l[i] - HR[i] - (uint64_t)br; r.l[i] = (uint64_t)d; br = (d >> 64) & 1; } }
-    return r;
+// tab[i] = f * base^i (Montgomery), i < count (base, f: plain integers; f = 1 for plain powers)
+int32_t bn254_fr_power_table(Ctx* ctx, const uint64_t base[4], const uint64_t f[4], uint64_t count, uint64_t* tab) {
+    const uint64_t n_hi = (count + 1023) / 1024;
+    Scratch seed(ctx);
+    GL355_TRY(seed.get((1024 + n_hi) * 32));
+    uint64_t* lo = seed.as<uint64_t>();
+    uint64_t* hi = lo + 4 * 1024;
+    hipLaunchKernelGGL(fr_twiddle_seed_kernel, dim3((uint32_t)((1024 + n_hi + 255) / 256)), dim3(256), 0, ctx->stream, lo, hi, n_hi, h_to_mont(h_from_words(base)));
+    // (lo hi) R * (f R) * R^-1 = lo hi f R: Montgomery again
+    hipLaunchKernelGGL(fr_power_mont_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, tab, count, lo, hi, h_to_mont(h_from_words(f)));
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
 }
-H256 h_mulmod(const H256& a, const H256& b) {          // double-and-add: called a few dozen times per API call
-    H256 r = {{0, 0, 0, 0}};
-    for (int i = 255; i >= 0; i--) {
-        r = h_addmod(r, r);
-        if ((b.l[i >> 6] >> (i & 63)) & 1) r = h_addmod(r, a);
+// The transform on resident data in Montgomery form: out[k] = post[k] * sum_i pre[i] in[i] w^(ik) (i < n_in, zero beyond; k < n_out), w from
+// `tw` (bn254_fr_twiddles: the caller picks the direction and owns the 1 / n, e.g. inside `post` or as `scale`).  `work`: n elements of
+// scratch; in may equal out.
+int32_t bn254_fr_ntt_mont(Ctx* ctx, const uint64_t* in, uint64_t n_in, uint64_t* out, uint64_t n_out, uint32_t log_n, const uint64_t* tw,
+                          const uint64_t* pre, const uint64_t* post, const uint64_t scale_plain[4] /* or null */, uint64_t* work) {
+    const uint64_t n = 1ull << log_n;
+    if (log_n == 0) {
+        GL355_HIP(ctx, hipMemcpyAsync(out, in, 32, hipMemcpyDeviceToDevice, ctx->stream));        // (pre / post of a 1-point transform: not needed by any caller)
+        return GL355_OK;
     }
-    return r;
-}
-H256 h_powmod(H256 a, const H256& e) {
-    H256 r = {{1, 0, 0, 0}};
-    for (int i = 255; i >= 0; i--) {
-        r = h_mulmod(r, r);
-        if ((e.l[i >> 6] >> (i & 63)) & 1) r = h_mulmod(r, a);
+    std::vector<uint32_t> ns;
+    ns.push_back(std::min(10u, log_n));
+    const uint32_t rem = log_n - ns[0], more = (rem + 5) / 6;
+    for (uint32_t k = 0; k < more; k++) ns.push_back(rem / more + (k < rem % more ? 1 : 0));
+    uint32_t s0 = 0;
+    const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, n / 1024);
+    for (size_t k = 0; k < ns.size(); k++) {
+        FrPass pa;
+        memset(&pa, 0, sizeof pa);
+        pa.first = k == 0; pa.last = k + 1 == ns.size();
+        pa.in = pa.first ? in : work;
+        pa.out = (pa.last && !(pa.first && in == out)) ? out : work;
+        pa.tw = tw; pa.log_n = log_n; pa.s0 = s0; pa.ns = ns[k];
+        pa.in_mont = 1; pa.out_mont = 1;
+        if (scale_plain) { pa.use_scale = 1; pa.scale = h_to_mont(h_from_words(scale_plain)); }
+        pa.n_in = n_in; pa.n_out = pa.out == out ? n_out : n;
+        pa.pre = pre;
+        pa.post = pa.out == out ? post : nullptr;
+        if (pa.out != out) pa.use_scale = 0;
+        hipLaunchKernelGGL(fr_fft_pass_kernel, dim3(tiles), dim3(256), 0, ctx->stream, pa);
+        s0 += ns[k];
     }
-    return r;
+    if (ns.size() == 1 && in == out) {
+        // single pass in place: the pass wrote `work` without post / scale (bit-reversed reads cannot run in place): apply them in the copy
+        hipLaunchKernelGGL(fr_scale_copy_kernel, dim3((uint32_t)((n_out + 255) / 256)), dim3(256), 0, ctx->stream, (const uint64_t*)work, out, n_out, post,
+                           scale_plain ? h_to_mont(h_from_words(scale_plain)) : to_u256(H256{{0, 0, 0, 0}}), scale_plain ? 1 : 0);
+    }
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
 }
-u256 to_u256(const H256& a) {
-    u256 r;
-    for (int i = 0; i < 4; i++) { r.l[2 * i] = (uint32_t)a.l[i]; r.l[2 * i + 1] = (uint32_t)(a.l[i] >> 32); }
-    return r;
-}
-}  // namespace
+}  // namespace gl355
 
 extern "C" {
 
@@ -1377,27 +1281,6 @@ int32_t gl355_bn254_g1_fixed_base_mul(gl355_ctx* h, const uint64_t base[8], cons
 
 
 // ---- KZG composites ------------------------------------------------------------------------------------------------------------
-static H256 h_from_words(const uint64_t w[4]) {
-    H256 a = {{w[0], w[1], w[2], w[3]}};
-    while (h_geq(a)) { u128 br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)a.l[i] - HR[i] - (uint64_t)br; a.l[i] = (uint64_t)d; br = (d >> 64) & 1; } }
-    return a;
-}
-static H256 h_submod(const H256& a, const H256& b) {
-    H256 nb; u128 br = 0;
-    for (int i = 0; i < 4; i++) { u128 d = (u128)HR[i] - b.l[i] - (uint64_t)br; nb.l[i] = (uint64_t)d; br = (d >> 64) & 1; }
-    if ((b.l[0] | b.l[1] | b.l[2] | b.l[3]) == 0) nb = H256{{0, 0, 0, 0}};
-    return h_addmod(a, nb);
-}
-static u256 h_to_mont(const H256& a) {
-    const H256 Rm = {{BN254C_FR_ONE_64[0], BN254C_FR_ONE_64[1], BN254C_FR_ONE_64[2], BN254C_FR_ONE_64[3]}};      // R mod r
-    return to_u256(h_mulmod(a, Rm));
-}
-static H256 h_root_of_unity(uint32_t log_n) {
-    H256 w = {{BN254C_FR_ROOT_64[0], BN254C_FR_ROOT_64[1], BN254C_FR_ROOT_64[2], BN254C_FR_ROOT_64[3]}};
-    for (uint32_t k = log_n; k < BN254C_FR_S; k++) w = h_mulmod(w, w);
-    return w;
-}
-
 // ParamsKZG::setup(k, rng) with the secret handed in (verifier_api.rs:77): g[i] = [tau^i] G1, g_lagrange[i] = [L_i(tau)] G1, G1 = (1, 2).
 // halo2 computes g_lagrange by an inverse FFT over the GROUP; here the Lagrange scalars are evaluated in Fr (one batched inversion per 16
 // points) and go through the same fixed-base kernel as the powers.  g_lagrange may be NULL.  Outputs are affine points (n x 8 words).
@@ -1465,8 +1348,11 @@ int32_t gl355_kzg_commit(gl355_ctx* h, const uint64_t* g, const uint64_t* poly, 
     return gl355_bn254_g1_msm(h, g, d_c, n, result);
 }
 
+}  // extern "C"
+
+namespace gl355 {
 // Q and E of the comment above the division kernels, levels chained on the stream; A and Q are device arrays (Q plain at the top level)
-static int32_t kzg_divide(Ctx* ctx, const uint64_t* A, uint64_t m, const H256& z, int a_is_mont, uint64_t* Q, int q_plain, uint64_t* E_mont) {
+int32_t kzg_divide(Ctx* ctx, const uint64_t* A, uint64_t m, const H256& z, int a_is_mont, uint64_t* Q, int q_plain, uint64_t* E_mont) {
     const u256 z_mont = h_to_mont(z);
     if (m <= KZG_DIV_CHUNK) {
         hipLaunchKernelGGL(kzg_div_walk_kernel, dim3(1), dim3(64), 0, ctx->stream, A, m, z_mont, a_is_mont, (const uint64_t*)nullptr, Q, q_plain, E_mont);
@@ -1487,6 +1373,10 @@ static int32_t kzg_divide(Ctx* ctx, const uint64_t* A, uint64_t m, const H256& z
     GL355_HIP(ctx, hipGetLastError());
     return GL355_OK;
 }
+
+}  // namespace gl355
+
+extern "C" {
 
 // The single-point KZG opening (what halo2's multiopen provers reduce to per rotation set): eval = p(z), witness = commit((p - p(z)) / (X - z)).
 // `coeffs` are the 2^log_n coefficients of p, `g` the monomial bases.  quotient (optional, 2^log_n x 4 words, device or host) receives the

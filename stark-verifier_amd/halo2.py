@@ -437,3 +437,84 @@ def export_desc(cs, k, digest):
         parts.append(prog_words(pi))
         parts.append(prog_words(pt))
     return np.concatenate([np.ascontiguousarray(p, dtype=np.uint64).reshape(-1) for p in parts])
+
+
+# ---- the prover behind the C ABI (include/gl355.h: gl355_plonk_keygen / gl355_plonk_prove) -----------------------------------------------
+STAGES = ("advice", "lookup_permute", "permutation", "lookup_product", "vanishing_random", "evaluate_h", "quotient_commit", "evaluations", "shplonk")
+
+
+def kzg_setup(ctx, k, tau, lagrange=True):
+    """ParamsKZG::<Bn256>::setup(k, rng) (verifier_api.rs:77) with the secret handed in: (g, g_lagrange) as [2^k][8] uint64 arrays"""
+    n = 1 << k
+    g = np.zeros((n, 8), dtype=np.uint64)
+    gl = np.zeros((n, 8), dtype=np.uint64) if lagrange else None
+    t = to_limbs([tau])[0]
+    ctx.check(ctx.lib.gl355_kzg_setup(ctx.h, t.ctypes.data, k, g.ctypes.data, gl.ctypes.data if lagrange else None))
+    return g, gl
+
+
+class PlonkProver:
+    """keygen_pk + create_proof of one circuit on one GPU context (chip/native_chip/test_utils.rs:57-95 through gl355_plonk_*).
+    g / g_lagrange: numpy arrays (copied to the device) or device pointers (ints; must outlive the prover)."""
+
+    def __init__(self, ctx, cs, k, g, g_lagrange, fixed, mapping, digest=None):
+        import ctypes as C
+        self.ctx, self.cs, self.k, self.n = ctx, cs, k, 1 << k
+        self.desc = export_desc(cs, k, 0 if digest is None else digest)
+        fixed = np.ascontiguousarray(fixed, dtype=np.uint64)
+        mapping = np.ascontiguousarray(mapping, dtype=np.uint32)
+        assert fixed.shape == (cs.num_fixed, self.n, 4) and mapping.shape == (len(cs.permutation), self.n, 2)
+        self._keep = (g, g_lagrange)
+        ptr = lambda a: a if isinstance(a, int) else a.ctypes.data       # noqa: E731
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.gl355_plonk_keygen(ctx.h, self.desc.ctypes.data, self.desc.size, ptr(g), ptr(g_lagrange), fixed.ctypes.data, mapping.ctypes.data, C.byref(self.h)))
+        info = np.zeros(8, dtype=np.uint64)
+        ctx.check(ctx.lib.gl355_plonk_pk_info(self.h, info.ctypes.data))
+        self.info = dict(k=int(info[0]), extended_k=int(info[1]), n_sets=int(info[2]), n_pieces=int(info[3]), usable=int(info[4]), proof_bytes=int(info[5]))
+        self.fixed_commitments = np.zeros((cs.num_fixed, 8), dtype=np.uint64)
+        self.sigma_commitments = np.zeros((len(cs.permutation), 8), dtype=np.uint64)
+        ctx.check(ctx.lib.gl355_plonk_pk_commitments(self.h, self.fixed_commitments.ctypes.data, self.sigma_commitments.ctypes.data))
+        self.digest = vk_digest(cs, k) if digest is None else digest
+        self.set_digest(self.digest)
+
+    def set_digest(self, digest):
+        d = to_limbs([digest])[0]
+        self.ctx.check(self.ctx.lib.gl355_plonk_pk_set_digest(self.h, d.ctypes.data))
+        self.digest = digest
+
+    def prove(self, advice, instances, seed, want_trace=False, timed=False):
+        """advice: [num_advice][n][4] uint64 (numpy, or a device pointer as int); instances: per instance column a list of integers;
+        seed: 32 bytes.  -> proof bytes (, trace dict)(, {stage: ms})"""
+        import ctypes as C
+        ctx = self.ctx
+        if not isinstance(advice, int):
+            advice = np.ascontiguousarray(advice, dtype=np.uint64)
+            assert advice.shape == (self.cs.num_advice, self.n, 4)
+        flat = to_limbs([v for col in instances for v in col]) if any(len(c) for c in instances) else np.zeros((1, 4), dtype=np.uint64)
+        lens = np.array([len(c) for c in instances] + [0], dtype=np.uint32)
+        buf = np.zeros(self.info["proof_bytes"], dtype=np.uint8)
+        out_len = C.c_uint64(0)
+        trace = np.zeros(32, dtype=np.uint64)
+        ms = np.zeros(len(STAGES), dtype=np.float64)
+        seed = bytes(seed)
+        assert len(seed) == 32
+        ctx.check(ctx.lib.gl355_plonk_prove(ctx.h, self.h, advice if isinstance(advice, int) else advice.ctypes.data, flat.ctypes.data, lens.ctypes.data, seed,
+                                            buf.ctypes.data, buf.size, C.byref(out_len), trace.ctypes.data if want_trace else None, ms.ctypes.data if timed else None))
+        out = [bytes(buf[:out_len.value])]
+        if want_trace:
+            t = from_limbs(trace.reshape(8, 4))
+            out.append(dict(zip(("theta", "beta", "gamma", "y", "x", "shplonk_y", "shplonk_v", "shplonk_u"), t)))
+        if timed:
+            out.append(dict(zip(STAGES, (float(v) for v in ms))))
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.gl355_plonk_pk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,110 @@
+"""GPU: SURVEY 8(f) N4 -- gl355_plonk_keygen / gl355_plonk_prove (the data-parallel stages of halo2's create_proof with SHPLONK and the Keccak256
+transcript, chip/native_chip/test_utils.rs:57-95) against the oracle's restatement (oracle/halo2_model.py): the same commitments of the
+verifying key, the same challenges, the same proof BYTES on the same (witness, seed) at k = 7 .. 10 over the reference's chip shape
+(arithmetic chip + nine range lookups + BN254-Poseidon chip, halo2_chips.py); proofs accepted by the independent verifier restatement
+(tests/halo2_verifier.py, opening check in the exponent under the known tau) incl. at k = 12 where the oracle prover is not run; errors."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import halo2_model as hm  # noqa: E402
+import halo2_verifier as hv  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+h2 = importlib.import_module("stark-verifier_amd.halo2")
+ch = importlib.import_module("stark-verifier_amd.halo2_chips")
+TAU = 0x1234567890ABCDEF1234567890ABCDEF0123456789ABCDEF % hm.R
+
+
+def pt(a):
+    x, y = h2.from_limbs(a[:4])[0], h2.from_limbs(a[4:])[0]
+    return None if (x, y) == (0, 0) else (x, y)
+
+
+def build(ctx, k, tb, n_perm=1, seed=0x355):
+    cs, cfg, w = ch.synthetic_circuit(k, table_bits=tb, n_permutations=n_perm, seed=seed)
+    g, gl_ = h2.kzg_setup(ctx, k, TAU)
+    prover = h2.PlonkProver(ctx, cs, k, g, gl_, w.fixed, w.assembly.mapping_array())
+    return cs, cfg, w, prover
+
+
+def test_keccak256_entry(ctx):
+    import ctypes as C
+    for m in (b"", b"abc", bytes(range(256)) * 5, b"z" * 135, b"z" * 136):
+        out = C.create_string_buffer(32)
+        assert ctx.lib.gl355_keccak256(m, len(m), out) == 0
+        assert out.raw == hm.keccak256(m)
+
+
+@pytest.mark.parametrize("k,tb", [(7, 5), (8, 6), (9, 7), (10, 7)])
+def test_proof_bytes_equal_the_oracle(ctx, k, tb):
+    cs, cfg, w, prover = build(ctx, k, tb)
+    params = hm.Params(k, TAU)
+    pk = hm.keygen(params, cs, w.fixed_ints(), w.assembly)
+    # the verifying key's commitments
+    assert [pt(c) for c in prover.fixed_commitments] == pk.fixed_commitments
+    assert [pt(c) for c in prover.sigma_commitments] == pk.sigma_commitments
+    seed = bytes((7 * i + k) & 0xFF for i in range(32))
+    tr = {}
+    want = hm.create_proof(params, pk, w.advice_ints(), w.instance, seed, prover.digest, tr)
+    got, trace = prover.prove(w.advice, w.instance, seed, want_trace=True)
+    for name in ("theta", "beta", "gamma", "y", "x"):
+        assert trace[name] == tr[name], name
+    for name in ("y", "v", "u"):
+        assert trace["shplonk_" + name] == tr["shplonk"][name], name
+    assert len(got) == len(want) == prover.info["proof_bytes"]
+    if got != want:
+        first = next(i for i in range(len(want)) if got[i] != want[i])
+        raise AssertionError("proof differs from the oracle's at byte %d of %d" % (first, len(want)))
+    vk = dict(digest=prover.digest, fixed_commitments=pk.fixed_commitments, sigma_commitments=pk.sigma_commitments)
+    assert hv.verify(k, cs, vk, w.instance, got, TAU)
+    # deterministic in (witness, seed); another seed -> other blinding, still valid
+    assert prover.prove(w.advice, w.instance, seed) == got
+    other = prover.prove(w.advice, w.instance, bytes(32))
+    assert other != got and hv.verify(k, cs, vk, w.instance, other, TAU)
+    prover.close()
+
+
+def test_k12_proof_passes_the_verifier(ctx):
+    k = 12
+    cs, cfg, w, prover = build(ctx, k, 9, n_perm=8)
+    vk = dict(digest=prover.digest, fixed_commitments=[pt(c) for c in prover.fixed_commitments], sigma_commitments=[pt(c) for c in prover.sigma_commitments])
+    proof, ms = prover.prove(w.advice, w.instance, bytes(range(32)), timed=True)
+    assert hv.verify(k, cs, vk, w.instance, proof, TAU)
+    assert set(ms) == set(h2.STAGES) and all(v >= 0 for v in ms.values())
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 4
+    with pytest.raises(hv.VerifyError):
+        hv.verify(k, cs, vk, w.instance, bytes(bad), TAU)
+    prover.close()
+
+
+def test_a_lookup_input_outside_the_table_is_an_error(gl, ctx):
+    k, tb = 8, 6
+    cs, cfg, w, prover = build(ctx, k, tb)
+    adv = w.advice.copy()
+    adv[cfg.arithmetic_config.r_limbs[0].index, 5, 0] = (1 << tb) + 3          # not a tb-bit value
+    with pytest.raises(gl.Gl355Error) as ei:
+        prover.prove(adv, w.instance, bytes(32))
+    assert ei.value.code == -1 and "lookup" in str(ei.value)
+    prover.close()
+
+
+def test_commit_columns_entry(ctx):
+    """gl355_kzg_commit_columns == one gl355_kzg_commit per column"""
+    k, cols = 10, 5
+    g, gl_ = h2.kzg_setup(ctx, k, TAU)
+    rng = np.random.default_rng(3)
+    vals = rng.integers(0, 1 << 62, (cols, 1 << k, 4), dtype=np.uint64)
+    vals[:, :, 3] >>= np.uint64(4)
+    out = np.zeros((cols, 8), dtype=np.uint64)
+    ctx.check(ctx.lib.gl355_kzg_commit_columns(ctx.h, gl_.ctypes.data, vals.ctypes.data, k, cols, out.ctypes.data))
+    for c in range(cols):
+        one = np.zeros(8, dtype=np.uint64)
+        ctx.check(ctx.lib.gl355_kzg_commit(ctx.h, gl_.ctypes.data, vals[c].ctypes.data, k, 0, one.ctypes.data))
+        assert np.array_equal(out[c], one)
