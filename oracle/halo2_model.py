@@ -281,7 +281,7 @@ def keygen(params, cs, fixed_values, assembly):
     for j in range(m):
         col = []
         for i in range(n):
-            cj, ci = assembly.mapping[j][i]
+            cj, ci = (int(v) for v in assembly.mapping[j][i])
             col.append(pow(DELTA, cj, R) * omega_pows[ci] % R)
         pk.sigma_values.append(col)
     pk.sigma_polys = [dom.lagrange_to_coeff(c) for c in pk.sigma_values]

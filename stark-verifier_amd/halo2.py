@@ -220,34 +220,41 @@ class ConstraintSystem:
 
 
 class Assembly:
-    """permutation::keygen::Assembly: the copy-constraint cycles over the equality-enabled columns (halo2 book, "Permutation argument")"""
+    """permutation::keygen::Assembly: the copy-constraint cycles over the equality-enabled columns (halo2 book, "Permutation argument"):
+    mapping[column][row] = the next cell of the cycle, aux = a representative of the cycle, sizes = its length (numpy arrays: a k = 23
+    circuit has 10^8 cells)"""
 
     def __init__(self, n, columns):
         self.n, self.columns = n, list(columns)
         m = len(self.columns)
-        self.mapping = [[(c, r) for r in range(n)] for c in range(m)]
-        self.aux = [[(c, r) for r in range(n)] for c in range(m)]
-        self.sizes = [[1] * n for _ in range(m)]
+        ident = np.empty((m, n, 2), dtype=np.uint32)
+        ident[:, :, 0] = np.arange(m, dtype=np.uint32)[:, None]
+        ident[:, :, 1] = np.arange(n, dtype=np.uint32)[None, :]
+        self.mapping = ident
+        self.aux = ident.copy()
+        self.sizes = np.ones((m, n), dtype=np.uint32)
 
     def copy(self, left_column, left_row, right_column, right_row):
         lc, rc = self.columns.index(left_column), self.columns.index(right_column)
-        left, right = self.aux[lc][left_row], self.aux[rc][right_row]
+        left, right = tuple(int(v) for v in self.aux[lc, left_row]), tuple(int(v) for v in self.aux[rc, right_row])
         if left == right:
             return
-        if self.sizes[left[0]][left[1]] < self.sizes[right[0]][right[1]]:
+        if self.sizes[left] < self.sizes[right]:
             left, right = right, left
-        self.sizes[left[0]][left[1]] += self.sizes[right[0]][right[1]]
+        self.sizes[left] += self.sizes[right]
         i = right
         while True:
-            self.aux[i[0]][i[1]] = left
-            i = self.mapping[i[0]][i[1]]
+            self.aux[i] = left
+            i = tuple(int(v) for v in self.mapping[i])
             if i == right:
                 break
-        self.mapping[lc][left_row], self.mapping[rc][right_row] = self.mapping[rc][right_row], self.mapping[lc][left_row]
+        tmp = self.mapping[lc, left_row].copy()
+        self.mapping[lc, left_row] = self.mapping[rc, right_row]
+        self.mapping[rc, right_row] = tmp
 
     def mapping_array(self):
         """[n_perm][n][2] uint32: (column position in the permutation, row) each cell maps to"""
-        return np.array(self.mapping, dtype=np.uint32).reshape(len(self.columns), self.n, 2)
+        return self.mapping
 
 
 # ---- compilation of expressions to the register programs of the descriptor ------------------------------------------------------

@@ -278,7 +278,7 @@ def synthetic_circuit(k, table_bits=16, seed=0x355, n_permutations=None, n_arith
     chained Poseidon permutations (69 rows each) down the state columns, random values in the state columns below them (selectors off).
     -> (cs, config, Witness)"""
     if modulus is None:                                     # the reference's p with its 16-bit limbs; a prime just under 2^(4 t) otherwise
-        modulus = GOLDILOCKS_MODULUS if table_bits >= 16 else (1 << (4 * table_bits)) - {4: 15, 5: 3, 6: 3, 7: 57}.get(table_bits, 1)
+        modulus = GOLDILOCKS_MODULUS if table_bits >= 16 else ((1 << (4 * table_bits)) - {4: 15, 5: 3, 6: 3, 7: 57}[table_bits] if table_bits <= 7 else (1 << 31) - 1)
     cs = h2.ConstraintSystem()
     cfg = AllChipConfig.configure(cs, table_bits, modulus)
     ar, po = cfg.arithmetic_config, cfg.poseidon_config
