@@ -61,6 +61,11 @@ struct gl355_plonk_pk {
     uint64_t *fixed_vals = nullptr, *fixed_polys = nullptr, *sigma_vals = nullptr, *sigma_polys = nullptr, *l_polys = nullptr /* l0 | l_last | l_active */;
     uint64_t *omega_pows = nullptr, *delta_pows = nullptr, *d_consts = nullptr;
     uint64_t *tw_fwd = nullptr, *tw_inv = nullptr, *tw_ext_inv = nullptr;
+    // the circuit's own polynomials on every coset of the extended domain, computed once at keygen (halo2's ProvingKey keeps fixed_cosets,
+    // the permutation's cosets and l0 / l_last / l_active the same way): [coset][fixed | sigma | l0 l_last l_active][n].  At the reference's
+    // k = 23 that is 8 x 28 x 256 MB = 57 GB of the 288 GB -- and 36 % of evaluate_h's transforms gone.  nullptr: recomputed per proof
+    uint64_t* fixed_cos = nullptr;
+    uint32_t n_fix_cos = 0;
     const uint64_t *g = nullptr, *g_lagrange = nullptr;                   // the caller's resident SRS (device) or owned copies
     uint32_t* d_gate_code = nullptr;
     std::vector<uint32_t*> d_lk_code;                                     // per lookup: input program, table program
@@ -290,6 +295,31 @@ int32_t lincomb(gl355_plonk_pk* pk, const std::vector<const uint64_t*>& polys, c
     return GL355_OK;
 }
 
+Fr plonk_zeta() {
+    const uint64_t zw[4] = {0xb8ca0b2d36636f23ull, 0xcc37a73fec2bc5e9ull, 0x048b6e193fd84104ull, 0x30644e72e131a029ull};      // Fr::ZETA
+    return Fr::from_words(zw);
+}
+// the key's polynomials (fixed | sigma | l0 l_last l_active) on cosets [c0, c1) of the extended domain: out[(c - c0)][poly][n]
+int32_t plonk_fixed_cosets(gl355_plonk_pk* pk, uint32_t c0, uint32_t c1, uint64_t* out, uint64_t* pre, uint64_t* work) {
+    const uint64_t n = pk->n;
+    const Fr ext_omega = Fr::root_of_unity(pk->ext_k);
+    const uint64_t one_w[4] = {1, 0, 0, 0};
+    Fr base = plonk_zeta() * ext_omega.pow_u64(c0);
+    for (uint32_t c = c0; c < c1; c++) {
+        uint64_t bw[4];
+        base.to_words(bw);
+        GL355_TRY(bn254_fr_power_table(pk->ctx, bw, one_w, n, pre));
+        uint64_t* dst = out + 4ull * (uint64_t)(c - c0) * pk->n_fix_cos * n;
+        for (uint32_t i = 0; i < pk->n_fix_cos; i++) {
+            const uint64_t* src = i < pk->n_fixed ? pk->fixed_polys + 4ull * i * n
+                                  : (i < pk->n_fixed + pk->n_perm ? pk->sigma_polys + 4ull * (i - pk->n_fixed) * n : pk->l_polys + 4ull * (i - pk->n_fixed - pk->n_perm) * n);
+            GL355_TRY(bn254_fr_ntt_mont(pk->ctx, src, n, dst + 4ull * i * n, n, pk->k, pk->tw_fwd, pre, nullptr, nullptr, work));
+        }
+        base = base * ext_omega;
+    }
+    return GL355_OK;
+}
+
 // coefficients (ascending) of the polynomial of degree < m through (pts[i], evs[i])
 std::vector<Fr> interpolate(const std::vector<Fr>& pts, const std::vector<Fr>& evs) {
     const size_t m = pts.size();
@@ -514,6 +544,21 @@ int32_t gl355_plonk_keygen(gl355_ctx* h, const uint64_t* desc, uint64_t words, c
     GL355_HIP(ctx, hipGetLastError());
     for (int c = 0; c < 3; c++) GL355_TRY(lagrange_to_coeff(k_, pk->l_polys + 4ull * c * n, pk->l_polys + 4ull * c * n, work.as<uint64_t>()));
     GL355_HIP(ctx, ctx->wait());
+    pk->n_fix_cos = pk->n_fixed + pk->n_perm + 3;
+    {
+        const uint32_t n_cosets = 1u << (pk->ext_k - pk->k);
+        const size_t bytes = (size_t)n_cosets * pk->n_fix_cos * n * 32;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        static const bool off = getenv("GL355_PLONK_NO_FIXED_COSETS") != nullptr;            // A/B and small-memory runs
+        if (!off && bytes < free_b / 3) {
+            GL355_TRY(D(bytes, &pk->fixed_cos));
+            Scratch pre(ctx);
+            GL355_TRY(pre.get(n * 32));
+            GL355_TRY(plonk_fixed_cosets(k_, 0, n_cosets, pk->fixed_cos, pre.as<uint64_t>(), work.as<uint64_t>()));
+            GL355_HIP(ctx, ctx->wait());
+        }
+    }
     *out = pk.release();
     return GL355_OK;
 }
@@ -733,65 +778,63 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
 
     // ---- evaluate_h -----------------------------------------------------------------------------------------------------------------------
     const Fr y = tr.squeeze_challenge();
-    uint64_t *h_ext = nullptr, *acc = nullptr, *cos = nullptr, *a_in = nullptr, *s_in = nullptr, *pre = nullptr;
-    const uint32_t n_cos_polys = n_all_cols + pk->n_perm + pk->n_sets + 3 + 3 * L;
+    uint64_t *h_ext = nullptr, *acc = nullptr, *cos = nullptr, *a_in = nullptr, *s_in = nullptr, *pre = nullptr, *fix_tmp = nullptr;
+    const uint32_t n_dyn = pk->n_advice + pk->n_instance + pk->n_sets + 3 * L;           // per-proof polynomials: advice | instance | perm z | lookups (A' S' z)
     GL355_TRY(D(N * 32, &h_ext));
     GL355_TRY(D(n * 32, &acc));
-    GL355_TRY(D((size_t)n_cos_polys * n * 32, &cos));
+    GL355_TRY(D((size_t)std::max(1u, n_dyn) * n * 32, &cos));
     GL355_TRY(D(n * 32, &a_in));
     GL355_TRY(D(n * 32, &s_in));
     GL355_TRY(D(n * 32, &pre));
+    if (!pk->fixed_cos) GL355_TRY(D((size_t)pk->n_fix_cos * n * 32, &fix_tmp));
     {
         Timer t(ctx, slot(GL355_PLONK_STAGE_EVALUATE_H));
-        // coset buffers: [adv | fix | inst][sigma][perm z][l0 l_last l_active][lookups: A' S' z]
         std::vector<const uint64_t*> src;
-        for (uint32_t kd = 0; kd < 3; kd++) for (uint32_t c = 0; c < kind_cols[kd]; c++) src.push_back(col_poly(kd, c));
-        for (uint32_t j = 0; j < pk->n_perm; j++) src.push_back(pk->sigma_polys + 4ull * j * n);
+        for (uint32_t c = 0; c < pk->n_advice; c++) src.push_back(adv_polys + 4ull * c * n);
+        for (uint32_t c = 0; c < pk->n_instance; c++) src.push_back(inst_polys + 4ull * c * n);
         for (uint32_t s = 0; s < pk->n_sets; s++) src.push_back(perm_polys + 4ull * s * n);
-        for (int c = 0; c < 3; c++) src.push_back(pk->l_polys + 4ull * c * n);
         for (uint32_t l = 0; l < 3 * L; l++) src.push_back(lk_polys + 4ull * l * n);
-        auto cbuf = [&](uint32_t i) { return cos + 4ull * i * n; };
-        const uint32_t o_sigma = n_all_cols, o_z = o_sigma + pk->n_perm, o_l = o_z + pk->n_sets, o_lk = o_l + 3;
-        // pointer tables into the coset buffers (they do not move from coset to coset)
+        auto dyn = [&](uint32_t i) -> const uint64_t* { return cos + 4ull * i * n; };
+        const uint32_t o_inst = pk->n_advice, o_z = o_inst + pk->n_instance, o_lk = o_z + pk->n_sets;
         const uint64_t** d_cos_cols = dp + n_all_cols;
         const uint64_t* const* d_cos_kind[3] = {d_cos_cols, d_cos_cols + pk->n_advice, d_cos_cols + pk->n_advice + pk->n_fixed};
         const uint64_t** d_cperm = d_perm_sig + pk->n_perm;
         const uint64_t** d_csig = d_cperm + pk->n_perm;
         const uint64_t** d_cz = d_csig + pk->n_perm;
-        {
-            std::vector<const uint64_t*> v;
-            for (uint32_t i = 0; i < n_all_cols; i++) v.push_back(cbuf(i));
-            GL355_TRY(ptrs_to_device(ctx, v, d_cos_cols));
-            v.clear();
-            auto flat = [&](uint32_t kind, uint32_t idx) { return (kind == 0 ? 0 : (kind == 1 ? pk->n_advice : pk->n_advice + pk->n_fixed)) + idx; };
-            for (uint32_t j = 0; j < pk->n_perm; j++) v.push_back(cbuf(flat(pk->perm_cols[j].first, pk->perm_cols[j].second)));
-            GL355_TRY(ptrs_to_device(ctx, v, d_cperm));
-            v.clear();
-            for (uint32_t j = 0; j < pk->n_perm; j++) v.push_back(cbuf(o_sigma + j));
-            GL355_TRY(ptrs_to_device(ctx, v, d_csig));
-            v.clear();
-            for (uint32_t s = 0; s < pk->n_sets; s++) v.push_back(cbuf(o_z + s));
-            GL355_TRY(ptrs_to_device(ctx, v, d_cz));
-        }
-        Fr zeta;
-        {
-            const uint64_t zw[4] = {0xb8ca0b2d36636f23ull, 0xcc37a73fec2bc5e9ull, 0x048b6e193fd84104ull, 0x30644e72e131a029ull};      // Fr::ZETA
-            zeta = Fr::from_words(zw);
-        }
         const Fr ext_omega = Fr::root_of_unity(pk->ext_k);
         const uint64_t one_w[4] = {1, 0, 0, 0};
-        Fr base = zeta;                                            // zeta * ext_omega^c
+        Fr base = plonk_zeta();                                    // zeta * ext_omega^c
         for (uint32_t c = 0; c < n_cosets; c++) {
+            // the key's polynomials on this coset: precomputed, or recomputed into fix_tmp
+            const uint64_t* fix = pk->fixed_cos ? pk->fixed_cos + 4ull * (uint64_t)c * pk->n_fix_cos * n : fix_tmp;
+            if (!pk->fixed_cos) GL355_TRY(plonk_fixed_cosets(pk, c, c + 1, fix_tmp, pre, work));
+            auto fixc = [&](uint32_t i) -> const uint64_t* { return fix + 4ull * i * n; };
+            auto col_cos = [&](uint32_t kind, uint32_t idx) -> const uint64_t* { return kind == 0 ? dyn(idx) : (kind == 1 ? fixc(idx) : dyn(o_inst + idx)); };
+            {
+                std::vector<const uint64_t*> v;
+                for (uint32_t kd = 0; kd < 3; kd++) for (uint32_t i = 0; i < kind_cols[kd]; i++) v.push_back(col_cos(kd, i));
+                GL355_TRY(ptrs_to_device(ctx, v, d_cos_cols));
+                v.clear();
+                for (uint32_t j = 0; j < pk->n_perm; j++) v.push_back(col_cos(pk->perm_cols[j].first, pk->perm_cols[j].second));
+                GL355_TRY(ptrs_to_device(ctx, v, d_cperm));
+                v.clear();
+                for (uint32_t j = 0; j < pk->n_perm; j++) v.push_back(fixc(pk->n_fixed + j));
+                GL355_TRY(ptrs_to_device(ctx, v, d_csig));
+                v.clear();
+                for (uint32_t s = 0; s < pk->n_sets; s++) v.push_back(dyn(o_z + s));
+                GL355_TRY(ptrs_to_device(ctx, v, d_cz));
+            }
+            const uint64_t *c_l0 = fixc(pk->n_fixed + pk->n_perm), *c_ll = c_l0 + 4 * n, *c_la = c_l0 + 8 * n;
             uint64_t bw[4];
             base.to_words(bw);
             GL355_TRY(bn254_fr_power_table(ctx, bw, one_w, n, pre));
-            for (uint32_t i = 0; i < n_cos_polys; i++) GL355_TRY(bn254_fr_ntt_mont(ctx, src[i], n, cbuf(i), n, pk->k, pk->tw_fwd, pre, nullptr, nullptr, work));
+            for (uint32_t i = 0; i < n_dyn; i++) GL355_TRY(bn254_fr_ntt_mont(ctx, src[i], n, cos + 4ull * i * n, n, pk->k, pk->tw_fwd, pre, nullptr, nullptr, work));
             // custom gates
             GL355_TRY(run_program(pk, pk->d_gate_code, (uint32_t)(pk->gate_code.size() / 4), d_cos_kind, y, nullptr, acc));
             if (pk->n_sets) {
                 PlkPermHArgs a;
                 a.n = n; a.n_sets = pk->n_sets; a.chunk_len = pk->chunk_len; a.n_perm = pk->n_perm; a.last_rot = last_rot; a.acc = acc;
-                a.l0 = cbuf(o_l); a.l_last = cbuf(o_l + 1); a.l_active = cbuf(o_l + 2);
+                a.l0 = c_l0; a.l_last = c_ll; a.l_active = c_la;
                 a.z = d_cz; a.sigma = d_csig; a.col = d_cperm; a.omega_pows = pk->omega_pows; a.delta_pows = pk->delta_pows;
                 a.y = to_dev(y); a.beta = to_dev(beta); a.gamma = to_dev(gamma); a.coset_base = to_dev(base);
                 hipLaunchKernelGGL(plk_perm_h_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, a);
@@ -801,8 +844,8 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
                 GL355_TRY(run_program(pk, pk->d_lk_code[2 * l], (uint32_t)(pk->lookups[l].in_code.size() / 4), d_cos_kind, theta, nullptr, a_in));
                 GL355_TRY(run_program(pk, pk->d_lk_code[2 * l + 1], (uint32_t)(pk->lookups[l].tab_code.size() / 4), d_cos_kind, theta, nullptr, s_in));
                 PlkLookupHArgs a;
-                a.n = n; a.acc = acc; a.l0 = cbuf(o_l); a.l_last = cbuf(o_l + 1); a.l_active = cbuf(o_l + 2);
-                a.ap = cbuf(o_lk + 3 * l); a.sp = cbuf(o_lk + 3 * l + 1); a.z = cbuf(o_lk + 3 * l + 2); a.a_in = a_in; a.s_in = s_in;
+                a.n = n; a.acc = acc; a.l0 = c_l0; a.l_last = c_ll; a.l_active = c_la;
+                a.ap = dyn(o_lk + 3 * l); a.sp = dyn(o_lk + 3 * l + 1); a.z = dyn(o_lk + 3 * l + 2); a.a_in = a_in; a.s_in = s_in;
                 a.y = to_dev(y); a.beta = to_dev(beta); a.gamma = to_dev(gamma);
                 hipLaunchKernelGGL(plk_lookup_h_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, a);
                 GL355_HIP(ctx, hipGetLastError());

@@ -65,6 +65,8 @@ def run(gl, ctx, k, verify=True, reps=2):
 
 
 if __name__ == "__main__":
+    import torch
+    torch.cuda.init()            # torch's bundled ROCm runtime first, then libgl355.so (tests/conftest.py has the reason)
     gl = importlib.import_module("stark-verifier_amd")
     ctx = gl.Context(0)
     for k in [int(a) for a in sys.argv[1:]] or [17, 20, 23]:
