@@ -115,6 +115,12 @@ struct FrPass {
     // resident form (the PLONK prover, plonk_bn254.hip): inputs already in Montgomery form / outputs left in it (post and scale are then
     // Montgomery values too)
     uint32_t in_mont, out_mont;
+    // no_gather: the first pass reads element i where the classic form reads bitrev(i) -- either the input already is in bit-reversed order
+    // (decimation in time then gives natural-order output without the scattered 32-byte reads: 1.05 of the 1.85 ms of a 2^23-point transform
+    // went into that one pass), or `dif` is set: decimation in frequency, natural-order input, stages from the top down with the butterfly
+    // (u + v, (u - v) w), bit-reversed output.  The passes of a dif transform run from the highest s0 down; `first` then marks the pass that
+    // reads the input (conversion, pre-multipliers, zero padding), `last` the s0 = 0 pass.
+    uint32_t no_gather, dif;
 };
 __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
     __shared__ uint32_t lds[8][1024];
@@ -129,7 +135,7 @@ __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
         const uint64_t i = base + ((uint64_t)r << a.s0) + c;
         u256 x;
         if (a.first) {
-            const uint64_t src = __brevll(i) >> (64 - a.log_n);
+            const uint64_t src = a.no_gather ? i : __brevll(i) >> (64 - a.log_n);
             if (src < a.n_in) {
                 x = a.in_mont ? load256(a.in + 4 * src) : m_from_int<F_R>(load256(a.in + 4 * src));
                 if (a.pre) x = m_mul<F_R>(x, load256(a.pre + 4 * src));
@@ -139,7 +145,8 @@ __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
         for (int l = 0; l < 8; l++) lds[l][e] = x.l[l];
     }
     __syncthreads();
-    for (uint32_t st = 1; st <= a.ns; st++) {
+    for (uint32_t it = 1; it <= a.ns; it++) {
+        const uint32_t st = a.dif ? a.ns + 1 - it : it;
         const uint32_t s = a.s0 + st, half = 1u << (st - 1);
         for (uint32_t b = tid; b < tile_elems / 2; b += 256) {
             const uint32_t q = b >> log_c, c = b & (C - 1);
@@ -150,8 +157,9 @@ __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
             u256 u, v;
 #pragma unroll
             for (int l = 0; l < 8; l++) { u.l[l] = lds[l][e0]; v.l[l] = lds[l][e1]; }
-            v = m_mul<F_R>(v, w);
-            const u256 p = m_add<F_R>(u, v), m = m_sub<F_R>(u, v);
+            u256 p, m;
+            if (a.dif) { p = m_add<F_R>(u, v); m = m_mul<F_R>(m_sub<F_R>(u, v), w); }
+            else { v = m_mul<F_R>(v, w); p = m_add<F_R>(u, v); m = m_sub<F_R>(u, v); }
 #pragma unroll
             for (int l = 0; l < 8; l++) { lds[l][e0] = p.l[l]; lds[l][e1] = m.l[l]; }
         }
@@ -945,6 +953,67 @@ int32_t bn254_fr_power_table(Ctx* ctx, const uint64_t base[4], const uint64_t f[
 // The transform on resident data in Montgomery form: out[k] = post[k] * sum_i pre[i] in[i] w^(ik) (i < n_in, zero beyond; k < n_out), w from
 // `tw` (bn254_fr_twiddles: the caller picks the direction and owns the 1 / n, e.g. inside `post` or as `scale`).  `work`: n elements of
 // scratch; in may equal out.
+// Decimation in frequency on resident Montgomery data: natural-order input (n_in values, zero beyond, times pre[i] if given), BIT-REVERSED
+// output: out[bitrev(k)] = sum_i pre[i] in[i] w^(ik).  No pass gathers; the first one goes in -> out, the others run in place on `out`.
+int32_t bn254_fr_ntt_mont_dif(Ctx* ctx, const uint64_t* in, uint64_t n_in, uint64_t* out, uint32_t log_n, const uint64_t* tw, const uint64_t* pre) {
+    const uint64_t n = 1ull << log_n;
+    if (log_n == 0) {
+        GL355_HIP(ctx, hipMemcpyAsync(out, in, 32, hipMemcpyDeviceToDevice, ctx->stream));
+        return GL355_OK;
+    }
+    std::vector<uint32_t> ns;
+    ns.push_back(std::min(10u, log_n));
+    const uint32_t rem = log_n - ns[0], more = (rem + 5) / 6;
+    for (uint32_t k = 0; k < more; k++) ns.push_back(rem / more + (k < rem % more ? 1 : 0));
+    std::vector<uint32_t> s0s(ns.size());
+    for (size_t k = 0, s0 = 0; k < ns.size(); k++) { s0s[k] = (uint32_t)s0; s0 += ns[k]; }
+    const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, n / 1024);
+    for (size_t k = ns.size(); k-- > 0;) {
+        FrPass pa;
+        memset(&pa, 0, sizeof pa);
+        pa.first = k + 1 == ns.size(); pa.last = k == 0;
+        pa.in = pa.first ? in : out;
+        pa.out = out;
+        pa.tw = tw; pa.log_n = log_n; pa.s0 = s0s[k]; pa.ns = ns[k];
+        pa.in_mont = 1; pa.out_mont = 1; pa.no_gather = 1; pa.dif = 1;
+        pa.n_in = n_in; pa.n_out = n;
+        pa.pre = pre;
+        hipLaunchKernelGGL(fr_fft_pass_kernel, dim3(tiles), dim3(256), 0, ctx->stream, pa);
+    }
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+// Decimation in time from BIT-REVERSED input (what bn254_fr_ntt_mont_dif leaves) to natural-order output, no gather either:
+// out[k] = post[k] * sum_i in[bitrev(i)] w^(ik), k < n_out.  in may equal out.
+int32_t bn254_fr_ntt_mont_from_bitrev(Ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t n_out, uint32_t log_n, const uint64_t* tw, const uint64_t* post,
+                                      const uint64_t scale_plain[4]) {
+    const uint64_t n = 1ull << log_n;
+    std::vector<uint32_t> ns;
+    ns.push_back(std::min(10u, log_n));
+    const uint32_t rem = log_n - ns[0], more = (rem + 5) / 6;
+    for (uint32_t k = 0; k < more; k++) ns.push_back(rem / more + (k < rem % more ? 1 : 0));
+    uint32_t s0 = 0;
+    const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, n / 1024);
+    // every pass reads and writes the same positions of its tile, so all of them but the last may run in place on the input ... which the
+    // caller may want to keep: the first pass goes in -> out when n_out == n, otherwise the intermediate passes need a full-size buffer
+    if (n_out != n && in != out) return ctx->fail(GL355_E_INVALID_ARG, "fr_ntt_from_bitrev: a truncated output needs the transform in place");
+    for (size_t k = 0; k < ns.size(); k++) {
+        FrPass pa;
+        memset(&pa, 0, sizeof pa);
+        pa.first = k == 0; pa.last = k + 1 == ns.size();
+        pa.in = pa.first ? in : out;
+        pa.out = out;
+        pa.tw = tw; pa.log_n = log_n; pa.s0 = s0; pa.ns = ns[k];
+        pa.in_mont = 1; pa.out_mont = 1; pa.no_gather = 1;
+        if (scale_plain) { pa.use_scale = 1; pa.scale = h_to_mont(h_from_words(scale_plain)); }
+        pa.n_in = n; pa.n_out = pa.last ? n_out : n;
+        pa.post = pa.last ? post : nullptr;
+        hipLaunchKernelGGL(fr_fft_pass_kernel, dim3(tiles), dim3(256), 0, ctx->stream, pa);
+        s0 += ns[k];
+    }
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
 int32_t bn254_fr_ntt_mont(Ctx* ctx, const uint64_t* in, uint64_t n_in, uint64_t* out, uint64_t n_out, uint32_t log_n, const uint64_t* tw,
                           const uint64_t* pre, const uint64_t* post, const uint64_t scale_plain[4] /* or null */, uint64_t* work) {
     const uint64_t n = 1ull << log_n;

@@ -230,6 +230,9 @@ int32_t bn254_fr_twiddles(Ctx* ctx, uint32_t log_n, bool inverse, uint64_t* tw /
 int32_t bn254_fr_power_table(Ctx* ctx, const uint64_t base[4], const uint64_t f[4], uint64_t count, uint64_t* tab);
 int32_t bn254_fr_ntt_mont(Ctx* ctx, const uint64_t* in, uint64_t n_in, uint64_t* out, uint64_t n_out, uint32_t log_n, const uint64_t* tw,
                           const uint64_t* pre, const uint64_t* post, const uint64_t scale_plain[4], uint64_t* work);
+int32_t bn254_fr_ntt_mont_dif(Ctx* ctx, const uint64_t* in, uint64_t n_in, uint64_t* out, uint32_t log_n, const uint64_t* tw, const uint64_t* pre);
+int32_t bn254_fr_ntt_mont_from_bitrev(Ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t n_out, uint32_t log_n, const uint64_t* tw, const uint64_t* post,
+                                      const uint64_t scale_plain[4]);
 // Q[i] = sum_{j > i} A[j] z^(j - i - 1), E = sum_j A[j] z^j on device arrays (see the division kernels)
 int32_t kzg_divide(Ctx* ctx, const uint64_t* A, uint64_t m, const H256& z, int a_is_mont, uint64_t* Q, int q_plain, uint64_t* E_mont);
 }  // namespace gl355

@@ -127,10 +127,11 @@ int32_t commit_columns(gl355_plonk_pk* pk, const uint64_t* bases, const uint64_t
 }
 
 int32_t run_program(gl355_plonk_pk* pk, const uint32_t* d_code, uint32_t n_instr, const uint64_t* const* const d_cols[3], const Fr& fold, const uint64_t* acc_in,
-                    uint64_t* acc_out) {
+                    uint64_t* acc_out, bool bitrev) {
     PlkEvalArgs a;
     memset(&a, 0, sizeof a);
     a.code = d_code; a.n_instr = n_instr; a.consts = pk->d_consts; a.n = pk->n; a.fold = to_dev(fold); a.acc_in = acc_in; a.acc_out = acc_out;
+    a.log_n = pk->k; a.bitrev = bitrev ? 1 : 0;
     for (int kd = 0; kd < 3; kd++) { a.cols[kd] = d_cols[kd]; a.q_col[kd] = pk->d_q[kd][0]; a.q_rot[kd] = pk->d_q[kd][1]; }
     hipLaunchKernelGGL(plk_eval_kernel, dim3(blocks(pk->n)), dim3(256), 0, pk->ctx->stream, a);
     GL355_HIP(pk->ctx, hipGetLastError());
@@ -313,7 +314,7 @@ int32_t plonk_fixed_cosets(gl355_plonk_pk* pk, uint32_t c0, uint32_t c1, uint64_
         for (uint32_t i = 0; i < pk->n_fix_cos; i++) {
             const uint64_t* src = i < pk->n_fixed ? pk->fixed_polys + 4ull * i * n
                                   : (i < pk->n_fixed + pk->n_perm ? pk->sigma_polys + 4ull * (i - pk->n_fixed) * n : pk->l_polys + 4ull * (i - pk->n_fixed - pk->n_perm) * n);
-            GL355_TRY(bn254_fr_ntt_mont(pk->ctx, src, n, dst + 4ull * i * n, n, pk->k, pk->tw_fwd, pre, nullptr, nullptr, work));
+            GL355_TRY(bn254_fr_ntt_mont_dif(pk->ctx, src, n, dst + 4ull * i * n, pk->k, pk->tw_fwd, pre));
         }
         base = base * ext_omega;
     }
@@ -684,8 +685,8 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     {
         Timer t(ctx, slot(GL355_PLONK_STAGE_LOOKUP_PERMUTE));
         for (uint32_t l = 0; l < L; l++) {
-            GL355_TRY(run_program(pk, pk->d_lk_code[2 * l], (uint32_t)(pk->lookups[l].in_code.size() / 4), d_val_cols, theta, nullptr, lkA + 4ull * l * n));
-            GL355_TRY(run_program(pk, pk->d_lk_code[2 * l + 1], (uint32_t)(pk->lookups[l].tab_code.size() / 4), d_val_cols, theta, nullptr, lkS + 4ull * l * n));
+            GL355_TRY(run_program(pk, pk->d_lk_code[2 * l], (uint32_t)(pk->lookups[l].in_code.size() / 4), d_val_cols, theta, nullptr, lkA + 4ull * l * n, false));
+            GL355_TRY(run_program(pk, pk->d_lk_code[2 * l + 1], (uint32_t)(pk->lookups[l].tab_code.size() / 4), d_val_cols, theta, nullptr, lkS + 4ull * l * n, false));
             uint64_t* Ap = lkAp + 8ull * l * n;
             uint64_t* Sp = Ap + 4 * n;
             GL355_TRY(permute_pair(ctx, lkA + 4ull * l * n, lkS + 4ull * l * n, u, Ap, Sp));
@@ -828,12 +829,12 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
             uint64_t bw[4];
             base.to_words(bw);
             GL355_TRY(bn254_fr_power_table(ctx, bw, one_w, n, pre));
-            for (uint32_t i = 0; i < n_dyn; i++) GL355_TRY(bn254_fr_ntt_mont(ctx, src[i], n, cos + 4ull * i * n, n, pk->k, pk->tw_fwd, pre, nullptr, nullptr, work));
+            for (uint32_t i = 0; i < n_dyn; i++) GL355_TRY(bn254_fr_ntt_mont_dif(ctx, src[i], n, cos + 4ull * i * n, pk->k, pk->tw_fwd, pre));
             // custom gates
-            GL355_TRY(run_program(pk, pk->d_gate_code, (uint32_t)(pk->gate_code.size() / 4), d_cos_kind, y, nullptr, acc));
+            GL355_TRY(run_program(pk, pk->d_gate_code, (uint32_t)(pk->gate_code.size() / 4), d_cos_kind, y, nullptr, acc, true));
             if (pk->n_sets) {
                 PlkPermHArgs a;
-                a.n = n; a.n_sets = pk->n_sets; a.chunk_len = pk->chunk_len; a.n_perm = pk->n_perm; a.last_rot = last_rot; a.acc = acc;
+                a.n = n; a.log_n = pk->k; a.n_sets = pk->n_sets; a.chunk_len = pk->chunk_len; a.n_perm = pk->n_perm; a.last_rot = last_rot; a.acc = acc;
                 a.l0 = c_l0; a.l_last = c_ll; a.l_active = c_la;
                 a.z = d_cz; a.sigma = d_csig; a.col = d_cperm; a.omega_pows = pk->omega_pows; a.delta_pows = pk->delta_pows;
                 a.y = to_dev(y); a.beta = to_dev(beta); a.gamma = to_dev(gamma); a.coset_base = to_dev(base);
@@ -841,24 +842,25 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
                 GL355_HIP(ctx, hipGetLastError());
             }
             for (uint32_t l = 0; l < L; l++) {
-                GL355_TRY(run_program(pk, pk->d_lk_code[2 * l], (uint32_t)(pk->lookups[l].in_code.size() / 4), d_cos_kind, theta, nullptr, a_in));
-                GL355_TRY(run_program(pk, pk->d_lk_code[2 * l + 1], (uint32_t)(pk->lookups[l].tab_code.size() / 4), d_cos_kind, theta, nullptr, s_in));
+                GL355_TRY(run_program(pk, pk->d_lk_code[2 * l], (uint32_t)(pk->lookups[l].in_code.size() / 4), d_cos_kind, theta, nullptr, a_in, true));
+                GL355_TRY(run_program(pk, pk->d_lk_code[2 * l + 1], (uint32_t)(pk->lookups[l].tab_code.size() / 4), d_cos_kind, theta, nullptr, s_in, true));
                 PlkLookupHArgs a;
-                a.n = n; a.acc = acc; a.l0 = c_l0; a.l_last = c_ll; a.l_active = c_la;
+                a.n = n; a.log_n = pk->k; a.acc = acc; a.l0 = c_l0; a.l_last = c_ll; a.l_active = c_la;
                 a.ap = dyn(o_lk + 3 * l); a.sp = dyn(o_lk + 3 * l + 1); a.z = dyn(o_lk + 3 * l + 2); a.a_in = a_in; a.s_in = s_in;
                 a.y = to_dev(y); a.beta = to_dev(beta); a.gamma = to_dev(gamma);
                 hipLaunchKernelGGL(plk_lookup_h_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, a);
                 GL355_HIP(ctx, hipGetLastError());
             }
             const Fr t_inv = (base.pow_u64(n) - Fr::one()).inv();                 // 1 / ((zeta omega_ext^c)^n - 1)
-            hipLaunchKernelGGL(plk_finish_h_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, (const uint64_t*)acc, n, e_bits, c, to_dev(t_inv), h_ext);
+            uint64_t blk = 0;                                                      // bitrev_e(c)
+            for (uint32_t b = 0; b < e_bits; b++) blk |= (uint64_t)((c >> b) & 1) << (e_bits - 1 - b);
+            hipLaunchKernelGGL(plk_finish_h_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, (const uint64_t*)acc, n, blk, to_dev(t_inv), h_ext);
             GL355_HIP(ctx, hipGetLastError());
             base = base * ext_omega;
         }
     }
     // ---- vanishing argument: h's coefficients, pieces, commitments ---------------------------------------------------------------------------
-    uint64_t* h_coeffs = nullptr;
-    GL355_TRY(D((size_t)pk->n_pieces * n * 32, &h_coeffs));
+    uint64_t* h_coeffs = h_ext;
     {
         Timer t(ctx, slot(GL355_PLONK_STAGE_QUOTIENT_COMMIT));
         // extended_to_coeff: inverse transform over the extended domain, coefficient i divided by zeta^i (and by the domain size)
@@ -868,7 +870,8 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
         uint64_t* post = nullptr;
         GL355_TRY(D((size_t)pk->n_pieces * n * 32, &post));
         GL355_TRY(bn254_fr_power_table(ctx, zi_w, ninv, (uint64_t)pk->n_pieces * n, post));
-        GL355_TRY(bn254_fr_ntt_mont(ctx, h_ext, N, h_coeffs, (uint64_t)pk->n_pieces * n, pk->ext_k, pk->tw_ext_inv, nullptr, post, nullptr, work));
+        // (h_ext is in bit-reversed order: decimation in time without a gather, in place; its first n_pieces n entries are the coefficients)
+        GL355_TRY(bn254_fr_ntt_mont_from_bitrev(ctx, h_ext, h_ext, (uint64_t)pk->n_pieces * n, pk->ext_k, pk->tw_ext_inv, post, nullptr));
         std::vector<uint64_t> pts(8ull * pk->n_pieces);
         GL355_TRY(commit_columns(pk, pk->g, h_coeffs, pk->n_pieces, pts.data()));
         for (uint32_t i = 0; i < pk->n_pieces; i++) tr.write_point(pts.data() + 8 * i);

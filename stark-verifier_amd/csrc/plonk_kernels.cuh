@@ -78,10 +78,18 @@ struct PlkEvalArgs {
     const int32_t* q_col[3];         // per kind: query -> column
     const int32_t* q_rot[3];         // per kind: query -> rotation
     uint64_t n;
+    uint32_t log_n, bitrev;          // bitrev: the columns hold point bitrev(i) at position i (cosets as bn254_fr_ntt_mont_dif leaves them)
     u256 fold;
     const uint64_t* acc_in;          // running sums to continue from, or null (zero)
     uint64_t* acc_out;
 };
+// position of the point `rot` steps after the point at position i
+GL_DEV uint64_t plk_rotated(uint64_t i, int32_t rot, uint64_t n, uint32_t log_n, uint32_t bitrev) {
+    if (rot == 0) return i;
+    if (!bitrev) return (uint64_t)((int64_t)i + (int64_t)n + rot) & (n - 1);
+    const uint64_t j = __brevll(i) >> (64 - log_n);
+    return __brevll((uint64_t)((int64_t)j + (int64_t)n + rot) & (n - 1)) >> (64 - log_n);
+}
 #define PLK_REG_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
 // the register file as twelve named values (an indexed array ends up in scratch memory)
 struct PlkRegs {
@@ -111,8 +119,7 @@ GL_DEV u256 plk_operand(const PlkEvalArgs& a, const PlkRegs& f, uint32_t operand
     if (kind == PLK_K_CONST) return load256(a.consts + 4 * idx);
     const uint32_t kd = kind - PLK_K_ADVICE;
     const int32_t col = a.q_col[kd][idx], rot = a.q_rot[kd][idx];
-    const uint64_t row = (uint64_t)((int64_t)i + (int64_t)a.n + rot) & (a.n - 1);
-    return load256(a.cols[kd][col] + 4 * row);
+    return load256(a.cols[kd][col] + 4 * plk_rotated(i, rot, a.n, a.log_n, a.bitrev));
 }
 __global__ void __launch_bounds__(256) plk_eval_kernel(PlkEvalArgs a) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -144,6 +151,7 @@ __global__ void __launch_bounds__(256) plk_eval_kernel(PlkEvalArgs a) {
 // then per set (z_s(omega X) prod (v + beta sigma + gamma) - z_s(X) prod (v + delta^j beta X + gamma)) l_active)
 struct PlkPermHArgs {
     uint64_t n;
+    uint32_t log_n;                  // the coset arrays are in bit-reversed order
     uint32_t n_sets, chunk_len, n_perm;
     int32_t last_rot;
     uint64_t* acc;
@@ -158,7 +166,7 @@ struct PlkPermHArgs {
 __global__ void __launch_bounds__(256) plk_perm_h_kernel(PlkPermHArgs a) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const uint64_t mask = a.n - 1, nxt = (i + 1) & mask, lst = (uint64_t)((int64_t)i + (int64_t)a.n + a.last_rot) & mask;
+    const uint64_t nxt = plk_rotated(i, 1, a.n, a.log_n, 1), lst = plk_rotated(i, a.last_rot, a.n, a.log_n, 1), nat = __brevll(i) >> (64 - a.log_n);
     u256 acc = load256(a.acc + 4 * i);
     const u256 l0 = load256(a.l0 + 4 * i), ll = load256(a.l_last + 4 * i), la = load256(a.l_active + 4 * i), one = fr_one();
     acc = m_add<F_R>(m_mul<F_R>(acc, a.y), m_mul<F_R>(l0, m_sub<F_R>(one, load256(a.z[0] + 4 * i))));
@@ -169,7 +177,7 @@ __global__ void __launch_bounds__(256) plk_perm_h_kernel(PlkPermHArgs a) {
 #pragma unroll 1
     for (uint32_t s = 1; s < a.n_sets; s++)
         acc = m_add<F_R>(m_mul<F_R>(acc, a.y), m_mul<F_R>(l0, m_sub<F_R>(load256(a.z[s] + 4 * i), load256(a.z[s - 1] + 4 * lst))));
-    const u256 bx = m_mul<F_R>(a.beta, m_mul<F_R>(a.coset_base, load256(a.omega_pows + 4 * i)));        // beta x
+    const u256 bx = m_mul<F_R>(a.beta, m_mul<F_R>(a.coset_base, load256(a.omega_pows + 4 * nat)));      // beta x
 #pragma unroll 1
     for (uint32_t s = 0; s < a.n_sets; s++) {
         u256 left = load256(a.z[s] + 4 * nxt), right = load256(a.z[s] + 4 * i);
@@ -188,6 +196,7 @@ __global__ void __launch_bounds__(256) plk_perm_h_kernel(PlkPermHArgs a) {
 // (a' - s')(a' - a'(omega^-1 X)) l_active
 struct PlkLookupHArgs {
     uint64_t n;
+    uint32_t log_n;
     uint64_t* acc;
     const uint64_t *l0, *l_last, *l_active, *z, *ap, *sp, *a_in, *s_in;
     u256 y, beta, gamma;
@@ -195,7 +204,7 @@ struct PlkLookupHArgs {
 __global__ void __launch_bounds__(256) plk_lookup_h_kernel(PlkLookupHArgs a) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const uint64_t mask = a.n - 1, nxt = (i + 1) & mask, prv = (i + a.n - 1) & mask;
+    const uint64_t nxt = plk_rotated(i, 1, a.n, a.log_n, 1), prv = plk_rotated(i, -1, a.n, a.log_n, 1);
     u256 acc = load256(a.acc + 4 * i);
     const u256 l0 = load256(a.l0 + 4 * i), ll = load256(a.l_last + 4 * i), la = load256(a.l_active + 4 * i), one = fr_one();
     const u256 z = load256(a.z + 4 * i), ap = load256(a.ap + 4 * i), sp = load256(a.sp + 4 * i);
@@ -209,11 +218,13 @@ __global__ void __launch_bounds__(256) plk_lookup_h_kernel(PlkLookupHArgs a) {
     acc = m_add<F_R>(m_mul<F_R>(acc, a.y), m_mul<F_R>(m_mul<F_R>(d, m_sub<F_R>(ap, load256(a.ap + 4 * prv))), la));
     store256(a.acc + 4 * i, acc);
 }
-// h on the extended domain, natural order: point i of coset c is extended index i 2^e + c; divided by X^n - 1, which is constant on a coset
-__global__ void plk_finish_h_kernel(const uint64_t* acc, uint64_t n, uint32_t log_ratio, uint32_t coset, u256 t_inv, uint64_t* h_ext) {
+// h on the extended domain in BIT-REVERSED order (what the gather-free inverse transform reads): point j of coset c is extended index
+// j 2^e + c, whose reversal is bitrev_e(c) 2^k + bitrev_k(j) -- the coset's own (bit-reversed) array, whole, at block bitrev_e(c).  Divided by
+// X^n - 1, which is constant on a coset.
+__global__ void plk_finish_h_kernel(const uint64_t* acc, uint64_t n, uint64_t block, u256 t_inv, uint64_t* h_ext) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    store256(h_ext + 4 * ((i << log_ratio) + coset), m_mul<F_R>(load256(acc + 4 * i), t_inv));
+    store256(h_ext + 4 * (block * n + i), m_mul<F_R>(load256(acc + 4 * i), t_inv));
 }
 
 // ---- grand products ----------------------------------------------------------------------------------------------------------------
@@ -252,7 +263,7 @@ __global__ void __launch_bounds__(256) plk_lookup_rows_kernel(const uint64_t* A,
 }
 // out[i] = num[i] / den[i]: a lane takes PLK_INV_CHUNK consecutive rows, one inversion per lane (Montgomery's trick); den is used as scratch.
 // A zero denominator (probability ~ n / r over the challenges) is reported through *bad.
-constexpr int PLK_INV_CHUNK = 16;
+constexpr int PLK_INV_CHUNK = 64;        // an inversion is ~380 products: 6 per row at 64 rows per lane (24 at 16)
 __global__ void __launch_bounds__(64) plk_batch_div_kernel(const uint64_t* num, uint64_t* den, uint64_t* out, uint64_t n, uint32_t* bad) {
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const uint64_t i0 = t * PLK_INV_CHUNK;
