@@ -60,7 +60,7 @@ struct gl355_plonk_pk {
     // device, Montgomery: values and coefficient forms
     uint64_t *fixed_vals = nullptr, *fixed_polys = nullptr, *sigma_vals = nullptr, *sigma_polys = nullptr, *l_polys = nullptr /* l0 | l_last | l_active */;
     uint64_t *omega_pows = nullptr, *delta_pows = nullptr, *d_consts = nullptr;
-    uint64_t *tw_fwd = nullptr, *tw_inv = nullptr, *tw_ext_inv = nullptr;
+    uint64_t *tw_fwd = nullptr, *tw_inv = nullptr;
     // the circuit's own polynomials on every coset of the extended domain, computed once at keygen (halo2's ProvingKey keeps fixed_cosets,
     // the permutation's cosets and l0 / l_last / l_active the same way): [coset][fixed | sigma | l0 l_last l_active][n].  At the reference's
     // k = 23 that is 8 x 28 x 256 MB = 57 GB of the 288 GB -- and 36 % of evaluate_h's transforms gone.  nullptr: recomputed per proof
@@ -405,7 +405,6 @@ int32_t gl355_plonk_keygen(gl355_ctx* h, const uint64_t* desc, uint64_t words, c
     pk->n_pieces = pk->degree - 1;
     pk->ext_k = pk->k;
     while ((1ull << pk->ext_k) < pk->n * pk->n_pieces) pk->ext_k++;
-    if (pk->ext_k > 26) return ctx->fail(GL355_E_UNSUPPORTED, "plonk_keygen: extended domain beyond 2^26");
     pk->chunk_len = pk->degree - 2;
     pk->n_sets = pk->n_perm ? (pk->n_perm + pk->chunk_len - 1) / pk->chunk_len : 0;
     pk->digest = Fr::from_words(desc + 16);
@@ -469,10 +468,8 @@ int32_t gl355_plonk_keygen(gl355_ctx* h, const uint64_t* desc, uint64_t words, c
     if (ptr_is_device(g_lagrange)) pk->g_lagrange = g_lagrange; else { uint64_t* d; GL355_TRY(D(n * 64, &d)); GL355_TRY(upload(ctx, d, g_lagrange, n * 64)); pk->g_lagrange = d; }
     GL355_TRY(D((n / 2 + 1) * 32, &pk->tw_fwd));
     GL355_TRY(D((n / 2 + 1) * 32, &pk->tw_inv));
-    GL355_TRY(D(((1ull << pk->ext_k) / 2 + 1) * 32, &pk->tw_ext_inv));
     GL355_TRY(bn254_fr_twiddles(ctx, pk->k, false, pk->tw_fwd));
     GL355_TRY(bn254_fr_twiddles(ctx, pk->k, true, pk->tw_inv));
-    GL355_TRY(bn254_fr_twiddles(ctx, pk->ext_k, true, pk->tw_ext_inv));
     const uint64_t one_w[4] = {1, 0, 0, 0};
     uint64_t w_w[4], d_w[4];
     Fr::root_of_unity(pk->k).to_words(w_w);
@@ -547,7 +544,7 @@ int32_t gl355_plonk_keygen(gl355_ctx* h, const uint64_t* desc, uint64_t words, c
     GL355_HIP(ctx, ctx->wait());
     pk->n_fix_cos = pk->n_fixed + pk->n_perm + 3;
     {
-        const uint32_t n_cosets = 1u << (pk->ext_k - pk->k);
+        const uint32_t n_cosets = pk->n_pieces;              // evaluate_h visits as many cosets as the quotient has pieces (see gl355_plonk_prove)
         const size_t bytes = (size_t)n_cosets * pk->n_fix_cos * n * 32;
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
@@ -596,8 +593,8 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
     if (!pk || pk->ctx != ctx || !seed || !proof || !proof_len || (pk->n_advice && !advice) || (pk->n_instance && !instance_lens))
         return ctx->fail(GL355_E_INVALID_ARG, "plonk_prove: null argument or a key of another context");
-    const uint64_t n = pk->n, u = pk->usable, N = 1ull << pk->ext_k;
-    const uint32_t e_bits = pk->ext_k - pk->k, n_cosets = 1u << e_bits;
+    const uint64_t n = pk->n, u = pk->usable;
+    const uint32_t n_cosets = pk->n_pieces;
     const int32_t last_rot = -(int32_t)(pk->bf + 1);
     const BlindKey key = blind_key_from_bytes(seed);
     double ms[GL355_PLONK_STAGES];
@@ -609,7 +606,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     struct Freer { Ctx* c; std::vector<void*>* v; ~Freer() { (void)c->wait(); for (void* p : *v) c->release(p); } } freer{ctx, &mine};
     auto D = [&](size_t bytes, uint64_t** ptr) -> int32_t { void* p = nullptr; GL355_TRY(ctx->alloc(std::max<size_t>(bytes, 32), &p)); mine.push_back(p); *ptr = (uint64_t*)p; return GL355_OK; };
     uint64_t* work = nullptr;
-    GL355_TRY(D(N * 32, &work));                              // FFT scratch, large enough for the extended transform
+    GL355_TRY(D(n * 32, &work));                              // FFT scratch of the natural-order transforms
     const Fr omega = Fr::root_of_unity(pk->k), omega_inv = omega.inv();
     auto rotate = [&](const Fr& x, int32_t r) { return x * (r >= 0 ? omega : omega_inv).pow_u64((uint64_t)(r >= 0 ? r : -r)); };
 
@@ -658,7 +655,6 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     }
     // column pointer tables (values / coefficient forms) on the device
     auto col_vals = [&](uint32_t kind, uint32_t idx) -> const uint64_t* { return (kind == 0 ? adv_vals : (kind == 1 ? pk->fixed_vals : inst_vals)) + 4ull * idx * n; };
-    auto col_poly = [&](uint32_t kind, uint32_t idx) -> const uint64_t* { return (kind == 0 ? adv_polys : (kind == 1 ? pk->fixed_polys : inst_polys)) + 4ull * idx * n; };
     const uint32_t kind_cols[3] = {pk->n_advice, pk->n_fixed, pk->n_instance};
     const uint32_t n_all_cols = pk->n_advice + pk->n_fixed + pk->n_instance;
     uint64_t* d_ptrs = nullptr;          // pointer tables: [values: adv | fix | inst][coset: adv | fix | inst][perm vals][perm sigma vals][coset perm cols][coset sigma][coset z]
@@ -675,11 +671,10 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     // ---- lookups: compress, permute, commit ----------------------------------------------------------------------------------------
     const Fr theta = tr.squeeze_challenge();
     const uint32_t L = pk->n_lookups;
-    uint64_t *lkA = nullptr, *lkS = nullptr, *lkAp = nullptr, *lkSp = nullptr, *lkZ = nullptr, *lk_polys = nullptr /* [L][3]: A', S', z */;
+    uint64_t *lkA = nullptr, *lkS = nullptr, *lkAp = nullptr, *lkZ = nullptr, *lk_polys = nullptr /* [L][3]: A', S', z */;
     GL355_TRY(D((size_t)std::max(1u, L) * n * 32, &lkA));
     GL355_TRY(D((size_t)std::max(1u, L) * n * 32, &lkS));
     GL355_TRY(D((size_t)std::max(1u, 2 * L) * n * 32, &lkAp));          // A'_0 S'_0 A'_1 S'_1 ... : one batched commitment
-    lkSp = lkAp + 4 * n;
     GL355_TRY(D((size_t)std::max(1u, L) * n * 32, &lkZ));
     GL355_TRY(D((size_t)std::max(1u, 3 * L) * n * 32, &lk_polys));
     {
@@ -781,7 +776,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     const Fr y = tr.squeeze_challenge();
     uint64_t *h_ext = nullptr, *acc = nullptr, *cos = nullptr, *a_in = nullptr, *s_in = nullptr, *pre = nullptr, *fix_tmp = nullptr;
     const uint32_t n_dyn = pk->n_advice + pk->n_instance + pk->n_sets + 3 * L;           // per-proof polynomials: advice | instance | perm z | lookups (A' S' z)
-    GL355_TRY(D(N * 32, &h_ext));
+    GL355_TRY(D((size_t)2 * pk->n_pieces * n * 32, &h_ext));          // [n_pieces] the quotient restricted to each coset, then [n_pieces] its pieces
     GL355_TRY(D(n * 32, &acc));
     GL355_TRY(D((size_t)std::max(1u, n_dyn) * n * 32, &cos));
     GL355_TRY(D(n * 32, &a_in));
@@ -852,26 +847,62 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
                 GL355_HIP(ctx, hipGetLastError());
             }
             const Fr t_inv = (base.pow_u64(n) - Fr::one()).inv();                 // 1 / ((zeta omega_ext^c)^n - 1)
-            uint64_t blk = 0;                                                      // bitrev_e(c)
-            for (uint32_t b = 0; b < e_bits; b++) blk |= (uint64_t)((c >> b) & 1) << (e_bits - 1 - b);
-            hipLaunchKernelGGL(plk_finish_h_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, (const uint64_t*)acc, n, blk, to_dev(t_inv), h_ext);
+            hipLaunchKernelGGL(plk_finish_h_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, (const uint64_t*)acc, n, (uint64_t)c, to_dev(t_inv), h_ext);
             GL355_HIP(ctx, hipGetLastError());
             base = base * ext_omega;
         }
     }
     // ---- vanishing argument: h's coefficients, pieces, commitments ---------------------------------------------------------------------------
-    uint64_t* h_coeffs = h_ext;
+    // halo2 evaluates h on the whole extended domain (2^(extended_k - k) cosets of the 2^k domain) and inverts one transform of that size.  The
+    // same polynomial follows from `degree - 1` cosets: h = sum_p X^(p n) h_p with deg h_p < n, and on the coset g_c H, X^n is the constant
+    // t_c = g_c^n, so h restricted to the coset IS the polynomial R_c = sum_p t_c^p h_p (degree < n): one inverse coset transform of size n
+    // per coset gives R_c, and the pieces are h_p = sum_c (V^-1)[p][c] R_c with the Vandermonde matrix V[c][p] = t_c^p -- a host-side inversion
+    // of a (degree - 1)^2 matrix and one linear combination per piece.  5 of 8 cosets at the reference's degree 6: 3/8 of evaluate_h's
+    // transforms and kernels gone, no transform over the extended domain at all, same bytes (the quotient is unique).
+    uint64_t* h_coeffs = h_ext + 4ull * pk->n_pieces * n;
     {
         Timer t(ctx, slot(GL355_PLONK_STAGE_QUOTIENT_COMMIT));
-        // extended_to_coeff: inverse transform over the extended domain, coefficient i divided by zeta^i (and by the domain size)
-        const uint64_t zi_w[4] = {0x8b17ea66b99c90ddull, 0x5bfc41088d8daaa7ull, 0xb3c4d79d41a91758ull, 0x0ull};                      // zeta^-1 = zeta^2
-        uint64_t ninv[4];
-        Fr::from_u64(N).inv().to_words(ninv);
-        uint64_t* post = nullptr;
-        GL355_TRY(D((size_t)pk->n_pieces * n * 32, &post));
-        GL355_TRY(bn254_fr_power_table(ctx, zi_w, ninv, (uint64_t)pk->n_pieces * n, post));
-        // (h_ext is in bit-reversed order: decimation in time without a gather, in place; its first n_pieces n entries are the coefficients)
-        GL355_TRY(bn254_fr_ntt_mont_from_bitrev(ctx, h_ext, h_ext, (uint64_t)pk->n_pieces * n, pk->ext_k, pk->tw_ext_inv, post, nullptr));
+        const uint32_t P = pk->n_pieces;
+        const Fr ext_omega = Fr::root_of_unity(pk->ext_k), n_inv = Fr::from_u64(n).inv();
+        std::vector<Fr> tc(P);
+        Fr base = plonk_zeta();
+        for (uint32_t c = 0; c < P; c++) {
+            // R_c: values on g_c H in bit-reversed order -> coefficients: inverse transform (no gather), coefficient i times g_c^-i / n
+            uint64_t bw[4], fw[4];
+            base.inv().to_words(bw);
+            n_inv.to_words(fw);
+            GL355_TRY(bn254_fr_power_table(ctx, bw, fw, n, pre));
+            GL355_TRY(bn254_fr_ntt_mont_from_bitrev(ctx, h_ext + 4ull * c * n, h_ext + 4ull * c * n, n, pk->k, pk->tw_inv, pre, nullptr));
+            tc[c] = base.pow_u64(n);
+            base = base * ext_omega;
+        }
+        // V^-1 by Gauss-Jordan over Fr (P <= 9)
+        std::vector<std::vector<Fr>> M(P, std::vector<Fr>(2 * P, Fr::zero()));
+        for (uint32_t c = 0; c < P; c++) {
+            Fr pw = Fr::one();
+            for (uint32_t q = 0; q < P; q++) { M[c][q] = pw; pw = pw * tc[c]; }
+            M[c][P + c] = Fr::one();
+        }
+        for (uint32_t col = 0; col < P; col++) {
+            uint32_t piv = col;
+            while (piv < P && M[piv][col].is_zero()) piv++;
+            if (piv == P) return ctx->fail(GL355_E_HIP, "plonk_prove: singular coset matrix (internal)");
+            std::swap(M[piv], M[col]);
+            const Fr inv = M[col][col].inv();
+            for (uint32_t j = 0; j < 2 * P; j++) M[col][j] = M[col][j] * inv;
+            for (uint32_t r = 0; r < P; r++) {
+                if (r == col || M[r][col].is_zero()) continue;
+                const Fr f = M[r][col];
+                for (uint32_t j = 0; j < 2 * P; j++) M[r][j] = M[r][j] - f * M[col][j];
+            }
+        }
+        std::vector<const uint64_t*> rs;
+        for (uint32_t c = 0; c < P; c++) rs.push_back(h_ext + 4ull * c * n);
+        for (uint32_t q = 0; q < P; q++) {
+            std::vector<Fr> cs(P);
+            for (uint32_t c = 0; c < P; c++) cs[c] = M[q][P + c];          // (V^-1)[q][c]
+            GL355_TRY(lincomb(pk, rs, cs, {}, nullptr, h_coeffs + 4ull * q * n));
+        }
         std::vector<uint64_t> pts(8ull * pk->n_pieces);
         GL355_TRY(commit_columns(pk, pk->g, h_coeffs, pk->n_pieces, pts.data()));
         for (uint32_t i = 0; i < pk->n_pieces; i++) tr.write_point(pts.data() + 8 * i);
