@@ -1174,7 +1174,18 @@ int32_t gl355_bn254_fr_coset_ntt(gl355_ctx* h, const uint64_t* in, uint32_t log_
     return so.finish();
 }
 
+}  // extern "C"
+namespace gl355 {
+// max_bits: every scalar of the call is below 2^max_bits (256: no promise).  Windows above that hold only zero digits: they are not built,
+// sorted or reduced (range-check columns are 16-bit values, the arithmetic chip's operands 64-bit: 2 and 5 windows of 20 bits instead of 13)
+int32_t bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t m, uint32_t max_bits, uint64_t* result);
+}
+extern "C" {
 static int32_t msm_run(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t m, uint64_t* result) {
+    return bn254_msm_bits(h, points, scalars, n, m, 256, result);
+}
+}  // extern "C"
+int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t m, uint32_t max_bits, uint64_t* result) {
     Ctx* ctx = ctx_of(h);
     if (!ctx) return GL355_E_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
@@ -1202,6 +1213,7 @@ static int32_t msm_run(gl355_ctx* h, const uint64_t* points, const uint64_t* sca
     if (c_force >= 4 && c_force <= 24) a.c = c_force;
     a.cb = a.c - 1;
     a.wps = 256 / a.c + 1;                                       // signed digits: the carry out of bit 255 needs a window of its own
+    if (max_bits < 256) a.wps = std::min(a.wps, (std::max(1u, max_bits) + a.c - 1) / a.c + 1);
     a.n_sets = m;
     a.n_windows = a.wps * m;
     const uint64_t nb = 1ull << a.cb, W = a.n_windows;
@@ -1314,6 +1326,7 @@ static int32_t msm_run(gl355_ctx* h, const uint64_t* points, const uint64_t* sca
     return GL355_OK;
 }
 
+extern "C" {
 int32_t gl355_bn254_g1_msm(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint64_t result[8]) {
     return msm_run(h, points, scalars, n, 1, result);
 }

@@ -109,19 +109,37 @@ int32_t lagrange_to_coeff(gl355_plonk_pk* pk, const uint64_t* vals, uint64_t* co
     return bn254_fr_ntt_mont(pk->ctx, vals, pk->n, coeffs, pk->n, pk->k, pk->tw_inv, nullptr, nullptr, ninv, work);
 }
 
-// commitments of `sets` columns (Montgomery scalars, [sets][n]) over n bases: plain copies of the scalars, then the batched MSM
+// commitments of `sets` columns (Montgomery scalars, [sets][n]) over n bases: plain copies of the scalars, their bit lengths (one OR
+// reduction per column), then batched MSMs over runs of neighbouring columns of the same length class -- windows above a column's bit
+// length are never built (range-check columns hold 16-bit values, the arithmetic chip's operands 64-bit ones)
 int32_t commit_columns(gl355_plonk_pk* pk, const uint64_t* bases, const uint64_t* cols_mont, uint32_t sets, uint64_t* out_host /* sets x 8 */) {
     Ctx* ctx = pk->ctx;
     const uint64_t n = pk->n;
-    // <= 2^27 scalars and <= 64 sets per batched MSM (bn254_curve.hip); 8 sets keep its sort scratch modest at k = 23
-    const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, (1ull << 27) / n));
+    if (!sets) return GL355_OK;
+    // <= 2^27 scalars and <= 64 sets per batched MSM (bn254_curve.hip)
+    const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, (1ull << 27) / n));
     Scratch plain(ctx);
-    GL355_TRY(plain.get((size_t)per * n * 32));
-    for (uint32_t s0 = 0; s0 < sets; s0 += per) {
-        const uint32_t m = std::min(per, sets - s0);
-        hipLaunchKernelGGL(plk_from_mont_kernel, dim3(blocks((uint64_t)m * n)), dim3(256), 0, ctx->stream, cols_mont + 4 * (uint64_t)s0 * n, plain.as<uint64_t>(), (uint64_t)m * n);
-        GL355_HIP(ctx, hipGetLastError());
-        GL355_TRY(gl355_bn254_g1_msm_batch(pk->handle, bases, plain.as<uint64_t>(), n, m, out_host + 8ull * s0));
+    GL355_TRY(plain.get((size_t)sets * n * 32 + (size_t)sets * 32));
+    uint64_t* d_plain = plain.as<uint64_t>();
+    unsigned long long* d_or = reinterpret_cast<unsigned long long*>(d_plain + 4ull * sets * n);
+    GL355_HIP(ctx, hipMemsetAsync(d_or, 0, (size_t)sets * 32, ctx->stream));
+    hipLaunchKernelGGL(plk_from_mont_kernel, dim3(blocks((uint64_t)sets * n)), dim3(256), 0, ctx->stream, cols_mont, d_plain, (uint64_t)sets * n);
+    hipLaunchKernelGGL(plk_column_or_kernel, dim3(blocks(n), sets), dim3(256), 0, ctx->stream, (const uint64_t*)d_plain, n, d_or);
+    GL355_HIP(ctx, hipGetLastError());
+    std::vector<unsigned long long> ors(4ull * sets);
+    GL355_HIP(ctx, ctx->d2h(ors.data(), d_or, (size_t)sets * 32));
+    GL355_HIP(ctx, ctx->wait());
+    std::vector<uint32_t> cls(sets);
+    for (uint32_t s = 0; s < sets; s++) {
+        uint32_t bits = 0;
+        for (int l = 3; l >= 0 && !bits; l--) if (ors[4 * s + l]) bits = 64 * l + 64 - (uint32_t)__builtin_clzll(ors[4 * s + l]);
+        cls[s] = (std::max(1u, bits) + 19) / 20;                 // classes of 20 bits (the MSM's windows are 17 .. 20 bits wide)
+    }
+    for (uint32_t s0 = 0; s0 < sets;) {
+        uint32_t m = 1;
+        while (s0 + m < sets && m < per && cls[s0 + m] == cls[s0]) m++;
+        GL355_TRY(bn254_msm_bits(pk->handle, bases, d_plain + 4ull * s0 * n, n, m, std::min(256u, 20 * cls[s0]), out_host + 8ull * s0));
+        s0 += m;
     }
     return GL355_OK;
 }
@@ -136,6 +154,19 @@ int32_t run_program(gl355_plonk_pk* pk, const uint32_t* d_code, uint32_t n_instr
     hipLaunchKernelGGL(plk_eval_kernel, dim3(blocks(pk->n)), dim3(256), 0, pk->ctx->stream, a);
     GL355_HIP(pk->ctx, hipGetLastError());
     return GL355_OK;
+}
+
+// a lookup expression list that is one column at the current rotation (the reference's nine range checks, arithmetic_chip.rs:140-151):
+// the "compressed" column is the column itself, no program run, no copy.  -> (kind, column) or kind = 3
+std::pair<uint32_t, uint32_t> single_query(const gl355_plonk_pk* pk, const std::vector<uint32_t>& code) {
+    if (code.size() == 4 && code[0] == PLK_OP_EMIT) {
+        const uint32_t kind = code[2] >> 24, idx = code[2] & 0xFFFFFFu;
+        if (kind >= PLK_K_ADVICE && kind <= PLK_K_INSTANCE) {
+            const auto& q = pk->queries[kind - PLK_K_ADVICE][idx];
+            if (q.second == 0) return {kind - PLK_K_ADVICE, (uint32_t)q.first};
+        }
+    }
+    return {3u, 0u};
 }
 
 // z[0] = *start, z[i] = z[i - 1] r[i - 1]
@@ -677,14 +708,19 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     GL355_TRY(D((size_t)std::max(1u, 2 * L) * n * 32, &lkAp));          // A'_0 S'_0 A'_1 S'_1 ... : one batched commitment
     GL355_TRY(D((size_t)std::max(1u, L) * n * 32, &lkZ));
     GL355_TRY(D((size_t)std::max(1u, 3 * L) * n * 32, &lk_polys));
+    std::vector<const uint64_t*> lk_a_ptr(L), lk_s_ptr(L);         // the compressed input / table columns (values)
+    for (uint32_t l = 0; l < L; l++) { lk_a_ptr[l] = lkA + 4ull * l * n; lk_s_ptr[l] = lkS + 4ull * l * n; }
     {
         Timer t(ctx, slot(GL355_PLONK_STAGE_LOOKUP_PERMUTE));
         for (uint32_t l = 0; l < L; l++) {
-            GL355_TRY(run_program(pk, pk->d_lk_code[2 * l], (uint32_t)(pk->lookups[l].in_code.size() / 4), d_val_cols, theta, nullptr, lkA + 4ull * l * n, false));
-            GL355_TRY(run_program(pk, pk->d_lk_code[2 * l + 1], (uint32_t)(pk->lookups[l].tab_code.size() / 4), d_val_cols, theta, nullptr, lkS + 4ull * l * n, false));
+            const auto qa = single_query(pk, pk->lookups[l].in_code), qs = single_query(pk, pk->lookups[l].tab_code);
+            if (qa.first < 3) lk_a_ptr[l] = col_vals(qa.first, qa.second);
+            else GL355_TRY(run_program(pk, pk->d_lk_code[2 * l], (uint32_t)(pk->lookups[l].in_code.size() / 4), d_val_cols, theta, nullptr, lkA + 4ull * l * n, false));
+            if (qs.first < 3) lk_s_ptr[l] = col_vals(qs.first, qs.second);
+            else GL355_TRY(run_program(pk, pk->d_lk_code[2 * l + 1], (uint32_t)(pk->lookups[l].tab_code.size() / 4), d_val_cols, theta, nullptr, lkS + 4ull * l * n, false));
             uint64_t* Ap = lkAp + 8ull * l * n;
             uint64_t* Sp = Ap + 4 * n;
-            GL355_TRY(permute_pair(ctx, lkA + 4ull * l * n, lkS + 4ull * l * n, u, Ap, Sp));
+            GL355_TRY(permute_pair(ctx, lk_a_ptr[l], lk_s_ptr[l], u, Ap, Sp));
             GL355_TRY(random_rows(ctx, key, PLK_STREAM_LOOKUP_PERMUTED, 2 * l, u, n - u, Ap + 4 * u));
             GL355_TRY(random_rows(ctx, key, PLK_STREAM_LOOKUP_PERMUTED, 2 * l + 1, u, n - u, Sp + 4 * u));
         }
@@ -744,7 +780,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
         Timer t(ctx, slot(GL355_PLONK_STAGE_LOOKUP_PRODUCT));
         for (uint32_t l = 0; l < L; l++) {
             const uint64_t* Ap = lkAp + 8ull * l * n;
-            hipLaunchKernelGGL(plk_lookup_rows_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, (const uint64_t*)(lkA + 4ull * l * n), (const uint64_t*)(lkS + 4ull * l * n), Ap, Ap + 4 * n, n,
+            hipLaunchKernelGGL(plk_lookup_rows_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, lk_a_ptr[l], lk_s_ptr[l], Ap, Ap + 4 * n, n,
                                to_dev(beta), to_dev(gamma), num, den);
             hipLaunchKernelGGL(plk_batch_div_kernel, dim3(blocks((n + PLK_INV_CHUNK - 1) / PLK_INV_CHUNK, 64)), dim3(64), 0, ctx->stream, (const uint64_t*)num, den, ratio, n, d_bad);
             GL355_HIP(ctx, hipGetLastError());
@@ -837,11 +873,13 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
                 GL355_HIP(ctx, hipGetLastError());
             }
             for (uint32_t l = 0; l < L; l++) {
-                GL355_TRY(run_program(pk, pk->d_lk_code[2 * l], (uint32_t)(pk->lookups[l].in_code.size() / 4), d_cos_kind, theta, nullptr, a_in, true));
-                GL355_TRY(run_program(pk, pk->d_lk_code[2 * l + 1], (uint32_t)(pk->lookups[l].tab_code.size() / 4), d_cos_kind, theta, nullptr, s_in, true));
+                const auto qa = single_query(pk, pk->lookups[l].in_code), qs = single_query(pk, pk->lookups[l].tab_code);
+                if (qa.first == 3) GL355_TRY(run_program(pk, pk->d_lk_code[2 * l], (uint32_t)(pk->lookups[l].in_code.size() / 4), d_cos_kind, theta, nullptr, a_in, true));
+                if (qs.first == 3) GL355_TRY(run_program(pk, pk->d_lk_code[2 * l + 1], (uint32_t)(pk->lookups[l].tab_code.size() / 4), d_cos_kind, theta, nullptr, s_in, true));
                 PlkLookupHArgs a;
                 a.n = n; a.log_n = pk->k; a.acc = acc; a.l0 = c_l0; a.l_last = c_ll; a.l_active = c_la;
-                a.ap = dyn(o_lk + 3 * l); a.sp = dyn(o_lk + 3 * l + 1); a.z = dyn(o_lk + 3 * l + 2); a.a_in = a_in; a.s_in = s_in;
+                a.ap = dyn(o_lk + 3 * l); a.sp = dyn(o_lk + 3 * l + 1); a.z = dyn(o_lk + 3 * l + 2);
+                a.a_in = qa.first < 3 ? col_cos(qa.first, qa.second) : a_in; a.s_in = qs.first < 3 ? col_cos(qs.first, qs.second) : s_in;
                 a.y = to_dev(y); a.beta = to_dev(beta); a.gamma = to_dev(gamma);
                 hipLaunchKernelGGL(plk_lookup_h_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, a);
                 GL355_HIP(ctx, hipGetLastError());

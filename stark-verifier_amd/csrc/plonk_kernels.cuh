@@ -328,6 +328,22 @@ __global__ void plk_limb_or_kernel(const uint64_t* v, uint64_t n, unsigned long 
     for (int o = 32; o; o >>= 1) { l1 |= __shfl_xor(l1, o); l2 |= __shfl_xor(l2, o); l3 |= __shfl_xor(l3, o); }
     if (__lane_id() == 0) { if (l1) atomicOr(out4 + 1, l1); if (l2) atomicOr(out4 + 2, l2); if (l3) atomicOr(out4 + 3, l3); }
 }
+// per column (blockIdx.y) the OR of every scalar's four limbs: the column's bit length
+__global__ void plk_column_or_kernel(const uint64_t* v, uint64_t n, unsigned long long* out /* [columns][4] */) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t* col = v + 4 * (uint64_t)blockIdx.y * n;
+    uint64_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    if (i < n) { l0 = col[4 * i]; l1 = col[4 * i + 1]; l2 = col[4 * i + 2]; l3 = col[4 * i + 3]; }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { l0 |= __shfl_xor(l0, o); l1 |= __shfl_xor(l1, o); l2 |= __shfl_xor(l2, o); l3 |= __shfl_xor(l3, o); }
+    if (__lane_id() == 0) {
+        unsigned long long* d = out + 4 * blockIdx.y;
+        if (l0) atomicOr(d, l0);
+        if (l1) atomicOr(d + 1, l1);
+        if (l2) atomicOr(d + 2, l2);
+        if (l3) atomicOr(d + 3, l3);
+    }
+}
 __global__ void plk_iota_kernel(uint32_t* idx, uint64_t n) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i < n) idx[i] = (uint32_t)i;
