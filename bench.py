@@ -671,6 +671,25 @@ def bn254_figures(gl, device):
     return out
 
 
+def halo2_figure(gl, device, k=23):
+    """SURVEY 8(f) N4 at the reference's size: halo2's create_proof (SHPLONK, Keccak256 transcript; chip/native_chip/test_utils.rs:57-95) over a
+    synthetic 2^23-row circuit with the reference's column / gate / lookup shape (tools/halo2_bench.py, stark-verifier_amd/halo2_chips.py), the
+    witness resident, per-stage wall milliseconds, the proof checked by the restated verifier (tests/halo2_verifier.py: a checker, not measured)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import halo2_bench
+    ctx = gl.Context(device)
+    try:
+        out = halo2_bench.run(gl, ctx, int(os.environ.get("GL355_BENCH_HALO2_K", k)))
+    finally:
+        ctx.close()
+    out["what"] = ("gl355_plonk_prove: advice commitments, lookup permutation, permutation / lookup grand products, evaluate_h on degree - 1 cosets, "
+                   "quotient pieces, evaluations, SHPLONK multi-open; witness synthesis and the Halo2 verifier circuit itself out of scope")
+    out["reference"] = "README.md:171-177: 505-511 s (Halo2 finalisation proof, k = 23, AWS r5.4xlarge, 16 vCPU)"
+    out["speedup_vs_readme_505s"] = round(505.0 / out["create_proof_s"], 1) if out.get("create_proof_s") else None
+    return out
+
+
 def thread_cpu_snapshot():
     """{tid: (comm, cpu seconds)} of the process's live threads (diagnostic: which threads burn host CPU; GL355_BENCH_THREAD_CPU=1)"""
     out = {}
@@ -1026,6 +1045,10 @@ def main_recursive(args):
                 line["bn254_finalisation_kernels"] = bn254_figures(gl, local_rank)
             except Exception as exc:
                 line["bn254_finalisation_kernels"] = {"error": repr(exc)}
+            try:
+                line["halo2_create_proof_k23"] = halo2_figure(gl, local_rank)
+            except Exception as exc:
+                line["halo2_create_proof_k23"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     if comm is not None:
         comm.barrier()

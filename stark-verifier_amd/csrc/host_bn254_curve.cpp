@@ -127,4 +127,25 @@ void bn254_g1_horner_host(const uint32_t* s, const uint32_t* wt, uint32_t n_wind
     memcpy(result + 4, y.l, 32);
 }
 
+// out = a + b for affine points as canonical integers (x | y, zeros = the identity): the host end of a commitment made in two parts
+void bn254_g1_add_host(const uint64_t a[8], const uint64_t b[8], uint64_t out[8]) {
+    auto lift = [](const uint64_t p[8]) {
+        Jac r;
+        bool ident = true;
+        for (int i = 0; i < 8; i++) ident = ident && p[i] == 0;
+        if (ident) { r.x = fq_one(); r.y = r.x; memset(r.z.l, 0, 32); return r; }
+        Fq x, y, r2;
+        memcpy(x.l, p, 32); memcpy(y.l, p + 4, 32); memcpy(r2.l, BN254C_FQ_R2_64, 32);
+        r.x = fq_mul(fq_canon(x), r2); r.y = fq_mul(fq_canon(y), r2); r.z = fq_one();
+        return r;
+    };
+    const Jac r = j_add(lift(a), lift(b));
+    if (j_is_identity(r)) { memset(out, 0, 64); return; }
+    const Fq zi = fq_inv(r.z), zi2 = fq_mul(zi, zi);
+    Fq one_int; memset(one_int.l, 0, 32); one_int.l[0] = 1;
+    const Fq x = fq_mul(fq_mul(r.x, zi2), one_int), y = fq_mul(fq_mul(r.y, fq_mul(zi2, zi)), one_int);
+    memcpy(out, x.l, 32);
+    memcpy(out + 4, y.l, 32);
+}
+
 }  // namespace gl355

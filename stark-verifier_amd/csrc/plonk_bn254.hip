@@ -32,6 +32,8 @@
 
 using namespace gl355;
 
+namespace gl355 { void bn254_g1_add_host(const uint64_t a[8], const uint64_t b[8], uint64_t out[8]); }      // host_bn254_curve.cpp
+
 namespace {
 
 constexpr uint64_t PLK_MAGIC = 0x4B4C503535334C47ull;       // "GL355PLK"
@@ -111,20 +113,25 @@ int32_t lagrange_to_coeff(gl355_plonk_pk* pk, const uint64_t* vals, uint64_t* co
 
 // commitments of `sets` columns (Montgomery scalars, [sets][n]) over n bases: plain copies of the scalars, their bit lengths (one OR
 // reduction per column), then batched MSMs over runs of neighbouring columns of the same length class -- windows above a column's bit
-// length are never built (range-check columns hold 16-bit values, the arithmetic chip's operands 64-bit ones)
-int32_t commit_columns(gl355_plonk_pk* pk, const uint64_t* bases, const uint64_t* cols_mont, uint32_t sets, uint64_t* out_host /* sets x 8 */) {
+// length are never built (range-check columns hold 16-bit values, the arithmetic chip's operands 64-bit ones, selectors 0 / 1).  Rows >= tail
+// (the blinding rows: full-size random scalars in every column) are committed by a second MSM over those few bases and added on the host.
+int32_t commit_columns(gl355_plonk_pk* pk, const uint64_t* bases, const uint64_t* cols_mont, uint32_t sets, uint64_t* out_host /* sets x 8 */, uint64_t tail = ~0ull) {
     Ctx* ctx = pk->ctx;
     const uint64_t n = pk->n;
     if (!sets) return GL355_OK;
+    tail = std::min(tail, n);
+    const uint64_t nt = n - tail;
     // <= 2^27 scalars and <= 64 sets per batched MSM (bn254_curve.hip)
     const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, (1ull << 27) / n));
     Scratch plain(ctx);
-    GL355_TRY(plain.get((size_t)sets * n * 32 + (size_t)sets * 32));
+    GL355_TRY(plain.get((size_t)sets * n * 32 + (size_t)sets * nt * 32 + (size_t)sets * 32));
     uint64_t* d_plain = plain.as<uint64_t>();
-    unsigned long long* d_or = reinterpret_cast<unsigned long long*>(d_plain + 4ull * sets * n);
+    uint64_t* d_tail = d_plain + 4ull * sets * n;
+    unsigned long long* d_or = reinterpret_cast<unsigned long long*>(d_tail + 4ull * sets * nt);
     GL355_HIP(ctx, hipMemsetAsync(d_or, 0, (size_t)sets * 32, ctx->stream));
-    hipLaunchKernelGGL(plk_from_mont_kernel, dim3(blocks((uint64_t)sets * n)), dim3(256), 0, ctx->stream, cols_mont, d_plain, (uint64_t)sets * n);
-    hipLaunchKernelGGL(plk_column_or_kernel, dim3(blocks(n), sets), dim3(256), 0, ctx->stream, (const uint64_t*)d_plain, n, d_or);
+    hipLaunchKernelGGL(plk_from_mont_body_kernel, dim3(blocks((uint64_t)sets * n)), dim3(256), 0, ctx->stream, cols_mont, d_plain, n, tail, (uint64_t)sets * n);
+    if (nt) hipLaunchKernelGGL(plk_from_mont_tail_kernel, dim3(blocks((uint64_t)sets * nt)), dim3(256), 0, ctx->stream, cols_mont, d_tail, n, tail, sets);
+    hipLaunchKernelGGL(plk_column_or_kernel, dim3((uint32_t)std::min<uint64_t>(256, blocks(n)), sets), dim3(256), 0, ctx->stream, (const uint64_t*)d_plain, n, d_or);
     GL355_HIP(ctx, hipGetLastError());
     std::vector<unsigned long long> ors(4ull * sets);
     GL355_HIP(ctx, ctx->d2h(ors.data(), d_or, (size_t)sets * 32));
@@ -140,6 +147,14 @@ int32_t commit_columns(gl355_plonk_pk* pk, const uint64_t* bases, const uint64_t
         while (s0 + m < sets && m < per && cls[s0 + m] == cls[s0]) m++;
         GL355_TRY(bn254_msm_bits(pk->handle, bases, d_plain + 4ull * s0 * n, n, m, std::min(256u, 20 * cls[s0]), out_host + 8ull * s0));
         s0 += m;
+    }
+    if (nt) {
+        std::vector<uint64_t> tails(8ull * sets);
+        for (uint32_t s0 = 0; s0 < sets; s0 += 64) {
+            const uint32_t m = std::min(64u, sets - s0);
+            GL355_TRY(bn254_msm_bits(pk->handle, bases + 8 * tail, d_tail + 4ull * s0 * nt, nt, m, 256, tails.data() + 8ull * s0));
+        }
+        for (uint32_t s = 0; s < sets; s++) bn254_g1_add_host(out_host + 8ull * s, tails.data() + 8ull * s, out_host + 8ull * s);
     }
     return GL355_OK;
 }
@@ -680,7 +695,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
         }
         for (uint32_t c = 0; c < pk->n_advice; c++) GL355_TRY(random_rows(ctx, key, PLK_STREAM_ADVICE, c, u, n - u, adv_vals + 4 * ((uint64_t)c * n + u)));
         std::vector<uint64_t> pts(8ull * pk->n_advice);
-        GL355_TRY(commit_columns(pk, pk->g_lagrange, adv_vals, pk->n_advice, pts.data()));
+        GL355_TRY(commit_columns(pk, pk->g_lagrange, adv_vals, pk->n_advice, pts.data(), u));
         for (uint32_t c = 0; c < pk->n_advice; c++) tr.write_point(pts.data() + 8 * c);
         for (uint32_t c = 0; c < pk->n_advice; c++) GL355_TRY(lagrange_to_coeff(pk, adv_vals + 4ull * c * n, adv_polys + 4ull * c * n, work));
     }
@@ -725,7 +740,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
             GL355_TRY(random_rows(ctx, key, PLK_STREAM_LOOKUP_PERMUTED, 2 * l + 1, u, n - u, Sp + 4 * u));
         }
         std::vector<uint64_t> pts(16ull * L);
-        GL355_TRY(commit_columns(pk, pk->g_lagrange, lkAp, 2 * L, pts.data()));
+        GL355_TRY(commit_columns(pk, pk->g_lagrange, lkAp, 2 * L, pts.data(), u));
         for (uint32_t l = 0; l < 2 * L; l++) tr.write_point(pts.data() + 8 * l);
         for (uint32_t l = 0; l < L; l++) {
             GL355_TRY(lagrange_to_coeff(pk, lkAp + 8ull * l * n, lk_polys + 12ull * l * n, work));

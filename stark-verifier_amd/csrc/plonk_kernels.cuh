@@ -328,20 +328,38 @@ __global__ void plk_limb_or_kernel(const uint64_t* v, uint64_t n, unsigned long 
     for (int o = 32; o; o >>= 1) { l1 |= __shfl_xor(l1, o); l2 |= __shfl_xor(l2, o); l3 |= __shfl_xor(l3, o); }
     if (__lane_id() == 0) { if (l1) atomicOr(out4 + 1, l1); if (l2) atomicOr(out4 + 2, l2); if (l3) atomicOr(out4 + 3, l3); }
 }
-// per column (blockIdx.y) the OR of every scalar's four limbs: the column's bit length
-__global__ void plk_column_or_kernel(const uint64_t* v, uint64_t n, unsigned long long* out /* [columns][4] */) {
-    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+// Montgomery -> plain copies of `cols` columns of n scalars with the rows >= tail zeroed (blinding rows are full-size random scalars: they
+// are committed by a second, tiny MSM so that the body keeps its short bit length)
+__global__ void plk_from_mont_body_kernel(const uint64_t* in, uint64_t* out, uint64_t n, uint64_t tail, uint64_t total) {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint64_t row = t % n;
+    store256(out + 4 * t, row < tail ? m_to_int<F_R>(load256(in + 4 * t)) : u_zero());
+}
+// the tails: out[c][r] = plain(in[c][tail + r]), r < n - tail
+__global__ void plk_from_mont_tail_kernel(const uint64_t* in, uint64_t* out, uint64_t n, uint64_t tail, uint32_t cols) {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, nt = n - tail;
+    if (t >= nt * cols) return;
+    const uint64_t c = t / nt, r = t % nt;
+    store256(out + 4 * t, m_to_int<F_R>(load256(in + 4 * (c * n + tail + r))));
+}
+// per column (blockIdx.y) the OR of every scalar's four limbs: the column's bit length.  A few hundred blocks per column stride over it and
+// issue one atomic each (one atomic per wave on the same four words serialised 131 072 of them: 14 ms per call at k = 23)
+__global__ void __launch_bounds__(256) plk_column_or_kernel(const uint64_t* v, uint64_t n, unsigned long long* out /* [columns][4] */) {
+    __shared__ unsigned long long sh[4][4];
     const uint64_t* col = v + 4 * (uint64_t)blockIdx.y * n;
     uint64_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-    if (i < n) { l0 = col[4 * i]; l1 = col[4 * i + 1]; l2 = col[4 * i + 2]; l3 = col[4 * i + 3]; }
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        l0 |= col[4 * i]; l1 |= col[4 * i + 1]; l2 |= col[4 * i + 2]; l3 |= col[4 * i + 3];
+    }
 #pragma unroll
     for (int o = 32; o; o >>= 1) { l0 |= __shfl_xor(l0, o); l1 |= __shfl_xor(l1, o); l2 |= __shfl_xor(l2, o); l3 |= __shfl_xor(l3, o); }
-    if (__lane_id() == 0) {
-        unsigned long long* d = out + 4 * blockIdx.y;
-        if (l0) atomicOr(d, l0);
-        if (l1) atomicOr(d + 1, l1);
-        if (l2) atomicOr(d + 2, l2);
-        if (l3) atomicOr(d + 3, l3);
+    const uint32_t wave = threadIdx.x >> 6;
+    if (__lane_id() == 0) { sh[wave][0] = l0; sh[wave][1] = l1; sh[wave][2] = l2; sh[wave][3] = l3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const unsigned long long o = sh[0][threadIdx.x] | sh[1][threadIdx.x] | sh[2][threadIdx.x] | sh[3][threadIdx.x];
+        if (o) atomicOr(out + 4 * blockIdx.y + threadIdx.x, o);
     }
 }
 __global__ void plk_iota_kernel(uint32_t* idx, uint64_t n) {
