@@ -671,6 +671,80 @@ def bn254_figures(gl, device):
     return out
 
 
+def aggregate_figure(gl, device, n_ctx=8, log_members=20, sizes=(2, 4, 8, 16, 32, 64, 128)):
+    """The reference's own benchmark flow (README.md:167-177, recursion.rs:285-346 `semaphore_aggregation`): N depth-20 Semaphore signals ->
+    pairwise aggregation tree of recursive proofs (recursion.rs:187-247) -> final wrap under the BN254-Poseidon config (wrapper.rs:35-56), each
+    stage ONE native call (gl355_semaphore_units, gl355_aggregate_units, gl355_circuit_prove_tape).  The level circuits are built once by the
+    Python builder (the reference rebuilds them inside every aggregate_signals call), persisted as artifacts, and the timed runs start from the
+    artifacts: `cold` = a fresh process state loading them from disk, `warm` = loaded."""
+    import shutil
+    import tempfile
+    sem = importlib.import_module("stark-verifier_amd.semaphore")
+    rec = importlib.import_module("stark-verifier_amd.recursion")
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    ctxs = [gl.Context(device) for _ in range(n_ctx)]
+    ctx = ctxs[0]
+    tmp = tempfile.mkdtemp(prefix="gl355_agg_")
+    try:
+        rng = np.random.default_rng(0x357)
+        sks = gl.api.rand_field(rng, (1 << log_members, 4))
+        keys = ctx.hash_no_pad(np.concatenate([sks, np.zeros_like(sks)], axis=1))
+        aset = sem.AccessSet(ctx, keys)
+        topic = gl.api.rand_field(rng, 4)
+        data, rows = aset.build(rng)
+        idx, _, _ = aset.witness_rows(rows, sks[0], topic, 0)
+        semc = plonk.NativeCircuit(ctx, data.export_blob(idx))
+        n_max = max(sizes)
+
+        def signals(n, first):
+            leaves, proofs, _ = plonk.semaphore_units(ctxs, semc, None, sks, topic, aset.tree.digests, np.arange(first, first + n, dtype=np.uint64), 7000, want_proofs=True)
+            return [(proofs[j], np.concatenate([aset.tree.cap[0], leaves[j]])) for j in range(n)]
+        t0 = time.perf_counter()
+        agg = rec.Aggregator(ctx, data.common())
+        sig = signals(n_max, 0)
+        proof, pis, cd = agg.aggregate(sig, seed=100, rng=rng, ctxs=ctxs)               # builds one circuit per level
+        wrap = rec.WrapperCircuit(ctx, cd).build([(proof, pis)], rng)
+        t_build = time.perf_counter() - t0
+        agg.save(tmp)
+        artifact_mb = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp)) / 1e6
+        out = {"what": "N depth-20 signals -> aggregation tree (N - 1 recursive proofs) -> BN254-Poseidon wrap; seconds on one MI355X, %d prover contexts; "
+                       "reference README.md:167-177 (AWS r5.4xlarge, 16 vCPU; its times include rebuilding every circuit)" % n_ctx,
+               "one_off_circuit_build_s": round(t_build, 2), "artifacts_MB": round(artifact_mb, 1), "level_degree_bits": [l.data.degree_bits for l in agg.levels],
+               "readme_s": {"2": 11, "4": 29, "8": 64, "16": 128, "32": 235, "64": 468, "128": 930}, "runs": {}}
+        # cold: artifacts from disk into a fresh Aggregator, then the largest tree
+        t0 = time.perf_counter()
+        agg2 = rec.Aggregator.load(ctx, tmp)
+        t_load = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sig = signals(n_max, 1000)
+        t_sig = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        p2, pi2, _ = agg2.aggregate_native(sig, seed=101, ctxs=ctxs)
+        t_tree = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        wrap.native().prove_tape(ctx, np.concatenate([p2, pi2]), 9)
+        t_wrap = time.perf_counter() - t0
+        out["cold_%d" % n_max] = {"artifact_load_s": round(t_load, 3), "signals_s": round(t_sig, 3), "tree_s": round(t_tree, 3), "wrap_s": round(t_wrap, 3),
+                                   "total_s": round(t_load + t_sig + t_tree + t_wrap, 3)}
+        for n in sizes:
+            t0 = time.perf_counter()
+            sig = signals(n, 2000)
+            t1 = time.perf_counter()
+            p2, pi2, _, ms = agg2.aggregate_native(sig, seed=102, ctxs=ctxs, timed=True)
+            t2 = time.perf_counter()
+            out["runs"][str(n)] = {"signals_s": round(t1 - t0, 3), "tree_s": round(t2 - t1, 3), "total_s": round(t2 - t0, 3), "level_ms": [round(v, 1) for v in ms]}
+        t0 = time.perf_counter()
+        wflat, wpis = wrap.native().prove_tape(ctx, np.concatenate([p2, pi2]), 10)
+        out["runs"][str(n_max)]["wrap_s"] = round(time.perf_counter() - t0, 3)
+        out["runs"][str(n_max)]["total_with_wrap_s"] = round(out["runs"][str(n_max)]["total_s"] + out["runs"][str(n_max)]["wrap_s"], 3)
+        assert np.array_equal(wpis[:4], aset.tree.cap[0]) and wpis.size == 4 + 8 * n_max
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+        for c in ctxs:
+            c.close()
+
+
 def halo2_figure(gl, device, k=23):
     """SURVEY 8(f) N4 at the reference's size: halo2's create_proof (SHPLONK, Keccak256 transcript; chip/native_chip/test_utils.rs:57-95) over a
     synthetic 2^23-row circuit with the reference's column / gate / lookup shape (tools/halo2_bench.py, stark-verifier_amd/halo2_chips.py), the
@@ -1045,6 +1119,11 @@ def main_recursive(args):
                 line["bn254_finalisation_kernels"] = bn254_figures(gl, local_rank)
             except Exception as exc:
                 line["bn254_finalisation_kernels"] = {"error": repr(exc)}
+            try:
+                if os.environ.get("GL355_BENCH_NO_AGGREGATE") != "1":
+                    line["aggregate"] = aggregate_figure(gl, local_rank)
+            except Exception as exc:
+                line["aggregate"] = {"error": repr(exc)}
             try:
                 line["halo2_create_proof_k23"] = halo2_figure(gl, local_rank)
             except Exception as exc:

@@ -66,6 +66,7 @@ SIGNATURES = {
     "gl355_last_error": (C.c_char_p, [vp]),
     "gl355_version": (C.c_char_p, []),
     "gl355_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
+    "gl355_aggregate_units": (C.c_int32, [vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint32, vp]),
     "gl355_keccak256": (C.c_int32, [vp, C.c_uint64, vp]),
     "gl355_kzg_commit_columns": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "gl355_plonk_keygen": (C.c_int32, [vp, vp, C.c_uint64, vp, vp, vp, vp, C.POINTER(vp)]),

@@ -198,3 +198,91 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
     for (auto& th : pool) th.join();
     return first_error.load();
 }
+
+// recursion.rs:187-247 `aggregate` as one native call: the binary aggregation tree over n_leaves = 2^n_levels proofs of one circuit.
+// levels[l] is the circuit that verifies two proofs of tree level l (level 0 = the leaves, e.g. Semaphore signals) -- one artifact per
+// level, loaded once with gl355_circuit_load (the reference rebuilds the circuit inside every aggregate_signals call,
+// recursion.rs:25-185).  The nodes of a level are independent (`par_chunks_exact(2)`, recursion.rs:211-227): every context takes the nodes
+// t, t + n_ctx, ... and proves them in lock-step batches (gl355_circuit_prove_tape_units); levels are separated by a join.  Node j of level l
+// has the blinding key gl355_derive_key(key_base, key_domain << 48 | l << 32 | j) (NULL key_base: fresh OS randomness per proof), so the
+// result does not depend on the number of contexts or on the batch size.
+extern "C" int32_t gl355_aggregate_units(gl355_ctx* const* ctxs, uint32_t n_ctx, const gl355_circuit_handle* const* levels, uint32_t n_levels,
+                                         const uint64_t* leaf_proofs, const uint64_t* leaf_public_inputs, uint32_t n_leaves, uint64_t leaf_words, uint32_t leaf_n_pi,
+                                         const uint8_t* key_base, uint64_t key_domain, uint64_t* proof_out, uint64_t proof_capacity_words,
+                                         uint64_t* public_inputs_out, uint32_t public_inputs_capacity, double* level_ms) {
+    if (!ctxs || n_ctx == 0 || !levels || n_levels == 0 || n_levels > 30 || !leaf_proofs || !leaf_public_inputs || !proof_out || !public_inputs_out) return GL355_E_INVALID_ARG;
+    for (uint32_t t = 0; t < n_ctx; t++)
+        if (!ctxs[t]) return GL355_E_INVALID_ARG;
+    Ctx* c0 = ctx_of(ctxs[0]);
+    if (n_leaves != (1u << n_levels)) return c0->fail(GL355_E_INVALID_ARG, "aggregate_units: 2^levels leaves expected");
+    // shapes: level l takes two proofs of level l - 1
+    std::vector<uint64_t> words(n_levels + 1), n_pi(n_levels + 1);
+    words[0] = leaf_words; n_pi[0] = leaf_n_pi;
+    for (uint32_t l = 0; l < n_levels; l++) {
+        if (!levels[l]) return c0->fail(GL355_E_INVALID_ARG, "aggregate_units: null level circuit");
+        uint64_t w = 0, inputs = 0;
+        uint32_t pi = 0;
+        GL355_TRY(gl355_circuit_info(levels[l], &w, &pi, nullptr, &inputs, nullptr));
+        if (inputs != 2 * (words[l] + n_pi[l])) return c0->fail(GL355_E_INVALID_ARG, "aggregate_units: a level circuit does not take two proofs of the level below");
+        words[l + 1] = w; n_pi[l + 1] = pi;
+    }
+    if (words[n_levels] > proof_capacity_words || n_pi[n_levels] > public_inputs_capacity) return c0->fail(GL355_E_INVALID_ARG, "aggregate_units: output buffers too small");
+    std::vector<uint64_t> cur_p(leaf_proofs, leaf_proofs + (size_t)n_leaves * leaf_words), cur_pi(leaf_public_inputs, leaf_public_inputs + (size_t)n_leaves * leaf_n_pi);
+    std::vector<uint64_t> nxt_p, nxt_pi;
+    uint32_t n_nodes = n_leaves;
+    for (uint32_t l = 0; l < n_levels; l++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        n_nodes >>= 1;
+        const uint64_t wi = words[l], pii = n_pi[l], wo = words[l + 1], pio = n_pi[l + 1], n_in = 2 * (wi + pii);
+        nxt_p.assign((size_t)n_nodes * wo, 0);
+        nxt_pi.assign((size_t)n_nodes * pio, 0);
+        const uint32_t workers = std::min(n_ctx, n_nodes);
+        const uint32_t units = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(8, GL355_MAX_UNITS), (n_nodes + workers - 1) / workers));
+        std::atomic<int32_t> first_error{GL355_OK};
+        auto worker = [&](uint32_t t) {
+            try {
+                std::vector<uint32_t> mine;
+                for (uint32_t j = t; j < n_nodes; j += workers) mine.push_back(j);
+                std::vector<uint64_t> inputs((size_t)units * n_in), flats((size_t)units * wo), pis((size_t)units * pio);
+                std::vector<uint8_t> keys((size_t)units * 32);
+                for (size_t b = 0; b < mine.size() && first_error.load() == GL355_OK; b += units) {
+                    const uint32_t nb = (uint32_t)std::min<size_t>(units, mine.size() - b);
+                    for (uint32_t k = 0; k < nb; k++) {
+                        const uint32_t j = mine[b + k];
+                        uint64_t* d = &inputs[(size_t)k * n_in];
+                        for (uint32_t side = 0; side < 2; side++) {
+                            memcpy(d, &cur_p[(size_t)(2 * j + side) * wi], wi * 8); d += wi;
+                            memcpy(d, &cur_pi[(size_t)(2 * j + side) * pii], pii * 8); d += pii;
+                        }
+                        if (key_base) gl355_derive_key(key_base, (key_domain << 48) | ((uint64_t)l << 32) | j, &keys[32 * k]);
+                    }
+                    const int32_t rc = gl355_circuit_prove_tape_units(ctxs[t], levels[l], nb, inputs.data(), n_in, key_base ? keys.data() : nullptr, flats.data(), pis.data());
+                    if (rc != GL355_OK) { int32_t e = GL355_OK; first_error.compare_exchange_strong(e, rc); return; }
+                    for (uint32_t k = 0; k < nb; k++) {
+                        memcpy(&nxt_p[(size_t)mine[b + k] * wo], &flats[(size_t)k * wo], wo * 8);
+                        memcpy(&nxt_pi[(size_t)mine[b + k] * pio], &pis[(size_t)k * pio], pio * 8);
+                    }
+                }
+            } catch (...) {
+                int32_t e = GL355_OK;
+                first_error.compare_exchange_strong(e, GL355_E_OOM);
+            }
+        };
+        std::vector<std::thread> pool;
+        try {
+            for (uint32_t t = 1; t < workers; t++) pool.emplace_back(worker, t);
+        } catch (...) {
+            int32_t e = GL355_OK;
+            first_error.compare_exchange_strong(e, GL355_E_OOM);
+        }
+        worker(0);
+        for (auto& th : pool) th.join();
+        if (first_error.load() != GL355_OK) return first_error.load();
+        cur_p.swap(nxt_p);
+        cur_pi.swap(nxt_pi);
+        if (level_ms) level_ms[l] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    memcpy(proof_out, cur_p.data(), words[n_levels] * 8);
+    memcpy(public_inputs_out, cur_pi.data(), n_pi[n_levels] * 8);
+    return GL355_OK;
+}

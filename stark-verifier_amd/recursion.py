@@ -577,3 +577,66 @@ class Aggregator:
             signals = nxt
             level += 1
         return signals[0][0], signals[0][1], self.commons[level]
+
+    # ---- the same tree through ONE native call (gl355_aggregate_units), and the level circuits as persisted artifacts --------------------
+    def native_levels(self, n_levels):
+        """the loaded artifacts (plonk.NativeCircuit) of the first n_levels level circuits"""
+        assert n_levels <= len(self.levels) and all(rc.data is not None for rc in self.levels[:n_levels]), "build the level circuits first (aggregate once, or load())"
+        return [rc.native() for rc in self.levels[:n_levels]]
+
+    def aggregate_native(self, signals, seed=None, ctxs=None, key_domain=0, timed=False):
+        """recursion.rs:187-247 by gl355_aggregate_units: every level's nodes in lock-step over the contexts, no Python between the
+        proofs.  Same keys as `aggregate` -> the same bytes on a seeded run.  -> (flat proof, public inputs, common data[, level ms])"""
+        from .plonk import key_bytes
+        n = len(signals)
+        n_levels = n.bit_length() - 1
+        assert n >= 2 and n == 1 << n_levels
+        nats = self.native_levels(n_levels) if getattr(self, "_loaded", None) is None else self._loaded[:n_levels]
+        ctxs = list(ctxs) if ctxs else [self.ctx]
+        lib = self.ctx.lib
+        handles = (C.c_void_p * n_levels)(*[nat.h for nat in nats])
+        cs = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        proofs = np.ascontiguousarray(np.stack([_u64(f) for f, _ in signals]))
+        pis = np.ascontiguousarray(np.stack([_u64(p) for _, p in signals]))
+        out = np.empty(nats[-1].proof_words, dtype=np.uint64)
+        opis = np.empty(nats[-1].n_public_inputs, dtype=np.uint64)
+        ms = np.zeros(n_levels, dtype=np.float64)
+        key = None if seed is None else key_bytes(seed)
+        rc = lib.gl355_aggregate_units(cs, len(ctxs), handles, n_levels, _ptr(proofs), _ptr(pis), n, proofs.shape[1], pis.shape[1], key, int(key_domain),
+                                       _ptr(out), out.size, _ptr(opis), opis.size, ms.ctypes.data)
+        if rc != 0:
+            from . import _lib
+            raise _lib.Gl355Error(rc, "; ".join((lib.gl355_last_error(c.h) or b"").decode() for c in ctxs))
+        res = (out, opis, self.commons[n_levels] if n_levels < len(self.commons) else None)
+        return res + ([float(v) for v in ms],) if timed else res
+
+    def save(self, directory):
+        """the level circuits as artifacts (gl355_circuit_load format) + the common data of every level: a later process aggregates without
+        building anything (the reference rebuilds every level circuit inside every aggregate_signals call, recursion.rs:25-185, 167)"""
+        import os
+        import pickle
+        os.makedirs(directory, exist_ok=True)
+        for l, rc in enumerate(self.levels):
+            if rc.data is None:
+                break
+            np.save(os.path.join(directory, "level%d.npy" % l), rc.native().blob)
+        with open(os.path.join(directory, "commons.pkl"), "wb") as f:
+            pickle.dump(self.commons, f)
+
+    @classmethod
+    def load(cls, ctx, directory):
+        """-> an Aggregator whose aggregate_native runs from the persisted artifacts (no gadget pass, no circuit build)"""
+        import os
+        import pickle
+        from .plonk import NativeCircuit
+        with open(os.path.join(directory, "commons.pkl"), "rb") as f:
+            commons = pickle.load(f)
+        agg = cls(ctx, commons[0])
+        agg.commons = commons
+        agg._loaded = []
+        l = 0
+        while os.path.exists(os.path.join(directory, "level%d.npy" % l)):
+            agg._loaded.append(NativeCircuit(ctx, np.load(os.path.join(directory, "level%d.npy" % l))))
+            l += 1
+        return agg
+

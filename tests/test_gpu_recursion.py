@@ -195,6 +195,33 @@ def test_aggregate_four_signals(gl, ctx, orc):
         pv.verify(orc, cd, o)
     other_domain, _, _ = agg.aggregate(sigs, seed=100, key_domain=3)
     assert not np.array_equal(other_domain, proof)
+    # the same tree through ONE native call (gl355_aggregate_units): byte-identical on the seeded run, with one and with two contexts, and
+    # from artifacts persisted to disk and loaded into a fresh Aggregator (no circuit is built, no Python runs between the proofs)
+    ctx3 = gl.Context(0)
+    for cs in ([ctx], [ctx, ctx3]):
+        n_proof, n_pis, n_cd, ms = agg.aggregate_native(sigs, seed=100, ctxs=cs, timed=True)
+        assert np.array_equal(n_proof, proof) and np.array_equal(n_pis, pis) and n_cd == cd and len(ms) == 2
+    n_dom, _, _ = agg.aggregate_native(sigs, seed=100, key_domain=3)
+    assert np.array_equal(n_dom, other_domain)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        agg.save(d)
+        agg2 = rec.Aggregator.load(ctx, d)
+        l_proof, l_pis, l_cd = agg2.aggregate_native(sigs, seed=100, ctxs=[ctx, ctx3])
+        assert np.array_equal(l_proof, proof) and np.array_equal(l_pis, pis) and l_cd == cd
+        two, two_pis, _ = agg2.aggregate_native(sigs[:2], seed=100)          # a smaller tree uses the first level only
+        assert two_pis.size == 4 + 8 + 8
+    fresh_n, pis_n, _ = agg.aggregate_native(sigs)                        # OS-random keys
+    assert not np.array_equal(fresh_n, proof) and np.array_equal(pis_n, pis)
+    o = plonk.parse_proof(cd, fresh_n)
+    o["public_inputs"] = pis
+    pv.verify(orc, cd, o)
+    bad = (sigs[1][0].copy(), sigs[1][1])
+    bad[0][40] ^= np.uint64(1)
+    with pytest.raises(gl.Gl355Error) as ei:
+        agg.aggregate_native([sigs[0], bad, sigs[2], sigs[3]], seed=1)
+    assert ei.value.code == -6                                            # GL355_E_WITNESS: an inner proof does not verify
+    ctx3.close()
     outer = plonk.parse_proof(cd, proof)
     outer["public_inputs"] = pis
     pv.verify(orc, cd, outer)
