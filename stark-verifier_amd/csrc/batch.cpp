@@ -205,7 +205,7 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
 // levels[l] is the circuit that verifies two proofs of tree level l (level 0 = the leaves, e.g. Semaphore signals) -- one artifact per
 // level, loaded once with gl355_circuit_load (the reference rebuilds the circuit inside every aggregate_signals call,
 // recursion.rs:25-185).  The nodes of a level are independent (`par_chunks_exact(2)`, recursion.rs:211-227): every context takes the nodes
-// t, t + n_ctx, ... and proves them in lock-step batches (gl355_circuit_prove_tape_units); levels are separated by a join.  Node j of level l
+// the contexts prove ready nodes in lock-step batches (gl355_circuit_prove_tape_units), see the scheduling note below.  Node j of level l
 // has the blinding key gl355_derive_key(key_base, key_domain << 48 | l << 32 | j) (NULL key_base: fresh OS randomness per proof), so the
 // result does not depend on the number of contexts or on the batch size.
 extern "C" int32_t gl355_aggregate_units(gl355_ctx* const* ctxs, uint32_t n_ctx, const gl355_circuit_handle* const* levels, uint32_t n_levels,
