@@ -500,11 +500,11 @@ int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx, const gl35
 /* recursion.rs:187-247 `aggregate` as ONE native call: the binary aggregation tree over n_leaves = 2^n_levels proofs of one circuit (the
  * reference's benchmark flow, README.md:167-177).  levels[l] = the circuit verifying two proofs of tree level l (level 0: the leaves), each
  * loaded once from its artifact (the reference rebuilds it inside every aggregate_signals call, recursion.rs:25-185).  The nodes of a level are
- * independent (par_chunks_exact(2), recursion.rs:211-227) and a node may start as soon as its two children are done: the contexts take ready nodes
- * (lowest level first, up to 8 of one level in lock-step), so the latency-bound top of the tree overlaps with the levels below.  Node j of level l is blinded with gl355_derive_key(key_base, key_domain << 48 | l << 32 | j) (key_base NULL: fresh OS randomness per proof),
+ * independent (par_chunks_exact(2), recursion.rs:211-227): context t proves nodes t, t + n_ctx, ... in lock-step batches; levels are separated by a
+ * join.  Node j of level l is blinded with gl355_derive_key(key_base, key_domain << 48 | l << 32 | j) (key_base NULL: fresh OS randomness per proof),
  * so the root does not depend on the number of contexts.  leaf_proofs [n_leaves][leaf_words], leaf_public_inputs [n_leaves][leaf_n_pi] (host);
  * proof_out / public_inputs_out receive the root proof (gl355_circuit_info(levels[n_levels - 1]) gives the sizes); level_ms (optional,
- * n_levels doubles): wall milliseconds from the first start to the last end of each level (they overlap).  GL355_E_WITNESS if an inner proof does not verify. */
+ * n_levels doubles): wall milliseconds per level.  GL355_E_WITNESS if an inner proof does not verify. */
 int32_t gl355_aggregate_units(gl355_ctx* const* ctxs, uint32_t n_ctx, const gl355_circuit_handle* const* levels, uint32_t n_levels,
                               const uint64_t* leaf_proofs, const uint64_t* leaf_public_inputs, uint32_t n_leaves, uint64_t leaf_words, uint32_t leaf_n_pi,
                               const uint8_t* key_base, uint64_t key_domain, uint64_t* proof_out, uint64_t proof_capacity_words,
