@@ -218,6 +218,22 @@ __device__ __noinline__ jac j_madd(jac p, u256 x2, u256 y2) {
     o.z = m_mul<F_Q>(p.z, h);
     return o;
 }
+// the same, inlined into its caller: as a call the mixed addition makes every kernel that uses it a 210-VGPR kernel (two waves per SIMD: the
+// convention keeps the callee's whole frame apart from the caller's); inlined, the bucket loops take 142 (three waves) -- the bucket
+// accumulation is bound by the latency of its random 64-byte point reads, which more resident waves cover
+GL_DEV jac j_madd_inl(const jac& p, const u256& x2, const u256& y2) {
+    if (j_is_identity(p)) { jac r; r.x = x2; r.y = y2; r.z = u_const(BN254C_FQ_ONE); return r; }
+    const u256 z1z1 = m_mul<F_Q>(p.z, p.z);
+    const u256 u2 = m_mul<F_Q>(x2, z1z1), s2 = m_mul<F_Q>(m_mul<F_Q>(y2, p.z), z1z1);
+    const u256 h = m_sub<F_Q>(u2, p.x), r = m_sub<F_Q>(s2, p.y);
+    if (m_is_zero<F_Q>(h)) return m_is_zero<F_Q>(r) ? j_double(p) : j_identity();
+    const u256 h2 = m_mul<F_Q>(h, h), h3 = m_mul<F_Q>(h2, h), v = m_mul<F_Q>(p.x, h2);
+    jac o;
+    o.x = m_sub<F_Q>(m_sub<F_Q>(m_mul<F_Q>(r, r), h3), m_add<F_Q>(v, v));
+    o.y = m_sub<F_Q>(m_mul<F_Q>(r, m_sub<F_Q>(v, o.x)), m_mul<F_Q>(p.y, h3));
+    o.z = m_mul<F_Q>(p.z, h);
+    return o;
+}
 __device__ __noinline__ jac j_add(jac p, jac q) {
     if (j_is_identity(p)) return q;
     if (j_is_identity(q)) return p;
@@ -585,7 +601,7 @@ GL_DEV jac msm_add_point(const MsmArgs& a, jac acc, uint32_t e) {      // e: poi
 #pragma unroll
     for (int j = 0; j < 8; j++) { x.l[j] = p[j]; y.l[j] = p[8 + j]; }
     if (e >> 31) y = m_sub<F_Q>(u_zero(), y);
-    return j_madd(acc, x, y);
+    return j_madd_inl(acc, x, y);
 }
 // one lane per (window, bucket), taken in the order above: sum of the bucket's points (big buckets: the kernels below)
 __global__ void __launch_bounds__(256) msm_bucket_kernel(MsmArgs a) {
