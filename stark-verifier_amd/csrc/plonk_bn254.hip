@@ -166,7 +166,7 @@ int32_t run_program(gl355_plonk_pk* pk, const uint32_t* d_code, uint32_t n_instr
     a.code = d_code; a.n_instr = n_instr; a.consts = pk->d_consts; a.n = pk->n; a.fold = to_dev(fold); a.acc_in = acc_in; a.acc_out = acc_out;
     a.log_n = pk->k; a.bitrev = bitrev ? 1 : 0;
     for (int kd = 0; kd < 3; kd++) { a.cols[kd] = d_cols[kd]; a.q_col[kd] = pk->d_q[kd][0]; a.q_rot[kd] = pk->d_q[kd][1]; }
-    hipLaunchKernelGGL(plk_eval_kernel, dim3(blocks(pk->n, PLK_EVAL_LANES)), dim3(PLK_EVAL_LANES), 0, pk->ctx->stream, a);
+    hipLaunchKernelGGL(plk_eval_kernel, dim3(blocks(pk->n)), dim3(256), 0, pk->ctx->stream, a);
     GL355_HIP(pk->ctx, hipGetLastError());
     return GL355_OK;
 }

@@ -66,8 +66,8 @@ __global__ void plk_sigma_kernel(const uint32_t* mapping /* [n_perm][n][2] */, u
 
 // ---- the expression evaluator ------------------------------------------------------------------------------------------------------
 // One lane per point of a 2^k-point domain (the value domain or one coset of the extended domain: in both a rotation by r is an index shift
-// by r).  The program is straight-line code over PLK_MAX_REGS 256-bit registers (in LDS, see below); operands name a register, a constant of
-// the pool or a column query.  EMIT
+// by r).  The program is straight-line code over PLK_MAX_REGS 256-bit registers; operands name a register, a constant of the pool or a
+// column query.  EMIT
 // folds a value into the running sum: sum = sum * fold + value -- `fold` is y for the constraint polynomials of evaluate_h and theta for the
 // expressions a lookup compresses.
 struct PlkEvalArgs {
@@ -90,50 +90,62 @@ GL_DEV uint64_t plk_rotated(uint64_t i, int32_t rot, uint64_t n, uint32_t log_n,
     const uint64_t j = __brevll(i) >> (64 - log_n);
     return __brevll((uint64_t)((int64_t)j + (int64_t)n + rot) & (n - 1)) >> (64 - log_n);
 }
-// The register file lives in LDS, one wave per workgroup: [register][limb][lane], so a register access is eight conflict-free
-// ds_read_b32 / ds_write_b32 at constant offsets from one address.  (A private array -- indexed, or twelve named values behind a switch on the
-// wave-uniform index -- is placed in scratch memory by the compiler: 400 bytes per lane behind the vector memory path, 16.4 ms for the
-// reference's gate program over 2^23 points.)  24 KB per wave: six waves per CU.
-constexpr uint32_t PLK_EVAL_LANES = 64;
-GL_DEV u256 plk_reg_read(const uint32_t* file, uint32_t reg, uint32_t lane) {
-    u256 v;
-#pragma unroll
-    for (int l = 0; l < 8; l++) v.l[l] = file[(reg * 8 + l) * PLK_EVAL_LANES + lane];
-    return v;
+// (Measured alternative: the file in LDS, [register][limb][lane] with one wave per workgroup -- no scratch, but 24 KB per wave leave six waves
+// per CU, and evaluate_h at k = 23 took 627 ms against 598 ms with the scratch-backed file below; the scratch lines of a wave stay in L2.)
+#define PLK_REG_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
+// the register file as twelve named values: the compiler still places it in scratch memory (400 bytes per lane), as it does an indexed array
+struct PlkRegs {
+#define PLK_DECL(K) u256 r##K;
+    PLK_REG_CASES(PLK_DECL)
+#undef PLK_DECL
+};
+GL_DEV u256 plk_reg_read(const PlkRegs& f, uint32_t i) {
+    switch (i) {
+#define PLK_RD(K) case K: return f.r##K;
+        PLK_REG_CASES(PLK_RD)
+#undef PLK_RD
+    default: return f.r0;
+    }
 }
-GL_DEV void plk_reg_write(uint32_t* file, uint32_t reg, uint32_t lane, const u256& v) {
-#pragma unroll
-    for (int l = 0; l < 8; l++) file[(reg * 8 + l) * PLK_EVAL_LANES + lane] = v.l[l];
+GL_DEV void plk_reg_write(PlkRegs& f, uint32_t i, const u256& v) {
+    switch (i) {
+#define PLK_WR(K) case K: f.r##K = v; break;
+        PLK_REG_CASES(PLK_WR)
+#undef PLK_WR
+    default: break;
+    }
 }
-GL_DEV u256 plk_operand(const PlkEvalArgs& a, const uint32_t* file, uint32_t lane, uint32_t operand, uint64_t i) {
+GL_DEV u256 plk_operand(const PlkEvalArgs& a, const PlkRegs& f, uint32_t operand, uint64_t i) {
     const uint32_t kind = operand >> 24, idx = operand & 0xFFFFFFu;
-    if (kind == PLK_K_REG) return plk_reg_read(file, idx, lane);
+    if (kind == PLK_K_REG) return plk_reg_read(f, idx);
     if (kind == PLK_K_CONST) return load256(a.consts + 4 * idx);
     const uint32_t kd = kind - PLK_K_ADVICE;
     const int32_t col = a.q_col[kd][idx], rot = a.q_rot[kd][idx];
     return load256(a.cols[kd][col] + 4 * plk_rotated(i, rot, a.n, a.log_n, a.bitrev));
 }
-__global__ void __launch_bounds__(PLK_EVAL_LANES) plk_eval_kernel(PlkEvalArgs a) {
-    __shared__ uint32_t file[PLK_MAX_REGS * 8 * PLK_EVAL_LANES];
-    const uint32_t lane = threadIdx.x;
-    const uint64_t i0 = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    const uint64_t i = i0 < a.n ? i0 : a.n - 1;          // the tail lanes of the last wave repeat the last point (no divergent exits around LDS)
+__global__ void __launch_bounds__(256) plk_eval_kernel(PlkEvalArgs a) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    PlkRegs f;
+#define PLK_ZERO(K) f.r##K = u_zero();
+    PLK_REG_CASES(PLK_ZERO)
+#undef PLK_ZERO
     u256 acc = a.acc_in ? load256(a.acc_in + 4 * i) : u_zero();
 #pragma unroll 1
     for (uint32_t pc = 0; pc < a.n_instr; pc++) {
         const uint32_t op = a.code[4 * pc], dst = a.code[4 * pc + 1], oa = a.code[4 * pc + 2], ob = a.code[4 * pc + 3];
-        const u256 x = plk_operand(a, file, lane, oa, i);
+        const u256 x = plk_operand(a, f, oa, i);
         if (op == PLK_OP_EMIT) { acc = m_add<F_R>(m_mul<F_R>(acc, a.fold), x); continue; }
         u256 v;
         if (op == PLK_OP_NEG) v = fr_neg(x);
         else if (op == PLK_OP_MOV) v = x;
         else {
-            const u256 y = plk_operand(a, file, lane, ob, i);
+            const u256 y = plk_operand(a, f, ob, i);
             v = op == PLK_OP_ADD ? m_add<F_R>(x, y) : (op == PLK_OP_SUB ? m_sub<F_R>(x, y) : m_mul<F_R>(x, y));
         }
-        plk_reg_write(file, dst, lane, v);
+        plk_reg_write(f, dst, v);
     }
-    if (i0 < a.n) store256(a.acc_out + 4 * i, acc);
+    store256(a.acc_out + 4 * i, acc);
 }
 
 // ---- evaluate_h: the permutation and lookup constraints on one coset ------------------------------------------------------------------
