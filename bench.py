@@ -294,9 +294,10 @@ def valu_probe(ctx):
 class ClockSampler:
     """shader clock during the timed region: gl355_clock_probe (one sleeping wave for 2 ms) on a context of its own every ~100 ms"""
 
-    def __init__(self, gl, device):
+    def __init__(self, gl, device, period=0.1):
         import threading
         self.ctx = gl.Context(device)
+        self.period = period
         self.samples, self.stop = [], threading.Event()
         self.thread = threading.Thread(target=self.run, daemon=True)
 
@@ -305,7 +306,7 @@ class ClockSampler:
         while not self.stop.is_set():
             if self.ctx.lib.gl355_clock_probe(self.ctx.h, 2000, C.byref(v)) == 0 and v.value > 0:
                 self.samples.append(v.value)
-            self.stop.wait(0.1)
+            self.stop.wait(self.period)
 
     def __enter__(self):
         self.thread.start()
@@ -426,11 +427,13 @@ def lde_figure(gl, device, steps=40, warm=12):
     ctx.sync()
     ctx.profile_enable(True)
     ctx.profile_read()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    ctx.sync()
-    dt = time.perf_counter() - t0
+    with ClockSampler(gl, device, period=0.004) as cs:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ctx.sync()
+        dt = time.perf_counter() - t0
+    clk = cs.summary()
     prof = {k: v for k, v in ctx.profile_read().items() if not k.startswith("host:")}
     ctx.profile_enable(False)
     alg = 8.0 * BATCH * (n + N)
@@ -445,7 +448,43 @@ def lde_figure(gl, device, steps=40, warm=12):
                          "traffic": traffic, "traffic_source": tsrc,
                          "hbm_moved_GBps": round(traffic / (kern_ms * 1e-3) / 1e9, 1) if kern_ms > 0 and traffic else None,
                          "valu_insts_per_lde": valu,
+                         "floors": lde_floors(alg, clk),
                          "kernels_ms_per_launch": {k: round(v[1] / max(1, v[0]), 4) for k, v in prof.items()}}}
+
+
+def lde_floors(alg_bytes, clk):
+    """What bounds the two-pass LDE from below, per pass: its HBM-side traffic at the copy rate the chip reaches (6.29 TB/s, MI355X_MICROARCH.md) and
+    its VALU instructions (rocprofv3 --pmc SQ_INSTS_VALU) at the issue cost of the pass's instruction mix (tools/isa_mix.py classes at 2 / 4 clk)
+    and the clock sampled during this run.  A pass cannot beat the larger of its two floors even with perfect overlap; the sum over the passes is the
+    ceiling of THIS arithmetic (64-bit modular butterflies as 24-bit-limb integer work on a 32-bit VALU) in this two-pass structure, and
+    `ceiling_frac_of_hbm_peak` is where the north star's ">= 50 % of HBM" target lands for it."""
+    try:
+        d = json.load(open(latest_profile("_lde_pmc.json")))
+        isa = json.load(open(latest_profile("_isa_mix.json")))["kernels"]
+    except Exception:
+        return None
+    if not clk:
+        return None
+    copy_peak = 6.29e12
+    out = {"clock_mhz": clk["mean_mhz"], "copy_peak_TBps": 6.29, "passes": {}}
+    total = 0.0
+    for name, e in d["kernels"].items():
+        f = isa.get(name, {}).get("f")
+        if not f:
+            continue
+        cost = sum(f[c] * NOMINAL_CLK[c] for c in VALU_CLASSES)
+        valu_ms = e["SQ_INSTS_VALU"] * cost / (N_SIMD * clk["mean_mhz"] * 1e6) * 1e3
+        mem_ms = e["hbm_bytes_per_launch"] / copy_peak * 1e3
+        out["passes"][name] = {"valu_floor_ms": round(valu_ms, 3), "mem_floor_ms": round(mem_ms, 3), "mix": f, "clk_per_inst": round(cost, 2)}
+        total += max(valu_ms, mem_ms)
+    if total <= 0:
+        return None
+    out["valu_floor_ms"] = round(sum(p["valu_floor_ms"] for p in out["passes"].values()), 3)
+    out["mem_floor_ms"] = round(sum(p["mem_floor_ms"] for p in out["passes"].values()), 3)
+    out["floor_ms_perfect_overlap"] = round(total, 3)
+    out["ceiling_GBps"] = round(alg_bytes / (total * 1e-3) / 1e9, 1)
+    out["ceiling_frac_of_hbm_peak"] = round(alg_bytes / (total * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return out
 
 
 def lde_pmc():
@@ -469,9 +508,9 @@ def merkle_figures(gl, device):
     g = torch.Generator(device="cuda")
     g.manual_seed(0x356)
     out = {"what": "gl355_merkle_build (leaf sponge + compression levels + cap, plonky2 digest layout), leaves resident, HIP events"}
-    # wave-level VALU instructions per second at the issue rate: 1024 SIMDs x 2.4 GHz (the clock these kernels hold when they run alone) / 4.0 clk
-    # per instruction of this mix (rocprofv3 --pmc, profiles/r03_pmc_traffic.json: hash_leaves_kernel 4.0 clk per VALU instruction per SIMD)
-    issue_peak = 1024 * 2.4e9 / 4.0
+    # the VALU roofline of these builds: 17 600 instructions per permutation and lane against the issue rate for hash_leaves_kernel's
+    # instruction mix (valu_peak) at the shader clock sampled while the builds run
+    mix, _, mix_src = valu_mix("hash_leaves_kernel")
     for log_n, L, cap in ((22, 4, 4), (22, 135, 4), (20, 4, 0)):
         n = 1 << log_n
         leaves = torch.randint(0, (1 << 63) - 1, (n, L), dtype=torch.int64, device="cuda", generator=g)
@@ -483,18 +522,26 @@ def merkle_figures(gl, device):
             ctx.check(lib.gl355_merkle_build(ctx.h, C.c_void_p(leaves.data_ptr()), n, L, cap, C.c_void_p(dig.data_ptr()), C.c_void_p(capb.data_ptr())))
         build()
         ctx.sync()
-        reps = 2 if L > 8 else 4
-        ctx.timer_start()
-        for _ in range(reps):
-            build()
-        ms = ctx.timer_stop() / reps
+        reps = 6 if L > 8 else 40
+        with ClockSampler(gl, device, period=0.01) as cs:
+            ctx.timer_start()
+            for _ in range(reps):
+                build()
+            ms = ctx.timer_stop() / reps
+        clk = cs.summary()
         perms = n * ((L + 7) // 8 if L > 4 else 0) + (n - (1 << cap))
         alg = 8.0 * n * L + 64.0 * (n - (1 << cap)) + 32.0 * (1 << cap)
         out["N=2^%d L=%d cap=%d" % (log_n, L, cap)] = {
             "ms": round(ms, 3), "permutations": perms, "Gperm_per_s": round(perms / ms / 1e6, 3),
             "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
                          "algorithmic_bytes": int(alg)},
-            "valu_frac": round(perms * 17600 / 64.0 / (ms * 1e-3) / issue_peak, 3)}
+            "valu": None}
+        if mix and clk:
+            ach_v = perms * 17600 / 64.0 / (ms * 1e-3) / 1e9
+            peak_v = valu_peak(mix, clk["mean_mhz"])
+            out["N=2^%d L=%d cap=%d" % (log_n, L, cap)]["valu"] = {
+                "bound": "valu", "achieved": round(ach_v, 1), "peak": round(peak_v, 1), "unit": "G wave-instructions/s", "frac": round(ach_v / peak_v, 4),
+                "clock_mhz": clk["mean_mhz"], "mix": mix, "formula": "permutations x 17 600 / 64 / time against 1024 SIMDs x clock / sum_c mix[c] x nominal_clk[c]"}
         del leaves, dig, capb
         torch.cuda.empty_cache()
     ctx.close()
