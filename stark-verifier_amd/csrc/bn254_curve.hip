@@ -1389,8 +1389,15 @@ int32_t gl355_kzg_setup(gl355_ctx* h, const uint64_t tau[4], uint32_t log_n, uin
     if (!tau || !g) return ctx->fail(GL355_E_INVALID_ARG, "kzg_setup: null argument");
     if (log_n > 26) return ctx->fail(GL355_E_UNSUPPORTED, "kzg_setup: log_n > 26");
     const uint64_t n = 1ull << log_n;
-    const H256 t = h_from_words(tau);
+    uint64_t tau_h[4];                                        // tau may be device memory like every other operand
+    if (ptr_is_device(tau)) { GL355_HIP(ctx, hipMemcpy(tau_h, tau, 32, hipMemcpyDeviceToHost)); } else memcpy(tau_h, tau, 32);
+    const H256 t = h_from_words(tau_h);
     const u256 tau_mont = h_to_mont(t);
+    {   // tau in the 2^log_n domain <=> tau^n = 1: refused whether or not the Lagrange bases are asked for (the header says so)
+        H256 tn = t;
+        for (uint32_t k = 0; k < log_n; k++) tn = h_mulmod(tn, tn);
+        if (tn.l[0] == 1 && (tn.l[1] | tn.l[2] | tn.l[3]) == 0) return ctx->fail(GL355_E_INVALID_ARG, "kzg_setup: tau lies in the evaluation domain");
+    }
     Scratch sc(ctx);
     GL355_TRY(sc.get((g_lagrange ? 2 : 1) * n * 32 + 64));
     uint64_t* d_s = sc.as<uint64_t>();
@@ -1495,7 +1502,9 @@ int32_t gl355_kzg_open(gl355_ctx* h, const uint64_t* g, const uint64_t* coeffs, 
     uint64_t* d_e = d_q + 4 * n;
     {
         ProfScope ps(ctx, "kzg_divide", n * 64);
-        GL355_TRY(kzg_divide(ctx, sp.as<uint64_t>(), n, h_from_words(z), 0, d_q, 1, d_e));
+        uint64_t z_h[4];
+        if (ptr_is_device(z)) { GL355_HIP(ctx, hipMemcpy(z_h, z, 32, hipMemcpyDeviceToHost)); } else memcpy(z_h, z, 32);
+        GL355_TRY(kzg_divide(ctx, sp.as<uint64_t>(), n, h_from_words(z_h), 0, d_q, 1, d_e));
         hipLaunchKernelGGL(kzg_from_mont1_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t*)d_e, d_e + 4);
         GL355_HIP(ctx, hipGetLastError());
     }

@@ -108,3 +108,58 @@ def test_commit_columns_entry(ctx):
         one = np.zeros(8, dtype=np.uint64)
         ctx.check(ctx.lib.gl355_kzg_commit(ctx.h, gl_.ctypes.data, vals[c].ctypes.data, k, 0, one.ctypes.data))
         assert np.array_equal(out[c], one)
+
+
+def test_malformed_descriptors_are_refused(gl, ctx):
+    """gl355_plonk_keygen on untrusted descriptors: wrong magic, truncation, a program operand out of range, a permutation column that is never
+    queried, an implausible shape -- an error code every time, never a crash"""
+    import ctypes as C
+    k = 7
+    cs, cfg, w = ch.synthetic_circuit(k, table_bits=5, n_permutations=1)
+    g, gl_ = h2.kzg_setup(ctx, k, TAU)
+    desc = h2.export_desc(cs, k, 1)
+    fixed = np.ascontiguousarray(w.fixed)
+    mapping = np.ascontiguousarray(w.assembly.mapping_array())
+
+    def keygen(d):
+        h = C.c_void_p()
+        rc = ctx.lib.gl355_plonk_keygen(ctx.h, d.ctypes.data, d.size, g.ctypes.data, gl_.ctypes.data, fixed.ctypes.data, mapping.ctypes.data, C.byref(h))
+        if rc == 0:
+            ctx.lib.gl355_plonk_pk_destroy(h)
+        return rc
+    assert keygen(desc) == 0
+    bad = desc.copy(); bad[0] ^= np.uint64(1)
+    assert keygen(bad) == -1
+    assert keygen(desc[:-3].copy()) == -1
+    assert keygen(desc[:20].copy()) == -1
+    bad = desc.copy(); bad[2] = 40                                   # k
+    assert keygen(bad) == -1
+    bad = desc.copy(); bad[8] = 2                                    # degree
+    assert keygen(bad) == -1
+    # the gate program starts after header (24) + permutation columns + queries + constants: poison one operand
+    off = 24 + int(desc[6]) + int(desc[10]) + int(desc[11]) + int(desc[12]) + 4 * int(desc[13])
+    bad = desc.copy()
+    words = bad[off:off + 2].view(np.uint32)
+    words[2] = (2 << 24) | 0xFFFF                                    # advice query 65535
+    assert keygen(bad) == -1
+    bad = desc.copy()
+    bad[off:off + 2].view(np.uint32)[1] = 99                         # destination register 99
+    assert keygen(bad) == -1
+    bad = desc.copy(); bad[24] = (np.uint64(7) << np.uint64(32))     # permutation column of kind 7
+    assert keygen(bad) == -1
+    m2 = mapping.copy(); m2[0, 0, 1] = 1 << 20                       # a sigma pointing outside the domain
+    h = C.c_void_p()
+    assert ctx.lib.gl355_plonk_keygen(ctx.h, desc.ctypes.data, desc.size, g.ctypes.data, gl_.ctypes.data, fixed.ctypes.data, m2.ctypes.data, C.byref(h)) == -1
+    # prove with a key of another context / too small a buffer
+    prover = h2.PlonkProver(ctx, cs, k, g, gl_, w.fixed, mapping)
+    ctx2 = gl.Context(0)
+    buf = np.zeros(prover.info["proof_bytes"], dtype=np.uint8)
+    n_out = C.c_uint64(0)
+    lens = np.array([2, 0], dtype=np.uint32)
+    inst = h2.to_limbs(w.instance[0])
+    args = (w.advice.ctypes.data, inst.ctypes.data, lens.ctypes.data, bytes(32))
+    assert ctx2.lib.gl355_plonk_prove(ctx2.h, prover.h, *args, buf.ctypes.data, buf.size, C.byref(n_out), None, None) == -1
+    assert ctx.lib.gl355_plonk_prove(ctx.h, prover.h, *args, buf.ctypes.data, 100, C.byref(n_out), None, None) == -1
+    assert n_out.value == prover.info["proof_bytes"]
+    ctx2.close()
+    prover.close()

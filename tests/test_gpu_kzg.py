@@ -83,7 +83,14 @@ def test_kzg_setup_vs_model(ctx, orc, log_n):
     if log_n >= 1:
         t = cv.scalars([pow(w, 1, R)])[0]
         assert ctx.lib.gl355_kzg_setup(ctx.h, t.ctypes.data, log_n, g.ctypes.data, gl.ctypes.data) == -1
+        assert ctx.lib.gl355_kzg_setup(ctx.h, t.ctypes.data, log_n, g.ctypes.data, None) == -1        # ... refused without the Lagrange bases too
     assert ctx.lib.gl355_kzg_setup(ctx.h, None, log_n, g.ctypes.data, None) == -1
+    # tau handed over in device memory, like any other operand (it used to be dereferenced on the host)
+    import torch
+    td = torch.from_numpy(cv.scalars([TAU])[0].view(np.int64)).cuda()
+    g2 = np.zeros_like(g)
+    ctx.check(ctx.lib.gl355_kzg_setup(ctx.h, td.data_ptr(), log_n, g2.ctypes.data, None))
+    assert np.array_equal(g2, g)
 
 
 @pytest.mark.parametrize("log_n", [0, 3, 6, 7, 10, 13])
