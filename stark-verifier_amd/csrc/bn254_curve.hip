@@ -249,6 +249,22 @@ __device__ __noinline__ jac j_add(jac p, jac q) {
     o.z = m_mul<F_Q>(m_mul<F_Q>(p.z, q.z), h);
     return o;
 }
+// inlined form for the reduction levels (same reason as j_madd_inl)
+GL_DEV jac j_add_inl(const jac& p, const jac& q) {
+    if (j_is_identity(p)) return q;
+    if (j_is_identity(q)) return p;
+    const u256 z1z1 = m_mul<F_Q>(p.z, p.z), z2z2 = m_mul<F_Q>(q.z, q.z);
+    const u256 u1 = m_mul<F_Q>(p.x, z2z2), u2 = m_mul<F_Q>(q.x, z1z1);
+    const u256 s1 = m_mul<F_Q>(m_mul<F_Q>(p.y, q.z), z2z2), s2 = m_mul<F_Q>(m_mul<F_Q>(q.y, p.z), z1z1);
+    const u256 h = m_sub<F_Q>(u2, u1), r = m_sub<F_Q>(s2, s1);
+    if (m_is_zero<F_Q>(h)) return m_is_zero<F_Q>(r) ? j_double(p) : j_identity();
+    const u256 h2 = m_mul<F_Q>(h, h), h3 = m_mul<F_Q>(h2, h), v = m_mul<F_Q>(u1, h2);
+    jac o;
+    o.x = m_sub<F_Q>(m_sub<F_Q>(m_mul<F_Q>(r, r), h3), m_add<F_Q>(v, v));
+    o.y = m_sub<F_Q>(m_mul<F_Q>(r, m_sub<F_Q>(v, o.x)), m_mul<F_Q>(s1, h3));
+    o.z = m_mul<F_Q>(m_mul<F_Q>(p.z, q.z), h);
+    return o;
+}
 GL_DEV void j_store(uint32_t* dst, const jac& p) {
 #pragma unroll
     for (int j = 0; j < 8; j++) { dst[j] = p.x.l[j]; dst[8 + j] = p.y.l[j]; dst[16 + j] = p.z.l[j]; }
@@ -721,13 +737,13 @@ __global__ void __launch_bounds__(64) msm_level_kernel(MsmLevel l) {
     const uint32_t* s_in = l.in_s + ((uint64_t)w * l.t_in + (uint64_t)v * k) * 24;
     jac run = j_identity(), acc = j_identity();
     for (uint32_t u = k; u-- > 0;) {
-        run = j_add(run, j_load(s_in + u * 24));
-        if (u) acc = j_add(acc, run);                             // acc = sum_u u * S_u: item u is counted in the u sums taken at u' = u .. 1
+        run = j_add_inl(run, j_load(s_in + u * 24));
+        if (u) acc = j_add_inl(acc, run);                             // acc = sum_u u * S_u: item u is counted in the u sums taken at u' = u .. 1
     }
     for (uint32_t d = 0; d < l.shift; d++) acc = j_double(acc);
     if (l.in_w) {
         const uint32_t* w_in = l.in_w + ((uint64_t)w * l.t_in + (uint64_t)v * k) * 24;
-        for (uint32_t u = 0; u < k; u++) acc = j_add(acc, j_load(w_in + u * 24));
+        for (uint32_t u = 0; u < k; u++) acc = j_add_inl(acc, j_load(w_in + u * 24));
     }
     j_store(l.out_s + ((uint64_t)w * groups + v) * 24, run);
     j_store(l.out_w + ((uint64_t)w * groups + v) * 24, acc);

@@ -84,6 +84,18 @@ def test_k12_proof_passes_the_verifier(ctx):
     prover.close()
 
 
+def test_k17_reference_table_size(ctx):
+    """k = 17: the smallest circuit that holds the reference's real 16-bit range table and the Goldilocks modulus (arithmetic_chip.rs:19,140-151);
+    64 chained Poseidon permutations, every usable row an arithmetic row; the proof passes the verifier restatement"""
+    k = 17
+    cs, cfg, w, prover = build(ctx, k, 16, n_perm=64)
+    assert cfg.arithmetic_config.modulus == ch.GOLDILOCKS_MODULUS and cs.degree() == 6 and len(cs.lookups) == 9 and cs.num_advice == 19
+    vk = dict(digest=prover.digest, fixed_commitments=[pt(c) for c in prover.fixed_commitments], sigma_commitments=[pt(c) for c in prover.sigma_commitments])
+    proof = prover.prove(w.advice, w.instance, bytes(range(32)))
+    assert hv.verify(k, cs, vk, w.instance, proof, TAU)
+    prover.close()
+
+
 def test_a_lookup_input_outside_the_table_is_an_error(gl, ctx):
     k, tb = 8, 6
     cs, cfg, w, prover = build(ctx, k, tb)
