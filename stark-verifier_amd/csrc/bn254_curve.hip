@@ -145,48 +145,10 @@ __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
         for (int l = 0; l < 8; l++) lds[l][e] = x.l[l];
     }
     __syncthreads();
-    // Stages in pairs: a lane takes the four tile rows r0 + {0, 1, 2, 3} 2^(st-1) of one column through stages st and st + 1 in registers --
-    // half the LDS traffic and barriers of one stage per round trip (four field products either way: the second stage's two twiddles differ).
-    // An odd stage count leaves one single stage (the last one executed).
-    uint32_t it = 1;
-    const bool pairs_on = tile_elems >= 1024;                 // (small transforms keep the single-stage form)
-    for (; pairs_on && it + 1 <= a.ns; it += 2) {
-        // decimation in time runs stages it, it + 1 upwards; decimation in frequency the mirror pair downwards
-        const uint32_t st = a.dif ? a.ns - it : it;              // the LOWER stage of the pair
-        const uint32_t lh = st - 1, half = 1u << lh;             // stage st spans `half` rows, stage st + 1 spans 2 half
-        for (uint32_t b = tid; b < tile_elems / 4; b += 256) {
-            const uint32_t q = b >> log_c, c = b & (C - 1);
-            const uint32_t pos = q & (half - 1);
-            const uint32_t r0 = ((q >> lh) << (lh + 2)) | pos;
-            const uint32_t e0 = (r0 << log_c) | c, es = half << log_c;
-            const uint64_t j1 = ((uint64_t)pos << a.s0) + c0 + c;                       // stage st, both butterflies
-            const uint64_t jb = ((uint64_t)(pos + half) << a.s0) + c0 + c;              // stage st + 1, second butterfly (first: j1)
-            const u256 w1 = load256(a.tw + 4 * (j1 << (a.log_n - (a.s0 + st))));
-            const u256 wa = load256(a.tw + 4 * (j1 << (a.log_n - (a.s0 + st + 1))));
-            const u256 wb = load256(a.tw + 4 * (jb << (a.log_n - (a.s0 + st + 1))));
-            u256 x0, x1, x2, x3;
-#pragma unroll
-            for (int l = 0; l < 8; l++) { x0.l[l] = lds[l][e0]; x1.l[l] = lds[l][e0 + es]; x2.l[l] = lds[l][e0 + 2 * es]; x3.l[l] = lds[l][e0 + 3 * es]; }
-            if (a.dif) {
-                // stage st + 1: (x0, x2) with wa, (x1, x3) with wb; then stage st: (x0, x1) and (x2, x3) with w1
-                u256 t = m_add<F_R>(x0, x2); x2 = m_mul<F_R>(m_sub<F_R>(x0, x2), wa); x0 = t;
-                t = m_add<F_R>(x1, x3); x3 = m_mul<F_R>(m_sub<F_R>(x1, x3), wb); x1 = t;
-                t = m_add<F_R>(x0, x1); x1 = m_mul<F_R>(m_sub<F_R>(x0, x1), w1); x0 = t;
-                t = m_add<F_R>(x2, x3); x3 = m_mul<F_R>(m_sub<F_R>(x2, x3), w1); x2 = t;
-            } else {
-                x1 = m_mul<F_R>(x1, w1); x3 = m_mul<F_R>(x3, w1);
-                u256 t = m_add<F_R>(x0, x1); x1 = m_sub<F_R>(x0, x1); x0 = t;
-                t = m_add<F_R>(x2, x3); x3 = m_sub<F_R>(x2, x3); x2 = t;
-                x2 = m_mul<F_R>(x2, wa); x3 = m_mul<F_R>(x3, wb);
-                t = m_add<F_R>(x0, x2); x2 = m_sub<F_R>(x0, x2); x0 = t;
-                t = m_add<F_R>(x1, x3); x3 = m_sub<F_R>(x1, x3); x1 = t;
-            }
-#pragma unroll
-            for (int l = 0; l < 8; l++) { lds[l][e0] = x0.l[l]; lds[l][e0 + es] = x1.l[l]; lds[l][e0 + 2 * es] = x2.l[l]; lds[l][e0 + 3 * es] = x3.l[l]; }
-        }
-        __syncthreads();
-    }
-    for (; it <= a.ns; it++) {
+    // (Two stages per LDS round trip -- four rows per lane in registers -- were built and measured: the pass kernel grows from 81 to 170 VGPRs
+    // (three waves per SIMD instead of six) and evaluate_h at k = 23 went from 594 to 641 ms, 744 ms capped at 128 VGPRs with spills.  One
+    // stage per round trip at six waves stays.)
+    for (uint32_t it = 1; it <= a.ns; it++) {
         const uint32_t st = a.dif ? a.ns + 1 - it : it;
         const uint32_t s = a.s0 + st, lh = st - 1, half = 1u << lh;
         for (uint32_t b = tid; b < tile_elems / 2; b += 256) {
