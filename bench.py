@@ -718,7 +718,7 @@ def bn254_figures(gl, device):
     return out
 
 
-def aggregate_figure(gl, device, n_ctx=8, log_members=20, sizes=(2, 4, 8, 16, 32, 64, 128)):
+def aggregate_figure(gl, device, n_ctx=16, log_members=20, sizes=(2, 4, 8, 16, 32, 64, 128)):
     """The reference's own benchmark flow (README.md:167-177, recursion.rs:285-346 `semaphore_aggregation`): N depth-20 Semaphore signals ->
     pairwise aggregation tree of recursive proofs (recursion.rs:187-247) -> final wrap under the BN254-Poseidon config (wrapper.rs:35-56), each
     stage ONE native call (gl355_semaphore_units, gl355_aggregate_units, gl355_circuit_prove_tape).  The level circuits are built once by the
