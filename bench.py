@@ -731,6 +731,11 @@ def aggregate_figure(gl, device, n_ctx=16, log_members=20, sizes=(2, 4, 8, 16, 3
     plonk = importlib.import_module("stark-verifier_amd.plonk")
     ctxs = [gl.Context(device) for _ in range(n_ctx)]
     ctx = ctxs[0]
+    # witness generation of a node = replaying its circuit's tape over the two inner proofs (host threads inside gl355_circuit_prove_tape_units):
+    # GL355_OPT_REPLAY_THREADS per context
+    rt = int(os.environ.get("GL355_BENCH_AGG_REPLAY_THREADS", max(1, min(8, host_cores() // 2))))
+    for c in ctxs:
+        c.set_option(3, rt)
     tmp = tempfile.mkdtemp(prefix="gl355_agg_")
     try:
         rng = np.random.default_rng(0x357)
@@ -754,8 +759,8 @@ def aggregate_figure(gl, device, n_ctx=16, log_members=20, sizes=(2, 4, 8, 16, 3
         t_build = time.perf_counter() - t0
         agg.save(tmp)
         artifact_mb = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp)) / 1e6
-        out = {"what": "N depth-20 signals -> aggregation tree (N - 1 recursive proofs) -> BN254-Poseidon wrap; seconds on one MI355X, %d prover contexts; "
-                       "reference README.md:167-177 (AWS r5.4xlarge, 16 vCPU; its times include rebuilding every circuit)" % n_ctx,
+        out = {"what": "N depth-20 signals -> aggregation tree (N - 1 recursive proofs) -> BN254-Poseidon wrap; seconds on one MI355X, %d prover contexts, "
+                       "%d tape-replay threads per context; reference README.md:167-177 (AWS r5.4xlarge, 16 vCPU; its times include rebuilding every circuit)" % (n_ctx, rt),
                "one_off_circuit_build_s": round(t_build, 2), "artifacts_MB": round(artifact_mb, 1), "level_degree_bits": [l.data.degree_bits for l in agg.levels],
                "readme_s": {"2": 11, "4": 29, "8": 64, "16": 128, "32": 235, "64": 468, "128": 930}, "runs": {}}
         # cold: artifacts from disk into a fresh Aggregator, then the largest tree
