@@ -320,8 +320,12 @@ class ClockSampler:
     def summary(self):
         if not self.samples:
             return None
-        return {"mean_mhz": round(sum(self.samples) / len(self.samples)), "min_mhz": round(min(self.samples)), "max_mhz": round(max(self.samples)),
-                "samples": len(self.samples)}
+        # a probe wave descheduled in mid-sleep (two processes on one device) reads a nonsense ratio: samples beyond 1.25x the
+        # median are dropped and counted
+        med = sorted(self.samples)[len(self.samples) // 2]
+        kept = [s for s in self.samples if s <= 1.25 * med]
+        return {"mean_mhz": round(sum(kept) / len(kept)), "min_mhz": round(min(kept)), "max_mhz": round(max(kept)),
+                "samples": len(kept), "dropped": len(self.samples) - len(kept)}
 
 
 def valu_mix(kernel=None):
