@@ -59,10 +59,32 @@ GL_DEV u256 u_cond_sub(const u256& a, const uint32_t* m) {
     return r;
 }
 // a * b * R^-1 (mod m), result < 2m for a, b < 2m
+//
+// Device build: one asm statement (bn254_mmul_asm.inc, written by tools/gen_mmul_asm.py, which explains the scheme): independent
+// multiply-adds against a bank of {t_j, 0} pairs + one carry chain per half-row, 128 v_mad_u64_u32 + 128 carry adds + 8 v_mul_lo, where
+// the compiled C below spends 128 + 118 64-bit adds + 268 moves.  GL355_BN254_MMUL_ASM=0 builds the C form (the A/B of DESIGN 4.8).
+#ifndef GL355_BN254_MMUL_ASM
+#define GL355_BN254_MMUL_ASM 1
+#endif
+#include "bn254_mmul_asm.inc"
 template <int F>
 __device__ __noinline__ u256 m_mul(u256 a, u256 b) {
     const uint32_t* M = f_mod<F>();
     const uint32_t n0 = F == F_Q ? BN254C_FQ_N0INV : BN254C_FR_N0INV;
+#if GL355_BN254_MMUL_ASM && defined(__HIP_DEVICE_COMPILE__)
+    u256 r;
+    uint32_t u8, mm;
+    uint64_t sd;
+    asm(GL355_MMUL_ASM_TEXT
+        : [r0] "=v"(r.l[0]), [r1] "=v"(r.l[1]), [r2] "=v"(r.l[2]), [r3] "=v"(r.l[3]), [r4] "=v"(r.l[4]), [r5] "=v"(r.l[5]), [r6] "=v"(r.l[6]),
+          [r7] "=v"(r.l[7]), [u8] "=&v"(u8), [mm] "=&v"(mm), [sd] "=&s"(sd)
+        : [a0] "v"(a.l[0]), [a1] "v"(a.l[1]), [a2] "v"(a.l[2]), [a3] "v"(a.l[3]), [a4] "v"(a.l[4]), [a5] "v"(a.l[5]), [a6] "v"(a.l[6]),
+          [a7] "v"(a.l[7]), [b0] "v"(b.l[0]), [b1] "v"(b.l[1]), [b2] "v"(b.l[2]), [b3] "v"(b.l[3]), [b4] "v"(b.l[4]), [b5] "v"(b.l[5]),
+          [b6] "v"(b.l[6]), [b7] "v"(b.l[7]), [M0] "s"(M[0]), [M1] "s"(M[1]), [M2] "s"(M[2]), [M3] "s"(M[3]), [M4] "s"(M[4]), [M5] "s"(M[5]),
+          [M6] "s"(M[6]), [M7] "s"(M[7]), [n0] "s"(n0)
+        : GL355_MMUL_ASM_CLOBBERS);
+    return r;
+#else
     uint32_t t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t t9 = 0;
 #pragma unroll
@@ -93,6 +115,7 @@ __device__ __noinline__ u256 m_mul(u256 a, u256 b) {
 #pragma unroll
     for (int j = 0; j < 8; j++) r.l[j] = t[j];
     return r;
+#endif
 }
 template <int F> GL_DEV u256 m_add(const u256& a, const u256& b) {
     u256 s;
