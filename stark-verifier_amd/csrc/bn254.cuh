@@ -15,6 +15,10 @@
 
 #define BN254_TABLE_QUAL __device__ __constant__ const
 #include "bn254_tables.h"
+#ifndef GL355_BN254_MMUL_ASM
+#define GL355_BN254_MMUL_ASM 1
+#endif
+#include "bn254_mmul_asm.inc"
 
 namespace gl355 {
 
@@ -24,6 +28,21 @@ struct fr8 { uint32_t l[8]; };
 __device__ __noinline__ fr8 fr_mul(fr8 a, fr8 b) {
     constexpr uint32_t M[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     constexpr uint32_t N0INV = 0xefffffffu;
+#if GL355_BN254_MMUL_ASM && defined(__HIP_DEVICE_COMPILE__)
+    // the hand-scheduled product of bn254_field.cuh (tools/gen_mmul_asm.py): 128 multiply-adds + 128 carry adds, no moves
+    fr8 q;
+    uint32_t u8, mm;
+    uint64_t sd;
+    asm(GL355_MMUL_ASM_TEXT
+        : [r0] "=v"(q.l[0]), [r1] "=v"(q.l[1]), [r2] "=v"(q.l[2]), [r3] "=v"(q.l[3]), [r4] "=v"(q.l[4]), [r5] "=v"(q.l[5]), [r6] "=v"(q.l[6]),
+          [r7] "=v"(q.l[7]), [u8] "=&v"(u8), [mm] "=&v"(mm), [sd] "=&s"(sd)
+        : [a0] "v"(a.l[0]), [a1] "v"(a.l[1]), [a2] "v"(a.l[2]), [a3] "v"(a.l[3]), [a4] "v"(a.l[4]), [a5] "v"(a.l[5]), [a6] "v"(a.l[6]),
+          [a7] "v"(a.l[7]), [b0] "v"(b.l[0]), [b1] "v"(b.l[1]), [b2] "v"(b.l[2]), [b3] "v"(b.l[3]), [b4] "v"(b.l[4]), [b5] "v"(b.l[5]),
+          [b6] "v"(b.l[6]), [b7] "v"(b.l[7]), [M0] "s"(M[0]), [M1] "s"(M[1]), [M2] "s"(M[2]), [M3] "s"(M[3]), [M4] "s"(M[4]), [M5] "s"(M[5]),
+          [M6] "s"(M[6]), [M7] "s"(M[7]), [n0] "s"(N0INV)
+        : GL355_MMUL_ASM_CLOBBERS);
+    return q;
+#else
     uint32_t t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t t9 = 0;
 #pragma unroll
@@ -54,6 +73,7 @@ __device__ __noinline__ fr8 fr_mul(fr8 a, fr8 b) {
 #pragma unroll
     for (int j = 0; j < 8; j++) r.l[j] = t[j];     // t[8] == 0 here: the result is < 2r < 2^256
     return r;
+#endif
 }
 
 // r = a - m if a >= m else a   (m: 8-limb constant table)
