@@ -1039,8 +1039,10 @@ def main_recursive(args):
         # BASELINE configs[3] as stated: ONE proof end to end.  One context, one unit per call (no lock-step partners, no pipelining):
         # gl355_semaphore_prove (witness + proof, n = 2^13) then gl355_circuit_prove_tape (tape replay + proof), host-visible wall time
         # (a lone unit has the rank's host cores to itself: its witness tape replays on up to 8 threads instead of the throughput setting)
+        # and polls its stream without sleeping: GL355_OPT_BLOCKING_SYNC 3)
         lat_rt = max(1, min(8, cores_per_rank // 2))
         all_sets[0].set_option(3, lat_rt)
+        all_sets[0].set_option(2, 3)
         lat = []
         for k in range(6):
             t_l = time.perf_counter()
@@ -1051,10 +1053,11 @@ def main_recursive(args):
         pr.prove_batch(9300, 1)                                                  # the same through the batch runtime (one unit)
         t_b1 = time.perf_counter() - t_b1
         all_sets[0].set_option(3, replay_threads)
+        all_sets[0].set_option(2, 2 if wait_mode == "poll" else 0)
         latency = {"what": "configs[3]: one depth-20 Semaphore signal + the recursive proof verifying it, one prover context, one unit, "
                            "host-visible wall time (witness generation, transcript, downloads included)",
                    "median_ms": round(1e3 * lat[len(lat) // 2], 2), "min_ms": round(1e3 * lat[0], 2), "max_ms": round(1e3 * lat[-1], 2),
-                   "runs": len(lat), "tape_replay_threads": lat_rt, "through_batch_runtime_ms": round(1e3 * t_b1, 2),
+                   "runs": len(lat), "tape_replay_threads": lat_rt, "stream_wait": "poll, no sleep", "through_batch_runtime_ms": round(1e3 * t_b1, 2),
                    "lockstep_8_units_ms_per_unit": round(1e3 * t_iso / 8, 2)}
         pr.sets = all_sets
         # host/device split of one context: wall time in Ctx::wait() ("host:stream_wait" pseudo-scope) against the wall time per unit

@@ -69,7 +69,8 @@ enum { GL355_OPT_MERKLE_LANES_LOG = 1,
        GL355_OPT_BLOCKING_SYNC = 2,     /* how the context's host thread waits for its stream: 0 hipStreamSynchronize (spins unless the
                                            device runs gl355_runtime_config(.., sleeping_waits)), 1 a blocking event, 2 poll + back-off
                                            (hipStreamQuery, 30-us sleeps): a few percent of a core per waiting context and ~30 us of
-                                           wake-up latency -- for ranks with more prover contexts than cores */
+                                           wake-up latency -- for ranks with more prover contexts than cores; 3 poll without sleeping (a lone proof's
+                                           latency setting: its ~40 waits each end within one poll of the completion) */
        GL355_OPT_REPLAY_THREADS = 3,    /* host threads gl355_circuit_prove_tape uses for a segmented tape (default 1) */
        GL355_OPT_NTT_SINGLE_PASS_MAX_LOG = 4, /* 12..14 (default 12): commit-path transforms of 2^13 / 2^14 points above this size run
                                            in two passes (a streaming 2- / 4-row column pass, then 4096-point limb rows, 3 tiles per

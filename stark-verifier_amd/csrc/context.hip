@@ -47,15 +47,17 @@ hipError_t Ctx::d2h(void* dst, const void* src, size_t bytes) {
 //   2  poll + back-off: hipStreamQuery in a loop, spinning for the first ~20 us and then sleeping 30 us between polls -- a waiting
 //      context costs a few percent of a core and wakes within ~30 us of completion, whatever the runtime's interrupt path does.
 //      This is what lets a rank run more prover contexts than it has cores.
+//   3  poll without ever sleeping: the latency setting of a lone proof (every wait ends within a poll of the completion; a sleep of
+//      30 us is 80 us and more with the default timer slack, and a unit has ~40 waits)
 hipError_t Ctx::wait_impl() {
-    if (blocking_sync == 2) {
+    if (blocking_sync == 2 || blocking_sync == 3) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
             const hipError_t q = hipStreamQuery(stream);
             if (q == hipSuccess) return hipSuccess;
             if (q != hipErrorNotReady) return q;
             (void)hipGetLastError();
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(20)) {
+            if (blocking_sync == 2 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(20)) {
                 struct timespec ts = {0, 30000};
                 nanosleep(&ts, nullptr);
             }
@@ -328,7 +330,7 @@ int32_t gl355_ctx_set_option(gl355_ctx* ctx, int32_t option, int64_t value) {
         ctx->c.batch_units = (uint32_t)value;
         return GL355_OK;
     case GL355_OPT_BLOCKING_SYNC:
-        if (value < 0 || value > 2) return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: BLOCKING_SYNC is 0 (runtime wait), 1 (blocking event) or 2 (poll + back-off)");
+        if (value < 0 || value > 3) return ctx->c.fail(GL355_E_INVALID_ARG, "set_option: BLOCKING_SYNC is 0 (runtime wait), 1 (blocking event), 2 (poll + back-off) or 3 (poll, no sleep)");
         ctx->c.blocking_sync = (int)value;
         return GL355_OK;
     case GL355_OPT_NTT_SINGLE_PASS_MAX_LOG:
