@@ -19,6 +19,7 @@
 #define GL355_BN254_MMUL_ASM 1
 #endif
 #include "bn254_mmul_asm.inc"
+#include "bn254_addsub_asm.cuh"
 
 namespace gl355 {
 
@@ -94,6 +95,13 @@ GL_DEV fr8 fr_cond_sub(fr8 a, const uint32_t* m) {
 // (a + b) brought back under 2r; a, b < 2r so the sum fits 256 bits (4r < 2^256)
 GL_DEV fr8 fr_add(fr8 a, fr8 b) {
     constexpr uint32_t TWO_R[8] = {0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u, 0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};
+#if GL355_BN254_MMUL_ASM && defined(__HIP_DEVICE_COMPILE__)
+    const bn_limbs q = bn254_add_asm(a.l, b.l, TWO_R);
+    fr8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.l[j] = q.l[j];
+    return r;
+#endif
     fr8 s;
     uint64_t c = 0;
 #pragma unroll
