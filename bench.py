@@ -801,6 +801,39 @@ def aggregate_figure(gl, device, n_ctx=16, log_members=20, sizes=(2, 4, 8, 16, 3
             c.close()
 
 
+def halo2_valu(clock_mhz):
+    """VALU roofline of the two kernels that carry the k = 23 proof (Fr transform passes, MSM bucket accumulation): dynamic wave instructions
+    per launch and their 64-bit share from the committed --pmc pass (profiles/rNN_halo2_k23_pmc_sq.txt), launch time from the committed
+    rocprofv3 kernel stats of the same tool, the rest of the mix from the shipped ISA -- the kernel's own body and the Montgomery product it
+    calls, weighted so that their 64-bit share matches the counter -- against 1024 SIMDs x the clock sampled during this run's proof."""
+    import csv
+    import re
+    pmc, st, isa = latest_profile("_halo2_k23_pmc_sq.txt"), latest_profile("_halo2_k23_kernel_stats.csv"), latest_profile("_isa_mix.json")
+    if not (pmc and st and isa and clock_mhz):
+        return None
+    isa = json.load(open(isa))["kernels"]
+    dur = {re.sub(r"^(void )?gl355::", "", r["Name"]).split("(")[0]: float(r["AverageNs"]) for r in csv.DictReader(open(st))}
+    out = {"clock_mhz": clock_mhz, "source": "profiles/%s + %s + %s" % tuple(os.path.basename(x) for x in (pmc, st, latest_profile("_isa_mix.json"))),
+           "formula": "insts_per_launch / avg_launch_s against 1024 SIMDs x clock / sum_c mix[c] x nominal_clk[c]", "kernels": {}}
+    for line in open(pmc):
+        name = re.sub(r"^gl355::", "", line.split("(")[0])
+        callee = {"fr_fft_pass_kernel": "u256 gl355::m_mul<0>", "msm_bucket_kernel": "u256 gl355::m_mul<1>"}.get(name)
+        if not callee or name not in dur or name not in isa or callee not in isa:
+            continue
+        c = {m.group(1): float(m.group(2)) for m in re.finditer(r"(SQ_\w+)=([0-9.e+]+)", line)}
+        n, f64 = c.get("SQ_INSTS_VALU"), c.get("SQ_INSTS_VALU_INT64", 0.0) / c.get("SQ_INSTS_VALU", 1.0)
+        b, m = isa[name]["f"], isa[callee]["f"]
+        al = min(1.0, max(0.0, (f64 - b["mad64"]) / (m["mad64"] - b["mad64"]))) if m["mad64"] != b["mad64"] else 1.0
+        mix = {k2: al * m[k2] + (1 - al) * b[k2] for k2 in VALU_CLASSES}
+        rest = mix["full32"] + mix["half32"]
+        mix = {"mad64": round(f64, 4), "full32": round((1 - f64) * mix["full32"] / rest, 4), "half32": round((1 - f64) * mix["half32"] / rest, 4)}
+        peak = valu_peak(mix, clock_mhz)
+        ach = n / (dur[name] * 1e-9) / 1e9
+        out["kernels"][name] = {"insts_per_launch": n, "avg_launch_ms": round(dur[name] * 1e-6, 4), "mix": mix, "product_share_of_instructions": round(al, 3),
+                                "achieved_ginst_s": round(ach, 1), "peak_ginst_s": round(peak, 1), "frac": round(ach / peak, 4)}
+    return out
+
+
 def halo2_figure(gl, device, k=23):
     """SURVEY 8(f) N4 at the reference's size: halo2's create_proof (SHPLONK, Keccak256 transcript; chip/native_chip/test_utils.rs:57-95) over a
     synthetic 2^23-row circuit with the reference's column / gate / lookup shape (tools/halo2_bench.py, stark-verifier_amd/halo2_chips.py), the
@@ -810,9 +843,12 @@ def halo2_figure(gl, device, k=23):
     import halo2_bench
     ctx = gl.Context(device)
     try:
-        out = halo2_bench.run(gl, ctx, int(os.environ.get("GL355_BENCH_HALO2_K", k)))
+        with ClockSampler(gl, device, period=0.05) as clk:
+            out = halo2_bench.run(gl, ctx, int(os.environ.get("GL355_BENCH_HALO2_K", k)))
     finally:
         ctx.close()
+    clock = clk.summary()
+    out["valu"] = halo2_valu(clock["mean_mhz"] if clock else None)
     out["what"] = ("gl355_plonk_prove: advice commitments, lookup permutation, permutation / lookup grand products, evaluate_h on degree - 1 cosets, "
                    "quotient pieces, evaluations, SHPLONK multi-open; witness synthesis and the Halo2 verifier circuit itself out of scope")
     out["reference"] = "README.md:171-177: 505-511 s (Halo2 finalisation proof, k = 23, AWS r5.4xlarge, 16 vCPU)"
