@@ -1123,7 +1123,8 @@ def main_recursive(args):
         # moved from the clock each probe ran at to the clock sampled during the timed region; f_c = the job's dynamic instruction mix
         # (SQ_INSTS_VALU_INT64 share + the shipped ISA's split of the rest).  The dominant kernel's own launch figures and the HBM-side
         # figure SURVEY 8(d) also asks for follow as sub-blocks.
-        units_per_s_gpu = units / elapsed / max(1, world)
+        # (the one-device rehearsal time-slices ONE GPU between the ranks: the whole job's rate is that device's rate)
+        units_per_s_gpu = units / elapsed / (1 if rehearsal else max(1, world))
         job_mix, insts_per_unit, mix_src = valu_mix(None)
         k_mix, k_insts, _ = valu_mix(dname)
         clock_mhz = job_clock["mean_mhz"] if job_clock else None

@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <fcntl.h>
 #include <poll.h>
 #include <sys/random.h>
 #include <rccl/rccl.h>
@@ -198,32 +199,64 @@ int32_t gl355_comm_create(gl355_ctx* h, int32_t backend, const uint8_t id[GL355_
             ::close(c->listen_fd); delete c;
             return GL355_E_UNSUPPORTED;
         }
-        // Accept until every rank has arrived or the deadline passes.  A connection that does not present (rank, token) within a few
-        // seconds -- a port scan, a stray client, a duplicate or out-of-range rank -- is closed and IGNORED; it neither claims a
-        // rank nor tears the communicator down.
+        // Accept until every rank has arrived or the ONE deadline passes.  Accepted sockets are non-blocking and polled together with the
+        // listener: a connection that stays silent (a port scan, a stray client) costs nothing but its slot until it is dropped after 5 s,
+        // and cannot hold real ranks back in the backlog.  A connection whose (rank, token) is complete and valid gets a 1-byte
+        // acknowledgement and claims its rank; anything else -- wrong token, duplicate or out-of-range rank -- is closed, which the
+        // peer sees at once (gl355_comm_create fails there instead of at its first gather).
+        struct Handshake { int32_t rank; uint8_t token[HOST_TOKEN_BYTES]; };
+        struct Pending { int fd; size_t got; Handshake hs; std::chrono::steady_clock::time_point since; };
+        std::vector<Pending> pending;
         const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
         int have = 1;
         while (have < world) {
-            const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+            const auto now = std::chrono::steady_clock::now();
+            const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - now).count();
             if (left <= 0) break;
-            pollfd pf{c->listen_fd, POLLIN, 0};
-            const int pr = ::poll(&pf, 1, (int)std::min<long long>(left, 1000));
+            for (size_t i = 0; i < pending.size();) {                 // silent for 5 s: dropped
+                if (now - pending[i].since > std::chrono::seconds(5)) { ::close(pending[i].fd); pending.erase(pending.begin() + i); }
+                else i++;
+            }
+            std::vector<pollfd> pfs(1 + pending.size());
+            pfs[0] = pollfd{c->listen_fd, POLLIN, 0};
+            for (size_t i = 0; i < pending.size(); i++) pfs[1 + i] = pollfd{pending[i].fd, POLLIN, 0};
+            const int pr = ::poll(pfs.data(), (nfds_t)pfs.size(), (int)std::min<long long>(left, 250));
             if (pr < 0 && errno != EINTR) break;
             if (pr <= 0) continue;
-            const int fd = ::accept(c->listen_fd, nullptr, nullptr);
-            if (fd < 0) continue;
-            set_io_timeouts(fd, 5);                       // the handshake itself must arrive promptly
-            struct { int32_t rank; uint8_t token[HOST_TOKEN_BYTES]; } hs;
-            if (!recv_all(fd, &hs, sizeof hs) || hs.rank <= 0 || hs.rank >= world || c->peers[hs.rank] >= 0 ||
-                memcmp(hs.token, id + HOST_TOKEN_OFFSET, HOST_TOKEN_BYTES) != 0) {
-                ::close(fd);
-                continue;
+            const size_t n_pending = pending.size();                  // sockets accepted below are polled on the next turn
+            if (pfs[0].revents & POLLIN) {
+                const int fd = ::accept4(c->listen_fd, nullptr, nullptr, SOCK_NONBLOCK);
+                if (fd >= 0) {
+                    if (pending.size() >= 1024) ::close(fd);          // bounded: a flood cannot exhaust descriptors
+                    else pending.push_back(Pending{fd, 0, Handshake{}, std::chrono::steady_clock::now()});
+                }
             }
-            setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-            set_io_timeouts(fd, comm_timeout_s());
-            c->peers[hs.rank] = fd;
-            have++;
+            std::vector<size_t> done;
+            for (size_t i = 0; i < n_pending; i++) {
+                if (!(pfs[1 + i].revents & (POLLIN | POLLHUP | POLLERR))) continue;
+                Pending& pe = pending[i];
+                const ssize_t r = ::recv(pe.fd, reinterpret_cast<char*>(&pe.hs) + pe.got, sizeof(Handshake) - pe.got, 0);
+                if (r < 0 && (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR)) continue;
+                if (r <= 0) { ::close(pe.fd); pe.fd = -1; done.push_back(i); continue; }
+                pe.got += (size_t)r;
+                if (pe.got < sizeof(Handshake)) continue;
+                const bool ok = pe.hs.rank > 0 && pe.hs.rank < world && c->peers[pe.hs.rank] < 0 &&
+                                memcmp(pe.hs.token, id + HOST_TOKEN_OFFSET, HOST_TOKEN_BYTES) == 0;
+                if (ok) {
+                    const int fl = fcntl(pe.fd, F_GETFL, 0);
+                    if (fl >= 0) (void)fcntl(pe.fd, F_SETFL, fl & ~O_NONBLOCK);
+                    setsockopt(pe.fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+                    set_io_timeouts(pe.fd, comm_timeout_s());
+                    const uint8_t ack = 1;
+                    if (send_all(pe.fd, &ack, 1)) { c->peers[pe.hs.rank] = pe.fd; have++; pe.fd = -1; }
+                }
+                if (pe.fd >= 0) ::close(pe.fd);
+                pe.fd = -1;
+                done.push_back(i);
+            }
+            for (size_t k = done.size(); k-- > 0;) pending.erase(pending.begin() + done[k]);
         }
+        for (const Pending& pe : pending) if (pe.fd >= 0) ::close(pe.fd);
         if (have < world) {
             gl355_comm_destroy(c);
             g_comm_error = "comm_create: not every rank presented a valid handshake before the deadline";
@@ -248,6 +281,15 @@ int32_t gl355_comm_create(gl355_ctx* h, int32_t backend, const uint8_t id[GL355_
             return GL355_E_UNSUPPORTED;
         }
         setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+        // rank 0 acknowledges a valid handshake with one byte and closes a rejected one: a stale id or token fails here, not at the first gather
+        set_io_timeouts(fd, 125);
+        uint8_t ack = 0;
+        if (!recv_all(fd, &ack, 1) || ack != 1) {
+            ::close(fd);
+            delete c;
+            g_comm_error = "comm_create: rank 0 rejected the handshake (stale id or token, duplicate rank) or never answered";
+            return GL355_E_UNSUPPORTED;
+        }
         set_io_timeouts(fd, comm_timeout_s());
         c->peers.assign(1, fd);
     }

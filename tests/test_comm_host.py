@@ -99,6 +99,47 @@ def test_host_comm_three_ranks():
         assert m == 12.0 and list(tiny.reshape(-1)) == [0, 1, 2]
 
 
+def _stale_worker(world, cid, q):
+    sys.path.insert(0, ROOT)
+    import time
+    par = importlib.import_module("stark-verifier_amd.parallel")
+    lib = importlib.import_module("stark-verifier_amd._lib").load()
+    t0 = time.time()
+    try:
+        par.Comm(None, par.COMM_HOST, cid, 1, world, lib=lib)
+        q.put(("stale", "accepted", time.time() - t0))
+    except Exception as exc:
+        q.put(("stale", repr(exc), time.time() - t0))
+
+
+@pytest.mark.timeout(120)
+def test_host_comm_rejected_rank_fails_at_create():
+    """a rank presenting a stale token is turned away by rank 0 (connection closed, no acknowledgement byte) and its
+    gl355_comm_create fails there and then -- not at its first gather -- while the real rank still gets in."""
+    import multiprocessing as mp
+    total, world = 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    par = importlib.import_module("stark-verifier_amd.parallel")
+    lib = importlib.import_module("stark-verifier_amd._lib").load()
+    cid = par.Comm.unique_id(lib, par.COMM_HOST, "127.0.0.1", port)
+    stale = par.Comm.unique_id(lib, par.COMM_HOST, "127.0.0.1", port)         # same address, another token
+    p0 = ctx.Process(target=_worker, args=(0, world, cid, total, q))
+    pbad = ctx.Process(target=_stale_worker, args=(world, stale, q))
+    p0.start()
+    pbad.start()
+    tag, what, dt = q.get(timeout=60)
+    assert tag == "stale" and what != "accepted" and "rejected" in what and dt < 30, (what, dt)
+    p1 = ctx.Process(target=_worker, args=(1, world, cid, total, q))
+    p1.start()
+    got = sorted(q.get(timeout=60)[0] for _ in range(2))
+    assert got == [0, 1]
+    for p in (p0, p1, pbad):
+        p.join(30)
+        assert p.exitcode == 0
+
+
 @pytest.mark.timeout(180)
 def test_host_comm_eight_ranks_cfg5_shape(orc):
     """BASELINE configs[4] without GPUs: 8 ranks (one process each, TCP back-end of the communicator) x 128 units -- the flow of

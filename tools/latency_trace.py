@@ -19,13 +19,23 @@ def run():
     gl = importlib.import_module("stark-verifier_amd")
     rt = int(os.environ.get("GL355_LAT_REPLAY_THREADS", "8"))
     pr = bench.RecursiveProvers(gl, 0, 1, 20, replay_threads=rt, blocking_sync=int(os.environ.get("GL355_LAT_SYNC", "2")))
+    if os.environ.get("GL355_LAT_WHAT") == "wrap":        # the BN254-Poseidon wrap proof (wrapper.rs:35-56) instead of a unit
+        import numpy as np
+        rec = importlib.import_module("stark-verifier_amd.recursion")
+        pr.unit(0, 9100)
+        inner, c0 = pr.last[0], pr.sets[0]
+        wc = rec.WrapperCircuit(c0, pr.inner_data.common()).build([inner], np.random.default_rng(3))
+        rows_w, pis_w = wc.witness([inner])
+        one = lambda k: pr.plonk.prove_sparse(c0, wc.data, wc.row_idx, rows_w, pis_w, k, flat_only=True)
+    else:
+        one = lambda k: pr.unit(0, k)
     for k in range(3):
-        pr.unit(0, 9100 + k)
+        one(9100 + k)
     lat = []
     for k in range(5):
         time.sleep(0.5)
         t0 = time.perf_counter()
-        pr.unit(0, 9200 + k)
+        one(9200 + k)
         lat.append(1e3 * (time.perf_counter() - t0))
     time.sleep(0.5)
     print("unit latencies ms", [round(x, 2) for x in lat])
