@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import halo2_model as hm  # noqa: E402
 import halo2_verifier as hv  # noqa: E402
+from halo2_circuits import plonk_with_tuple_lookup  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 h2 = importlib.import_module("stark-verifier_amd.halo2")
@@ -67,6 +68,27 @@ def test_proof_bytes_equal_the_oracle(ctx, k, tb):
     assert prover.prove(w.advice, w.instance, seed) == got
     other = prover.prove(w.advice, w.instance, bytes(32))
     assert other != got and hv.verify(k, cs, vk, w.instance, other, TAU)
+    prover.close()
+
+
+@pytest.mark.parametrize("k,tb", [(7, 5), (9, 6)])
+def test_second_circuit_family_bytes_equal_the_oracle(ctx, k, tb):
+    cs, w = plonk_with_tuple_lookup(k, tb)
+    assert cs.degree() == 5 and len(cs.permutation) == 4 and cs.num_instance == 1 and len(cs.lookups[0][1]) == 2
+    g, gl_ = h2.kzg_setup(ctx, k, TAU)
+    prover = h2.PlonkProver(ctx, cs, k, g, gl_, w.fixed, w.assembly.mapping_array())
+    params = hm.Params(k, TAU)
+    pk = hm.keygen(params, cs, w.fixed_ints(), w.assembly)
+    assert [pt(c) for c in prover.fixed_commitments] == pk.fixed_commitments
+    assert [pt(c) for c in prover.sigma_commitments] == pk.sigma_commitments
+    seed = bytes((3 * i + k) & 0xFF for i in range(32))
+    want = hm.create_proof(params, pk, w.advice_ints(), w.instance, seed, prover.digest, {})
+    got = prover.prove(w.advice, w.instance, seed)
+    assert got == want
+    vk = dict(digest=prover.digest, fixed_commitments=pk.fixed_commitments, sigma_commitments=pk.sigma_commitments)
+    assert hv.verify(k, cs, vk, w.instance, got, TAU)
+    with pytest.raises(hv.VerifyError):                              # another public input: refused
+        hv.verify(k, cs, vk, [[w.instance[0][0] + 1, w.instance[0][1]]], got, TAU)
     prover.close()
 
 

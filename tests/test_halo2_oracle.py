@@ -108,6 +108,31 @@ def test_oracle_proof_verifies_and_tampering_is_rejected():
     assert proof2 != proof and hv.verify(k, cs2, vk2, w2.instance, proof2, TAU)
 
 
+def test_second_circuit_family_verifies():
+    """vanilla PLONK gates + a rotation + a two-column lookup with product inputs + an instance column in the permutation (tests/halo2_circuits.py):
+    the oracle's proof passes the verifier restatement; other public inputs, a broken copy and a broken lookup do not give an accepted proof"""
+    from halo2_circuits import plonk_with_tuple_lookup
+    k = 7
+    cs, w = plonk_with_tuple_lookup(k, 5)
+    assert cs.degree() == 5 and cs.chunk_len() == 3 and len(cs.permutation) == 4 and cs.num_instance == 1
+    params = hm.Params(k, TAU)
+    pk = hm.keygen(params, cs, w.fixed_ints(), w.assembly)
+    digest = h2.vk_digest(cs, k)
+    vk = dict(digest=digest, fixed_commitments=pk.fixed_commitments, sigma_commitments=pk.sigma_commitments)
+    proof = hm.create_proof(params, pk, w.advice_ints(), w.instance, bytes(32), digest)
+    assert hv.verify(k, cs, vk, w.instance, proof, TAU)
+    with pytest.raises(hv.VerifyError):
+        hv.verify(k, cs, vk, [[w.instance[0][0] + 1, w.instance[0][1]]], proof, TAU)
+    adv = w.advice_ints()
+    adv[1][3] += 1                                     # b of row 3 is a copy of c of row 2 (and the gate of row 3 breaks with it)
+    with pytest.raises((AssertionError, hv.VerifyError)):
+        hv.verify(k, cs, vk, w.instance, hm.create_proof(params, pk, adv, w.instance, bytes(32), digest), TAU)
+    adv = w.advice_ints()
+    adv[0][4], adv[2][4] = 40, 3 * 40 + 1              # row 4 looks (a, c) up: the gate still holds, 40 is outside the 5-bit table
+    with pytest.raises((AssertionError, hv.VerifyError)):
+        hv.verify(k, cs, vk, w.instance, hm.create_proof(params, pk, adv, w.instance, bytes(32), digest), TAU)
+
+
 def test_unsatisfied_witness_has_no_quotient():
     k = 7
     cs, cfg, w = ch.synthetic_circuit(k, table_bits=5, n_permutations=1)
