@@ -1268,34 +1268,54 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
         t >>= kb; shift += kb;
         lvl_words += 2ull * W * t * 24;
     }
-    // big-bucket work list: a bucket of sz > MSM_BIG points makes ceil(sz / slice) items with slice >= MSM_BIG_WG_POINTS, so over all
-    // buckets at most W n / MSM_BIG_WG_POINTS + (number of big buckets) items, and at most W n / MSM_BIG big buckets
-    a.max_big = (uint32_t)(W * n / MSM_BIG + 1);
-    a.max_items = (uint32_t)(W * n / MSM_MID_SLICE + a.max_big + 1);   // (mid-size buckets: items of MSM_MID_SLICE points)
     // the two-level sort: from 2^11 buckets per window on (below that the histograms are small and the point count with them)
     static const bool old_sort = getenv("GL355_EXP_MSM_OLD_SORT") != nullptr;    // A/B: device-scope atomics per point and window
     const bool two_level = !old_sort && a.cb > MSM_FINE_BITS;
     a.cbits = two_level ? a.cb - MSM_FINE_BITS : 0;
     const uint64_t nbin = 1ull << a.cbits;
     a.chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, 32 * nbin), 1ull << 20);
+    // WINDOW CHUNKS ON TWO STREAMS (measured, off by default).  The windows are independent until the host combines them, and an MSM's
+    // phases are bound by different things: the sort by memory (scattered 4- and 8-byte writes), bucket accumulation by the VALU (0.81 of its
+    // issue rate), the bucket reduction by latency -- at k = 23 the sort and the reduction are 11.5 % and 10.3 % of a proof's kernel time
+    // next to 21.5 % of accumulation.  With GL355_EXP_MSM_CHUNKS = K > 1 the windows are cut into K chunks that alternate between the
+    // context's stream and a second one, chunk i + 1 starting its sort when chunk i has finished its own, so that sort (i + 1) could run
+    // under accumulate (i) and reduce (i) under accumulate (i + 1).  The k = 23 proof: K = 1 / 2 / 4 / 6 -> 1.143 / 1.142 / 1.151 / 1.207 s:
+    // the accumulation kernel's waves hold the CUs' registers, the other stream's kernels get in only as it drains, and the smaller
+    // launches lose what the overlap gains.  One chunk on one stream stays the default.
+    static const uint32_t chunks_env = getenv("GL355_EXP_MSM_CHUNKS") ? (uint32_t)atoi(getenv("GL355_EXP_MSM_CHUNKS")) : 1;
+    const uint32_t K = (two_level && n >= (1ull << 18)) ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)chunks_env, W, 8})) : 1;
+    std::vector<uint32_t> w_lo(K + 1);
+    for (uint32_t i = 0; i <= K; i++) w_lo[i] = (uint32_t)(W * i / K);
+    // big-bucket work list: a bucket of sz > MSM_BIG points makes ceil(sz / slice) items with slice >= MSM_BIG_WG_POINTS, so over all
+    // buckets at most W n / MSM_BIG_WG_POINTS + (number of big buckets) items, and at most W n / MSM_BIG big buckets (per chunk: its windows)
+    std::vector<uint32_t> c_max_big(K), c_max_items(K);
+    uint64_t tot_items = 0, tot_big = 0, lvl_words_all = 0;
+    std::vector<uint64_t> c_lvl_words(K);
+    for (uint32_t i = 0; i < K; i++) {
+        const uint64_t Wc = w_lo[i + 1] - w_lo[i];
+        c_max_big[i] = (uint32_t)(Wc * n / MSM_BIG + 1);
+        c_max_items[i] = (uint32_t)(Wc * n / MSM_MID_SLICE + c_max_big[i] + 1);   // (mid-size buckets: items of MSM_MID_SLICE points)
+        tot_items += c_max_items[i]; tot_big += c_max_big[i];
+        c_lvl_words[i] = lvl_words / W * Wc;
+        lvl_words_all += c_lvl_words[i];
+    }
     const uint64_t sort_words = two_level ? 3 * W * n + 3 * W * nbin + 2 : 0;
     Scratch buf(ctx);
-    const uint64_t words32 = n * 16 + 3 * W * nb + W * n + W * nb * 24 + MSM_SIZE_BINS + lvl_words + 64 +
-                             2 + 2ull * a.max_items + 3ull * a.max_big + 24ull * a.max_items + sort_words;
+    const uint64_t words32 = n * 16 + 3 * W * nb + W * n + W * nb * 24 + (uint64_t)K * (MSM_SIZE_BINS + 2) + lvl_words_all + 64 +
+                             2ull * tot_items + 3ull * tot_big + 24ull * tot_items + sort_words;
     GL355_TRY(buf.get(words32 * 4 + 64));
     uint32_t* p = buf.as<uint32_t>();
     a.pm = p; p += n * 16;
     a.hist = p; p += W * nb;
-    a.size_hist = p; p += MSM_SIZE_BINS;                          // cleared together with the histograms
-    a.big_counters = p; p += 2;                                   // ... and so are these
+    uint32_t* small = p; p += (uint64_t)K * (MSM_SIZE_BINS + 2);  // per chunk: size histogram + the two work-list counters, cleared with the histograms
     a.cursor = p; p += W * nb;
     a.order = p; p += W * nb;
     a.idx = p; p += W * n;
     a.buckets = p; p += W * nb * 24;
-    a.big_items = p; p += 2ull * a.max_items;
-    a.big_buckets = p; p += 3ull * a.max_big;
-    a.big_partial = p; p += 24ull * a.max_items;
-    uint32_t* lvl = p; p += lvl_words;
+    uint32_t* items_all = p; p += 2ull * tot_items;
+    uint32_t* bigb_all = p; p += 3ull * tot_big;
+    uint32_t* partial_all = p; p += 24ull * tot_items;
+    uint32_t* lvl = p; p += lvl_words_all;
     if (two_level) {
         p += (2 - ((uintptr_t)p / 4) % 2) % 2;                      // 8-byte alignment of the pairs
         a.pairs = p; p += 2 * W * n;
@@ -1305,58 +1325,106 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
         a.coarse_start = p; p += W * nbin;
         GL355_HIP(ctx, hipMemsetAsync(a.coarse_cnt, 0, 2 * W * nbin * 4, ctx->stream));
     }
-    GL355_HIP(ctx, hipMemsetAsync(a.hist, 0, (W * nb + MSM_SIZE_BINS + 2) * 4, ctx->stream));
-    const uint32_t blk = (uint32_t)((n + 255) / 256), bblk = (uint32_t)((W * nb + 255) / 256);
-    const uint32_t *fin_s = a.buckets, *fin_w = nullptr;
+    GL355_HIP(ctx, hipMemsetAsync(a.hist, 0, (W * nb + (uint64_t)K * (MSM_SIZE_BINS + 2)) * 4, ctx->stream));
+    const uint32_t blk = (uint32_t)((n + 255) / 256);
+    std::vector<const uint32_t*> fin_s(K), fin_w(K, nullptr);
+    std::vector<const uint32_t*> counters(K);
     {
         ProfScope ps(ctx, "bn254_g1_msm", n * (64 + 32ull * m));
-        if (two_level) {
-            const dim3 cgrid((uint32_t)((n + a.chunk - 1) / a.chunk), (uint32_t)W);
-            hipLaunchKernelGGL(msm_digits_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
-            hipLaunchKernelGGL(msm_coarse_count_kernel, cgrid, dim3(256), nbin * 4, ctx->stream, a);
-            hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3((uint32_t)W), dim3(1024), 0, ctx->stream, a);
-            hipLaunchKernelGGL(msm_coarse_scatter_kernel, cgrid, dim3(256), nbin * 8, ctx->stream, a);
-            hipLaunchKernelGGL(msm_fine_sort_kernel, dim3((uint32_t)nbin, (uint32_t)W), dim3(256), 0, ctx->stream, a);
-        } else {
-            hipLaunchKernelGGL(msm_prepare_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
-            hipLaunchKernelGGL(msm_scan_kernel, dim3((uint32_t)W), dim3(1024), 0, ctx->stream, a);
-            hipLaunchKernelGGL(msm_scatter_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
+        hipStream_t st[2] = {ctx->stream, ctx->stream};
+        hipEvent_t ev_ready = nullptr;
+        if (two_level) hipLaunchKernelGGL(msm_digits_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
+        if (K > 1) {
+            GL355_TRY(ctx->aux_stream_get(&st[1]));
+            GL355_TRY(ctx->order_event(0, &ev_ready));
+            GL355_HIP(ctx, hipEventRecord(ev_ready, ctx->stream));          // digits, cleared histograms: what every chunk starts from
+            GL355_HIP(ctx, hipStreamWaitEvent(st[1], ev_ready, 0));
         }
-        hipLaunchKernelGGL(msm_size_hist_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_order_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_big_list_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_mid_partial_kernel, dim3(std::min<uint32_t>((a.max_items + 255) / 256, 2048)), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_big_partial_kernel, dim3(std::min<uint32_t>(a.max_items, 1536)), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_mid_final_kernel, dim3(std::min<uint32_t>((a.max_big + 63) / 64, 1024)), dim3(64), 0, ctx->stream, a);
-        hipLaunchKernelGGL(msm_big_final_kernel, dim3(std::min<uint32_t>(a.max_big, 512)), dim3(256), 0, ctx->stream, a);
-        for (const Lv& lv : levels) {
-            MsmLevel l;
-            l.in_s = fin_s; l.in_w = fin_w; l.t_in = lv.t_in; l.kbits = lv.kbits; l.shift = lv.shift; l.n_windows = (uint32_t)W;
-            const uint64_t groups = lv.t_in >> lv.kbits;
-            l.out_s = lvl; lvl += W * groups * 24;
-            l.out_w = lvl; lvl += W * groups * 24;
-            // eight lanes per group where a level is latency-bound (few groups); the large first levels are throughput-bound and the scan
-            // costs them twice the wave-level additions.  GL355_EXP_MSM_COOP_MAX: largest W x groups that runs the cooperative form (0 = never)
-            static const uint64_t coop_max = getenv("GL355_EXP_MSM_COOP_MAX") ? strtoull(getenv("GL355_EXP_MSM_COOP_MAX"), nullptr, 10) : 16384;
-            if (lv.kbits == 3 && W * groups <= coop_max) hipLaunchKernelGGL(msm_level_coop_kernel, dim3((uint32_t)((W * groups + 7) / 8)), dim3(64), 0, ctx->stream, l);
-            else hipLaunchKernelGGL(msm_level_kernel, dim3((uint32_t)((W * groups + 63) / 64)), dim3(64), 0, ctx->stream, l);
-            fin_s = l.out_s; fin_w = l.out_w;
+        uint64_t off_items = 0, off_big = 0;
+        for (uint32_t ci = 0; ci < K; ci++) {
+            hipStream_t s_ = st[ci & 1];
+            const uint64_t w0 = w_lo[ci], Wc = w_lo[ci + 1] - w0;
+            MsmArgs c = a;                                                  // the chunk's windows as a job of its own: every per-window array shifted
+            c.n_windows = (uint32_t)Wc;
+            c.hist += w0 * nb; c.cursor += w0 * nb; c.order += w0 * nb; c.idx += w0 * n; c.buckets += w0 * nb * 24;
+            c.size_hist = small + (uint64_t)ci * (MSM_SIZE_BINS + 2); c.big_counters = c.size_hist + MSM_SIZE_BINS;
+            c.max_items = c_max_items[ci]; c.max_big = c_max_big[ci];
+            c.big_items = items_all + 2 * off_items; c.big_partial = partial_all + 24 * off_items; c.big_buckets = bigb_all + 3 * off_big;
+            off_items += c.max_items; off_big += c.max_big;
+            counters[ci] = c.big_counters;
+            if (two_level) { c.pairs += 2 * w0 * n; c.dig += w0 * n; c.coarse_cnt += w0 * nbin; c.coarse_fill += w0 * nbin; c.coarse_start += w0 * nbin; }
+            const uint32_t bblk = (uint32_t)((Wc * nb + 255) / 256);
+            if (ci > 0 && K > 1) {                                          // this chunk's sort starts when the previous chunk's has finished
+                hipEvent_t e;
+                GL355_TRY(ctx->order_event(ci, &e));
+                GL355_HIP(ctx, hipStreamWaitEvent(s_, e, 0));
+            }
+            if (two_level) {
+                const dim3 cgrid((uint32_t)((n + c.chunk - 1) / c.chunk), (uint32_t)Wc);
+                hipLaunchKernelGGL(msm_coarse_count_kernel, cgrid, dim3(256), nbin * 4, s_, c);
+                hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3((uint32_t)Wc), dim3(1024), 0, s_, c);
+                hipLaunchKernelGGL(msm_coarse_scatter_kernel, cgrid, dim3(256), nbin * 8, s_, c);
+                hipLaunchKernelGGL(msm_fine_sort_kernel, dim3((uint32_t)nbin, (uint32_t)Wc), dim3(256), 0, s_, c);
+            } else {
+                hipLaunchKernelGGL(msm_prepare_kernel, dim3(blk), dim3(256), 0, s_, c);
+                hipLaunchKernelGGL(msm_scan_kernel, dim3((uint32_t)Wc), dim3(1024), 0, s_, c);
+                hipLaunchKernelGGL(msm_scatter_kernel, dim3(blk), dim3(256), 0, s_, c);
+            }
+            if (ci + 1 < K) {
+                hipEvent_t e;
+                GL355_TRY(ctx->order_event(ci + 1, &e));
+                GL355_HIP(ctx, hipEventRecord(e, s_));
+            }
+            hipLaunchKernelGGL(msm_size_hist_kernel, dim3(bblk), dim3(256), 0, s_, c);
+            hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(64), 0, s_, c);
+            hipLaunchKernelGGL(msm_order_kernel, dim3(bblk), dim3(256), 0, s_, c);
+            hipLaunchKernelGGL(msm_big_list_kernel, dim3(bblk), dim3(256), 0, s_, c);
+            hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, s_, c);
+            hipLaunchKernelGGL(msm_mid_partial_kernel, dim3(std::min<uint32_t>((c.max_items + 255) / 256, 2048)), dim3(256), 0, s_, c);
+            hipLaunchKernelGGL(msm_big_partial_kernel, dim3(std::min<uint32_t>(c.max_items, 1536)), dim3(256), 0, s_, c);
+            hipLaunchKernelGGL(msm_mid_final_kernel, dim3(std::min<uint32_t>((c.max_big + 63) / 64, 1024)), dim3(64), 0, s_, c);
+            hipLaunchKernelGGL(msm_big_final_kernel, dim3(std::min<uint32_t>(c.max_big, 512)), dim3(256), 0, s_, c);
+            const uint32_t *cs = c.buckets, *cw = nullptr;
+            uint32_t* lv_p = lvl;
+            lvl += c_lvl_words[ci];
+            for (const Lv& lv : levels) {
+                MsmLevel l;
+                l.in_s = cs; l.in_w = cw; l.t_in = lv.t_in; l.kbits = lv.kbits; l.shift = lv.shift; l.n_windows = (uint32_t)Wc;
+                const uint64_t groups = lv.t_in >> lv.kbits;
+                l.out_s = lv_p; lv_p += Wc * groups * 24;
+                l.out_w = lv_p; lv_p += Wc * groups * 24;
+                // eight lanes per group where a level is latency-bound (few groups); the large first levels are throughput-bound and the scan
+                // costs them twice the wave-level additions.  GL355_EXP_MSM_COOP_MAX: largest W x groups that runs the cooperative form (0 = never)
+                static const uint64_t coop_max = getenv("GL355_EXP_MSM_COOP_MAX") ? strtoull(getenv("GL355_EXP_MSM_COOP_MAX"), nullptr, 10) : 16384;
+                if (lv.kbits == 3 && Wc * groups <= coop_max) hipLaunchKernelGGL(msm_level_coop_kernel, dim3((uint32_t)((Wc * groups + 7) / 8)), dim3(64), 0, s_, l);
+                else hipLaunchKernelGGL(msm_level_kernel, dim3((uint32_t)((Wc * groups + 63) / 64)), dim3(64), 0, s_, l);
+                cs = l.out_s; cw = l.out_w;
+            }
+            fin_s[ci] = cs; fin_w[ci] = cw;
+        }
+        if (K > 1) {                                                        // the context's stream continues when the second one is done
+            hipEvent_t e;
+            GL355_TRY(ctx->order_event(K, &e));
+            GL355_HIP(ctx, hipEventRecord(e, st[1]));
+            GL355_HIP(ctx, hipStreamWaitEvent(ctx->stream, e, 0));
         }
         GL355_HIP(ctx, hipGetLastError());
     }
     // per window S (and Wt when there was at least one level): 2 x W Jacobian points to the host, which combines the windows
-    std::vector<uint32_t> hs(W * 24), hw(W * 24, 0);
-    uint32_t big_used[2] = {0, 0};
-    GL355_HIP(ctx, ctx->d2h(big_used, a.big_counters, 8));
-    GL355_HIP(ctx, ctx->d2h(hs.data(), fin_s, W * 96));
-    if (fin_w) GL355_HIP(ctx, ctx->d2h(hw.data(), fin_w, W * 96));
+    std::vector<uint32_t> hs(W * 24), hw(W * 24, 0), big_used(2ull * K, 0);
+    for (uint32_t ci = 0; ci < K; ci++) {
+        const uint64_t w0 = w_lo[ci], Wc = w_lo[ci + 1] - w0;
+        GL355_HIP(ctx, ctx->d2h(big_used.data() + 2 * ci, counters[ci], 8));
+        GL355_HIP(ctx, ctx->d2h(hs.data() + w0 * 24, fin_s[ci], Wc * 96));
+        if (fin_w[ci]) GL355_HIP(ctx, ctx->d2h(hw.data() + w0 * 24, fin_w[ci], Wc * 96));
+    }
     GL355_HIP(ctx, ctx->wait());
-    if (big_used[0] > a.max_items || big_used[1] > a.max_big) return ctx->fail(GL355_E_HIP, "bn254_g1_msm: big-bucket work list overflow (internal bound)");
+    for (uint32_t ci = 0; ci < K; ci++)
+        if (big_used[2 * ci] > c_max_items[ci] || big_used[2 * ci + 1] > c_max_big[ci]) return ctx->fail(GL355_E_HIP, "bn254_g1_msm: big-bucket work list overflow (internal bound)");
+    const bool have_w = !levels.empty();
     std::vector<uint64_t> res(8ull * m);
     for (uint32_t set = 0; set < m; set++)
-        bn254_g1_horner_host(hs.data() + 24ull * set * a.wps, fin_w ? hw.data() + 24ull * set * a.wps : nullptr, a.wps, a.c, res.data() + 8 * set);
+        bn254_g1_horner_host(hs.data() + 24ull * set * a.wps, have_w ? hw.data() + 24ull * set * a.wps : nullptr, a.wps, a.c, res.data() + 8 * set);
     if (dev_result) { GL355_HIP(ctx, hipMemcpyAsync(result, res.data(), 64ull * m, hipMemcpyHostToDevice, ctx->stream)); GL355_HIP(ctx, ctx->wait()); }
     else memcpy(result, res.data(), 64ull * m);
     return GL355_OK;

@@ -73,6 +73,21 @@ hipError_t Ctx::wait_impl() {
     return hipEventSynchronize(sync_ev);
 }
 
+int32_t Ctx::aux_stream_get(hipStream_t* out) {
+    if (!aux_stream) GL355_HIP(this, hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+    *out = aux_stream;
+    return GL355_OK;
+}
+int32_t Ctx::order_event(size_t i, hipEvent_t* out) {
+    while (order_ev.size() <= i) {
+        hipEvent_t e = nullptr;
+        GL355_HIP(this, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        order_ev.push_back(e);
+    }
+    *out = order_ev[i];
+    return GL355_OK;
+}
+
 hipEvent_t Ctx::prof_event() {
     if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -305,6 +320,8 @@ int32_t gl355_ctx_destroy(gl355_ctx* ctx) {
     if (c.pinned_buf) (void)hipHostFree(c.pinned_buf);
     c.runtime_buffers_free();
     if (c.rt_copy_stream) (void)hipStreamDestroy(c.rt_copy_stream);
+    if (c.aux_stream) (void)hipStreamDestroy(c.aux_stream);
+    for (hipEvent_t e : c.order_ev) if (e) (void)hipEventDestroy(e);
     if (c.sync_ev) (void)hipEventDestroy(c.sync_ev);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);

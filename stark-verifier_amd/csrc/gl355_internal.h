@@ -106,6 +106,12 @@ struct Ctx {
     size_t rt_bytes = 0, rt_aux_bytes = 0;
     bool device_replay = true;        // GL355_OPT_DEVICE_REPLAY
     hipStream_t rt_copy_stream = nullptr;
+    // second compute stream of the context (the MSM runs its window chunks on two streams so that one chunk's sort -- memory-bound -- and
+    // reduction -- latency-bound -- overlap the neighbour's bucket accumulation -- VALU-bound); created on first use
+    hipStream_t aux_stream = nullptr;
+    std::vector<hipEvent_t> order_ev;       // untimed events for cross-stream ordering, grown on demand
+    int32_t aux_stream_get(hipStream_t* out);
+    int32_t order_event(size_t i, hipEvent_t* out);
     int32_t runtime_buffers(size_t bytes, size_t aux_bytes, uint64_t* rows[2], uint64_t* drows[2], void* aux[2], hipStream_t* copy_stream);
     void runtime_buffers_free();
     void release_all();
