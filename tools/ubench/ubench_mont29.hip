@@ -42,7 +42,7 @@ __device__ __forceinline__ u256 from29(const f29& a) {       // limbs normalised
     return r;
 }
 // a * b * 2^-261 mod m (some representative, limbs < 2^29): a's limbs may be up to 2^30, b's < 2^29
-__device__ __noinline__ f29 mont29(f29 a, f29 b) {
+__device__ __forceinline__ f29 mont29(f29 a, f29 b) {
     uint64_t t[10];
 #pragma unroll
     for (int j = 0; j < 10; j++) t[j] = 0;
