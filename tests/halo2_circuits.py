@@ -81,3 +81,150 @@ def plonk_with_tuple_lookup(k, tb, seed=11):
     w.assembly.copy(a, 0, pub, 0)
     w.assembly.copy(c, 3, pub, 1)
     return cs, w
+
+
+def random_circuit(k, seed):
+    """A satisfiable circuit drawn from `seed`: 2-4 free advice columns and 1-2 free fixed columns of random values, an optional instance
+    column; 1-3 gates q_g (E_g - d_g) where E_g is a random expression (sums, products, scalings, negations, constants; advice at rotations
+    -2 .. 2, fixed at -1 .. 1, instance at 0 .. 1; degree <= 3) and d_g a result column assigned row by row; 0-2 lookups of 1-2 columns whose
+    inputs are q_l F_j (F_j random, degree <= 2) and whose table columns are filled with exactly the tuples the rows need (one of them read
+    through a scaled table expression); copy constraints among advice cells, into the instance column and from a fixed column.
+    -> (cs, witness)"""
+    import random
+    rng = random.Random(seed)
+    R = hm.R
+    cs = h2.ConstraintSystem()
+    n = 1 << k
+    free = [cs.advice_column() for _ in range(rng.randint(2, 4))]
+    ffix = [cs.fixed_column() for _ in range(rng.randint(1, 2))]
+    inst = cs.instance_column() if rng.random() < 0.7 else None
+    n_inst = rng.randint(1, 4) if inst is not None else 0
+
+    def leaf():
+        r = rng.random()
+        if r < 0.6:
+            return cs.query_advice(rng.choice(free), rng.randint(-2, 2))
+        if r < 0.8:
+            return cs.query_fixed(rng.choice(ffix), rng.randint(-1, 1))
+        if r < 0.9 and inst is not None:
+            return cs.query_instance(inst, rng.randint(0, 1))
+        return h2.Expression.constant(rng.randrange(R))
+
+    def expr(max_deg, depth=0):
+        if max_deg <= 1 or depth >= 3 or rng.random() < 0.25:
+            return leaf()
+        r = rng.random()
+        if r < 0.4:
+            return expr(max_deg, depth + 1) + expr(max_deg, depth + 1)
+        if r < 0.5:
+            return expr(max_deg, depth + 1) - expr(max_deg, depth + 1)
+        if r < 0.8:
+            da = rng.randint(1, max_deg - 1)
+            return expr(da, depth + 1) * expr(max_deg - da, depth + 1)
+        if r < 0.9:
+            return expr(max_deg, depth + 1) * rng.randrange(1, R)
+        return -expr(max_deg, depth + 1)
+
+    gates = []
+    for g in range(rng.randint(1, 3)):
+        d, q, e = cs.advice_column(), cs.fixed_column(), expr(3)
+        cs.create_gate("g%d" % g, [cs.query_fixed(q) * (e - cs.query_advice(d))])
+        gates.append((d, q, e))
+    lookups = []
+    for li in range(rng.randint(0, 2)):
+        ql = cs.fixed_column()
+        fs = [expr(2) for _ in range(rng.randint(1, 2))]
+        tabs = [cs.lookup_table_column() for _ in fs]
+        scale = rng.randrange(2, 1000) if rng.random() < 0.5 else None           # the first table column read through a scaled expression
+        tab_exprs = [(cs.query_fixed(t) * scale if (j == 0 and scale) else cs.query_fixed(t)) for j, t in enumerate(tabs)]
+        cs.lookup("l%d" % li, [(cs.query_fixed(ql) * f, te) for f, te in zip(fs, tab_exprs)])
+        lookups.append((ql, fs, tabs, scale))
+    eq_adv = rng.sample(free, rng.randint(1, len(free)))
+    for c in eq_adv:
+        cs.enable_equality(c)
+    if inst is not None:
+        cs.enable_equality(inst)
+    const_col = ffix[0] if rng.random() < 0.5 else None
+    if const_col is not None:
+        cs.enable_equality(const_col)
+    w = ch.Witness(cs, k)
+    u = w.usable
+    A = [[rng.randrange(R) for _ in range(u)] + [0] * (n - u) for _ in range(cs.num_advice)]
+    F = [[0] * n for _ in range(cs.num_fixed)]
+    for c in ffix:
+        F[c.index] = [rng.randrange(R) for _ in range(u)] + [0] * (n - u)
+    inst_vals = [rng.randrange(R) for _ in range(n_inst)]
+    # copy constraints first (they fix values), among rows that exist
+    for _ in range(rng.randint(1, 6)):
+        ca, cb = rng.choice(eq_adv), rng.choice(eq_adv)
+        ra, rb = rng.randrange(u), rng.randrange(u)
+        A[cb.index][rb] = A[ca.index][ra]
+        w.assembly.copy(ca, ra, cb, rb)
+    cells_fixed = set()
+    if inst is not None:
+        for j in range(rng.randint(1, n_inst)):
+            ca, ra = rng.choice(eq_adv), rng.randrange(u)
+            inst_vals[j] = A[ca.index][ra]
+            w.assembly.copy(ca, ra, inst, j)
+            cells_fixed.add((ca.index, ra))
+    if const_col is not None:
+        for _ in range(2):
+            ca, ra, rf = rng.choice(eq_adv), rng.randrange(u), rng.randrange(u)
+            if (ca.index, ra) in cells_fixed:
+                continue
+            A[ca.index][ra] = F[const_col.index][rf]
+            w.assembly.copy(const_col, rf, ca, ra)
+    # the cycles may have chained cells: settle every cycle on one value (the representative's)
+    perm_cols = cs.permutation
+    for ci, col in enumerate(perm_cols):
+        for r in range(n):
+            rep_c, rep_r = (int(v) for v in w.assembly.aux[ci, r])
+            if (rep_c, rep_r) == (ci, r):
+                continue
+            src = perm_cols[rep_c]
+            val = A[src.index][rep_r] if src.kind == h2.ADVICE else (F[src.index][rep_r] if src.kind == h2.FIXED else (inst_vals[rep_r] if rep_r < n_inst else 0))
+            if col.kind == h2.ADVICE:
+                A[col.index][r] = val
+            elif col.kind == h2.INSTANCE:
+                inst_vals[r] = val
+            else:
+                assert F[col.index][r] == val or src.kind != h2.FIXED
+                F[col.index][r] = val
+
+    def at(row):
+        def q(kind, qi):
+            col, rot = cs.queries[kind][qi]
+            rr = (row + rot) % n
+            if kind == h2.ADVICE:
+                return A[col][rr]
+            if kind == h2.FIXED:
+                return F[col][rr]
+            return inst_vals[rr] if rr < n_inst else 0
+        return q
+    lo, hi = 2, u - 2
+    for d, q, e in gates:
+        for r in range(lo, hi):
+            if rng.random() < 0.7:
+                F[q.index][r] = 1
+                A[d.index][r] = e.evaluate(at(r))
+    for ql, fs, tabs, scale in lookups:
+        rows = [r for r in range(lo, hi) if rng.random() < 0.4]
+        for r in rows:
+            F[ql.index][r] = 1
+        tuples = [tuple([0] * len(fs))] + [tuple(f.evaluate(at(r)) for f in fs) for r in rows]
+        inv = pow(scale, -1, R) if scale else 1
+        for i in range(n):
+            t = tuples[i] if i < len(tuples) else tuples[rng.randrange(len(tuples))]
+            for j, tc in enumerate(tabs):
+                F[tc.index][i] = t[j] * (inv if j == 0 else 1) % R
+    for c in range(cs.num_advice):
+        for r in range(n):
+            if A[c][r]:
+                w.set_int(w.advice, c, r, A[c][r])
+    for c in range(cs.num_fixed):
+        for r in range(n):
+            if F[c][r]:
+                w.set_int(w.fixed, c, r, F[c][r])
+    if inst is not None:
+        w.instance[inst.index] = inst_vals
+    return cs, w

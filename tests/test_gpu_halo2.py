@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import halo2_model as hm  # noqa: E402
 import halo2_verifier as hv  # noqa: E402
-from halo2_circuits import plonk_with_tuple_lookup  # noqa: E402
+from halo2_circuits import plonk_with_tuple_lookup, random_circuit  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 h2 = importlib.import_module("stark-verifier_amd.halo2")
@@ -89,6 +89,30 @@ def test_second_circuit_family_bytes_equal_the_oracle(ctx, k, tb):
     assert hv.verify(k, cs, vk, w.instance, got, TAU)
     with pytest.raises(hv.VerifyError):                              # another public input: refused
         hv.verify(k, cs, vk, [[w.instance[0][0] + 1, w.instance[0][1]]], got, TAU)
+    prover.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_circuits_bytes_equal_the_oracle(ctx, seed):
+    """circuits drawn at random (tests/halo2_circuits.random_circuit: random gate expressions with rotations -2 .. 2 on advice, fixed and
+    instance queries, 0-2 lookups of 1-2 columns with expression inputs and scaled table expressions, copy constraints through advice,
+    instance and fixed cells; degree 3 .. 7): verifying-key commitments, proof bytes == the oracle's, accepted by the verifier restatement"""
+    k = 6 + seed % 3
+    cs, w = random_circuit(k, seed)
+    g, gl_ = h2.kzg_setup(ctx, k, TAU)
+    prover = h2.PlonkProver(ctx, cs, k, g, gl_, w.fixed, w.assembly.mapping_array())
+    params = hm.Params(k, TAU)
+    pk = hm.keygen(params, cs, w.fixed_ints(), w.assembly)
+    assert [pt(c) for c in prover.fixed_commitments] == pk.fixed_commitments
+    assert [pt(c) for c in prover.sigma_commitments] == pk.sigma_commitments
+    seed_bytes = bytes((5 * i + seed) & 0xFF for i in range(32))
+    want = hm.create_proof(params, pk, w.advice_ints(), w.instance, seed_bytes, prover.digest, {})
+    got = prover.prove(w.advice, w.instance, seed_bytes)
+    if got != want:
+        first = next(i for i in range(min(len(want), len(got))) if got[i] != want[i]) if len(got) == len(want) else -1
+        raise AssertionError("seed %d (degree %d, %d lookups): proof differs from the oracle's at byte %d of %d / %d" % (seed, cs.degree(), len(cs.lookups), first, len(got), len(want)))
+    vk = dict(digest=prover.digest, fixed_commitments=pk.fixed_commitments, sigma_commitments=pk.sigma_commitments)
+    assert hv.verify(k, cs, vk, w.instance, got, TAU)
     prover.close()
 
 

@@ -133,6 +133,35 @@ def test_second_circuit_family_verifies():
         hv.verify(k, cs, vk, w.instance, hm.create_proof(params, pk, adv, w.instance, bytes(32), digest), TAU)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_circuits_verify(seed):
+    """tests/halo2_circuits.random_circuit: the oracle's proof of a circuit drawn at random passes the verifier restatement; a changed
+    result cell does not"""
+    from halo2_circuits import random_circuit
+    k = 6 + seed % 2
+    cs, w = random_circuit(k, seed)
+    params = hm.Params(k, TAU)
+    pk = hm.keygen(params, cs, w.fixed_ints(), w.assembly)
+    digest = h2.vk_digest(cs, k)
+    vk = dict(digest=digest, fixed_commitments=pk.fixed_commitments, sigma_commitments=pk.sigma_commitments)
+    proof = hm.create_proof(params, pk, w.advice_ints(), w.instance, bytes(32), digest)
+    assert hv.verify(k, cs, vk, w.instance, proof, TAU)
+    # the first gate's result column, on a row its selector switches on
+    fixed = w.fixed_ints()
+    q_col = next(i for i in range(cs.num_fixed) if any(fixed[i][r] == 1 for r in range(2, w.usable - 2)) and set(fixed[i]) <= {0, 1})
+    row = next(r for r in range(2, w.usable - 2) if fixed[q_col][r] == 1)
+    adv = w.advice_ints()
+    noticed = 0
+    for c in range(cs.num_advice):
+        adv2 = [list(col) for col in adv]
+        adv2[c][row] = (adv2[c][row] + 1) % hm.R
+        try:
+            hv.verify(k, cs, vk, w.instance, hm.create_proof(params, pk, adv2, w.instance, bytes(32), digest), TAU)
+        except (AssertionError, hv.VerifyError):          # the quotient has a remainder, or the verifier refuses
+            noticed += 1
+    assert noticed >= 1, "no single-cell change on row %d was noticed" % row
+
+
 def test_unsatisfied_witness_has_no_quotient():
     k = 7
     cs, cfg, w = ch.synthetic_circuit(k, table_bits=5, n_permutations=1)
