@@ -147,7 +147,9 @@ __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
     __syncthreads();
     // (Two stages per LDS round trip -- four rows per lane in registers -- were built and measured: the pass kernel grows from 81 to 170 VGPRs
     // (three waves per SIMD instead of six) and evaluate_h at k = 23 went from 594 to 641 ms, 744 ms capped at 128 VGPRs with spills.  One
-    // stage per round trip at six waves stays.)
+    // stage per round trip at six waves stays.  Round 4, after the product was written by hand: the product inlined into the butterfly (no call,
+    // no operand moves) and both of a thread's twiddles fetched before its first product changed nothing -- evaluate_h 452.5 and 458 against
+    // 451 ms -- the pass is neither call- nor twiddle-latency-bound; it runs at 0.72 of the VALU rate of its mix.)
     for (uint32_t it = 1; it <= a.ns; it++) {
         const uint32_t st = a.dif ? a.ns + 1 - it : it;
         const uint32_t s = a.s0 + st, lh = st - 1, half = 1u << lh;
