@@ -300,7 +300,7 @@ struct MsmArgs {
     uint64_t* result;           // [8]
     // buckets of more than MSM_BIG points (skewed scalars: selector columns of 0 / 1, constants, the sparse top window) are summed by
     // whole workgroups instead of one lane
-    uint32_t* big_counters;     // [2]           work items, big buckets
+    uint32_t* big_counters;     // [4]           work items, big buckets; of those, the items / buckets of more than MSM_MID points (workgroup path)
     uint32_t* big_items;        // [max_items][2] bucket id, first point of the item (relative to the bucket)
     uint32_t* big_buckets;      // [max_big][3]  bucket id, first item, items
     uint32_t* big_partial;      // [max_items][24]
@@ -656,6 +656,7 @@ __global__ void __launch_bounds__(256) msm_big_list_kernel(MsmArgs a) {
     if (sz <= MSM_BIG) return;
     const uint32_t slice = msm_big_slice(sz), cnt = (sz + slice - 1) / slice;
     const uint32_t first = atomicAdd(a.big_counters, cnt), slot = atomicAdd(a.big_counters + 1, 1u);
+    if (sz > MSM_MID) { atomicAdd(a.big_counters + 2, cnt); atomicAdd(a.big_counters + 3, 1u); }
     if (first + cnt > a.max_items || slot >= a.max_big) return;   // cannot happen: the bounds are sums over all points (host side)
     for (uint32_t c = 0; c < cnt; c++) { a.big_items[2 * (first + c)] = id; a.big_items[2 * (first + c) + 1] = c * slice; }
     a.big_buckets[3 * slot] = id; a.big_buckets[3 * slot + 1] = first; a.big_buckets[3 * slot + 2] = cnt;
@@ -696,6 +697,9 @@ __global__ void __launch_bounds__(64) msm_mid_final_kernel(MsmArgs a) {
 }
 __global__ void __launch_bounds__(256) msm_big_partial_kernel(MsmArgs a) {      // a fixed grid walks the work list (usually empty)
     __shared__ uint32_t sh[256 * 24];
+    // (the list holds the lane items of the mid-size buckets too -- 2^17 of them for the top window of a uniform 2^23-point MSM -- and walking
+    // it just to skip them was 2 ms per call: nothing to do unless some bucket takes the workgroup path)
+    if (a.big_counters[2] == 0) return;
     const uint32_t n_items = *a.big_counters;
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
         const uint32_t id = a.big_items[2 * it], off = a.big_items[2 * it + 1], w = id >> a.cb;
@@ -711,6 +715,7 @@ __global__ void __launch_bounds__(256) msm_big_partial_kernel(MsmArgs a) {      
 }
 __global__ void __launch_bounds__(256) msm_big_final_kernel(MsmArgs a) {
     __shared__ uint32_t sh[256 * 24];
+    if (a.big_counters[3] == 0) return;
     const uint32_t n_big = a.big_counters[1];
     for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
         const uint32_t id = a.big_buckets[3 * b], first = a.big_buckets[3 * b + 1], cnt = a.big_buckets[3 * b + 2];
@@ -1303,13 +1308,13 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
     }
     const uint64_t sort_words = two_level ? 3 * W * n + 3 * W * nbin + 2 : 0;
     Scratch buf(ctx);
-    const uint64_t words32 = n * 16 + 3 * W * nb + W * n + W * nb * 24 + (uint64_t)K * (MSM_SIZE_BINS + 2) + lvl_words_all + 64 +
+    const uint64_t words32 = n * 16 + 3 * W * nb + W * n + W * nb * 24 + (uint64_t)K * (MSM_SIZE_BINS + 4) + lvl_words_all + 64 +
                              2ull * tot_items + 3ull * tot_big + 24ull * tot_items + sort_words;
     GL355_TRY(buf.get(words32 * 4 + 64));
     uint32_t* p = buf.as<uint32_t>();
     a.pm = p; p += n * 16;
     a.hist = p; p += W * nb;
-    uint32_t* small = p; p += (uint64_t)K * (MSM_SIZE_BINS + 2);  // per chunk: size histogram + the two work-list counters, cleared with the histograms
+    uint32_t* small = p; p += (uint64_t)K * (MSM_SIZE_BINS + 4);  // per chunk: size histogram + the two work-list counters, cleared with the histograms
     a.cursor = p; p += W * nb;
     a.order = p; p += W * nb;
     a.idx = p; p += W * n;
@@ -1327,7 +1332,7 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
         a.coarse_start = p; p += W * nbin;
         GL355_HIP(ctx, hipMemsetAsync(a.coarse_cnt, 0, 2 * W * nbin * 4, ctx->stream));
     }
-    GL355_HIP(ctx, hipMemsetAsync(a.hist, 0, (W * nb + (uint64_t)K * (MSM_SIZE_BINS + 2)) * 4, ctx->stream));
+    GL355_HIP(ctx, hipMemsetAsync(a.hist, 0, (W * nb + (uint64_t)K * (MSM_SIZE_BINS + 4)) * 4, ctx->stream));
     const uint32_t blk = (uint32_t)((n + 255) / 256);
     std::vector<const uint32_t*> fin_s(K), fin_w(K, nullptr);
     std::vector<const uint32_t*> counters(K);
@@ -1349,7 +1354,7 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
             MsmArgs c = a;                                                  // the chunk's windows as a job of its own: every per-window array shifted
             c.n_windows = (uint32_t)Wc;
             c.hist += w0 * nb; c.cursor += w0 * nb; c.order += w0 * nb; c.idx += w0 * n; c.buckets += w0 * nb * 24;
-            c.size_hist = small + (uint64_t)ci * (MSM_SIZE_BINS + 2); c.big_counters = c.size_hist + MSM_SIZE_BINS;
+            c.size_hist = small + (uint64_t)ci * (MSM_SIZE_BINS + 4); c.big_counters = c.size_hist + MSM_SIZE_BINS;
             c.max_items = c_max_items[ci]; c.max_big = c_max_big[ci];
             c.big_items = items_all + 2 * off_items; c.big_partial = partial_all + 24 * off_items; c.big_buckets = bigb_all + 3 * off_big;
             off_items += c.max_items; off_big += c.max_big;
