@@ -1006,7 +1006,7 @@ int32_t bn254_fr_ntt_mont_dif(Ctx* ctx, const uint64_t* in, uint64_t n_in, uint6
     }
     std::vector<uint32_t> ns;
     ns.push_back(std::min(10u, log_n));
-    const uint32_t rem = log_n - ns[0], more = (rem + 5) / 6;
+    const uint32_t rem = log_n - ns[0], more = (rem + 6) / 7;
     for (uint32_t k = 0; k < more; k++) ns.push_back(rem / more + (k < rem % more ? 1 : 0));
     std::vector<uint32_t> s0s(ns.size());
     for (size_t k = 0, s0 = 0; k < ns.size(); k++) { s0s[k] = (uint32_t)s0; s0 += ns[k]; }
@@ -1033,7 +1033,7 @@ int32_t bn254_fr_ntt_mont_from_bitrev(Ctx* ctx, const uint64_t* in, uint64_t* ou
     const uint64_t n = 1ull << log_n;
     std::vector<uint32_t> ns;
     ns.push_back(std::min(10u, log_n));
-    const uint32_t rem = log_n - ns[0], more = (rem + 5) / 6;
+    const uint32_t rem = log_n - ns[0], more = (rem + 6) / 7;
     for (uint32_t k = 0; k < more; k++) ns.push_back(rem / more + (k < rem % more ? 1 : 0));
     uint32_t s0 = 0;
     const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, n / 1024);
@@ -1066,7 +1066,7 @@ int32_t bn254_fr_ntt_mont(Ctx* ctx, const uint64_t* in, uint64_t n_in, uint64_t*
     }
     std::vector<uint32_t> ns;
     ns.push_back(std::min(10u, log_n));
-    const uint32_t rem = log_n - ns[0], more = (rem + 5) / 6;
+    const uint32_t rem = log_n - ns[0], more = (rem + 6) / 7;
     for (uint32_t k = 0; k < more; k++) ns.push_back(rem / more + (k < rem % more ? 1 : 0));
     uint32_t s0 = 0;
     const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, n / 1024);
@@ -1155,7 +1155,7 @@ static int32_t fr_ntt_run(Ctx* ctx, const uint64_t* in, uint32_t log_in, uint64_
             // stages per pass: ten in the first (contiguous blocks), the rest in passes of at most six
             std::vector<uint32_t> ns;
             ns.push_back(std::min(10u, log_n));
-            const uint32_t rem = log_n - ns[0], more = (rem + 5) / 6;
+            const uint32_t rem = log_n - ns[0], more = (rem + 6) / 7;
             for (uint32_t k = 0; k < more; k++) ns.push_back(rem / more + (k < rem % more ? 1 : 0));
             uint32_t s0 = 0;
             const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, n / 1024);
