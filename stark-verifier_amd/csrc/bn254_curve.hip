@@ -1254,6 +1254,8 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
     static const uint32_t c_force = getenv("GL355_EXP_MSM_C") ? (uint32_t)atoi(getenv("GL355_EXP_MSM_C")) : 0;     // experiments
     a.c = lg <= 6 ? 4 : (lg <= 18 ? lg - 2 : (lg <= 22 ? 17 : 20));
     if (c_force >= 4 && c_force <= 24) a.c = c_force;
+    static const uint32_t c_big = getenv("GL355_EXP_MSM_C_BIG") ? (uint32_t)atoi(getenv("GL355_EXP_MSM_C_BIG")) : 0;   // ... of the 2^23-point calls only: k = 23 proof 1.155 / 1.115 / 1.118 / 1.235 s for c = 18 / 19 / 20 / 21
+    if (c_big >= 4 && c_big <= 24 && lg >= 23) a.c = c_big;
     a.cb = a.c - 1;
     a.wps = 256 / a.c + 1;                                       // signed digits: the carry out of bit 255 needs a window of its own
     if (max_bits < 256) a.wps = std::min(a.wps, (std::max(1u, max_bits) + a.c - 1) / a.c + 1);
