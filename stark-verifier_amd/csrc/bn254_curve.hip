@@ -16,6 +16,7 @@
 // structure for the hardware (integer VALU bound like everything else here), not yet a tuned one: no signed digits, no batched
 // affine additions, FFT stages one global pass each.
 #include "bn254_field.cuh"
+#include "bn254_f29.cuh"
 #include <vector>
 
 namespace gl355 {
@@ -361,6 +362,18 @@ GL_DEV uint32_t msm_wave_inc(uint32_t* counter, uint32_t key, bool active) {
     if (!done) slot = atomicAdd(counter + key, 1u);
     return slot;
 }
+// GL355_MSM_F29 (default 1): the bucket loops add in the 29-bit-limb form of bn254_f29.cuh, whose Montgomery radix is 2^261: the point table
+// then holds x 2^261, y 2^261 (one product by the Montgomery form of 32 more per coordinate and MSM).  0: the 8 x 32-bit mixed addition.
+#ifndef GL355_MSM_F29
+#define GL355_MSM_F29 1
+#endif
+GL_DEV u256 msm_table_form(const u256& v_mont) {
+#if GL355_MSM_F29
+    return m_canon<F_Q>(m_mul<F_Q>(v_mont, u_const(FQ_C32)));
+#else
+    return v_mont;
+#endif
+}
 __global__ void msm_prepare_kernel(MsmArgs a) {          // points to Montgomery form + digit histograms
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     bool live = i < a.n;                                  // every lane stays for the wave-level combining below
@@ -368,7 +381,7 @@ __global__ void msm_prepare_kernel(MsmArgs a) {          // points to Montgomery
     const u256 x = load256(a.points + 8 * ii), y = load256(a.points + 8 * ii + 4);
     const bool ident = u_is_zero(x) && u_is_zero(y);
     if (live) {
-        const u256 xm = ident ? u_zero() : m_from_int<F_Q>(x), ym = ident ? u_zero() : m_from_int<F_Q>(y);
+        const u256 xm = ident ? u_zero() : msm_table_form(m_from_int<F_Q>(x)), ym = ident ? u_zero() : msm_table_form(m_from_int<F_Q>(y));
         uint32_t* d = a.pm + 16 * i;
 #pragma unroll
         for (int j = 0; j < 8; j++) { d[j] = xm.l[j]; d[8 + j] = ym.l[j]; }
@@ -443,7 +456,7 @@ __global__ void msm_digits_kernel(MsmArgs a) {            // points to Montgomer
     if (i >= a.n) return;
     const u256 x = load256(a.points + 8 * i), y = load256(a.points + 8 * i + 4);
     const bool ident = u_is_zero(x) && u_is_zero(y);
-    const u256 xm = ident ? u_zero() : m_from_int<F_Q>(x), ym = ident ? u_zero() : m_from_int<F_Q>(y);
+    const u256 xm = ident ? u_zero() : msm_table_form(m_from_int<F_Q>(x)), ym = ident ? u_zero() : msm_table_form(m_from_int<F_Q>(y));
     uint32_t* d = a.pm + 16 * i;
 #pragma unroll
     for (int j = 0; j < 8; j++) { d[j] = xm.l[j]; d[8 + j] = ym.l[j]; }
@@ -625,6 +638,67 @@ GL_DEV jac msm_add_point(const MsmArgs& a, jac acc, uint32_t e) {      // e: poi
     if (e >> 31) y = m_sub<F_Q>(u_zero(), y);
     return j_madd_inl(acc, x, y);
 }
+#if GL355_MSM_F29
+// The accumulator of a bucket loop in the 29-bit-limb form.  Bounds (in units of q; "n" = limbs normalised): x < 5.2 n, y < 3.3 n, z < 1.3 n.
+struct jac29 { f29 x, y, z; bool ident; };
+GL_DEV jac jac29_lower(const jac29& p) {                            // -> the R = 2^256 Jacobian form of the reduction kernels
+    if (p.ident) return j_identity();
+    jac r;
+    r.x = f29_lower(p.x); r.y = f29_lower(p.y); r.z = f29_lower(p.z);
+    return r;
+}
+// the rare branch: the bucket's sum and the point share their x.  Equal points: the sum is twice the AFFINE point (a = 0 curve:
+// XX = x^2, YY = y^2, S = 2 ((x + YY)^2 - XX - YY^2), M = 3 XX, X3 = M^2 - 2 S, Y3 = M (S - X3) - 8 YY^2, Z3 = 2 y), in the same lazy form with
+// a product by one wherever a bound would pass what the lent constants cover; opposite points: the identity.
+GL_DEV void jac29_same_x(jac29& acc, const f29& x2, const f29& y2, bool equal) {
+    if (!equal) { acc.ident = true; return; }
+    const f29 one = f29_const(FQ29_ONE);
+    const f29 xx = f29_mul(x2, x2), yy = f29_mul(y2, y2), yyyy = f29_mul(yy, yy);
+    const f29 t = f29_norm(f29_add(x2, yy));
+    const f29 s0 = f29_norm(f29_sub(f29_mul(t, t), f29_norm(f29_add(xx, yyyy)), FQ29_C4));          // < 5.1
+    const f29 sv = f29_mul(f29_norm(f29_add(s0, s0)), one);                                             // S < 1.1
+    const f29 mv = f29_norm(f29_add(xx, f29_add(xx, xx)));                                              // M < 3.1
+    const f29 x3 = f29_norm(f29_sub(f29_mul(mv, mv), f29_norm(f29_add(sv, sv)), FQ29_C4));            // < 5.1
+    const f29 y4 = f29_norm(f29_add(f29_norm(f29_add(yyyy, yyyy)), f29_norm(f29_add(yyyy, yyyy))));    // 4 YY^2 < 4.2
+    f29 y3 = f29_mul(f29_sub(sv, x3, FQ29_C8), mv);
+    y3 = f29_norm(f29_sub(y3, y4, FQ29_C8));
+    y3 = f29_norm(f29_sub(y3, y4, FQ29_C8));                                                            // < 17.3
+    acc.x = x3; acc.y = f29_mul(y3, one); acc.z = f29_mul(f29_norm(f29_add(y2, y2)), one);
+}
+// acc += (x2, +-y2): 11 products, sums and differences without carries, five re-normalisations
+GL_DEV void msm_add_point29(const MsmArgs& a, jac29& acc, uint32_t e) {
+    const uint32_t* p = a.pm + 16ull * (e & 0x7fffffffu);
+    u256 x8, y8;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { x8.l[j] = p[j]; y8.l[j] = p[8 + j]; }
+    const f29 x2 = f29_from_u256(x8);
+    f29 y2 = f29_from_u256(y8);                                      // < q, n
+    if (e >> 31) y2 = f29_norm(f29_neg(y2, FQ29_C2));                 // 2 q - y < 2 q, n
+    if (acc.ident) { acc.x = x2; acc.y = y2; acc.z = f29_const(FQ29_ONE); acc.ident = false; return; }
+    const f29 z1z1 = f29_mul(acc.z, acc.z);
+    const f29 u2 = f29_mul(x2, z1z1), s2 = f29_mul(f29_mul(y2, acc.z), z1z1);
+    const f29 h = f29_norm(f29_sub(u2, acc.x, FQ29_C8));            // < 9.3, n
+    const f29 h2 = f29_mul(h, h);
+    const f29 r = f29_norm(f29_sub(s2, acc.y, FQ29_C4));            // < 5.3, n
+    if (f29_is_zero_mod(h2)) { jac29_same_x(acc, x2, y2, f29_is_zero_mod(f29_mul(r, r))); return; }
+    const f29 h3 = f29_mul(h2, h), v = f29_mul(acc.x, h2);
+    const f29 w = f29_norm(f29_add(h3, f29_add(v, v)));              // h^3 + 2 v < 3.9, n
+    const f29 x3 = f29_norm(f29_sub(f29_mul(r, r), w, FQ29_C4));     // < 5.3, n
+    const f29 m1 = f29_mul(f29_sub(v, x3, FQ29_C8), r);              // (v + 8 q - x3 < 9.3) r
+    const f29 y3 = f29_norm(f29_sub(m1, f29_mul(acc.y, h3), FQ29_C2));   // < 3.3, n
+    acc.z = f29_mul(acc.z, h);
+    acc.x = x3; acc.y = y3;
+}
+#define MSM_ACC_T jac29
+#define MSM_ACC_INIT(A) jac29 A; A.ident = true
+#define MSM_ACC_ADD(ARGS, A, E) msm_add_point29(ARGS, A, E)
+#define MSM_ACC_JAC(A) jac29_lower(A)
+#else
+#define MSM_ACC_T jac
+#define MSM_ACC_INIT(A) jac A = j_identity()
+#define MSM_ACC_ADD(ARGS, A, E) A = msm_add_point(ARGS, A, E)
+#define MSM_ACC_JAC(A) (A)
+#endif
 // one lane per (window, bucket), taken in the order above: sum of the bucket's points (big buckets: the kernels below)
 __global__ void __launch_bounds__(256) msm_bucket_kernel(MsmArgs a) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -632,9 +706,9 @@ __global__ void __launch_bounds__(256) msm_bucket_kernel(MsmArgs a) {
     const uint32_t id = a.order[g], w = id >> a.cb;
     const uint32_t lo = a.hist[id], hi = a.cursor[id];
     if (hi - lo > MSM_BIG) return;
-    jac acc = j_identity();
-    for (uint32_t k = lo; k < hi; k++) acc = msm_add_point(a, acc, a.idx[(uint64_t)w * a.n + k]);
-    j_store(a.buckets + (uint64_t)id * 24, acc);
+    MSM_ACC_INIT(acc);
+    for (uint32_t k = lo; k < hi; k++) MSM_ACC_ADD(a, acc, a.idx[(uint64_t)w * a.n + k]);
+    j_store(a.buckets + (uint64_t)id * 24, MSM_ACC_JAC(acc));
 }
 // ---- big buckets: a work list (bucket, slice) built on the device, one workgroup per slice (lanes stride through the slice, then a
 // tree over the 256 lane sums in LDS), one workgroup per big bucket for the slices' sums.  One lane per bucket made a 2^20-point MSM
@@ -679,9 +753,9 @@ __global__ void __launch_bounds__(256) msm_mid_partial_kernel(MsmArgs a) {
         const uint32_t base = a.hist[id], end = a.cursor[id];
         if (end - base > MSM_MID) continue;                        // a workgroup item (below)
         const uint32_t lo = base + off, hi = min(end, lo + MSM_MID_SLICE);
-        jac acc = j_identity();
-        for (uint32_t k = lo; k < hi; k++) acc = msm_add_point(a, acc, a.idx[(uint64_t)w * a.n + k]);
-        j_store(a.big_partial + 24ull * it, acc);
+        MSM_ACC_INIT(acc);
+        for (uint32_t k = lo; k < hi; k++) MSM_ACC_ADD(a, acc, a.idx[(uint64_t)w * a.n + k]);
+        j_store(a.big_partial + 24ull * it, MSM_ACC_JAC(acc));
     }
 }
 // ... and one lane per mid-size bucket for its partial sums
@@ -706,8 +780,9 @@ __global__ void __launch_bounds__(256) msm_big_partial_kernel(MsmArgs a) {      
         if (a.cursor[id] - a.hist[id] <= MSM_MID) continue;        // a lane item (above); block-uniform
         const uint32_t lo = a.hist[id] + off, end = a.cursor[id];
         const uint32_t hi = min(end, lo + msm_big_slice(end - a.hist[id]));
-        jac acc = j_identity();
-        for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) acc = msm_add_point(a, acc, a.idx[(uint64_t)w * a.n + k]);
+        MSM_ACC_INIT(acc29);
+        for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) MSM_ACC_ADD(a, acc29, a.idx[(uint64_t)w * a.n + k]);
+        jac acc = MSM_ACC_JAC(acc29);
         acc = msm_wg_tree(acc, sh);
         if (threadIdx.x == 0) j_store(a.big_partial + 24ull * it, acc);
         __syncthreads();

@@ -121,6 +121,10 @@ def test_g1_msm_two_level_sort_sizes(ctx, orc, n):
     sc[5] = 0; vals[5] = 0                                    # a zero scalar
     pts[7] = pts[0]; mult[7] = mult[0]                        # a repeated base
     pts[9, 4:] = cv.scalars([pm.Q - cv.ints(pts[1:2, 4:])[0]])[0]; pts[9, :4] = pts[1, :4]; mult[9] = -mult[1]    # the opposite of base 1
+    # ... and pairs that meet in the SAME bucket of every window: a base twice under one scalar (the sum doubles), a base and its opposite
+    # under one scalar (the sum is the identity, and the bucket goes on from there)
+    pts[11] = pts[10]; mult[11] = mult[10]; sc[11] = sc[10]; vals[11] = vals[10]
+    pts[13, 4:] = cv.scalars([pm.Q - cv.ints(pts[12:13, 4:])[0]])[0]; pts[13, :4] = pts[12, :4]; mult[13] = -mult[12]; sc[13] = sc[12]; vals[13] = vals[12]
     k = int(sum(int(v) * m for v, m in zip(vals, mult)) % pm.R)
     assert cv._unpt(gpu_msm(ctx, pts, sc)) == cv.mul(pm.G, k)
 
