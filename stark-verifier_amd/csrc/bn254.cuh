@@ -10,11 +10,29 @@
 // operands < 2r stay < 2r WITHOUT the final conditional subtraction; sums are brought back under 2r by one conditional
 // subtraction of 2r, and values are canonicalised only when they leave the permutation.  fr_mul is deliberately not
 // inlined: a round calls it 28-40 times and the inlined body (~450 instructions) would not fit the instruction cache.
+//
+// Round 4: GL355_BN254_HASH_F29 (default 1) runs the same permutation on nine 29-bit limbs with Montgomery radix 2^261 (bn254_f29.cuh, tables
+// bn254_tables29.h from the same generator): products as carry-free column sums, INLINED, sums without carries or conditional subtractions
+// (a value may grow to ~85 r over the 60 partial rounds; anything below 2^261 ~ 169 r is a legal operand of the next product).  These kernels
+// run at one wave per SIMD or less -- the small Merkle levels of a wrap proof are chains of dependent products -- and there the form is
+// twice as fast per product as the 8 x 32-bit asm one (tools/ubench/ubench_mont29.hip with 256 blocks: 943 against 1 850 clocks).
 #pragma once
 #include "gl_field.cuh"
 
+#ifndef GL355_BN254_HASH_F29
+#define GL355_BN254_HASH_F29 1
+#endif
 #define BN254_TABLE_QUAL __device__ __constant__ const
 #include "bn254_tables.h"
+#if GL355_BN254_HASH_F29
+#include "bn254_f29.cuh"
+#include "bn254_tables29.h"
+#define BNT(NAME) BN254F_##NAME
+#define FR_W 9
+#else
+#define BNT(NAME) BN254_##NAME
+#define FR_W 8
+#endif
 #ifndef GL355_BN254_MMUL_ASM
 #define GL355_BN254_MMUL_ASM 1
 #endif
@@ -23,6 +41,36 @@
 
 namespace gl355 {
 
+#if GL355_BN254_HASH_F29
+typedef f29 fr8;                                      // (the name stays: "an Fr element of the hasher")
+GL_DEV fr8 fr_mul(const fr8& a, const fr8& b) { return f29_mul_fr(a, b); }        // a's limbs < 2^30.6, b's < 2^29
+GL_DEV fr8 fr_add(const fr8& a, const fr8& b) { return f29_norm(f29_add(a, b)); }  // limbs back under 2^29; the VALUE is left to grow
+GL_DEV fr8 fr_pow5(const fr8& a) {
+    const fr8 a2 = fr_mul(a, a), a4 = fr_mul(a2, a2);
+    return fr_mul(a4, a);
+}
+GL_DEV fr8 fr_const(const uint32_t* p) { return f29_const(p); }
+GL_DEV fr8 fr_zero() { fr8 r; for (int j = 0; j < 9; j++) r.l[j] = 0; return r; }
+// a plain integer below 2^256 (four 64-bit words) into the Montgomery form, and a value (< 169 r) back to its canonical integer
+GL_DEV fr8 fr_enter(const uint64_t a[4]) {
+    u256 x;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { x.l[2 * i] = (uint32_t)a[i]; x.l[2 * i + 1] = (uint32_t)(a[i] >> 32); }
+    return fr_mul(f29_from_u256(x), fr_const(BN254F_R2));
+}
+GL_DEV void fr_leave(const fr8& xm, uint64_t a[4]) {
+    fr8 one = fr_zero();
+    one.l[0] = 1;
+    fr8 x = fr_mul(xm, one);                          // x 2^-261: < r + 1, i.e. canonical or exactly r (for zero)
+    uint32_t e = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) e |= x.l[j] ^ FR29_R[j];
+    if (e == 0) x = fr_zero();
+    const u256 w = f29_to_u256(x);
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = (uint64_t)w.l[2 * i] | ((uint64_t)w.l[2 * i + 1] << 32);
+}
+#else
 struct fr8 { uint32_t l[8]; };
 
 // a * b * R^-1 (mod r), result < 2r for a, b < 2r
@@ -123,6 +171,24 @@ GL_DEV fr8 fr_const(const uint32_t* p) {
     return r;
 }
 
+GL_DEV fr8 fr_zero() { fr8 r; for (int j = 0; j < 8; j++) r.l[j] = 0; return r; }
+GL_DEV fr8 fr_enter(const uint64_t a[4]) {
+    fr8 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { r.l[2 * i] = (uint32_t)a[i]; r.l[2 * i + 1] = (uint32_t)(a[i] >> 32); }
+    return fr_mul(r, fr_const(BN254_R2));
+}
+GL_DEV void fr_leave(fr8 xm, uint64_t a[4]) {
+    fr8 one;
+#pragma unroll
+    for (int j = 0; j < 8; j++) one.l[j] = j == 0 ? 1u : 0u;
+    fr8 x = fr_mul(xm, one);                       // x * R^-1: out of Montgomery form, < 2r
+    x = fr_cond_sub(x, BN254_MOD);
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = (uint64_t)x.l[2 * i] | ((uint64_t)x.l[2 * i + 1] << 32);
+}
+#endif
+
 // three Goldilocks elements -> x0 + x1 p + x2 p^2 (< 2^192, no reduction needed), then into Montgomery form
 GL_DEV fr8 fr_encode3(uint64_t x0, uint64_t x1, uint64_t x2) {
     // a = x2; a = a * p + x1; a = a * p + x0 with p = 2^64 - 2^32 + 1: a * p = (a << 64) - (a << 32) + a
@@ -141,22 +207,13 @@ GL_DEV fr8 fr_encode3(uint64_t x0, uint64_t x1, uint64_t x2) {
 #pragma unroll
         for (int i = 0; i < 4; i++) a[i] = o[i];
     }
-    fr8 r;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { r.l[2 * i] = (uint32_t)a[i]; r.l[2 * i + 1] = (uint32_t)(a[i] >> 32); }
-    return fr_mul(r, fr_const(BN254_R2));
+    return fr_enter(a);
 }
 
 // canonical Fr value (leaves Montgomery form) -> its three low base-p digits
-GL_DEV void fr_decode3(fr8 xm, uint64_t out[3]) {
-    fr8 one;
-#pragma unroll
-    for (int j = 0; j < 8; j++) one.l[j] = j == 0 ? 1u : 0u;
-    fr8 x = fr_mul(xm, one);                       // x * R^-1: out of Montgomery form, < 2r
-    x = fr_cond_sub(x, BN254_MOD);
+GL_DEV void fr_decode3(const fr8& xm, uint64_t out[3]) {
     uint64_t a[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) a[i] = (uint64_t)x.l[2 * i] | ((uint64_t)x.l[2 * i + 1] << 32);
+    fr_leave(xm, a);
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         // remainder: Horner over the 64-bit limbs with 2^64 = 2^32 - 1 (mod p)
@@ -200,13 +257,13 @@ GL_DEV void fr_decode3(fr8 xm, uint64_t out[3]) {
 // then per round x^5 on element 0 and 9 products instead of 25 -- 1 056 products per permutation instead of 2 000.
 GL_DEV void bn254_full_round(fr8 (&s)[5], int rnd) {
 #pragma unroll
-    for (int i = 0; i < 5; i++) s[i] = fr_pow5(fr_add(s[i], fr_const(BN254_RC[5 * rnd + i])));
+    for (int i = 0; i < 5; i++) s[i] = fr_pow5(fr_add(s[i], fr_const(BNT(RC)[5 * rnd + i])));
     fr8 n[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) {
-        fr8 acc = fr_mul(s[0], fr_const(BN254_MDS[5 * i]));
+        fr8 acc = fr_mul(s[0], fr_const(BNT(MDS)[5 * i]));
 #pragma unroll
-        for (int j = 1; j < 5; j++) acc = fr_add(acc, fr_mul(s[j], fr_const(BN254_MDS[5 * i + j])));
+        for (int j = 1; j < 5; j++) acc = fr_add(acc, fr_mul(s[j], fr_const(BNT(MDS)[5 * i + j])));
         n[i] = acc;
     }
 #pragma unroll
@@ -217,15 +274,15 @@ GL_DEV void bn254_permute_fr(fr8 (&s)[5]) {
     for (int rnd = 0; rnd < 4; rnd++) bn254_full_round(s, rnd);
     // ---- 60 partial rounds ----
 #pragma unroll
-    for (int i = 0; i < 5; i++) s[i] = fr_add(s[i], fr_const(BN254_PART_FIRST[i]));
+    for (int i = 0; i < 5; i++) s[i] = fr_add(s[i], fr_const(BNT(PART_FIRST)[i]));
     {
         fr8 n[5];
         n[0] = s[0];
 #pragma unroll
         for (int c = 1; c < 5; c++) {
-            fr8 acc = fr_mul(s[1], fr_const(BN254_PART_INIT[c - 1]));
+            fr8 acc = fr_mul(s[1], fr_const(BNT(PART_INIT)[c - 1]));
 #pragma unroll
-            for (int r = 2; r < 5; r++) acc = fr_add(acc, fr_mul(s[r], fr_const(BN254_PART_INIT[(r - 1) * 4 + (c - 1)])));
+            for (int r = 2; r < 5; r++) acc = fr_add(acc, fr_mul(s[r], fr_const(BNT(PART_INIT)[(r - 1) * 4 + (c - 1)])));
             n[c] = acc;
         }
 #pragma unroll
@@ -234,12 +291,12 @@ GL_DEV void bn254_permute_fr(fr8 (&s)[5]) {
 #pragma unroll 1
     for (int r = 0; r < 60; r++) {
         fr8 s0 = fr_pow5(s[0]);
-        if (r < 59) s0 = fr_add(s0, fr_const(BN254_PART_POST[r]));
-        fr8 d = fr_mul(s0, fr_const(BN254_PART_M00[0]));
+        if (r < 59) s0 = fr_add(s0, fr_const(BNT(PART_POST)[r]));
+        fr8 d = fr_mul(s0, fr_const(BNT(PART_M00)[0]));
 #pragma unroll
         for (int i = 1; i < 5; i++) {
-            d = fr_add(d, fr_mul(s[i], fr_const(BN254_PART_WHAT[4 * r + (i - 1)])));
-            s[i] = fr_add(s[i], fr_mul(s0, fr_const(BN254_PART_VS[4 * r + (i - 1)])));
+            d = fr_add(d, fr_mul(s[i], fr_const(BNT(PART_WHAT)[4 * r + (i - 1)])));
+            s[i] = fr_add(s[i], fr_mul(s0, fr_const(BNT(PART_VS)[4 * r + (i - 1)])));
         }
         s[0] = d;
     }
@@ -252,8 +309,7 @@ GL_DEV void bn254_permute(uint64_t (&s)[12]) {
     fr8 st[5];
 #pragma unroll
     for (int i = 0; i < 4; i++) st[i] = fr_encode3(s[3 * i], s[3 * i + 1], s[3 * i + 2]);
-#pragma unroll
-    for (int j = 0; j < 8; j++) st[4].l[j] = 0;
+    st[4] = fr_zero();
     bn254_permute_fr(st);
 #pragma unroll
     for (int i = 0; i < 4; i++) {

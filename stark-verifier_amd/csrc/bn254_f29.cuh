@@ -88,8 +88,9 @@ GL_DEV f29 f29_neg(const f29& b, const uint32_t* C) {
     for (int j = 0; j < 9; j++) r.l[j] = C[j] - b.l[j];
     return r;
 }
-// a * b * 2^-261 mod q: a's limbs < 2^30.6, b's < 2^29, a b < 2^261 q.  Result: limbs < 2^29, value < a b / 2^261 + q.
-GL_DEV f29 f29_mul(const f29& a, const f29& b) {
+// a * b * 2^-261 mod m (m, n0 = -m^-1 mod 2^29: compile-time constants): a's limbs < 2^30.6, b's < 2^29.  Result: limbs < 2^29 (the top one takes
+// what is left), value < a b / 2^261 + m -- anything whose product stays below 2^261 m is a legal operand, so sums may pile up between products.
+GL_DEV f29 f29_mul_mod(const f29& a, const f29& b, const uint32_t* M, uint32_t n0) {
     uint64_t t[10];
 #pragma unroll
     for (int j = 0; j < 10; j++) t[j] = 0;
@@ -97,9 +98,9 @@ GL_DEV f29 f29_mul(const f29& a, const f29& b) {
     for (int i = 0; i < 9; i++) {
 #pragma unroll
         for (int j = 0; j < 9; j++) t[j] += (uint64_t)a.l[j] * b.l[i];
-        const uint32_t m = ((uint32_t)t[0] * F29_N0) & F29_MASK;
+        const uint32_t m = ((uint32_t)t[0] * n0) & F29_MASK;
 #pragma unroll
-        for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * FQ29_Q[j];
+        for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * M[j];
         const uint64_t c = t[0] >> 29;
 #pragma unroll
         for (int j = 0; j < 9; j++) t[j] = t[j + 1];
@@ -112,6 +113,11 @@ GL_DEV f29 f29_mul(const f29& a, const f29& b) {
     r.l[8] = (uint32_t)t[8];
     return r;
 }
+GL_DEV f29 f29_mul(const f29& a, const f29& b) { return f29_mul_mod(a, b, FQ29_Q, F29_N0); }               // the base field (the MSM)
+// the scalar field (the BN254-Poseidon hasher, bn254.cuh): r on 29-bit limbs, -r^-1 mod 2^29
+F29_DEF(FR29_R, 0x10000001, 0x1f0fac9f, 0x0e5c2450, 0x07d090f3, 0x1585d283, 0x02db40c0, 0x00a6e141, 0x0e5c2634, 0x0030644e)
+#define FR29_N0 0x0fffffffu
+GL_DEV f29 f29_mul_fr(const f29& a, const f29& b) { return f29_mul_mod(a, b, FR29_R, FR29_N0); }
 // a product's result (normalised, < 1.3 q, = 0 mod q)  <=>  it is 0 or q
 GL_DEV bool f29_is_zero_mod(const f29& a) {
     uint32_t z = 0, e = 0;

@@ -100,14 +100,14 @@ __global__ void __launch_bounds__(256) bn254_merkle_level_kernel(uint64_t* diges
 GL_DEV fr8 lds_load_fr(const uint32_t* p) {
     fr8 r;
 #pragma unroll
-    for (int k = 0; k < 8; k++) r.l[k] = p[k];
+    for (int k = 0; k < FR_W; k++) r.l[k] = p[k];
     return r;
 }
 
 // block = 64 threads = two 32-lane groups = two parent nodes of layer `layer`
 __global__ void __launch_bounds__(64) bn254_merkle_level_lanes_kernel(uint64_t* digests, uint64_t* cap, uint32_t sub_bits, uint32_t layer,
                                                                      uint64_t n_nodes) {
-    __shared__ uint32_t tile[2][25 * 8];
+    __shared__ uint32_t tile[2][25 * FR_W];
     const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
     const bool act = l < 25;
     const int i = act ? l / 5 : 0, j = act ? l % 5 : 0;
@@ -127,12 +127,12 @@ __global__ void __launch_bounds__(64) bn254_merkle_level_lanes_kernel(uint64_t* 
         e[q] = idx < 8 ? tree[child * 4 + idx] : 0;
     }
     fr8 s = fr_encode3(e[0], e[1], e[2]);            // column 4 (and the padding of column 2, 3) encodes zeros
-    const fr8 m = fr_const(BN254_MDS[5 * i + j]);
+    const fr8 m = fr_const(BNT(MDS)[5 * i + j]);
     uint32_t* my = tile[grp];
-    fr8 rc = fr_const(BN254_RC[j]);
+    fr8 rc = fr_const(BNT(RC)[j]);
 #pragma unroll 1
     for (int rnd = 0; rnd < 68; rnd++) {
-        const fr8 rc_next = fr_const(BN254_RC[5 * (rnd < 67 ? rnd + 1 : 67) + j]);   // prefetch: the index depends on the lane
+        const fr8 rc_next = fr_const(BNT(RC)[5 * (rnd < 67 ? rnd + 1 : 67) + j]);   // prefetch: the index depends on the lane
         s = fr_add(s, rc);
         rc = rc_next;
         const fr8 sb = fr_pow5(s);
@@ -141,12 +141,12 @@ __global__ void __launch_bounds__(64) bn254_merkle_level_lanes_kernel(uint64_t* 
         const fr8 p = fr_mul(s, m);
         if (act) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) my[(5 * i + j) * 8 + q] = p.l[q];
+            for (int q = 0; q < FR_W; q++) my[(5 * i + j) * FR_W + q] = p.l[q];
         }
         GL_WAVE_LDS_SYNC();
-        fr8 acc = lds_load_fr(my + (5 * j) * 8);     // new s_j = sum_c M[j][c] s_c: row j of the product tile
+        fr8 acc = lds_load_fr(my + (5 * j) * FR_W);     // new s_j = sum_c M[j][c] s_c: row j of the product tile
 #pragma unroll
-        for (int c = 1; c < 5; c++) acc = fr_add(acc, lds_load_fr(my + (5 * j + c) * 8));
+        for (int c = 1; c < 5; c++) acc = fr_add(acc, lds_load_fr(my + (5 * j + c) * FR_W));
         GL_WAVE_LDS_SYNC();
         s = acc;
     }

@@ -7,6 +7,7 @@
 // the domain change (a * b * 2^-256 = mont29(a, b * 2^5)).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 #include "bn254_field.cuh"
@@ -89,8 +90,8 @@ __global__ void __launch_bounds__(256) k_mont29(uint64_t* data, int iters) {
     for (int k = 0; k < 8; k++) r = u_cond_sub(r, f_mod<F_R>());
     store256(data + 8 * i, r);
 }
-int main() {
-    const int blocks = 4096, iters = 512;
+int main(int argc, char** argv) {
+    const int blocks = argc > 1 ? atoi(argv[1]) : 4096, iters = 512;      // 256 blocks = one wave per SIMD: the latency-bound regime of the small Merkle levels
     const size_t n = (size_t)blocks * 256;
     std::vector<uint64_t> h(n * 8);
     uint64_t s = 88172645463325252ull;
