@@ -817,8 +817,11 @@ def halo2_valu(clock_mhz):
            "formula": "insts_per_launch / avg_launch_s against 1024 SIMDs x clock / sum_c mix[c] x nominal_clk[c]", "kernels": {}}
     for line in open(pmc):
         name = re.sub(r"^gl355::", "", line.split("(")[0])
-        callee = {"fr_fft_pass_kernel": "u256 gl355::m_mul<0>", "msm_bucket_kernel": "u256 gl355::m_mul<1>"}.get(name)
-        if not callee or name not in dur or name not in isa or callee not in isa:
+        if name not in ("fr_fft_pass_kernel", "msm_bucket_kernel") or name not in dur or name not in isa:
+            continue
+        # the transform pass calls the 8 x 32-bit asm product; the bucket loops inline their 29-bit-limb products (the kernel's own histogram)
+        callee = {"fr_fft_pass_kernel": "u256 gl355::m_mul<0>"}.get(name, name)
+        if callee not in isa:
             continue
         c = {m.group(1): float(m.group(2)) for m in re.finditer(r"(SQ_\w+)=([0-9.e+]+)", line)}
         n, f64 = c.get("SQ_INSTS_VALU"), c.get("SQ_INSTS_VALU_INT64", 0.0) / c.get("SQ_INSTS_VALU", 1.0)
