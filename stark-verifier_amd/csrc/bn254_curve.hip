@@ -689,6 +689,52 @@ GL_DEV void msm_add_point29(const MsmArgs& a, jac29& acc, uint32_t e) {
     acc.z = f29_mul(acc.z, h);
     acc.x = x3; acc.y = y3;
 }
+// ---- Jacobian + Jacobian and doubling in the same form, for the reduction levels (chains of dependent additions on few lanes: the regime
+// where the inlined 29-bit product is twice the called asm one).  Coordinates stay below 12 q with normalised limbs: inputs (X, Y, Z) < 12 q
+// give X3 < 5.2, Y3 < 3.3, Z3 < 1.1 (addition) and X3 < 9.3, Y3 < 1.2, Z3 < 2.2 (doubling).
+GL_DEV void jac29_double(jac29& p) {
+    if (p.ident) return;
+    const f29 one = f29_const(FQ29_ONE);
+    const f29 A = f29_mul(p.x, p.x), B = f29_mul(p.y, p.y), C = f29_mul(B, B);
+    const f29 t = f29_norm(f29_add(p.x, B));
+    const f29 d0 = f29_norm(f29_sub(f29_mul(t, t), f29_norm(f29_add(A, C)), FQ29_C4));        // (X + B)^2 - A - C < 6.2
+    const f29 dr = f29_mul(d0, one);
+    const f29 D = f29_norm(f29_add(dr, dr));                                                     // < 2.1
+    const f29 E = f29_norm(f29_add(A, f29_add(A, A)));                                           // < 5.6
+    const f29 x3 = f29_norm(f29_sub(f29_mul(E, E), f29_norm(f29_add(D, D)), FQ29_C8));          // < 9.3
+    const f29 c4 = f29_norm(f29_add(f29_norm(f29_add(C, C)), f29_norm(f29_add(C, C))));          // 4 C < 4.1
+    f29 y3 = f29_mul(f29_sub(D, x3, FQ29_C16), E);                                               // (D + 16 q - X3 < 18.2) E
+    y3 = f29_norm(f29_sub(y3, c4, FQ29_C8));
+    y3 = f29_norm(f29_sub(y3, c4, FQ29_C8));                                                     // < 17.7
+    const f29 yz = f29_mul(p.y, p.z);
+    p.x = x3; p.y = f29_mul(y3, one); p.z = f29_norm(f29_add(yz, yz));
+}
+GL_DEV void jac29_add(jac29& p, const jac29& q) {
+    if (q.ident) return;
+    if (p.ident) { p = q; return; }
+    const f29 z1z1 = f29_mul(p.z, p.z), z2z2 = f29_mul(q.z, q.z);
+    const f29 u1 = f29_mul(p.x, z2z2), u2 = f29_mul(q.x, z1z1);
+    const f29 s1 = f29_mul(p.y, f29_mul(q.z, z2z2)), s2 = f29_mul(q.y, f29_mul(p.z, z1z1));
+    const f29 h = f29_norm(f29_sub(u2, u1, FQ29_C2)), r = f29_norm(f29_sub(s2, s1, FQ29_C2));
+    const f29 h2 = f29_mul(h, h);
+    if (f29_is_zero_mod(h2)) {                                       // the same x: twice the point, or the identity
+        if (f29_is_zero_mod(f29_mul(r, r))) jac29_double(p); else p.ident = true;
+        return;
+    }
+    const f29 h3 = f29_mul(h2, h), v = f29_mul(u1, h2);
+    const f29 w = f29_norm(f29_add(h3, f29_add(v, v)));
+    const f29 x3 = f29_norm(f29_sub(f29_mul(r, r), w, FQ29_C4));
+    const f29 m1 = f29_mul(f29_sub(v, x3, FQ29_C8), r);
+    p.y = f29_norm(f29_sub(m1, f29_mul(s1, h3), FQ29_C2));
+    p.z = f29_mul(f29_mul(p.z, q.z), h);
+    p.x = x3;
+}
+GL_DEV jac29 jac29_lift(const jac& p) {                              // the 8 x 32-bit R-domain point in this form (three products)
+    jac29 r;
+    r.ident = j_is_identity(p);
+    if (!r.ident) { r.x = f29_lift_inl(p.x); r.y = f29_lift_inl(p.y); r.z = f29_lift_inl(p.z); }
+    return r;
+}
 #define MSM_ACC_T jac29
 #define MSM_ACC_INIT(A) jac29 A; A.ident = true
 #define MSM_ACC_ADD(ARGS, A, E) msm_add_point29(ARGS, A, E)
@@ -821,6 +867,21 @@ __global__ void __launch_bounds__(64) msm_level_kernel(MsmLevel l) {
     if (g >= groups * l.n_windows) return;
     const uint32_t w = g / groups, v = g % groups, k = 1u << l.kbits;
     const uint32_t* s_in = l.in_s + ((uint64_t)w * l.t_in + (uint64_t)v * k) * 24;
+#if GL355_MSM_F29
+    jac29 run, acc;
+    run.ident = acc.ident = true;
+    for (uint32_t u = k; u-- > 0;) {
+        jac29_add(run, jac29_lift(j_load(s_in + u * 24)));
+        if (u) jac29_add(acc, run);                                   // acc = sum_u u * S_u: item u is counted in the u sums taken at u' = u .. 1
+    }
+    for (uint32_t d = 0; d < l.shift; d++) jac29_double(acc);
+    if (l.in_w) {
+        const uint32_t* w_in = l.in_w + ((uint64_t)w * l.t_in + (uint64_t)v * k) * 24;
+        for (uint32_t u = 0; u < k; u++) jac29_add(acc, jac29_lift(j_load(w_in + u * 24)));
+    }
+    j_store(l.out_s + ((uint64_t)w * groups + v) * 24, jac29_lower(run));
+    j_store(l.out_w + ((uint64_t)w * groups + v) * 24, jac29_lower(acc));
+#else
     jac run = j_identity(), acc = j_identity();
     for (uint32_t u = k; u-- > 0;) {
         run = j_add_inl(run, j_load(s_in + u * 24));
@@ -833,6 +894,7 @@ __global__ void __launch_bounds__(64) msm_level_kernel(MsmLevel l) {
     }
     j_store(l.out_s + ((uint64_t)w * groups + v) * 24, run);
     j_store(l.out_w + ((uint64_t)w * groups + v) * 24, acc);
+#endif
 }
 
 // The same level with EIGHT LANES PER GROUP (kbits == 3).  A level is pure latency -- one lane's chain of ~26 dependent additions of ~30 us

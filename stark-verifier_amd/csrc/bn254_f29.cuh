@@ -25,6 +25,8 @@ F29_DEF(FQ29_R256, 0x058f0d9d, 0x1aea1c6e, 0x11c2cf74, 0x11d651eb, 0x1462c0a7, 0
 F29_DEF(FQ29_C2, 0x30f9fa8e, 0x2208c16c, 0x38e5469d, 0x25aa45a0, 0x2b0bb2ef, 0x25b68180, 0x214dc281, 0x3cb84c67, 0x0060c89b)
 F29_DEF(FQ29_C4, 0x21f3f51c, 0x241182da, 0x31ca8d3b, 0x2b548b42, 0x361765df, 0x2b6d0301, 0x229b8503, 0x397098cf, 0x00c19138)
 F29_DEF(FQ29_C8, 0x23e7ea38, 0x282305b5, 0x23951a77, 0x36a91686, 0x2c2ecbbf, 0x36da0604, 0x25370a07, 0x32e1319f, 0x01832272)
+F29_DEF(FQ29_C16, 0x27cfd470, 0x30460b6b, 0x272a34ef, 0x2d522d0d, 0x385d9780, 0x2db40c09, 0x2a6e1410, 0x25c2633f, 0x030644e6)
+F29_DEF(FQ29_LIFT, 0x13349ca1, 0x1a5d84a8, 0x0a3e5cac, 0x100249e0, 0x12b951e8, 0x0e92d304, 0x14cb95b3, 0x041b9d3d, 0x00058003)     // 2^266 mod q
 // 32 * 2^256 mod q as 8 x 32-bit words: the Montgomery form (R = 2^256) of 32, which lifts an R-domain value into the R' domain
 __device__ __constant__ const uint32_t FQ_C32[8] = {0x157ccc21, 0x4e8384eb, 0x0ce148c3, 0xfb90a602, 0x819caa36, 0x5301fa84, 0x563d4475, 0x0dc83629};
 
@@ -129,5 +131,7 @@ GL_DEV bool f29_is_zero_mod(const f29& a) {
 // an R-domain 8 x 32-bit value (< 2q) in the R' domain on 29-bit limbs, and back (normalised limbs, any value below 2^261 -> < 1.3 q)
 GL_DEV f29 f29_lift(const u256& a) { return f29_from_u256(m_mul<F_Q>(a, u_const(FQ_C32))); }
 GL_DEV u256 f29_lower(const f29& a) { return f29_to_u256(f29_mul(a, f29_const(FQ29_R256))); }
+// the same lift with a 29-bit product instead of the called 8 x 32-bit one: x 2^256 (sliced) times 2^266 / 2^261
+GL_DEV f29 f29_lift_inl(const u256& a) { return f29_mul(f29_from_u256(a), f29_const(FQ29_LIFT)); }
 
 }  // namespace gl355
