@@ -906,6 +906,50 @@ GL_DEV jac j_shfl_down(const jac& p, uint32_t d) {
     for (int j = 0; j < 8; j++) { r.x.l[j] = __shfl_down(p.x.l[j], d, 8); r.y.l[j] = __shfl_down(p.y.l[j], d, 8); r.z.l[j] = __shfl_down(p.z.l[j], d, 8); }
     return r;
 }
+#if GL355_MSM_F29
+GL_DEV jac29 jac29_shfl_down(const jac29& p, uint32_t d) {
+    jac29 r;
+#pragma unroll
+    for (int j = 0; j < 9; j++) { r.x.l[j] = __shfl_down(p.x.l[j], d, 8); r.y.l[j] = __shfl_down(p.y.l[j], d, 8); r.z.l[j] = __shfl_down(p.z.l[j], d, 8); }
+    r.ident = __shfl_down((int)p.ident, d, 8) != 0;
+    return r;
+}
+__global__ void __launch_bounds__(64) msm_level_coop_kernel(MsmLevel l) {
+    const uint32_t groups = l.t_in >> 3, total = groups * l.n_windows;
+    const uint32_t gq = blockIdx.x * 8 + (threadIdx.x >> 3), u = threadIdx.x & 7;
+    const bool live = gq < total;
+    const uint32_t g = live ? gq : total - 1;                        // idle groups of the last block redo the last one (lanes stay for the shuffles)
+    const uint32_t w = g / groups, v = g % groups;
+    const uint64_t item = (uint64_t)w * l.t_in + (uint64_t)v * 8 + u;
+    jac29 x = jac29_lift(j_load(l.in_s + item * 24));
+#pragma unroll 1
+    for (uint32_t d = 1; d < 8; d <<= 1) {                           // x_u = S_u + ... + S_7
+        const jac29 y = jac29_shfl_down(x, d);
+        if (u + d < 8) jac29_add(x, y);
+    }
+    jac29 acc = x;                                                    // sum_{u >= 1} run_u = sum_u u S_u
+    if (!u) acc.ident = true;
+#pragma unroll 1
+    for (uint32_t d = 4; d >= 1; d >>= 1) {
+        const jac29 y = jac29_shfl_down(acc, d);
+        if (u < d) jac29_add(acc, y);
+    }
+    if (u == 0) for (uint32_t d = 0; d < l.shift; d++) jac29_double(acc);
+    if (l.in_w) {
+        jac29 wt = jac29_lift(j_load(l.in_w + item * 24));
+#pragma unroll 1
+        for (uint32_t d = 4; d >= 1; d >>= 1) {
+            const jac29 y = jac29_shfl_down(wt, d);
+            if (u < d) jac29_add(wt, y);
+        }
+        if (u == 0) jac29_add(acc, wt);
+    }
+    if (u == 0 && live) {
+        j_store(l.out_s + ((uint64_t)w * groups + v) * 24, jac29_lower(x));
+        j_store(l.out_w + ((uint64_t)w * groups + v) * 24, jac29_lower(acc));
+    }
+}
+#else
 __global__ void __launch_bounds__(64) msm_level_coop_kernel(MsmLevel l) {
     const uint32_t groups = l.t_in >> 3, total = groups * l.n_windows;
     const uint32_t gq = blockIdx.x * 8 + (threadIdx.x >> 3), u = threadIdx.x & 7;
@@ -940,6 +984,7 @@ __global__ void __launch_bounds__(64) msm_level_coop_kernel(MsmLevel l) {
         j_store(l.out_w + ((uint64_t)w * groups + v) * 24, acc);
     }
 }
+#endif
 
 // ================================================================ fixed-base batch multiplication ===================
 // out[i] = scalars[i] * base for one base point: what ParamsKZG::setup does for the powers of tau ([s^i] G, verifier_api.rs:77).
