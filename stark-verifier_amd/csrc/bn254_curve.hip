@@ -125,7 +125,7 @@ struct FrPass {
 };
 __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
     __shared__ uint32_t lds[8][1024];
-    const uint32_t R = 1u << a.ns, tile_elems = min(1024u, 1u << a.log_n), C = tile_elems >> a.ns, log_c = 31 - __clz(C);
+    const uint32_t tile_elems = min(1024u, 1u << a.log_n), C = tile_elems >> a.ns, log_c = 31 - __clz(C);
     const uint32_t tid = threadIdx.x;
     // tiles: (hi, c_blk) with c_blk < 2^s0 / C
     const uint32_t cblks = (1u << a.s0) >> log_c;
