@@ -150,7 +150,9 @@ __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
     // (three waves per SIMD instead of six) and evaluate_h at k = 23 went from 594 to 641 ms, 744 ms capped at 128 VGPRs with spills.  One
     // stage per round trip at six waves stays.  Round 4, after the product was written by hand: the product inlined into the butterfly (no call,
     // no operand moves) and both of a thread's twiddles fetched before its first product changed nothing -- evaluate_h 452.5 and 458 against
-    // 451 ms -- the pass is neither call- nor twiddle-latency-bound; it runs at 0.72 of the VALU rate of its mix.)
+    // 451 ms -- the pass is neither call- nor twiddle-latency-bound; it runs at 0.72 of the VALU rate of its mix.  The butterflies on nine
+    // 29-bit limbs (bn254_f29.cuh: inlined product against twiddles in the 2^261 form, sums reduced on the top limb, 36 KB of LDS) were built
+    // too: evaluate_h 442 against 435 ms -- the product it saves is paid back in limb planes, normalisations and a block less per CU.)
     for (uint32_t it = 1; it <= a.ns; it++) {
         const uint32_t st = a.dif ? a.ns + 1 - it : it;
         const uint32_t s = a.s0 + st, lh = st - 1, half = 1u << lh;
