@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X prover hot path ("Measurement").
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W        (N > 1: under torch.distributed.run, or plain -- it then starts its N ranks itself)
 
 Default workload `recursive` (BASELINE.json metric "recursive plonky2 proofs/sec (Semaphore d=20)", configs[3]; sharded
 over ranks it is configs[4]): one UNIT = one depth-20 Semaphore signal (make_signal, access_set.rs:61-104: witness, proof at
@@ -874,6 +874,9 @@ def thread_cpu_snapshot():
     return out
 
 
+_STORE_KEEPALIVE = []
+
+
 def open_comm(lib, par, ctx, rank, world, rehearsal, dev=None):
     """The exchange of the N > 1 job through the C ABI (gl355_comm_*): RCCL over xGMI, or TCP between the host processes in the
     one-device rehearsal.  The 128-byte communicator id travels through the launcher's key-value store (torchrun's TCPStore,
@@ -885,6 +888,9 @@ def open_comm(lib, par, ctx, rank, world, rehearsal, dev=None):
     addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"])
     agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
     store = TCPStore(addr, port, world, (rank == 0 and not agent_store), timedelta(seconds=300), multi_tenant=True)
+    # rank 0 may be the store's server (no agent store): the server must outlive every other rank's reads of the flags below, so the object is
+    # kept for the life of the process (all ranks pass a communicator barrier before they exit)
+    _STORE_KEEPALIVE.append(store)
     store = PrefixStore("gl355_bench/%s" % os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), store)
     backend = par.COMM_HOST if rehearsal else par.COMM_RCCL
     # phase 1: can every rank bind its communicator library?  (a rank that cannot must not leave the others inside ncclCommInitRank)
@@ -1240,13 +1246,61 @@ def main_recursive(args):
         comm.close()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here (one process per GPU, the same command line, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment -- exactly what torch.distributed.run would set), stream their output through,
+    and exit with the first non-zero code after ending the others.  Rank 0 alone prints the JSON line.  The ranks rendezvous through
+    open_comm's TCPStore on 127.0.0.1 (rank 0 hosts it) and exchange through gl355_comm_* (RCCL), as under an external launcher."""
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GL355_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(0.2)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("[bench] rank %d exited with code %d: ending the other ranks\n" % (procs.index(p), code))
+                    for q in live:          # the process groups started above, nothing else
+                        try:
+                            os.killpg(q.pid, signal.SIGTERM)
+                        except OSError:
+                            pass
+    except KeyboardInterrupt:
+        rc = 130
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["recursive", "lde", "semaphore"], default="recursive",
+    ap.add_argument("--workload", choices=["recursive", "lde", "semaphore", "exchange"], default="recursive",
                     help="recursive = Semaphore d=20 signal + recursive proof per unit (default; BASELINE configs[3]/[4]); "
                          "lde = configs[1]; semaphore = the signals alone")
     ap.add_argument("--proofs-per-step", type=int, default=128,
@@ -1257,17 +1311,63 @@ def main():
                          "(round 3, final kernels: 8 -> 289.6, 9 -> 291.7, 10 -> 291.4, 11 -> 290.5, 16 -> 249 units/s; profiles/r03b_contexts_sweep.txt)")
     ap.add_argument("--log-members", type=int, default=20, help="log2 of the access-set size (tree depth)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)        # no external launcher: this process becomes the launcher of its N ranks
     if args.threads <= 0:
         args.threads = 10 if host_cores() // max(1, int(os.environ.get("WORLD_SIZE", "1"))) >= 12 else 8
     # two hardware queues per prover context (proving stream + side stream): the HIP runtime's default is 4, streams then share queues and a latency-bound
     # Merkle-top kernel on one stream holds up the streams behind it (measured 164 -> 172 proofs/s at 16 contexts).  Read when
     # the HIP runtime initialises, i.e. before torch / libgl355 touch the device (they are imported by the main_* functions).
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, 2 * int(os.environ.get("GL355_BENCH_CONTEXTS", args.threads)))))
+    if args.workload == "exchange":
+        return main_exchange(args)
     if args.workload == "semaphore":
         return main_semaphore(args)
     if args.workload == "recursive":
         return main_recursive(args)
     return main_lde(args)
+
+
+def main_exchange(args):
+    """The N > 1 plumbing alone, no prover: launch, rendezvous, block partition, one gl355_gather_digests of 64 B per unit per step, rank
+    order of the gathered leaves, rank 0 alone printing.  With GL355_BENCH_ONE_DEVICE=1 the communicator is the TCP one and no GPU is
+    touched (tests/test_bench_launch.py runs it on CPU); otherwise RCCL, one rank per device.  Not a measurement of anything."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    rehearsal = os.environ.get("GL355_BENCH_ONE_DEVICE") == "1"
+    lib = importlib.import_module("stark-verifier_amd._lib").load(init_torch=False)
+    par = importlib.import_module("stark-verifier_amd.parallel")
+    ctx, dev = None, None
+    if not rehearsal:
+        import torch
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        ctx = importlib.import_module("stark-verifier_amd").Context(local_rank)
+    comm = open_comm(lib, par, ctx, rank, world, rehearsal, dev)
+    per = args.proofs_per_step
+    total = per * world
+    lo, hi = par.shard_range(total, rank, world)
+    ok = True
+    t0 = time.perf_counter()
+    for step in range(args.warmup + args.steps):
+        local = (np.arange(lo, hi, dtype=np.uint64)[:, None] * np.uint64(8) + np.arange(8, dtype=np.uint64)[None, :]) + np.uint64(step << 32)
+        allv = comm.gather(local) if comm is not None else local
+        want = (np.arange(total, dtype=np.uint64)[:, None] * np.uint64(8) + np.arange(8, dtype=np.uint64)[None, :]) + np.uint64(step << 32)
+        ok = ok and np.array_equal(allv, want)
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        comm.barrier()
+        elapsed = comm.max(elapsed)
+    if rank == 0:
+        print(json.dumps({"metric": "exchange plumbing (no prover)", "value": round(total * (args.warmup + args.steps) / elapsed, 1), "unit": "leaves/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "leaves_in_rank_order": bool(ok),
+                          "exchange": getattr(comm, "backend_name", "none (world 1)"),
+                          "launcher": "bench.py itself" if os.environ.get("GL355_BENCH_SELF_LAUNCHED") == "1" else "external"}), flush=True)
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+    if not ok:
+        raise SystemExit(4)
 
 
 def main_lde(args):

@@ -99,3 +99,21 @@ def test_two_rank_cpp_host_flow(tmp_path):
     one = subprocess.check_output([exe, art, "3", "2", "8"], text=True, env=env)       # the same 8 units (members 12..19 mod 8) in one process
     root = lambda o: re.search(r"aggregation root ([0-9a-f ]+)", o).group(1).strip()
     assert root(two) == root(one)
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launched_two_ranks_one_device():
+    """`python bench.py --gpus 2` with no launcher around it -- the default (recursive) workload, both ranks on cuda:0
+    (GL355_BENCH_ONE_DEVICE=1: the exchange then runs over the C ABI's TCP communicator, RCCL refuses two ranks on one device).  The
+    launcher starts the ranks, they rendezvous, shard the units, gather the leaves, and rank 0 alone prints the line."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                "GPU_MAX_HW_QUEUES")}
+    env.update(GL355_BENCH_ONE_DEVICE="1", GL355_BENCH_CONTEXTS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--proofs-per-step", "16",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["unit"] == "proofs/s"
