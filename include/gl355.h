@@ -603,7 +603,12 @@ int32_t gl355_kzg_open(gl355_ctx* ctx, const uint64_t* g, const uint64_t* coeffs
  *                            (permutation::keygen::Assembly); g / g_lagrange = ParamsKZG's two bases (device pointers are used in place and must
  *                            outlive the key, host arrays are copied).  The key lives on the context's device.
  *   gl355_plonk_pk_info      [k, extended k, permutation sets, quotient pieces, usable rows, proof bytes, fixed columns, permutation columns]
- *   gl355_plonk_pk_commitments / _set_digest   the verifying key's commitments; replace the transcript's initial scalar (e.g. by a hash of them)
+ *   gl355_plonk_pk_commitments   the verifying key's fixed and permutation commitments
+ *   gl355_plonk_pk_digest / _set_digest   the transcript's initial scalar (halo2: vk.transcript_repr).  A descriptor whose digest field
+ *                            (header words 16..19) is zero gets, at keygen, Keccak-256(descriptor words | fixed commitments | sigma
+ *                            commitments, all as little-endian u64) read as a big-endian integer mod r -- the PINNED key, so circuits that
+ *                            differ only in fixed values or copy constraints start different transcripts; a non-zero field is used as given;
+ *                            _set_digest replaces it (a host that computed halo2's own transcript_repr)
  *   gl355_plonk_prove        one proof: advice [advice columns][2^k] scalars (rows >= usable are overwritten by blinding values), instances =
  *                            the instance columns' values back to back with instance_lens[column] values each, seed = 32 bytes that fix every
  *                            random scalar (ChaCha20 block (counter = index, nonce = (stream, a, index >> 32)) -> 512-bit little-endian integer
@@ -622,6 +627,7 @@ int32_t gl355_plonk_keygen(gl355_ctx* ctx, const uint64_t* desc, uint64_t desc_w
                            const uint32_t* mapping, gl355_plonk_pk** out);
 int32_t gl355_plonk_pk_info(const gl355_plonk_pk* pk, uint64_t info[8]);
 int32_t gl355_plonk_pk_commitments(const gl355_plonk_pk* pk, uint64_t* fixed_commitments, uint64_t* sigma_commitments);
+int32_t gl355_plonk_pk_digest(const gl355_plonk_pk* pk, uint64_t digest[4]);
 int32_t gl355_plonk_pk_set_digest(gl355_plonk_pk* pk, const uint64_t digest[4]);
 int32_t gl355_plonk_prove(gl355_ctx* ctx, gl355_plonk_pk* pk, const uint64_t* advice, const uint64_t* instances, const uint32_t* instance_lens, const uint8_t seed[32],
                           uint8_t* proof, uint64_t capacity, uint64_t* proof_len, uint64_t* trace, double* stage_ms);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "gl355_plonk_keygen": (C.c_int32, [vp, vp, C.c_uint64, vp, vp, vp, vp, C.POINTER(vp)]),
     "gl355_plonk_pk_info": (C.c_int32, [vp, vp]),
     "gl355_plonk_pk_commitments": (C.c_int32, [vp, vp, vp]),
+    "gl355_plonk_pk_digest": (C.c_int32, [vp, vp]),
     "gl355_plonk_pk_set_digest": (C.c_int32, [vp, vp]),
     "gl355_plonk_prove": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), vp, vp]),
     "gl355_plonk_pk_destroy": (C.c_int32, [vp]),

@@ -24,6 +24,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include <algorithm>
 #include <chrono>
 #include <memory>
 
@@ -506,6 +507,17 @@ int32_t gl355_plonk_keygen(gl355_ctx* h, const uint64_t* desc, uint64_t words, c
         for (auto& q : pk->queries[pc.first]) ok = ok || (q.first == (int32_t)pc.second && q.second == 0);
         if (!ok) return ctx->fail(GL355_E_INVALID_ARG, "plonk_keygen: a permutation column is not queried at the current rotation");
     }
+    // SHPLONK's linear combination carries at most four low-order correction terms per polynomial (PlkLincombArgs::low): a column queried at
+    // five or more distinct rotations is refused HERE, not at the end of every proof.  The arguments' own polynomials are opened
+    // at <= 3 points (z: x, wx, w^last x; permuted input: x, w^-1 x).
+    for (int kd = 0; kd < 2; kd++) {
+        std::vector<std::vector<int32_t>> rots(kind_cols[kd]);
+        for (auto& q : pk->queries[kd]) {
+            auto& r = rots[q.first];
+            if (std::find(r.begin(), r.end(), q.second) == r.end()) r.push_back(q.second);
+            if (r.size() > 4) return ctx->fail(GL355_E_UNSUPPORTED, "plonk_keygen: a column is queried at more than four distinct rotations");
+        }
+    }
     // ---- device side
     const uint64_t n = pk->n;
     gl355_plonk_pk* k_ = pk.get();
@@ -569,19 +581,38 @@ int32_t gl355_plonk_keygen(gl355_ctx* h, const uint64_t* desc, uint64_t words, c
     if (pk->n_perm) {
         Staged sm(ctx);
         GL355_TRY(sm.open(mapping, (size_t)pk->n_perm * n * 8, 1));
-        // (a host check of the mapping's range would cost a pass over 2^k x columns entries; the kernel clamps nothing, so check here)
-        if (!ptr_is_device(mapping)) {
-            for (uint64_t t = 0; t < (uint64_t)pk->n_perm * n; t++)
-                if (mapping[2 * t] >= pk->n_perm || mapping[2 * t + 1] >= n) return ctx->fail(GL355_E_INVALID_ARG, "plonk_keygen: permutation mapping out of range");
-        }
+        // the range of every entry is checked by the kernel itself (host and device mappings alike): an entry outside [0, n_perm) x [0, n)
+        // raises the flag and reads nothing
+        Scratch flag(ctx);
+        GL355_TRY(flag.get(32));
+        GL355_HIP(ctx, hipMemsetAsync(flag.as<uint32_t>(), 0, 4, ctx->stream));
         hipLaunchKernelGGL(plk_sigma_kernel, dim3(blocks((uint64_t)pk->n_perm * n)), dim3(256), 0, ctx->stream, sm.as<uint32_t>(), n, pk->n_perm, (const uint64_t*)pk->delta_pows,
-                           (const uint64_t*)pk->omega_pows, pk->sigma_vals);
+                           (const uint64_t*)pk->omega_pows, pk->sigma_vals, flag.as<uint32_t>());
         GL355_HIP(ctx, hipGetLastError());
+        uint32_t bad = 0;
+        GL355_HIP(ctx, ctx->d2h(&bad, flag.as<uint32_t>(), 4));
         GL355_HIP(ctx, ctx->wait());
+        if (bad) return ctx->fail(GL355_E_INVALID_ARG, "plonk_keygen: permutation mapping out of range");
     }
     pk->sigma_commitments.assign(8ull * pk->n_perm, 0);
     GL355_TRY(commit_columns(k_, pk->g_lagrange, pk->sigma_vals, pk->n_perm, pk->sigma_commitments.data()));
     for (uint32_t c = 0; c < pk->n_perm; c++) GL355_TRY(lagrange_to_coeff(k_, pk->sigma_vals + 4ull * c * n, pk->sigma_polys + 4ull * c * n, work.as<uint64_t>()));
+    // the transcript's initial scalar (halo2: vk.transcript_repr, a hash of the PINNED verifying key -- shape, fixed commitments, permutation
+    // commitments): a descriptor whose digest field is zero gets Keccak-256 over (the whole descriptor | fixed commitments | sigma
+    // commitments), as a big-endian integer mod r, so two circuits that differ only in fixed values or copy constraints never share a
+    // Fiat-Shamir prefix and a C caller cannot forget the step.  A non-zero field is taken as given (a host that computed
+    // halo2's own transcript_repr); gl355_plonk_pk_set_digest still overrides.
+    if (!(desc[16] | desc[17] | desc[18] | desc[19])) {
+        std::vector<uint8_t> pre((size_t)words * 8 + (pk->fixed_commitments.size() + pk->sigma_commitments.size()) * 8);
+        memcpy(pre.data(), desc, (size_t)words * 8);
+        if (!pk->fixed_commitments.empty()) memcpy(pre.data() + (size_t)words * 8, pk->fixed_commitments.data(), pk->fixed_commitments.size() * 8);
+        if (!pk->sigma_commitments.empty()) memcpy(pre.data() + (size_t)words * 8 + pk->fixed_commitments.size() * 8, pk->sigma_commitments.data(), pk->sigma_commitments.size() * 8);
+        uint8_t hsh[32];
+        keccak256_host(pre.data(), pre.size(), hsh);
+        uint64_t w[4];
+        for (int i = 0; i < 4; i++) { w[i] = 0; for (int b = 0; b < 8; b++) w[i] |= (uint64_t)hsh[31 - (8 * i + b)] << (8 * b); }
+        pk->digest = Fr::from_words(w);
+    }
     // l_0, l_last, l_active_row
     GL355_TRY(D(3 * n * 32, &pk->l_polys));
     hipLaunchKernelGGL(plk_indicator_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, pk->l_polys, pk->l_polys + 4 * n, pk->l_polys + 8 * n, n, pk->usable);
@@ -623,6 +654,12 @@ int32_t gl355_plonk_pk_commitments(const gl355_plonk_pk* pk, uint64_t* fixed_c, 
     if (!pk) return GL355_E_INVALID_ARG;
     if (fixed_c && !pk->fixed_commitments.empty()) memcpy(fixed_c, pk->fixed_commitments.data(), pk->fixed_commitments.size() * 8);
     if (sigma_c && !pk->sigma_commitments.empty()) memcpy(sigma_c, pk->sigma_commitments.data(), pk->sigma_commitments.size() * 8);
+    return GL355_OK;
+}
+
+int32_t gl355_plonk_pk_digest(const gl355_plonk_pk* pk, uint64_t digest[4]) {
+    if (!pk || !digest) return GL355_E_INVALID_ARG;
+    pk->digest.to_words(digest);
     return GL355_OK;
 }
 
@@ -1014,8 +1051,10 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
         for (size_t i = 0; i < n_written; i++) tr.write_scalar(evals[i]);
     }
     // evaluation of (poly id, point) from the table above
+    bool eval_missing = false;              // a (polynomial, point) pair SHPLONK asks for that the evaluation stage never computed: an internal error, not a zero
     auto eval_of = [&](uint32_t id, const Fr& pt) -> Fr {
         for (size_t i = 0; i < qs.size(); i++) if (qs[i].poly_id == id && qs[i].point == pt) return evals[i];
+        eval_missing = true;
         return Fr::zero();
     };
 
@@ -1079,6 +1118,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
             for (size_t m : sets[s].members) {
                 std::vector<Fr> ev;
                 for (auto& p : sets[s].pts) ev.push_back(eval_of(polys[m].id, p));
+                if (eval_missing) return ctx->fail(GL355_E_UNSUPPORTED, "plonk_prove: an opening asks for an evaluation that was not computed");
                 r_coeffs[s].push_back(interpolate(sets[s].pts, ev));
                 for (size_t t = 0; t < low.size(); t++) low[t] = low[t] + yj * r_coeffs[s].back()[t];
                 ps.push_back(polys[m].poly);

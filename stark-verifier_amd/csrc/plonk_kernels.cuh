@@ -57,10 +57,11 @@ __global__ void plk_indicator_kernel(uint64_t* l0, uint64_t* llast, uint64_t* la
 }
 // sigma_j[i] = delta^(column) omega^(row) of the cell (j, i) maps to (permutation::keygen::Assembly::build_pk)
 __global__ void plk_sigma_kernel(const uint32_t* mapping /* [n_perm][n][2] */, uint64_t n, uint32_t n_perm, const uint64_t* delta_pows, const uint64_t* omega_pows,
-                                 uint64_t* out /* [n_perm][n] */) {
+                                 uint64_t* out /* [n_perm][n] */, uint32_t* out_of_range) {
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n * n_perm) return;
     const uint32_t cj = mapping[2 * t], ci = mapping[2 * t + 1];
+    if (cj >= n_perm || ci >= n) { atomicOr(out_of_range, 1u); return; }
     store256(out + 4 * t, m_mul<F_R>(load256(delta_pows + 4 * cj), load256(omega_pows + 4 * ci)));
 }
 

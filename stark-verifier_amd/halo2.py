@@ -193,7 +193,7 @@ class ConstraintSystem:
 
     # ---- derived shape (plonk::ConstraintSystem::degree / blinding_factors, permutation::Argument, lookup::Argument) --
     def degree(self):
-        d = 3 if self.permutation else 1                               # permutation::Argument::required_degree
+        d = 3                                                           # permutation::Argument::required_degree: 3 with or without columns
         for _, ins, tabs in self.lookups:                               # lookup::Argument::required_degree
             di = max([1] + [e.degree() for e in ins])
             dt = max([1] + [e.degree() for e in tabs])
@@ -393,16 +393,16 @@ def from_limbs(a):
     return [int(r[0]) | (int(r[1]) << 64) | (int(r[2]) << 128) | (int(r[3]) << 192) for r in a]
 
 
-def vk_digest(cs, k, fixed_commitments=(), sigma_commitments=()):
-    """the scalar the transcript starts from (halo2: vk.transcript_repr, a hash of the pinned verifying key): here SHA-256 of the
-    shape and the key's commitments, reduced mod r -- a stand-in with the same role (halo2's Blake2b-of-debug-string cannot be restated)"""
-    import hashlib
-    h = hashlib.sha256()
-    h.update(repr((k, cs.num_advice, cs.num_fixed, cs.num_instance, cs.degree(), cs.blinding_factors(), cs.queries,
-                   [(c.kind, c.index) for c in cs.permutation], len(cs.all_gate_polys()), len(cs.lookups))).encode())
-    for pt in list(fixed_commitments) + list(sigma_commitments):
-        h.update(np.asarray(pt, dtype=np.uint64).tobytes())
-    return int.from_bytes(h.digest(), "big") % R
+def vk_digest(cs, k, fixed_commitments, sigma_commitments, keccak256):
+    """the scalar the transcript starts from (halo2: vk.transcript_repr, a hash of the PINNED verifying key): Keccak-256 over the descriptor
+    (digest field zero: shape, queries, permutation columns, gate and lookup programs) and the key's fixed and permutation commitments
+    ([cols][8] uint64: x, y little-endian words; the identity = zeros), read as a big-endian integer mod r -- what gl355_plonk_keygen derives
+    itself (include/gl355.h).  A stand-in with transcript_repr's role (halo2's Blake2b-of-debug-string cannot be restated); it binds the
+    fixed values and the copy constraints through their commitments.  keccak256: bytes -> 32 bytes (the caller's implementation: the
+    checker recomputes the digest with its own)."""
+    pre = export_desc(cs, k, 0).tobytes()
+    pre += np.ascontiguousarray(fixed_commitments, dtype=np.uint64).tobytes() + np.ascontiguousarray(sigma_commitments, dtype=np.uint64).tobytes()
+    return int.from_bytes(keccak256(pre), "big") % R
 
 
 def export_desc(cs, k, digest):
@@ -481,8 +481,12 @@ class PlonkProver:
         self.fixed_commitments = np.zeros((cs.num_fixed, 8), dtype=np.uint64)
         self.sigma_commitments = np.zeros((len(cs.permutation), 8), dtype=np.uint64)
         ctx.check(ctx.lib.gl355_plonk_pk_commitments(self.h, self.fixed_commitments.ctypes.data, self.sigma_commitments.ctypes.data))
-        self.digest = vk_digest(cs, k) if digest is None else digest
-        self.set_digest(self.digest)
+        if digest is None:          # derived by keygen from the descriptor and the commitments above
+            d = np.zeros(4, dtype=np.uint64)
+            ctx.check(ctx.lib.gl355_plonk_pk_digest(self.h, d.ctypes.data))
+            self.digest = from_limbs(d)[0]
+        else:
+            self.set_digest(digest)
 
     def set_digest(self, digest):
         d = to_limbs([digest])[0]

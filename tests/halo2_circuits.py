@@ -15,6 +15,22 @@ h2 = importlib.import_module("stark-verifier_amd.halo2")
 ch = importlib.import_module("stark-verifier_amd.halo2_chips")
 
 
+def points_to_words(pts):
+    """[(x, y) | None] -> [len][8] uint64 (x, y little-endian words; the identity = zeros): the layout of gl355_plonk_pk_commitments"""
+    out = np.zeros((len(pts), 8), dtype=np.uint64)
+    for i, p in enumerate(pts):
+        if p is not None:
+            for j in range(4):
+                out[i, j] = (p[0] >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+                out[i, 4 + j] = (p[1] >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def oracle_vk_digest(cs, k, pk):
+    """the transcript's initial scalar recomputed on the checker's side: the oracle's own commitments and the oracle's own Keccak-256"""
+    return h2.vk_digest(cs, k, points_to_words(pk.fixed_commitments), points_to_words(pk.sigma_commitments), hm.keccak256)
+
+
 def plonk_with_tuple_lookup(k, tb, seed=11):
     """A second circuit family, unlike the reference's chips on purpose: vanilla PLONK arithmetic (q_a a + q_b b + q_m a b + q_c + q_o c), a gate with
     a rotation (q_n (a(wX) - a - b)), a TWO-column lookup whose inputs are products (q_l a, q_l c) into the table (t, 3 t + 1), and a permutation

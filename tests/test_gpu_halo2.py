@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import halo2_model as hm  # noqa: E402
 import halo2_verifier as hv  # noqa: E402
-from halo2_circuits import plonk_with_tuple_lookup, random_circuit  # noqa: E402
+from halo2_circuits import oracle_vk_digest, plonk_with_tuple_lookup, random_circuit  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 h2 = importlib.import_module("stark-verifier_amd.halo2")
@@ -50,6 +50,8 @@ def test_proof_bytes_equal_the_oracle(ctx, k, tb):
     # the verifying key's commitments
     assert [pt(c) for c in prover.fixed_commitments] == pk.fixed_commitments
     assert [pt(c) for c in prover.sigma_commitments] == pk.sigma_commitments
+    # the transcript's initial scalar, derived by gl355_plonk_keygen from the pinned key == recomputed from the oracle's commitments
+    assert prover.digest == oracle_vk_digest(cs, k, pk)
     seed = bytes((7 * i + k) & 0xFF for i in range(32))
     tr = {}
     want = hm.create_proof(params, pk, w.advice_ints(), w.instance, seed, prover.digest, tr)
@@ -221,3 +223,27 @@ def test_malformed_descriptors_are_refused(gl, ctx):
     assert n_out.value == prover.info["proof_bytes"]
     ctx2.close()
     prover.close()
+
+
+def test_digest_binds_the_fixed_columns(ctx):
+    """same shape, one fixed cell changed (a cell no constraint reads with the witness used: the proof still verifies) -> another
+    verifying-key digest, hence another theta: the key is bound into every challenge"""
+    k = 7
+    cs, cfg, w = ch.synthetic_circuit(k, table_bits=5, n_permutations=1)
+    g, gl_ = h2.kzg_setup(ctx, k, TAU)
+    mapping = w.assembly.mapping_array()
+    p0 = h2.PlonkProver(ctx, cs, k, g, gl_, w.fixed, mapping)
+    fixed2 = w.fixed.copy()
+    row = w.usable + 1                                  # a blinding row: outside every gate's active rows
+    fixed2[0, row, 0] ^= np.uint64(1)
+    p1 = h2.PlonkProver(ctx, cs, k, g, gl_, fixed2, mapping)
+    assert p0.digest != p1.digest
+    seed = bytes(range(32))
+    _, t0 = p0.prove(w.advice, w.instance, seed, want_trace=True)
+    _, t1 = p1.prove(w.advice, w.instance, seed, want_trace=True)
+    assert t0["theta"] != t1["theta"]
+    # an explicit digest in the descriptor is used as given, and gl355_plonk_pk_set_digest overrides
+    p2 = h2.PlonkProver(ctx, cs, k, g, gl_, w.fixed, mapping, digest=12345)
+    assert p2.digest == 12345
+    for p in (p0, p1, p2):
+        p.close()
