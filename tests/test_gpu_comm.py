@@ -116,4 +116,4 @@ def test_bench_self_launched_two_ranks_one_device():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["value"] > 0 and line["unit"] == "proofs/s"
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["unit"] == "recursive proofs/s"
