@@ -36,7 +36,10 @@ __global__ void __launch_bounds__(256) poseidon_permute_kernel(uint64_t* states,
 
 
 // one lane = one leaf: overwrite-mode sponge over ceil(len/8) chunks
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) hash_leaves_kernel(LeafArgs a) {
+#ifndef PSD_LEAF_WAVES
+#define PSD_LEAF_WAVES 4
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PSD_LEAF_WAVES))) hash_leaves_kernel(LeafArgs a) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= a.n_leaves) return;
     uint64_t s[12];

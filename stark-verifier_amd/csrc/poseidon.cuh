@@ -82,24 +82,179 @@ GL_DEV void psd_mds(uint64_t (&s)[12], const uint64_t* rc) {
 }
 
 
-// 30 rounds of (constants, S-box on every element [4 + 4 full rounds] or on element 0 [22 partial rounds], MDS).  The partial
-// rounds run in the naive form as well: a v_mad_u64_u32 by a 6-bit MDS entry is far cheaper than the 64x64 modular products
-// of the factored form (measured, profiles/r01_poseidon_dense_vs_sparse.txt).  Round r's MDS adds round r+1's constants
-// (PSD_ALL_RC row 30 is zero).
-GL_DEV void psd_permute(uint64_t (&s)[12]) {
+// ---- the 22 partial rounds in BLOCK form (round 5) ------------------------------------------------------------------------------
+// Only lane 0 meets the S-box in a partial round, so over a block of B = 11 rounds lanes 1..11 are a linear function of the state u that
+// entered the block and of the block's S-box outputs x_0..x_{B-1} (gates/poseidon.rs:504-589 factors the same linearity round by round;
+// here it is unrolled over a block, tools/gen_poseidon_tables.py has the algebra and a limb-exact model):
+//     y_j  = <alpha_j, u> + sum_{i<j} x_i kappa_{j-1-i} + gamma_j     (lane 0 entering round j of the block),   x_j = y_j^7
+//     s'_r = <(A^B)_r, u> + sum_{i<B} x_i beta_{B-1-i}[r] + Gamma_r   (the state leaving the block)
+// Every output is ONE dot product with 64-bit constants, reduced once: 429 multiply-accumulates + 22 reductions per block where the dense form
+// spends 11 x 144 small-constant multiply-accumulates + 11 x 12 reductions -- 6 864 instead of 8 976 vector instructions for the 22 rounds.
+// A multiply-accumulate x * c costs six v_mad_u64_u32 and nothing else: x is split ONCE into limbs of 22 / 22 / 20 bits (each x and u is used by
+// 11..22 outputs), the table holds (c, 2^22 c, 2^44 c) mod p, limb k times the low / high half of the k-th constant goes into the low / high
+// accumulator; 66 products < 2^54 and a 32-bit constant cannot overflow 64 bits, and psd_recombine folds al + ah 2^32 as for an MDS row.
+// (the tables are NOT const-qualified on the device: with the values visible the compiler strength-reduces the small ones into 64-bit shifts and
+// adds, keeps every limb as a zero-extended register PAIR for them -- 174 VGPRs -- and materialises the rest as 32-bit literals with a wait state each)
+#undef PSD_TABLE_QUAL
+#define PSD_TABLE_QUAL __device__ __constant__
+#include "poseidon_ktables.h"
+
+GL_DEV void psd_split(uint64_t x, uint32_t (&l)[3]) {
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    l[0] = lo & 0x3FFFFFu;
+    l[1] = __builtin_amdgcn_alignbit(hi, lo, 22) & 0x3FFFFFu;
+    l[2] = hi >> 12;
+}
+// c: the three table words of this multiply-accumulate, wave-uniform (SGPRs: the multiplier of every multiply-add)
+typedef const __attribute__((address_space(4))) uint64_t* psd_ktab;      // constant address space: wave-uniform reads become scalar loads
+GL_DEV void psd_mac(uint64_t& lo, uint64_t& hi, const uint32_t (&l)[3], const uint64_t (&c)[3]) {
+    const uint64_t c0 = c[0], c1 = c[1], c2 = c[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+    // written out: in C the compiler keeps one zero-extended 64-bit copy of every limb (a register PAIR each, 132 VGPRs of limbs) and truncates
+    // it at each use.  src0 = the constant (SGPR, the one constant-bus operand), src1 = the limb; the carry-out pair is never read.
+    uint64_t unused;
+    asm("v_mad_u64_u32 %0, %2, %3, %9, %0\n\tv_mad_u64_u32 %1, %2, %4, %9, %1\n\t"
+        "v_mad_u64_u32 %0, %2, %5, %10, %0\n\tv_mad_u64_u32 %1, %2, %6, %10, %1\n\t"
+        "v_mad_u64_u32 %0, %2, %7, %11, %0\n\tv_mad_u64_u32 %1, %2, %8, %11, %1"
+        : "+v"(lo), "+v"(hi), "=&s"(unused)
+        : "s"((uint32_t)c0), "s"((uint32_t)(c0 >> 32)), "s"((uint32_t)c1), "s"((uint32_t)(c1 >> 32)), "s"((uint32_t)c2), "s"((uint32_t)(c2 >> 32)),
+          "v"(l[0]), "v"(l[1]), "v"(l[2]));
+#else
+    lo += (uint64_t)l[0] * (uint32_t)c0 + (uint64_t)l[1] * (uint32_t)c1 + (uint64_t)l[2] * (uint32_t)c2;
+    hi += (uint64_t)l[0] * (uint32_t)(c0 >> 32) + (uint64_t)l[1] * (uint32_t)(c1 >> 32) + (uint64_t)l[2] * (uint32_t)(c2 >> 32);
+#endif
+}
+// the first multiply-accumulate of an output: the accumulators start from the additive constant's halves.  Inside the statement, so that the
+// constant is read where the group's other constants are (a C initialisation is copied to VGPRs right behind its scalar load: a wait of its own).
+GL_DEV void psd_mac_first(uint64_t& lo, uint64_t& hi, const uint32_t (&l)[3], const uint64_t (&c)[3], const uint64_t (&add)[2]) {
+    const uint64_t c0 = c[0], c1 = c[1], c2 = c[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t unused;
+    asm("v_mov_b64 %0, %12\n\tv_mov_b64 %1, %13\n\t"
+        "v_mad_u64_u32 %0, %2, %3, %9, %0\n\tv_mad_u64_u32 %1, %2, %4, %9, %1\n\t"
+        "v_mad_u64_u32 %0, %2, %5, %10, %0\n\tv_mad_u64_u32 %1, %2, %6, %10, %1\n\t"
+        "v_mad_u64_u32 %0, %2, %7, %11, %0\n\tv_mad_u64_u32 %1, %2, %8, %11, %1"
+        : "=&v"(lo), "=&v"(hi), "=&s"(unused)
+        : "s"((uint32_t)c0), "s"((uint32_t)(c0 >> 32)), "s"((uint32_t)c1), "s"((uint32_t)(c1 >> 32)), "s"((uint32_t)c2), "s"((uint32_t)(c2 >> 32)),
+          "v"(l[0]), "v"(l[1]), "v"(l[2]), "s"(add[0]), "s"(add[1]));
+#else
+    lo = add[0]; hi = add[1];
+    psd_mac(lo, hi, l, c);
+#endif
+}
+#ifndef PSD_K_GROUP
+#define PSD_K_GROUP 5      // multiply-accumulates per group of scalar loads: 6 SGPRs of constants each, two groups in flight
+#endif
+// The block's table is consumed front to back.  Scalar loads return out of order, so the only wait is "all of them": a group's constants are
+// therefore requested one group AHEAD -- the first multiply-accumulate of a group waits for the group's constants (requested while the previous
+// group was being consumed), then the next group's loads are issued, then the remaining multiply-accumulates run under their latency.  The
+// scheduling barriers pin that order; without them the scheduler either issues the loads of a whole dot product (132 SGPRs, spilled into VGPR
+// lanes) or waits for each group right after requesting it (a lonely wave then sits through the scalar-cache latency 90 times per block).
+struct PsdK {
+    uint64_t w[PSD_K_GROUP][3];     // (c, 2^22 c, 2^44 c) of the group's multiply-accumulates
+    uint64_t a[2];                  // when the group opens an output: the output's additive constant (low half, high half)
+};
+template <int N, bool WITH_ADD>
+GL_DEV void psd_kload(PsdK& k, psd_ktab c, psd_ktab add) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add_canonical(s[i], PSD_ALL_RC[i]);
-    // two rounds per iteration (4 + 22 + 4: a pair is never mixed), so the state ping-pongs between two register sets
-    // instead of being copied back at the loop edge
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) k.w[i][j] = c[3 * i + j];
+    if constexpr (WITH_ADD) { k.a[0] = add[0]; k.a[1] = add[1]; }
+}
+// -> al + ah 2^32 = add + sum_{t < 11} ul[t] c[t] + sum_{t < NX} xl[t] c[11 + t], folded to a u64.  k: this output's first group (requested
+// earlier); on return the NEXT output's first group (table position c + 3 (11 + NX), additive constant add_next), requested, if HAS_NEXT.
+template <int NX, bool HAS_NEXT, int XCAP>
+GL_DEV uint64_t psd_dot(const uint32_t (&ul)[11][3], const uint32_t (&xl)[XCAP][3], psd_ktab c, PsdK& k, psd_ktab add_next) {
+    constexpr int G = PSD_K_GROUP, NT = 11 + NX, NG = (NT + G - 1) / G;
+    uint64_t lo, hi;
+    PsdK cur = k;
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const int n = NT - g * G < G ? NT - g * G : G;
+        PsdK nxt;
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const int t = g * G + i;
+            if (t == 0) psd_mac_first(lo, hi, ul[0], cur.w[0], cur.a);
+            else if (i < n) {
+                if (t < 11) psd_mac(lo, hi, ul[t], cur.w[i]);
+                else psd_mac(lo, hi, xl[t - 11], cur.w[i]);
+            }
+            if (i == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < NG) {
+                    if (NT - (g + 1) * G >= G) psd_kload<G, false>(nxt, c + 3 * (g + 1) * G, add_next);
+                    else psd_kload<(NT % G ? NT % G : G), false>(nxt, c + 3 * (g + 1) * G, add_next);
+                } else if constexpr (HAS_NEXT) {
+                    psd_kload<G, true>(nxt, c + 3 * NT, add_next);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    k = cur;
+    return psd_recombine(lo, hi);
+}
+template <int J>
+GL_DEV void psd_block_lane0(const uint32_t (&ul)[11][3], uint32_t (&xl)[PSD_K_BLOCK][3], psd_ktab mac, psd_ktab add, PsdK& k) {
+    if constexpr (J < PSD_K_BLOCK) {
+        const uint64_t y = psd_dot<J, true>(ul, xl, mac + 3 * (11 * (J - 1) + (J - 1) * J / 2), k, add + 2 * J);
+        psd_split(psd_sbox(y), xl[J]);
+        __builtin_amdgcn_sched_barrier(0);
+        psd_block_lane0<J + 1>(ul, xl, mac, add, k);
+    }
+}
+template <int R>
+GL_DEV void psd_block_out(uint64_t (&s)[12], const uint32_t (&ul)[11][3], const uint32_t (&xl)[PSD_K_BLOCK][3], psd_ktab mac, psd_ktab add, PsdK& k) {
+    constexpr int B = PSD_K_BLOCK;
+    if constexpr (R < 12) {
+        s[R] = psd_dot<B, (R < 11)>(ul, xl, mac + 3 * (11 * (B - 1) + (B - 1) * B / 2 + (11 + B) * R), k, add + 2 * (B + R));
+        __builtin_amdgcn_sched_barrier(0);
+        psd_block_out<R + 1>(s, ul, xl, mac, add, k);
+    }
+}
+GL_DEV void psd_partial_rounds_block(uint64_t (&s)[12]) {
+    constexpr int B = PSD_K_BLOCK;
+#pragma unroll 1
+    for (int blk = 0; blk < 22 / B; blk++) {
+        psd_ktab add = (psd_ktab)PSD_K_ADD + blk * 2 * (B - 1 + 12);
+        psd_ktab mac = (psd_ktab)PSD_K_MAC;
+        asm volatile("" : "+s"(mac));         // re-read per block: hoisted out of this loop the table would sit in ~2 600 SGPRs
+        PsdK k;
+        psd_kload<PSD_K_GROUP, true>(k, mac, add);        // y_1's first group, under the first S-box
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t ul[11][3], xl[B][3];
+#pragma unroll
+        for (int i = 0; i < 11; i++) psd_split(s[i + 1], ul[i]);
+        psd_split(psd_sbox(s[0]), xl[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        psd_block_lane0<1>(ul, xl, mac, add, k);
+        psd_block_out<0>(s, ul, xl, mac, add, k);
+    }
+}
+
+// 30 rounds of (constants, S-box on every element [4 + 4 full rounds] or on element 0 [22 partial rounds], MDS); round r's MDS adds round
+// r+1's constants (PSD_ALL_RC row 30 is zero).  PSD_PARTIAL_FORM 1 (default): the partial rounds in the block form above; 0: the dense form
+// for all 30 rounds (rounds 1-4: a v_mad_u64_u32 by a 6-bit MDS entry beat the 64x64 modular products of the round-by-round factored form,
+// profiles/r01_poseidon_dense_vs_sparse.txt; the block form needs neither -- A/B in profiles/r05_poseidon_block_vs_dense.txt).
+#ifndef PSD_PARTIAL_FORM
+#define PSD_PARTIAL_FORM 1
+#endif
 #ifndef PSD_ROUNDS_PER_ITER
 #define PSD_ROUNDS_PER_ITER 2
 #endif
+template <bool FULL>
+GL_DEV void psd_dense_rounds(uint64_t (&s)[12], int r0, int r1) {
+    // two rounds per iteration (4 + 22 + 4: a pair is never mixed), so the state ping-pongs between two register sets
+    // instead of being copied back at the loop edge
 #pragma unroll 1
-    for (int r = 0; r < 30; r += PSD_ROUNDS_PER_ITER) {
-        const bool full = r < 4 || r >= 26;
+    for (int r = r0; r < r1; r += PSD_ROUNDS_PER_ITER) {
 #pragma unroll
         for (int h = 0; h < PSD_ROUNDS_PER_ITER; h++) {
-            if (full) {
+            if (FULL) {
 #pragma unroll
                 for (int i = 0; i < 12; i++) s[i] = psd_sbox(s[i]);
             } else {
@@ -108,6 +263,17 @@ GL_DEV void psd_permute(uint64_t (&s)[12]) {
             psd_mds(s, &PSD_ALL_RC[12 * (r + h + 1)]);
         }
     }
+}
+GL_DEV void psd_permute(uint64_t (&s)[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add_canonical(s[i], PSD_ALL_RC[i]);
+    psd_dense_rounds<true>(s, 0, 4);
+#if PSD_PARTIAL_FORM == 1
+    psd_partial_rounds_block(s);
+#else
+    psd_dense_rounds<false>(s, 4, 26);
+#endif
+    psd_dense_rounds<true>(s, 26, 30);
 }
 
 // digest of <= 4 elements is the elements themselves, zero padded (chip/merkle_proof_chip.rs:52-57);

@@ -197,6 +197,151 @@ def check_reference(tb):
     return ok
 
 
+# ----------------------------------------------------------------------------------------------
+# The "block" form of the partial rounds (round 5; stark-verifier_amd/csrc/poseidon.cuh, psd_partial_rounds_block).
+# Only lane 0 meets the S-box in a partial round, so over a block of B rounds the other eleven lanes are a LINEAR function of the state
+# u that entered the block and of the S-box outputs x_0 .. x_{B-1}.  With A = M * diag(0,1,..,1) and m0 = M e0 (a round is
+# s <- A s + x m0 + C):
+#     y_j  = <alpha_j, u> + sum_{i<j} x_i kappa_{j-1-i} + gamma_j        alpha_j = e0^T A^j,  kappa_k = e0^T A^k m0      (j = 1 .. B-1; y_0 = u_0)
+#     s'_r = <(A^B)_r, u> + sum_{i<B} x_i beta_{B-1-i}[r] + Gamma_r       beta_k = A^k m0                                   (r = 0 .. 11)
+# alpha_j, kappa, beta, A^B do not depend on the block; gamma / Gamma collect the round constants of the block's rounds (the last block's Gamma
+# includes the constants of the first closing full round, as the dense form's "MDS adds the next round's constants" did).  Every
+# output is ONE dot product with constants, reduced once -- 429 multiply-accumulates and 22 reductions per block of 11 rounds against
+# 11 x 144 small-constant multiply-accumulates and 11 x 12 reductions of the dense form.
+# A multiply-accumulate x * c: x is split once into limbs of 22 / 22 / 20 bits and multiplied with the 32-bit halves of c, 2^22 c, 2^44 c
+# (mod p): six 32 x 32 + 64 multiply-adds into two accumulators (low halves, high halves) that cannot overflow (66 products < 2^54).
+K_BLOCK = 11
+
+
+def kform_tables(rc):
+    m = mds_matrix()
+    a = [[0 if j == 0 else m[i][j] for j in range(T)] for i in range(T)]          # A = M P
+    m0 = [m[i][0] for i in range(T)]
+    B = K_BLOCK
+    apow = [[[1 if i == j else 0 for j in range(T)] for i in range(T)]]
+    for _ in range(B):
+        apow.append(mat_mul(a, apow[-1]))
+    alpha = [apow[j][0] for j in range(B)]                                        # row 0 of A^j
+    beta = [mat_vec(apow[k], m0) for k in range(B)]
+    kappa = [beta[k][0] for k in range(B)]
+    mac = []                                                                      # consumption order
+    for j in range(1, B):
+        assert alpha[j][0] == 0
+        mac += alpha[j][1:]
+        mac += [kappa[j - 1 - i] for i in range(j)]
+    for r in range(T):
+        assert apow[B][r][0] == 0
+        mac += apow[B][r][1:]
+        mac += [beta[B - 1 - i][r] for i in range(B)]
+    assert len(mac) == sum(11 + j for j in range(1, B)) + T * (11 + B)
+    add = []
+    for blk in range(R_P // B):
+        q0 = blk * B
+        cs = [rc[HALF_F + q0 + i + 1] if HALF_F + q0 + i + 1 < 2 * HALF_F + R_P else [0] * T for i in range(B)]       # C_{q0+i+1}
+        for j in range(1, B):
+            add.append(sum(mat_vec(apow[j - 1 - i], cs[i])[0] for i in range(j)) % P)
+        gam = [0] * T
+        for i in range(B):
+            gam = [(x + y) % P for x, y in zip(gam, mat_vec(apow[B - 1 - i], cs[i]))]
+        add += gam
+    return dict(mac=mac, add=add, B=B)
+
+
+def k_split(x):
+    return [x & 0x3FFFFF, (x >> 22) & 0x3FFFFF, x >> 44]
+
+
+def k_triple(c):
+    return [c, (c << 22) % P, (c << 44) % P]
+
+
+def k_recombine(al, ah):
+    """al + ah 2^32 for al, ah < 2^61 -> some u64 congruent to it (psd_recombine)"""
+    assert al < (1 << 61) and ah < (1 << 61)
+    mid = (al >> 32) + (ah & 0xFFFFFFFF)
+    top = (ah >> 32) + (mid >> 32)
+    x = (al & 0xFFFFFFFF) | ((mid & 0xFFFFFFFF) << 32)
+    r = x + top * 0xFFFFFFFF
+    if r >> 64:
+        r = (r & ((1 << 64) - 1)) + 0xFFFFFFFF
+        assert r < (1 << 64)
+    return r
+
+
+def k_mul64(a, b):
+    """the kernels' product of two arbitrary u64: a u64 congruent to a b, not necessarily canonical (modelled as canonical + p when that fits)"""
+    r = a * b % P
+    return r + P if (a ^ b) & 1 and r + P < (1 << 64) else r
+
+
+def permute_kform(state, rc, kt, noncanonical=False):
+    """the device algorithm, limb for limb: dense full rounds, block-form partial rounds"""
+    m = mds_matrix()
+    mul = k_mul64 if noncanonical else (lambda a, b: a * b % P)
+
+    def sbox64(x):
+        x2 = mul(x, x); x4 = mul(x2, x2); x3 = mul(x, x2)
+        return mul(x3, x4)
+    s = [(x + c) % P for x, c in zip(state, rc[0])]
+    for r in range(HALF_F):
+        s = [(v + c) % P for v, c in zip(mat_vec(m, [sbox64(x) for x in s]), rc[r + 1])]
+    if noncanonical:
+        s = [v + P if v + P < (1 << 64) and v & 1 else v for v in s]
+    B = kt["B"]
+    for blk in range(R_P // B):
+        pos = 0
+        addc = kt["add"][blk * (B - 1 + T): (blk + 1) * (B - 1 + T)]
+        ul = [k_split(v) for v in s[1:]]
+        xl = []
+        y = s[0]
+        out = []
+        for j in range(B + T):
+            if j < B:
+                if j > 0:
+                    c = addc[j - 1]
+                else:
+                    xl.append(k_split(sbox64(y)))
+                    continue
+                terms = ul + xl[:j]
+            else:
+                c = addc[B - 1 + (j - B)]
+                terms = ul + xl
+            lo, hi = c & 0xFFFFFFFF, c >> 32
+            for lim in terms:
+                tr = k_triple(kt["mac"][pos]); pos += 1
+                for k in range(3):
+                    lo += lim[k] * (tr[k] & 0xFFFFFFFF)
+                    hi += lim[k] * (tr[k] >> 32)
+            v = k_recombine(lo, hi)
+            if j < B:
+                xl.append(k_split(sbox64(v)))
+            else:
+                out.append(v)
+        assert pos == len(kt["mac"])
+        s = out
+    s = [v % P for v in s]
+    for r in range(HALF_F + R_P, 2 * HALF_F + R_P):
+        nxt = rc[r + 1] if r + 1 < 2 * HALF_F + R_P else [0] * T
+        s = [(v + c) % P for v, c in zip(mat_vec(m, [sbox64(x) % P for x in s]), nxt)]
+    return s
+
+
+def emit_kform(kt):
+    hdr = ("// GENERATED by tools/gen_poseidon_tables.py -- do not edit.\n"
+           "// Block form of Poseidon-Goldilocks' 22 partial rounds (two blocks of %d): see the generator for the algebra.\n"
+           "// PSD_K_MAC[%d][3]: per multiply-accumulate, in consumption order, (c, 2^22 c, 2^44 c) mod p; per block 10 lane-0 inputs y_1..y_10\n"
+           "//   (11 state terms + j S-box terms each) then the 12 lanes of the outgoing state (11 + 11 terms each).\n"
+           "// PSD_K_ADD[2][22][2]: per block the additive constants of y_1..y_10 and of the 12 outgoing lanes, as (low 32 bits, high 32 bits).\n"
+           "#pragma once\n#include <stdint.h>\n#ifndef PSD_TABLE_QUAL\n#define PSD_TABLE_QUAL static const\n#endif\n") % (kt["B"], len(kt["mac"]))
+    q = "PSD_TABLE_QUAL"
+    macs = [v for c in kt["mac"] for v in k_triple(c)]
+    adds = [v for c in kt["add"] for v in (c & 0xFFFFFFFF, c >> 32)]
+    body = "#define PSD_K_BLOCK %d\n#define PSD_K_MACS %d\n" % (kt["B"], len(kt["mac"]))
+    body += c_array("PSD_K_MAC", macs, qual=q) + "\n" + c_array("PSD_K_ADD", adds, 4, qual=q) + "\n"
+    with open(os.path.join(ROOT, "stark-verifier_amd", "csrc", "poseidon_ktables.h"), "w") as f:
+        f.write(hdr + body)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check-reference", action="store_true")
@@ -210,8 +355,16 @@ def main():
         assert permute_naive(st, rc) == permute_fast(st, rc, tb), "fast != naive"
     kat0 = permute_naive([0] * 12, rc)
     assert kat0[0] == 0x3c18a9786cb0b359, hex(kat0[0])
+    kt = kform_tables(rc)
+    edge = [[0] * 12, [P - 1] * 12, [1] + [0] * 11, [(1 << 32) - 1] * 12, [P - (1 << 32)] * 12]
+    for st in edge + [[rnd.randrange(P) for _ in range(T)] for _ in range(24)]:
+        want = permute_naive(st, rc)
+        assert permute_kform(st, rc, kt) == want, "block form != naive"
+        assert permute_kform(st, rc, kt, noncanonical=True) == want, "block form != naive on non-canonical intermediates"
     emit(rc, tb)
-    print("tables written; fast == naive on 8 random states; permute(0)[0] = %016x" % kat0[0])
+    emit_kform(kt)
+    print("tables written; fast == naive on 8 random states, block form == naive on 29 states (limb model, accumulator bounds asserted); "
+          "permute(0)[0] = %016x" % kat0[0])
     if args.check_reference:
         ok = check_reference(tb)
         print("derived tables == reference literal tables:", ok)
