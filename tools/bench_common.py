@@ -1,0 +1,299 @@
+"""Shared pieces of bench.py and tools/bench_blocks.py: profile look-ups (the committed rocprofv3 --pmc passes), the VALU roofline's mix / peak,
+the shader-clock sampler, and the N > 1 exchange (open_comm).  Moved out of bench.py in round 5: no behaviour change."""
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+LOG_N, RATE_BITS, BATCH = 17, 3, 135
+LDE_PER_STEP = 8      # --workload lde: LDEs of BATCH columns per step
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def host_cores():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a 256-thread host with a 128-CPU
+    quota runs 256 OpenMP threads ten times slower than 128)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def latest_profile(suffix):
+    """profiles/rNN<suffix> of the latest round that has one (bench.py cannot collect PMC counters itself: they come from the
+    committed rocprofv3 --pmc passes)"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]" + suffix)))
+    return c[-1] if c else None
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (bench.py cannot collect PMC counters
+    itself); None when no pass covers the kernel."""
+    path = latest_profile("_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        return d["kernels"][kernel]["bytes_per_launch_corrected"], "profiles/%s: %s" % (os.path.basename(path), d["_source"])
+    except Exception:
+        return None, None
+
+
+N_SIMD = 1024                     # 256 CUs x 4 SIMDs
+VALU_CLASSES = ("full32", "half32", "mad64")
+
+
+def valu_probe(ctx):
+    """gl355_valu_probe (csrc/valu_probe.hip) on this device, in this run: per instruction class the chip-wide issue rate of a kernel that
+    only issues that class (G wave-instructions/s), the shader clock read inside that kernel, and the cost in shader cycles per wave
+    instruction per SIMD that follows from the two (no assumed frequency anywhere)."""
+    rates = (C.c_double * 3)()
+    mhz = (C.c_double * 3)()
+    ctx.check(ctx.lib.gl355_valu_probe(ctx.h, rates, mhz))
+    return {c: {"rate_ginst_s": round(rates[i], 1), "shader_mhz": round(mhz[i]),
+                "clk_per_wave_inst_per_simd": round(mhz[i] * 1e6 * N_SIMD / (rates[i] * 1e9), 3) if rates[i] > 0 else None}
+            for i, c in enumerate(VALU_CLASSES)}
+
+
+class ClockSampler:
+    """shader clock during the timed region: gl355_clock_probe (one sleeping wave for 2 ms) on a context of its own every ~100 ms"""
+
+    def __init__(self, gl, device, period=0.1):
+        import threading
+        self.ctx = gl.Context(device)
+        self.period = period
+        self.samples, self.stop = [], threading.Event()
+        self.thread = threading.Thread(target=self.run, daemon=True)
+
+    def run(self):
+        v = C.c_double(0)
+        while not self.stop.is_set():
+            if self.ctx.lib.gl355_clock_probe(self.ctx.h, 2000, C.byref(v)) == 0 and v.value > 0:
+                self.samples.append(v.value)
+            self.stop.wait(self.period)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop.set()
+        self.thread.join()
+        self.ctx.close()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        # a probe wave descheduled in mid-sleep (two processes on one device) reads a nonsense ratio: samples beyond 1.25x the
+        # median are dropped and counted
+        med = sorted(self.samples)[len(self.samples) // 2]
+        kept = [s for s in self.samples if s <= 1.25 * med]
+        return {"mean_mhz": round(sum(kept) / len(kept)), "min_mhz": round(min(kept)), "max_mhz": round(max(kept)),
+                "samples": len(kept), "dropped": len(self.samples) - len(kept)}
+
+
+def valu_mix(kernel=None):
+    """Instruction-class fractions of `kernel` (None: of the whole unit, every kernel weighted by its dynamic instruction count).
+    mad64 share: dynamic, SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU of the committed --pmc pass when it carries those counters; the rest
+    splits into full32 / half32 as the kernel's shipped ISA does (profiles/rNN_isa_mix.json, tools/isa_mix.py).  Without the INT64
+    counters everything comes from the static histogram.  -> (fractions, dynamic VALU instructions per launch or per unit, source)"""
+    try:
+        pmc = json.load(open(latest_profile("_pmc_traffic.json")))
+        isa = json.load(open(latest_profile("_isa_mix.json")))["kernels"]
+    except Exception:
+        return None, None, None
+    src = "profiles/%s + profiles/%s" % (os.path.basename(latest_profile("_pmc_traffic.json")), os.path.basename(latest_profile("_isa_mix.json")))
+
+    def static_f(name):
+        k = isa.get(name)
+        if k is None:      # template instances: name<...>
+            cands = [v for n, v in isa.items() if n.split("<")[0] == name]
+            if not cands:
+                return None
+            tot = sum(v["valu_static"] for v in cands)
+            return {c: sum(v[c] for v in cands) / tot for c in VALU_CLASSES}
+        return dict(k["f"])
+
+    def one(name, e):
+        f = static_f(name.split("<")[0]) or {"full32": 0.11, "half32": 0.36, "mad64": 0.53}
+        n = e.get("valu_insts_per_launch")
+        i64 = e.get("valu_int64_per_launch")
+        if n and i64 is not None:
+            rest = f["full32"] + f["half32"]
+            m = i64 / n
+            f = {"mad64": m, "full32": (1 - m) * f["full32"] / rest, "half32": (1 - m) * f["half32"] / rest}
+        return f, n
+    if kernel is not None:
+        e = pmc["kernels"].get(kernel)
+        if not e or not e.get("valu_insts_per_launch"):
+            return None, None, None
+        f, n = one(kernel, e)
+        return {c: round(f[c], 4) for c in VALU_CLASSES}, n, src
+    job = pmc.get("job")
+    if not job:
+        return None, None, None
+    tot, acc = 0.0, {c: 0.0 for c in VALU_CLASSES}
+    for name, e in pmc["kernels"].items():
+        if not e.get("valu_insts_per_launch") or name.startswith("vp_"):
+            continue
+        f, n = one(name, e)
+        w = n * e.get("sq_launches", e.get("launches", 0))
+        tot += w
+        for c in VALU_CLASSES:
+            acc[c] += w * f[c]
+    if tot <= 0:
+        return None, None, None
+    return {c: round(acc[c] / tot, 4) for c in VALU_CLASSES}, job["valu_insts_per_unit"], src
+
+
+NOMINAL_CLK = {"full32": 2.0, "half32": 4.0, "mad64": 4.0}
+
+
+def valu_peak(mix, clock_mhz):
+    """G wave-instructions/s the chip can issue at `clock_mhz` for instructions that split as `mix`: 1024 SIMDs x clock / the mix-weighted
+    issue cost.  No kernel can exceed it (every class priced at the hardware's issue rate), so achieved / peak <= 1 by construction."""
+    cost = sum(mix[c] * NOMINAL_CLK[c] for c in VALU_CLASSES)
+    return N_SIMD * clock_mhz * 1e6 / cost / 1e9
+
+
+def valu_peak_probe(mix, classes, clock_mhz=None):
+    """the same with the class rates the probe kernels reached in this run (moved to `clock_mhz` if given)"""
+    t = 0.0
+    for c in VALU_CLASSES:
+        r = classes[c]["rate_ginst_s"]
+        if clock_mhz and classes[c]["shader_mhz"]:
+            r = r * clock_mhz / classes[c]["shader_mhz"]
+        if r <= 0:
+            return None
+        t += mix[c] / r
+    return 1.0 / t if t > 0 else None
+
+
+class _TorchComm:
+    """stand-in with the Comm interface over torch.distributed -- used ONLY if some rank cannot bind librccl for the gl355
+    communicator (reported in the JSON line as config.exchange); the product's exchange is gl355_gather_digests"""
+
+    def __init__(self, dist, dev):
+        self.dist, self.dev, self.backend_name = dist, dev, "torch.distributed (gl355 RCCL communicator unavailable on some rank)"
+
+    def gather(self, local):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.uint64).view(np.int64)).to(self.dev)
+        parts = [torch.empty_like(t) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(parts, t)
+        return torch.cat(parts, dim=0).cpu().numpy().view(np.uint64)
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max(self, v):
+        import torch
+        t = torch.tensor([v], dtype=torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+def thread_cpu_snapshot():
+    """{tid: (comm, cpu seconds)} of the process's live threads (diagnostic: which threads burn host CPU; GL355_BENCH_THREAD_CPU=1)"""
+    out = {}
+    tck = os.sysconf("SC_CLK_TCK")
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            st = open("/proc/self/task/%s/stat" % tid).read()
+            comm = st[st.index("(") + 1:st.rindex(")")]
+            f = st[st.rindex(")") + 2:].split()
+            out[int(tid)] = (comm, (int(f[11]) + int(f[12])) / tck)
+        except Exception:
+            pass
+    return out
+
+
+_STORE_KEEPALIVE = []
+
+
+def open_comm(lib, par, ctx, rank, world, rehearsal, dev=None):
+    """The exchange of the N > 1 job through the C ABI (gl355_comm_*): RCCL over xGMI, or TCP between the host processes in the
+    one-device rehearsal.  The 128-byte communicator id travels through the launcher's key-value store (torchrun's TCPStore,
+    MASTER_ADDR / MASTER_PORT) -- plumbing a Rust host would do with its own launcher; no torch collective is involved."""
+    if world == 1:
+        return None
+    from datetime import timedelta
+    from torch.distributed import PrefixStore, TCPStore
+    addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"])
+    agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    store = TCPStore(addr, port, world, (rank == 0 and not agent_store), timedelta(seconds=300), multi_tenant=True)
+    # rank 0 may be the store's server (no agent store): the server must outlive every other rank's reads of the flags below, so the object is
+    # kept for the life of the process (all ranks pass a communicator barrier before they exit)
+    _STORE_KEEPALIVE.append(store)
+    store = PrefixStore("gl355_bench/%s" % os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), store)
+    backend = par.COMM_HOST if rehearsal else par.COMM_RCCL
+    # phase 1: can every rank bind its communicator library?  (a rank that cannot must not leave the others inside ncclCommInitRank)
+    ok, cid, why = True, b"", ""
+    try:
+        if backend == par.COMM_HOST:
+            import socket
+            if rank == 0:
+                s = socket.socket(); s.bind((addr if addr[0].isdigit() else "127.0.0.1", 0)); hp = s.getsockname()[1]; s.close()
+                cid = par.Comm.unique_id(lib, backend, addr if addr[0].isdigit() else "127.0.0.1", hp)
+        else:
+            cid = par.Comm.unique_id(lib, backend)          # every rank: proves librccl binds here; rank 0's id is the one used
+    except Exception as exc:
+        ok, why = False, repr(exc)
+    store.set("ok/%d" % rank, b"1" if ok else why.encode()[:200] or b"0")
+    if rank == 0 and ok:
+        store.set("id", cid)
+    flags = [bytes(store.get("ok/%d" % r)) for r in range(world)]
+    created_failed = False
+    if all(f == b"1" for f in flags):
+        # phase 2: the communicator itself (ncclCommInitRank is collective).  Every rank reports whether it came up; the job uses it only if
+        # all did -- a communicator that exists on some ranks only would hang the first gather
+        comm, err = None, ""
+        try:
+            if os.environ.get("GL355_BENCH_FORCE_COMM_FAIL") == "1":      # test hook for the fall-back below
+                raise RuntimeError("forced failure (GL355_BENCH_FORCE_COMM_FAIL)")
+            comm = par.Comm(ctx, backend, bytes(store.get("id")), rank, world, lib=lib)
+        except Exception as exc:
+            err = repr(exc)
+        store.set("up/%d" % rank, b"1" if comm is not None else (err.encode()[:200] or b"0"))
+        flags = [bytes(store.get("up/%d" % r)) for r in range(world)]
+        if all(f == b"1" for f in flags):
+            comm.backend_name = "gl355_gather_digests over RCCL (ncclAllGather)" if backend == par.COMM_RCCL else "gl355_gather_digests over TCP (one-device rehearsal)"
+            return comm
+        if comm is not None:
+            comm.close()
+        created_failed = True
+    why = [f for f in flags if f != b"1"][:1]
+    # --gpus N > 1 measures the RCCL exchange of SURVEY 8(e): when the RCCL communicator cannot be created on every rank the run FAILS
+    # (every rank sees the same flags, so every rank exits) instead of quietly measuring something else.  GL355_BENCH_ALLOW_STANDIN=1
+    # (never set by the driver) lets the 64-byte-per-unit exchange run over torch.distributed instead; the line then says so in
+    # config.exchange.  The one-device rehearsal never had RCCL to begin with.
+    if not rehearsal and os.environ.get("GL355_BENCH_ALLOW_STANDIN") != "1":
+        sys.stderr.write("[bench] rank %d: the RCCL communicator (gl355_comm_create) is unavailable: %s -- refusing to substitute another "
+                         "exchange (set GL355_BENCH_ALLOW_STANDIN=1 to allow the torch.distributed stand-in)\n" % (rank, why))
+        sys.stderr.flush()
+        os._exit(3)
+    sys.stderr.write("[bench] rank %d: gl355 communicator unavailable (%s); using torch.distributed for the exchange\n" % (rank, why))
+    import torch.distributed as dist
+    # the exchange is 64 bytes per unit: when the RCCL communicator could not be CREATED (rather than librccl not binding), RCCL itself is
+    # suspect, so the stand-in runs over gloo on host tensors
+    if rehearsal or created_failed:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        c = _TorchComm(dist, "cpu")
+        c.backend_name = "torch.distributed gloo on host tensors (gl355 communicator could not be created on some rank)" if created_failed else c.backend_name
+        return c
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    return _TorchComm(dist, dev)

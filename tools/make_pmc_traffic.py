@@ -47,7 +47,7 @@ for kern, v in fetch.items():
             e["valu_int32_per_launch"] = s["SQ_INSTS_VALU_INT32"][0]
     kernels[short(kern)] = e
 doc = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over `python bench.py --steps 1 --warmup 0 --proofs-per-step 16 "
-                  "--threads 1 --no-cpu-baseline` (one context, lock-step batches of 8 units; tools/prof_round2.sh, tools/make_pmc_traffic.py), per-dispatch averages in KB; FETCH_SIZE doubled "
+                  "--threads 1 --no-cpu-baseline` (one context, lock-step batches of 8 units; tools/prof_round5.sh, tools/make_pmc_traffic.py), per-dispatch averages in KB; FETCH_SIZE doubled "
                   "per the gfx950 note of MI355X_MICROARCH.md (HBM section); WRITE_SIZE taken as reported",
        "_valu_note": "SQ_INSTS_VALU (wave instructions, whole chip) / 1024 SIMDs vs SQ_BUSY_CYCLES / 32 shader engines, same rocprofv3 --pmc run: "
                      "cycles per VALU instruction per SIMD; the issue floor measured by tools/ubench is ~4.2-4.4",
