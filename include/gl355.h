@@ -609,6 +609,9 @@ int32_t gl355_kzg_open(gl355_ctx* ctx, const uint64_t* g, const uint64_t* coeffs
  *                            commitments, all as little-endian u64) read as a big-endian integer mod r -- the PINNED key, so circuits that
  *                            differ only in fixed values or copy constraints start different transcripts; a non-zero field is used as given;
  *                            _set_digest replaces it (a host that computed halo2's own transcript_repr)
+ *   gl355_plonk_pk_export_quotient   inspection hook: the NEXT gl355_plonk_prove on this key copies the quotient's coefficient pieces h_0 .. h_{P-1}
+ *                            (P = info[3]; canonical integers, [P][2^k][4] words, host memory) to host_out.  The prover builds them from degree - 1
+ *                            cosets of size 2^k instead of halo2's extended domain; the hook lets a test compare the two coefficient for coefficient.
  *   gl355_plonk_prove        one proof: advice [advice columns][2^k] scalars (rows >= usable are overwritten by blinding values), instances =
  *                            the instance columns' values back to back with instance_lens[column] values each, seed = 32 bytes that fix every
  *                            random scalar (ChaCha20 block (counter = index, nonce = (stream, a, index >> 32)) -> 512-bit little-endian integer
@@ -629,6 +632,7 @@ int32_t gl355_plonk_pk_info(const gl355_plonk_pk* pk, uint64_t info[8]);
 int32_t gl355_plonk_pk_commitments(const gl355_plonk_pk* pk, uint64_t* fixed_commitments, uint64_t* sigma_commitments);
 int32_t gl355_plonk_pk_digest(const gl355_plonk_pk* pk, uint64_t digest[4]);
 int32_t gl355_plonk_pk_set_digest(gl355_plonk_pk* pk, const uint64_t digest[4]);
+int32_t gl355_plonk_pk_export_quotient(gl355_plonk_pk* pk, uint64_t* host_out /* [quotient pieces][2^k][4], or NULL */);
 int32_t gl355_plonk_prove(gl355_ctx* ctx, gl355_plonk_pk* pk, const uint64_t* advice, const uint64_t* instances, const uint32_t* instance_lens, const uint8_t seed[32],
                           uint8_t* proof, uint64_t capacity, uint64_t* proof_len, uint64_t* trace, double* stage_ms);
 int32_t gl355_plonk_pk_destroy(gl355_plonk_pk* pk);

@@ -74,6 +74,7 @@ SIGNATURES = {
     "gl355_plonk_pk_commitments": (C.c_int32, [vp, vp, vp]),
     "gl355_plonk_pk_digest": (C.c_int32, [vp, vp]),
     "gl355_plonk_pk_set_digest": (C.c_int32, [vp, vp]),
+    "gl355_plonk_pk_export_quotient": (C.c_int32, [vp, vp]),
     "gl355_plonk_prove": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), vp, vp]),
     "gl355_plonk_pk_destroy": (C.c_int32, [vp]),
     "gl355_valu_probe": (C.c_int32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

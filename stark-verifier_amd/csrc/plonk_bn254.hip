@@ -69,6 +69,7 @@ struct gl355_plonk_pk {
     // k = 23 that is 8 x 28 x 256 MB = 57 GB of the 288 GB -- and 36 % of evaluate_h's transforms gone.  nullptr: recomputed per proof
     uint64_t* fixed_cos = nullptr;
     uint32_t n_fix_cos = 0;
+    uint64_t* export_quotient = nullptr;                                  // host buffer the next proof's quotient pieces are copied to (inspection hook)
     const uint64_t *g = nullptr, *g_lagrange = nullptr;                   // the caller's resident SRS (device) or owned copies
     uint32_t* d_gate_code = nullptr;
     std::vector<uint32_t*> d_lk_code;                                     // per lookup: input program, table program
@@ -663,6 +664,12 @@ int32_t gl355_plonk_pk_digest(const gl355_plonk_pk* pk, uint64_t digest[4]) {
     return GL355_OK;
 }
 
+int32_t gl355_plonk_pk_export_quotient(gl355_plonk_pk* pk, uint64_t* host_out) {
+    if (!pk) return GL355_E_INVALID_ARG;
+    pk->export_quotient = host_out;
+    return GL355_OK;
+}
+
 int32_t gl355_plonk_pk_set_digest(gl355_plonk_pk* pk, const uint64_t digest[4]) {
     if (!pk || !digest) return GL355_E_INVALID_ARG;
     pk->digest = Fr::from_words(digest);
@@ -992,6 +999,15 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
             std::vector<Fr> cs(P);
             for (uint32_t c = 0; c < P; c++) cs[c] = M[q][P + c];          // (V^-1)[q][c]
             GL355_TRY(lincomb(pk, rs, cs, {}, nullptr, h_coeffs + 4ull * q * n));
+        }
+        if (pk->export_quotient) {             // gl355_plonk_pk_export_quotient: the pieces as canonical integers, for a comparison with the extended-domain quotient
+            uint64_t* plain = nullptr;
+            GL355_TRY(D((size_t)P * n * 32, &plain));
+            hipLaunchKernelGGL(plk_from_mont_kernel, dim3(blocks((uint64_t)P * n)), dim3(256), 0, ctx->stream, (const uint64_t*)h_coeffs, plain, (uint64_t)P * n);
+            GL355_HIP(ctx, hipGetLastError());
+            GL355_HIP(ctx, ctx->d2h(pk->export_quotient, plain, (size_t)P * n * 32));
+            GL355_HIP(ctx, ctx->wait());
+            pk->export_quotient = nullptr;
         }
         std::vector<uint64_t> pts(8ull * pk->n_pieces);
         GL355_TRY(commit_columns(pk, pk->g, h_coeffs, pk->n_pieces, pts.data()));

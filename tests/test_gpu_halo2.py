@@ -42,7 +42,7 @@ def test_keccak256_entry(ctx):
         assert out.raw == hm.keccak256(m)
 
 
-@pytest.mark.parametrize("k,tb", [(7, 5), (8, 6), (9, 7), (10, 7)])
+@pytest.mark.parametrize("k,tb", [(7, 5), (8, 6), (9, 7), (10, 7), (12, 9), (13, 10)])
 def test_proof_bytes_equal_the_oracle(ctx, k, tb):
     cs, cfg, w, prover = build(ctx, k, tb)
     params = hm.Params(k, TAU)
@@ -247,3 +247,60 @@ def test_digest_binds_the_fixed_columns(ctx):
     assert p2.digest == 12345
     for p in (p0, p1, p2):
         p.close()
+
+
+def test_coset_quotient_equals_the_extended_domain_quotient(ctx):
+    """The one algorithmic departure from halo2: evaluate_h runs on degree - 1 cosets of size 2^k and recovers the pieces h_p by a
+    Vandermonde solve; halo2 (and oracle/halo2_model.py) divides on the extended domain of 2^extended_k points and splits the coefficient vector.
+    gl355_plonk_pk_export_quotient hands out the prover's pieces: they equal the oracle's coefficient for coefficient (k = 10, 5 pieces)."""
+    k, tb = 10, 7
+    cs, cfg, w, prover = build(ctx, k, tb)
+    params = hm.Params(k, TAU)
+    pk = hm.keygen(params, cs, w.fixed_ints(), w.assembly)
+    seed = bytes((11 * i + 5) & 0xFF for i in range(32))
+    tr = {}
+    want = hm.create_proof(params, pk, w.advice_ints(), w.instance, seed, prover.digest, tr)
+    P, n = prover.info["n_pieces"], 1 << k
+    assert P == cs.degree() - 1 == len(tr["h_pieces"]) and prover.info["extended_k"] > k
+    out = np.zeros((P, n, 4), dtype=np.uint64)
+    ctx.check(ctx.lib.gl355_plonk_pk_export_quotient(prover.h, out.ctypes.data))
+    got = prover.prove(w.advice, w.instance, seed)
+    assert got == want
+    for p in range(P):
+        mine = h2.from_limbs(out[p])
+        assert mine == [int(v) for v in tr["h_pieces"][p]], "quotient piece %d differs from the extended-domain quotient" % p
+    assert any(any(tr["h_pieces"][p]) for p in range(P))
+    # the hook is one-shot: the next proof leaves the buffer alone
+    out[:] = 0
+    prover.prove(w.advice, w.instance, seed)
+    assert not out.any()
+    prover.close()
+
+
+def test_reference_shape_k20_is_accepted_by_the_verifier_restatement(ctx):
+    """k = 20 on the reference's chip shape (16-bit range table, 64 chained BN254-Poseidon permutations), SRS and witness resident on the device:
+    three proofs under different blinding seeds pass tests/halo2_verifier.py (was tools/halo2_verify_many.py, outside pytest: VERDICT r4 #5)"""
+    import torch
+    k = 20
+    cs, cfg, w = ch.synthetic_circuit(k, table_bits=16, n_permutations=64, seed=0x355 + k)
+    n = 1 << k
+    g = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    gl_ = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    tau = h2.to_limbs([TAU])[0]
+    ctx.check(ctx.lib.gl355_kzg_setup(ctx.h, tau.ctypes.data, k, g.data_ptr(), gl_.data_ptr()))
+    prover = h2.PlonkProver(ctx, cs, k, g.data_ptr(), gl_.data_ptr(), w.fixed, w.assembly.mapping_array())
+    vk = dict(digest=prover.digest, fixed_commitments=[pt(c) for c in prover.fixed_commitments], sigma_commitments=[pt(c) for c in prover.sigma_commitments])
+    adv = torch.from_numpy(w.advice.view(np.int64)).cuda()
+    proofs = set()
+    for s in range(3):
+        proof = prover.prove(adv.data_ptr(), w.instance, bytes([17 * s + 3]) * 32)
+        assert hv.verify(k, cs, vk, w.instance, proof, TAU % h2.R)
+        proofs.add(proof)
+    assert len(proofs) == 3
+    bad = bytearray(proof)
+    bad[100] ^= 4
+    with pytest.raises(hv.VerifyError):
+        hv.verify(k, cs, vk, w.instance, bytes(bad), TAU % h2.R)
+    prover.close()
+    del adv, g, gl_
+    torch.cuda.empty_cache()
