@@ -86,7 +86,13 @@ __global__ void __launch_bounds__(256) bitrev_tiled_kernel(const uint64_t* in, u
                                                          uint64_t out_col_stride) {
     __shared__ uint64_t t0[32][33], t1[32][33];
     const uint32_t mid_bits = log_n - 10;
-    const uint32_t m = blockIdx.x, rm = brev(m, mid_bits);
+    // Block order (round 5): a tile's 32 rows are 2^(log_n - 5) words apart -- 1 MB at 2^22 points -- so a block touches 32 pages on the read side
+    // and 32 on the write side, and with m = blockIdx the write side of neighbouring blocks (rev m) is scattered over the whole column: 1.8 TB/s at
+    // 2^22, 1.7 at 2^23 against 2.5 at 2^21.  256 consecutive blocks now take every combination of the LOW four and the HIGH four bits of m: their
+    // reads (low bits vary) and their writes (rev of the high bits varies) both fall into 32 runs of 4 KB.
+    uint32_t m = blockIdx.x;
+    if (mid_bits >= 8) m = ((m >> 4 & 15u) << (mid_bits - 4)) | ((m >> 8) << 4) | (m & 15u);
+    const uint32_t rm = brev(m, mid_bits);
     const bool in_place = in == out;
     if (in_place && m > rm) return;
     const uint64_t col = blockIdx.y;
@@ -357,13 +363,34 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         static const bool no3 = getenv("GL355_EXP_NTT_NO_3PASS") != nullptr;
         const bool three = !no3 && !ntt_r16_only() && !inv && p.log_n >= 22 && p.n_cosets == 1 && !p.pre_lo && !p.post_lo && p.scale == 1 &&
                            p.out_col_stride == (1ull << p.log_n) && p.coset_slot[0] == 0;
-        if (three) { l2 = 17; l1 = p.log_n - l2; }
+        // Round 5: from 2^21 points on the same shape runs in TWO passes with 4096-point limb rows: the column pass over 2^(log_n - 12) = 2^9 .. 2^11
+        // points on 8192- / 16384-element tiles (16 columns per tile at 2^21 / 2^22, 8 at 2^23: launch_cols_r8_big) -- 32 bytes of HBM traffic per
+        // element instead of the 48 of three passes.  2^23 (2^11-point columns, 16384-element tiles with the CU to themselves) measured slower than
+        // three passes and stays there.  GL355_EXP_NTT_BIG_COLS=0: the forms above (A/B); =13 / 14: force the tile size (and allow 2^23).
+        static const int big_env = getenv("GL355_EXP_NTT_BIG_COLS") ? atoi(getenv("GL355_EXP_NTT_BIG_COLS")) : -1;
+        const bool big_shape = !ntt_r16_only() && !inv && p.log_n >= 21 && p.log_n <= (big_env > 0 ? 23u : 22u) && p.n_cosets == 1 && !p.pre_lo && !p.post_lo && p.scale == 1 &&
+                               p.out_col_stride == (1ull << p.log_n) && p.coset_slot[0] == 0 && ntt_l24_on() && ntt_l24_rows_on();
+        uint32_t big_lt = 0;
+        if (big_shape && big_env != 0) {
+            big_lt = p.log_n <= 22 ? 13 : 14;          // measured (profiles/r05_ntt_big_ab.txt): 2^22 on 8-column 8192-element tiles beats 16-column 16384-element ones
+            if ((big_env == 13 && p.log_n <= 22) || (big_env == 14 && p.log_n >= 22)) big_lt = (uint32_t)big_env;
+        }
+        static const int big_row_env = getenv("GL355_EXP_NTT_BIG_ROW") ? atoi(getenv("GL355_EXP_NTT_BIG_ROW")) : 0;       // experiments: row size 12 / 13 / 14
+        uint32_t big_row = 12;
+        if (big_lt && big_row_env >= 12 && big_row_env <= 14 && p.log_n - big_row_env >= 9) {
+            big_row = (uint32_t)big_row_env;
+            const uint32_t c = p.log_n - big_row;           // column points: 9 -> tile 13, 10 -> 13 or 14 as asked, 11 -> 14
+            big_lt = c == 9 ? 13 : (c == 11 ? 14 : big_lt);
+        }
+        const bool three_now = three && !big_lt;
+        if (big_lt) { l2 = big_row; l1 = p.log_n - big_row; }
+        else if (three) { l2 = 17; l1 = p.log_n - l2; }
         a.in = p.in; a.out = p.out;
         a.in_col_stride = p.in_col_stride; a.out_col_stride = p.out_col_stride;
         a.log_rows = l2;  // log2(N2): row stride of the N1 x N2 matrix
         a.pre_lo = p.pre_lo; a.pre_hi = p.pre_hi;
         a.step_lo = step_lo; a.step_hi = step_hi;
-        if (p.log_n <= 20 || three) {
+        if (p.log_n <= 20 || three_now || big_lt) {
             // full-size tables (<= 8 MiB each; the three-pass form: up to 128 MiB of 288 GiB): 1 load + 1 modmul per element instead
             // of 2 + 2 (beyond 2^20 measured a wash for the radix-16 kernels: 2^21 slower, 2^22 / 2^23 +2-3 %)
             if (p.pre_lo && ((uint64_t)p.n_cosets << p.log_n) <= (1ull << 21)) {
@@ -378,8 +405,12 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
             }
         }
         a.in_bitrev = 0; a.out_natural = 0; a.canon = 0;
-        { ProfScope ps(ctx, "ntt_cols_pass1", ((uint64_t)p.batch << p.log_n) * 8); GL355_HIP(ctx, launch_cols(a, l1, inv, ctx->stream)); }
-        if (three) {
+        {
+            ProfScope ps(ctx, "ntt_cols_pass1", ((uint64_t)p.batch << p.log_n) * 8);
+            if (big_lt) GL355_HIP(ctx, launch_cols_r8_big(a, l1, big_lt, ctx->stream));
+            else GL355_HIP(ctx, launch_cols(a, l1, inv, ctx->stream));
+        }
+        if (three_now) {
             NttPlan sub;
             sub.in = p.out; sub.out = p.out;
             sub.in_col_stride = sub.out_col_stride = 1ull << l2;

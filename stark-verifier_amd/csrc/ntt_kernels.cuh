@@ -256,6 +256,7 @@ struct PassArgs {
 // radix-8 commit-path kernels, compiled in ntt_r8.hip
 hipError_t launch_rows_r8(const PassArgs& a, uint32_t log_t, bool inv, hipStream_t s);
 hipError_t launch_cols_r8(const PassArgs& a, uint32_t log_t, bool inv, hipStream_t s);
+hipError_t launch_cols_r8_big(const PassArgs& a, uint32_t log_t, uint32_t lt, hipStream_t s);
 hipError_t launch_cols_r8_cosets(const PassArgs& a, uint32_t log_t, hipStream_t s);
 
 // Row pass: each row = 2^LOG_T contiguous elements; a tile packs 2^(LT-LOG_T) rows.
@@ -519,16 +520,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) n
 }
 
 // Column pass of the commit path (full step table, PRE = full pre table, nothing else) with radix-8 rounds: 8 elements per thread, 512 threads per tile.
-template <int LOG_T, bool PRE, int WPE, bool INV = false>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_cols_r8_kernel(PassArgs a) {
+// LT: log2 of the tile (12: 4096 elements on 512 threads; 13 / 14: 8192 / 16384 elements on 1024 threads, round 5 -- column passes over 2^9 .. 2^11
+// points with 16- / 8-column tiles, so that a 2^21 .. 2^23-point transform is TWO passes with 4096-point rows instead of three).  A tile of 8
+// columns moves 64-byte halves of 128-byte lines: with PAIR the tile holding the other halves runs on the same XCD right after it (blocks are
+// dealt to the XCDs round-robin: block 8 q + x takes tile 2 (8 (q >> 1) + x) + (q & 1), as in ntt_cols_r8_nat_kernel).
+template <int LOG_T, bool PRE, int WPE, bool INV = false, int LT = 12>
+__global__ void __launch_bounds__(LT == 12 ? 512 : 1024) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_cols_r8_kernel(PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
-    constexpr int LT = 12, NT = 512;
+    constexpr int NT = LT == 12 ? 512 : 1024, EPT = (1 << LT) / NT;
     constexpr int LOG_TC = LT - LOG_T, TC = 1 << LOG_TC;
+    static_assert(LOG_TC >= 0, "tile smaller than a column");
     const int tid = threadIdx.x;
     const uint32_t log_n2 = a.log_rows;
     const uint64_t n2 = 1ull << log_n2;
-    const uint32_t coset = blockIdx.x % a.n_cosets;
-    const uint64_t tile = blockIdx.x / a.n_cosets;
+    uint64_t bt = blockIdx.x;
+    if constexpr (LT > 12 && TC * 8 < 128) {
+        if ((gridDim.x & 15) == 0 && a.n_cosets == 1) { const uint64_t q = bt >> 3, xcd = bt & 7; bt = ((((q >> 1) << 3) + xcd) << 1) + (q & 1); }
+    }
+    const uint32_t coset = bt % a.n_cosets;
+    const uint64_t tile = bt / a.n_cosets;
     const uint64_t tiles_per_col = n2 >> LOG_TC;
     const uint64_t col = tile / tiles_per_col;
     const uint64_t c0 = (tile % tiles_per_col) << LOG_TC;
@@ -542,7 +552,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
         if constexpr (GL355_NTT_KO & 64) out[go + r * 16] = v;      // padded row stride (timing experiment: channel camping?)
         else out[go] = v;
     };
-    if constexpr (LOG_T >= 4 && GL355_NTT_R8_DIRECT != 0) {
+    if constexpr (LOG_T >= 4 && GL355_NTT_R8_DIRECT != 0 && EPT == 8) {
         uint64_t x[16];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -555,7 +565,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
         dif_last_round_sink<LT, R8Last<LOG_T>::RHO, INV>(lds, LOG_TC, tid, NT, store);
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < EPT; i++) {
             const uint32_t g = tid + i * NT;
             const uint32_t r = g >> LOG_TC, cc = g & (TC - 1);
             const uint64_t gi = ((uint64_t)r << log_n2) + c0 + cc;
@@ -566,7 +576,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
         __syncthreads();
         dif_tile_r8<LT, LOG_T, INV>(lds, a.tw_r8, LOG_TC, tid, NT);
 #pragma unroll
-        for (int i = 0; i < 8; i++) store(tid + i * NT, lds[lds_phys(tid + i * NT)]);
+        for (int i = 0; i < EPT; i++) store(tid + i * NT, lds[lds_phys(tid + i * NT)]);
     }
 }
 

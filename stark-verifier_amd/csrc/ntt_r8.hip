@@ -89,6 +89,42 @@ hipError_t launch_cols_r8(const PassArgs& a, uint32_t log_t, bool inv, hipStream
     return hipGetLastError();
 }
 
+// forward column passes over 2^9 .. 2^11 points on 8192- / 16384-element tiles (lt = 13, 14): the first pass of a 2^21 .. 2^23-point transform whose
+// second pass is 4096-point rows.  lt = 13: two 1024-thread blocks per CU at <= 64 VGPRs; lt = 14: the 136-KB tile has the CU to itself.
+template <int LOG_T, int LT>
+static hipError_t launch_cols8_big_t(const PassArgs& a, hipStream_t s) {
+    constexpr int WPE = LT == 13 ? 8 : 4;
+    const size_t shmem = ((1u << LT) + (1u << (LT - 4))) * sizeof(uint64_t);
+    const uint64_t blocks = ((1ull << a.log_rows) >> (LT - LOG_T)) * a.batch * a.n_cosets;
+    if (a.pre_full) {
+        auto k = ntt_cols_r8_kernel<LOG_T, true, WPE, false, LT>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(1024), shmem, s, a);
+    } else {
+        auto k = ntt_cols_r8_kernel<LOG_T, false, WPE, false, LT>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(1024), shmem, s, a);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_cols_r8_big(const PassArgs& a, uint32_t log_t, uint32_t lt, hipStream_t s) {
+    if (lt == 13) {
+        switch (log_t) {
+            case 9: return launch_cols8_big_t<9, 13>(a, s);
+            case 10: return launch_cols8_big_t<10, 13>(a, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (lt == 14) {
+        switch (log_t) {
+            case 10: return launch_cols8_big_t<10, 14>(a, s);
+            case 11: return launch_cols8_big_t<11, 14>(a, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
 // natural -> natural in two passes (ntt_kernels.cuh): pass 0 over a.log_n - a.log_rows... the caller sets a.log_rows = log2 of the row stride;
 // tiles of 4096 elements while 8 adjacent columns fit (log_t <= 9), 8192 elements for log_t = 10
 template <int LT, int LOG_T, int PASS>

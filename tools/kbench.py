@@ -136,6 +136,9 @@ def main():
         bench_lde(ctx, 14, 3, 135)
         bench_lde(ctx, 15, 3, 135)
         bench_lde(ctx, 12, 3, 135)
+    if what == "nttbig":    # cfg-2 (C): forward NTT, batch 16, 2^19 .. 2^23 points (bit-reversed output, the two-pass / three-pass boundary)
+        for ln in (19, 20, 21, 22, 23):
+            bench_ntt(ctx, ln, 16, reps=10)
     if what in ("ntt", "all"):
         for b in (1, 16, 135):
             bench_ntt(ctx, 20, b)
