@@ -81,10 +81,22 @@ struct gl355_plonk_pk {
 namespace {
 
 // ---- small helpers over the context ------------------------------------------------------------------------------------------------
+// GL355_PLONK_MEM_TRACE=1: at the end of every stage, the scratch allocator's live and cached bytes and the device's free memory (stderr)
+static void mem_trace(Ctx* ctx, const char* what) {
+    static const bool on = getenv("GL355_PLONK_MEM_TRACE") != nullptr;
+    if (!on) return;
+    size_t live = 0, cached = 0, fr = 0, tot = 0;
+    for (auto& b : ctx->blocks) (b.used ? live : cached) += b.size;
+    (void)hipMemGetInfo(&fr, &tot);
+    fprintf(stderr, "[plonk mem] %-18s scratch live %7.2f GB  cached %7.2f GB  device used %7.2f GB\n", what, live / 1e9, cached / 1e9, (tot - fr) / 1e9);
+}
 struct Timer {
-    Ctx* ctx; double* slot; std::chrono::steady_clock::time_point t0;
-    Timer(Ctx* c, double* s) : ctx(c), slot(s), t0(std::chrono::steady_clock::now()) {}
-    ~Timer() { if (slot) { (void)ctx->wait(); *slot += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } }
+    Ctx* ctx; double* slot; std::chrono::steady_clock::time_point t0; const char* name;
+    Timer(Ctx* c, double* s, const char* nm = "stage") : ctx(c), slot(s), t0(std::chrono::steady_clock::now()), name(nm) {}
+    ~Timer() {
+        if (slot) { (void)ctx->wait(); *slot += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+        mem_trace(ctx, name);
+    }
 };
 
 int32_t upload(Ctx* ctx, void* dst, const void* src, size_t bytes) {
@@ -729,7 +741,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     GL355_TRY(D(std::max<uint32_t>(1, pk->n_advice) * n * 32, &adv_vals));
     GL355_TRY(D(std::max<uint32_t>(1, pk->n_advice) * n * 32, &adv_polys));
     {
-        Timer t(ctx, slot(GL355_PLONK_STAGE_ADVICE));
+        Timer t(ctx, slot(GL355_PLONK_STAGE_ADVICE), "advice");
         if (pk->n_advice) {
             Staged sa(ctx);
             GL355_TRY(sa.open(advice, (size_t)pk->n_advice * n * 32, 1));
@@ -770,7 +782,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     std::vector<const uint64_t*> lk_a_ptr(L), lk_s_ptr(L);         // the compressed input / table columns (values)
     for (uint32_t l = 0; l < L; l++) { lk_a_ptr[l] = lkA + 4ull * l * n; lk_s_ptr[l] = lkS + 4ull * l * n; }
     {
-        Timer t(ctx, slot(GL355_PLONK_STAGE_LOOKUP_PERMUTE));
+        Timer t(ctx, slot(GL355_PLONK_STAGE_LOOKUP_PERMUTE), "lookup_permute");
         for (uint32_t l = 0; l < L; l++) {
             const auto qa = single_query(pk, pk->lookups[l].in_code), qs = single_query(pk, pk->lookups[l].tab_code);
             if (qa.first < 3) lk_a_ptr[l] = col_vals(qa.first, qa.second);
@@ -811,7 +823,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     const uint64_t** d_perm_vals = dp + 2 * n_all_cols;
     const uint64_t** d_perm_sig = d_perm_vals + pk->n_perm;
     {
-        Timer t(ctx, slot(GL355_PLONK_STAGE_PERMUTATION));
+        Timer t(ctx, slot(GL355_PLONK_STAGE_PERMUTATION), "permutation");
         std::vector<const uint64_t*> pv, psg;
         for (uint32_t j = 0; j < pk->n_perm; j++) { pv.push_back(col_vals(pk->perm_cols[j].first, pk->perm_cols[j].second)); psg.push_back(pk->sigma_vals + 4ull * j * n); }
         GL355_TRY(ptrs_to_device(ctx, pv, d_perm_vals));
@@ -836,7 +848,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     }
     // ---- lookup grand products --------------------------------------------------------------------------------------------------------
     {
-        Timer t(ctx, slot(GL355_PLONK_STAGE_LOOKUP_PRODUCT));
+        Timer t(ctx, slot(GL355_PLONK_STAGE_LOOKUP_PRODUCT), "lookup_product");
         for (uint32_t l = 0; l < L; l++) {
             const uint64_t* Ap = lkAp + 8ull * l * n;
             hipLaunchKernelGGL(plk_lookup_rows_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, lk_a_ptr[l], lk_s_ptr[l], Ap, Ap + 4 * n, n,
@@ -860,7 +872,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     uint64_t* random_poly = nullptr;
     GL355_TRY(D(n * 32, &random_poly));
     {
-        Timer t(ctx, slot(GL355_PLONK_STAGE_VANISHING_RANDOM));
+        Timer t(ctx, slot(GL355_PLONK_STAGE_VANISHING_RANDOM), "vanishing_random");
         GL355_TRY(random_rows(ctx, key, PLK_STREAM_RANDOM_POLY, 0, 0, n, random_poly));
         uint64_t pt[8];
         GL355_TRY(commit_columns(pk, pk->g, random_poly, 1, pt));
@@ -879,7 +891,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     GL355_TRY(D(n * 32, &pre));
     if (!pk->fixed_cos) GL355_TRY(D((size_t)pk->n_fix_cos * n * 32, &fix_tmp));
     {
-        Timer t(ctx, slot(GL355_PLONK_STAGE_EVALUATE_H));
+        Timer t(ctx, slot(GL355_PLONK_STAGE_EVALUATE_H), "evaluate_h");
         std::vector<const uint64_t*> src;
         for (uint32_t c = 0; c < pk->n_advice; c++) src.push_back(adv_polys + 4ull * c * n);
         for (uint32_t c = 0; c < pk->n_instance; c++) src.push_back(inst_polys + 4ull * c * n);
@@ -958,7 +970,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     // transforms and kernels gone, no transform over the extended domain at all, same bytes (the quotient is unique).
     uint64_t* h_coeffs = h_ext + 4ull * pk->n_pieces * n;
     {
-        Timer t(ctx, slot(GL355_PLONK_STAGE_QUOTIENT_COMMIT));
+        Timer t(ctx, slot(GL355_PLONK_STAGE_QUOTIENT_COMMIT), "quotient_commit");
         const uint32_t P = pk->n_pieces;
         const Fr ext_omega = Fr::root_of_unity(pk->ext_k), n_inv = Fr::from_u64(n).inv();
         std::vector<Fr> tc(P);
@@ -1032,7 +1044,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     GL355_TRY(D(n * 32, &h_poly));
     std::vector<Fr> evals;
     {
-        Timer t(ctx, slot(GL355_PLONK_STAGE_EVALUATIONS));
+        Timer t(ctx, slot(GL355_PLONK_STAGE_EVALUATIONS), "evaluations");
         // h(X) = sum_i x^(n i) h_i(X)
         {
             std::vector<const uint64_t*> ps;
@@ -1076,7 +1088,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
 
     // ---- SHPLONK -------------------------------------------------------------------------------------------------------------------------------
     {
-        Timer t(ctx, slot(GL355_PLONK_STAGE_SHPLONK));
+        Timer t(ctx, slot(GL355_PLONK_STAGE_SHPLONK), "shplonk");
         // the opening queries in create_proof's order
         struct OQ { uint32_t id; const uint64_t* poly; Fr point; };
         std::vector<OQ> oq;
