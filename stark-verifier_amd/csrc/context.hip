@@ -161,6 +161,12 @@ int32_t Ctx::runtime_buffers(size_t bytes, size_t aux_bytes, uint64_t* rows[2], 
     *copy_stream = rt_copy_stream;
     return GL355_OK;
 }
+void Ctx::trim() {
+    (void)wait_impl();
+    for (auto it = blocks.begin(); it != blocks.end();) {
+        if (!it->used) { (void)hipFree(it->p); it = blocks.erase(it); } else ++it;
+    }
+}
 void Ctx::release_all() {
     for (auto& b : blocks) (void)hipFree(b.p);
     blocks.clear();

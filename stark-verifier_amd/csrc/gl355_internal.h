@@ -115,6 +115,7 @@ struct Ctx {
     int32_t runtime_buffers(size_t bytes, size_t aux_bytes, uint64_t* rows[2], uint64_t* drows[2], void* aux[2], hipStream_t* copy_stream);
     void runtime_buffers_free();
     void release_all();
+    void trim();                // hipFree every cached block that is not in use (after a one-off phase with large temporaries, e.g. a keygen)
     // lo[c*4096 + j] = bases[c]^j, hi[c*4096 + j] = bases[c]^(4096 j)
     int32_t pow_tables_multi(const std::vector<uint64_t>& bases, const uint64_t** lo, const uint64_t** hi);
     int32_t pow_tables(uint64_t base, const uint64_t** lo, const uint64_t** hi) {

@@ -157,8 +157,11 @@ int32_t commit_columns(gl355_plonk_pk* pk, const uint64_t* bases, const uint64_t
         cls[s] = (std::max(1u, bits) + 19) / 20;                 // classes of 20 bits (the MSM's windows are 17 .. 20 bits wide)
     }
     for (uint32_t s0 = 0; s0 < sets;) {
+        // ... and <= 72 windows per call: the sort's scratch is ~230 MB per window at k = 23 (nine full-size columns in one call held 29 GB of the
+        // context's cache for the rest of the proof; five + four cost the same time)
+        const uint32_t max_m = std::max(1u, 72u / (cls[s0] + 1));
         uint32_t m = 1;
-        while (s0 + m < sets && m < per && cls[s0 + m] == cls[s0]) m++;
+        while (s0 + m < sets && m < per && m < max_m && cls[s0 + m] == cls[s0]) m++;
         GL355_TRY(bn254_msm_bits(pk->handle, bases, d_plain + 4ull * s0 * n, n, m, std::min(256u, 20 * cls[s0]), out_host + 8ull * s0));
         s0 += m;
     }
@@ -647,6 +650,10 @@ int32_t gl355_plonk_keygen(gl355_ctx* h, const uint64_t* desc, uint64_t words, c
             GL355_HIP(ctx, ctx->wait());
         }
     }
+    // keygen's temporaries (staged fixed values and mapping, the MSM scratch of 25 commitments, transform scratch: 66 GB at k = 23) are of no use
+    // to a proof: back to the device, not into the context's cache
+    work.reset();
+    ctx->trim();
     *out = pk.release();
     return GL355_OK;
 }
@@ -707,6 +714,14 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     std::vector<void*> mine;                                  // this proof's device buffers
     struct Freer { Ctx* c; std::vector<void*>* v; ~Freer() { (void)c->wait(); for (void* p : *v) c->release(p); } } freer{ctx, &mine};
     auto D = [&](size_t bytes, uint64_t** ptr) -> int32_t { void* p = nullptr; GL355_TRY(ctx->alloc(std::max<size_t>(bytes, 32), &p)); mine.push_back(p); *ptr = (uint64_t*)p; return GL355_OK; };
+    // a proof buffer that no later stage reads goes back to the context's allocator at once (everything runs on the context's stream, so a later
+    // owner of the block is ordered behind its last reader); what is still held at the end is released by `freer`
+    auto Free = [&](uint64_t*& ptr) {
+        if (!ptr) return;
+        for (auto it = mine.begin(); it != mine.end(); ++it) if (*it == (void*)ptr) { mine.erase(it); break; }
+        ctx->release(ptr);
+        ptr = nullptr;
+    };
     uint64_t* work = nullptr;
     GL355_TRY(D(n * 32, &work));                              // FFT scratch of the natural-order transforms
     const Fr omega = Fr::root_of_unity(pk->k), omega_inv = omega.inv();
@@ -774,21 +789,33 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     const Fr theta = tr.squeeze_challenge();
     const uint32_t L = pk->n_lookups;
     uint64_t *lkA = nullptr, *lkS = nullptr, *lkAp = nullptr, *lkZ = nullptr, *lk_polys = nullptr /* [L][3]: A', S', z */;
-    GL355_TRY(D((size_t)std::max(1u, L) * n * 32, &lkA));
-    GL355_TRY(D((size_t)std::max(1u, L) * n * 32, &lkS));
+    // compressed input / table columns only for the lookups whose expressions are not a single column query (none of the reference's nine)
+    uint32_t n_lk_a = 0, n_lk_s = 0;
+    for (uint32_t l = 0; l < L; l++) {
+        if (single_query(pk, pk->lookups[l].in_code).first >= 3) n_lk_a++;
+        if (single_query(pk, pk->lookups[l].tab_code).first >= 3) n_lk_s++;
+    }
+    GL355_TRY(D((size_t)std::max(1u, n_lk_a) * n * 32, &lkA));
+    GL355_TRY(D((size_t)std::max(1u, n_lk_s) * n * 32, &lkS));
     GL355_TRY(D((size_t)std::max(1u, 2 * L) * n * 32, &lkAp));          // A'_0 S'_0 A'_1 S'_1 ... : one batched commitment
     GL355_TRY(D((size_t)std::max(1u, L) * n * 32, &lkZ));
     GL355_TRY(D((size_t)std::max(1u, 3 * L) * n * 32, &lk_polys));
     std::vector<const uint64_t*> lk_a_ptr(L), lk_s_ptr(L);         // the compressed input / table columns (values)
-    for (uint32_t l = 0; l < L; l++) { lk_a_ptr[l] = lkA + 4ull * l * n; lk_s_ptr[l] = lkS + 4ull * l * n; }
+    {
+        uint32_t ia = 0, is = 0;
+        for (uint32_t l = 0; l < L; l++) {
+            lk_a_ptr[l] = single_query(pk, pk->lookups[l].in_code).first >= 3 ? lkA + 4ull * (ia++) * n : nullptr;
+            lk_s_ptr[l] = single_query(pk, pk->lookups[l].tab_code).first >= 3 ? lkS + 4ull * (is++) * n : nullptr;
+        }
+    }
     {
         Timer t(ctx, slot(GL355_PLONK_STAGE_LOOKUP_PERMUTE), "lookup_permute");
         for (uint32_t l = 0; l < L; l++) {
             const auto qa = single_query(pk, pk->lookups[l].in_code), qs = single_query(pk, pk->lookups[l].tab_code);
             if (qa.first < 3) lk_a_ptr[l] = col_vals(qa.first, qa.second);
-            else GL355_TRY(run_program(pk, pk->d_lk_code[2 * l], (uint32_t)(pk->lookups[l].in_code.size() / 4), d_val_cols, theta, nullptr, lkA + 4ull * l * n, false));
+            else GL355_TRY(run_program(pk, pk->d_lk_code[2 * l], (uint32_t)(pk->lookups[l].in_code.size() / 4), d_val_cols, theta, nullptr, const_cast<uint64_t*>(lk_a_ptr[l]), false));
             if (qs.first < 3) lk_s_ptr[l] = col_vals(qs.first, qs.second);
-            else GL355_TRY(run_program(pk, pk->d_lk_code[2 * l + 1], (uint32_t)(pk->lookups[l].tab_code.size() / 4), d_val_cols, theta, nullptr, lkS + 4ull * l * n, false));
+            else GL355_TRY(run_program(pk, pk->d_lk_code[2 * l + 1], (uint32_t)(pk->lookups[l].tab_code.size() / 4), d_val_cols, theta, nullptr, const_cast<uint64_t*>(lk_s_ptr[l]), false));
             uint64_t* Ap = lkAp + 8ull * l * n;
             uint64_t* Sp = Ap + 4 * n;
             GL355_TRY(permute_pair(ctx, lk_a_ptr[l], lk_s_ptr[l], u, Ap, Sp));
@@ -868,6 +895,8 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
         GL355_HIP(ctx, ctx->wait());
         if (bad) return ctx->fail(GL355_E_INVALID_ARG, "plonk_prove: a grand-product denominator is zero under these challenges (retry with another transcript input)");
     }
+    // the value forms have done their work (commitments, grand products): from here on only coefficient forms are read
+    Free(adv_vals); Free(lkA); Free(lkS); Free(lkAp); Free(lkZ); Free(perm_z); Free(num); Free(den); Free(ratio);
     // ---- vanishing argument: the random polynomial -----------------------------------------------------------------------------------------
     uint64_t* random_poly = nullptr;
     GL355_TRY(D(n * 32, &random_poly));
@@ -883,7 +912,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     const Fr y = tr.squeeze_challenge();
     uint64_t *h_ext = nullptr, *acc = nullptr, *cos = nullptr, *a_in = nullptr, *s_in = nullptr, *pre = nullptr, *fix_tmp = nullptr;
     const uint32_t n_dyn = pk->n_advice + pk->n_instance + pk->n_sets + 3 * L;           // per-proof polynomials: advice | instance | perm z | lookups (A' S' z)
-    GL355_TRY(D((size_t)2 * pk->n_pieces * n * 32, &h_ext));          // [n_pieces] the quotient restricted to each coset, then [n_pieces] its pieces
+    GL355_TRY(D((size_t)pk->n_pieces * n * 32, &h_ext));              // [n_pieces] the quotient restricted to each coset
     GL355_TRY(D(n * 32, &acc));
     GL355_TRY(D((size_t)std::max(1u, n_dyn) * n * 32, &cos));
     GL355_TRY(D(n * 32, &a_in));
@@ -968,7 +997,9 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     // per coset gives R_c, and the pieces are h_p = sum_c (V^-1)[p][c] R_c with the Vandermonde matrix V[c][p] = t_c^p -- a host-side inversion
     // of a (degree - 1)^2 matrix and one linear combination per piece.  5 of 8 cosets at the reference's degree 6: 3/8 of evaluate_h's
     // transforms and kernels gone, no transform over the extended domain at all, same bytes (the quotient is unique).
-    uint64_t* h_coeffs = h_ext + 4ull * pk->n_pieces * n;
+    Free(cos); Free(acc); Free(a_in); Free(s_in); Free(fix_tmp);
+    uint64_t* h_coeffs = nullptr;                                      // [n_pieces] the quotient's pieces
+    GL355_TRY(D((size_t)pk->n_pieces * n * 32, &h_coeffs));
     {
         Timer t(ctx, slot(GL355_PLONK_STAGE_QUOTIENT_COMMIT), "quotient_commit");
         const uint32_t P = pk->n_pieces;
