@@ -174,18 +174,23 @@ def lde_pmc():
         return None, None, None
 
 
+PSD_VALU_PER_PERM, PSD_MAD_PER_PERM = 15700, 9952
+
+
 def merkle_figures(gl, device):
     """BASELINE configs[2] / SURVEY cfg-3: MerkleTree::new over 2^22 leaves -- (L = 4, cap 4) the FRI-layer shape, (L = 135, cap 4)
     the wires-like shape (4.5 GB of leaves) -- and the Semaphore group tree (2^20 leaves, L = 4, cap 0, signal.rs:40); row-major leaves
-    resident in HBM, gl355_merkle_build, HIP-event time per build.  The kernels are integer-VALU work (a permutation is 17.6 k VALU
-    instructions): `valu_frac` prices the build's permutations at that count against the chip's issue rate."""
+    resident in HBM, gl355_merkle_build, HIP-event time per build.  The kernels are integer-VALU work (a permutation is 15.7 k VALU
+    instructions, 9 952 of them v_mad_u64_u32, DESIGN 4.2): `valu` prices the build's permutations at that count against the chip's issue rate;
+    `valu.multiply_adds_only` prices just the multiply-adds the formulation needs (the distance to a kernel that issued nothing else)."""
     import torch
     ctx = gl.Context(device)
     lib = ctx.lib
     g = torch.Generator(device="cuda")
     g.manual_seed(0x356)
     out = {"what": "gl355_merkle_build (leaf sponge + compression levels + cap, plonky2 digest layout), leaves resident, HIP events"}
-    # the VALU roofline of these builds: 17 600 instructions per permutation and lane against the issue rate for hash_leaves_kernel's
+    # the VALU roofline of these builds: PSD_VALU_PER_PERM instructions per permutation and lane (static count of the shipped ISA: 8 full rounds x 1 068 +
+    # 2 blocks x 3 520 + the first constant layer; profiles/r05_poseidon_block_vs_dense.txt) against the issue rate for hash_leaves_kernel's
     # instruction mix (valu_peak) at the shader clock sampled while the builds run
     mix, _, mix_src = valu_mix("hash_leaves_kernel")
     for log_n, L, cap in ((22, 4, 4), (22, 135, 4), (20, 4, 0)):
@@ -214,11 +219,15 @@ def merkle_figures(gl, device):
                          "algorithmic_bytes": int(alg)},
             "valu": None}
         if mix and clk:
-            ach_v = perms * 17600 / 64.0 / (ms * 1e-3) / 1e9
+            ach_v = perms * PSD_VALU_PER_PERM / 64.0 / (ms * 1e-3) / 1e9
+            ach_m = perms * PSD_MAD_PER_PERM / 64.0 / (ms * 1e-3) / 1e9
+            peak_m = N_SIMD * clk["mean_mhz"] * 1e6 / NOMINAL_CLK["mad64"] / 1e9
             peak_v = valu_peak(mix, clk["mean_mhz"])
             out["N=2^%d L=%d cap=%d" % (log_n, L, cap)]["valu"] = {
                 "bound": "valu", "achieved": round(ach_v, 1), "peak": round(peak_v, 1), "unit": "G wave-instructions/s", "frac": round(ach_v / peak_v, 4),
-                "clock_mhz": clk["mean_mhz"], "mix": mix, "formula": "permutations x 17 600 / 64 / time against 1024 SIMDs x clock / sum_c mix[c] x nominal_clk[c]"}
+                "clock_mhz": clk["mean_mhz"], "mix": mix, "formula": "permutations x %d / 64 / time against 1024 SIMDs x clock / sum_c mix[c] x nominal_clk[c]" % PSD_VALU_PER_PERM,
+                "multiply_adds_only": {"achieved": round(ach_m, 1), "peak": round(peak_m, 1), "unit": "G v_mad_u64_u32/s (wave level)", "frac": round(ach_m / peak_m, 4),
+                                       "formula": "permutations x %d / 64 / time against 1024 SIMDs x clock / 4 clk" % PSD_MAD_PER_PERM}}
         del leaves, dig, capb
         torch.cuda.empty_cache()
     ctx.close()
