@@ -154,6 +154,18 @@ def test_poseidon_permute(ctx, orc):
     eq(ctx.poseidon_permute(st), orc.permute(st))
 
 
+def test_poseidon_permute_many_states(ctx, orc):
+    """65 536 states over the whole u64 range (non-canonical representatives included) and sparse / high-bit patterns through the block-form
+    partial rounds (poseidon.cuh, round 5): every lane of many waves, both blocks, against the oracle's naive permutation"""
+    rng = np.random.default_rng(0x3A6)
+    st = rng.integers(0, 1 << 64, (1 << 16, 12), dtype=np.uint64)
+    st[:4096] &= np.uint64(0xFFFFFFFF00000000)                     # empty low halves
+    st[4096:8192] |= np.uint64(0x00000000FFFFFFFF)                 # saturated low halves
+    st[8192:12288, 1:] = 0                                         # only lane 0 populated
+    st[12288:16384, 0] = 0                                         # lane 0 empty
+    eq(ctx.poseidon_permute(st), orc.permute(st))
+
+
 @pytest.mark.parametrize("length", [0, 1, 3, 4, 5, 8, 9, 16, 17, 85, 135, 139])
 def test_hash_no_pad_and_leaves(ctx, orc, length):
     rng = np.random.default_rng(0x3B5 + length)
