@@ -168,6 +168,87 @@ GL_HD uint64_t gl_mul(uint64_t a, uint64_t b) {
 
 GL_HD uint64_t gl_sqr(uint64_t a) { return gl_mul(a, a); }
 
+// N independent products in lock-step, stage by stage (round 5).  The five carry steps of a product each need two wait states between the VALU
+// instruction that writes the carry (an SGPR pair) and the one that reads it; inside ONE product nothing else can go there (s_nop: 1.7 % of a
+// full-occupancy hash kernel, 18 % of one at one wave per SIMD, profiles/r05_poseidon_block_vs_dense.txt).  With N products issued round-robin the
+// partners' instructions ARE the wait states: every stage is its own asm statement (so the compiler still names the 32-bit halves of the 64-bit
+// intermediates for free), pinned in this order by scheduling barriers; N = 2 needs one extra wait state in front of the first product's readers
+// (its writer is one instruction back; the second product then has the first one's nop + instruction behind its writer), N >= 3 none.  Anything
+// the compiler adds between two statements only adds wait states.  Each product keeps its carry in its own SGPR pair.
+#if defined(__HIP_DEVICE_COMPILE__) && GL_MUL_VARIANT == 1
+template <int N>
+GL_DEV void gl_mul_multi(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
+    static_assert(N >= 1 && N <= 4, "1 .. 4 products");
+#define GL_MM_SB() __builtin_amdgcn_sched_barrier(0)
+    // the nop in front of a carry READER of product j
+#define GL_MM_NOP(j) (N == 1 ? "s_nop 1\n\t" : (N == 2 && (j) == 0 ? "s_nop 0\n\t" : ""))
+    uint32_t a0[N], a1[N], b0[N], b1[N], ch[N], x0[N], x1[N], m[N];
+    uint64_t t[N], u[N], v[N], w[N], c[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) { a0[j] = (uint32_t)a[j]; a1[j] = (uint32_t)(a[j] >> 32); b0[j] = (uint32_t)b[j]; b1[j] = (uint32_t)(b[j] >> 32); }
+#pragma unroll
+    for (int j = 0; j < N; j++) { t[j] = (uint64_t)a0[j] * b0[j]; u[j] = (uint64_t)a0[j] * b1[j] + (t[j] >> 32); }
+    GL_MM_SB();
+#pragma unroll
+    for (int j = 0; j < N; j++) { asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(v[j]), "=s"(c[j]) : "v"(a1[j]), "v"(b0[j]), "v"(u[j])); GL_MM_SB(); }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (N == 1) asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(ch[j]) : "s"(c[j]));
+        else if (N == 2 && j == 0) asm("s_nop 0\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(ch[j]) : "s"(c[j]));
+        else asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(ch[j]) : "s"(c[j]));
+        GL_MM_SB();
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) w[j] = (uint64_t)a1[j] * b1[j] + (((uint64_t)ch[j] << 32) | (v[j] >> 32));
+    GL_MM_SB();
+    // x = (t_lo, v_lo) - w_hi, a borrow repaid with -EPS
+#pragma unroll
+    for (int j = 0; j < N; j++) { asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(x0[j]), "=s"(c[j]) : "v"((uint32_t)t[j]), "v"((uint32_t)(w[j] >> 32))); GL_MM_SB(); }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (N == 1) asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, 0, %1" : "=v"(x1[j]), "+s"(c[j]) : "v"((uint32_t)v[j]));
+        else if (N == 2 && j == 0) asm("s_nop 0\n\tv_subb_co_u32_e64 %0, %1, %2, 0, %1" : "=v"(x1[j]), "+s"(c[j]) : "v"((uint32_t)v[j]));
+        else asm("v_subb_co_u32_e64 %0, %1, %2, 0, %1" : "=v"(x1[j]), "+s"(c[j]) : "v"((uint32_t)v[j]));
+        GL_MM_SB();
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (N == 1) asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m[j]) : "s"(c[j]));
+        else if (N == 2 && j == 0) asm("s_nop 0\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m[j]) : "s"(c[j]));
+        else asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m[j]) : "s"(c[j]));
+        GL_MM_SB();
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) { asm("v_sub_co_u32_e64 %0, %1, %0, %2" : "+v"(x0[j]), "=s"(c[j]) : "v"(m[j])); GL_MM_SB(); }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (N == 1) asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %0, 0, %1" : "+v"(x1[j]), "+s"(c[j]));
+        else if (N == 2 && j == 0) asm("s_nop 0\n\tv_subb_co_u32_e64 %0, %1, %0, 0, %1" : "+v"(x1[j]), "+s"(c[j]));
+        else asm("v_subb_co_u32_e64 %0, %1, %0, 0, %1" : "+v"(x1[j]), "+s"(c[j]));
+        GL_MM_SB();
+    }
+    // + w_lo * EPS, the carry-out repaid with +EPS
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const uint64_t x = ((uint64_t)x1[j] << 32) | x0[j];
+        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r[j]), "=s"(c[j]) : "v"((uint32_t)w[j]), "v"(x));
+        GL_MM_SB();
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (N == 1) asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m[j]) : "s"(c[j]));
+        else if (N == 2 && j == 0) asm("s_nop 0\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m[j]) : "s"(c[j]));
+        else asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m[j]) : "s"(c[j]));
+        GL_MM_SB();
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) r[j] += (uint64_t)m[j];
+#undef GL_MM_NOP
+#undef GL_MM_SB
+}
+#endif
+
+
 // a * c for a small constant c < 2^32 (MDS entries, W = 7, ...): two mads instead of four
 GL_HD uint64_t gl_mul_small(uint64_t a, uint32_t c) {
     uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);

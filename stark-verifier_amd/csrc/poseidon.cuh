@@ -14,9 +14,33 @@
 
 namespace gl355 {
 
+// x^7 = (x x^2)(x^2 x^2).  PSD_SBOX_INTERLEAVE 1 (default, round 5): x^3 and x^4 of one S-box, and everything of the two S-boxes of psd_sbox2, go
+// through gl_mul_multi, whose products fill each other's carry wait states; 0: one product after the other (A/B).
+#ifndef PSD_SBOX_INTERLEAVE
+#define PSD_SBOX_INTERLEAVE 1
+#endif
 GL_DEV uint64_t psd_sbox(uint64_t x) {
+#if PSD_SBOX_INTERLEAVE && defined(__HIP_DEVICE_COMPILE__) && GL_MUL_VARIANT == 1
+    const uint64_t x2 = gl_sqr(x);
+    const uint64_t a[2] = {x, x2}, b[2] = {x2, x2};
+    uint64_t r[2];
+    gl_mul_multi<2>(a, b, r);
+    return gl_mul(r[0], r[1]);
+#else
     uint64_t x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x, x2);
     return gl_mul(x3, x4);
+#endif
+}
+GL_DEV void psd_sbox2(uint64_t& x, uint64_t& y) {
+#if PSD_SBOX_INTERLEAVE && defined(__HIP_DEVICE_COMPILE__) && GL_MUL_VARIANT == 1
+    uint64_t sq[2];
+    { const uint64_t a[2] = {x, y}; gl_mul_multi<2>(a, a, sq); }
+    uint64_t r[4];
+    { const uint64_t a[4] = {x, sq[0], y, sq[1]}, b[4] = {sq[0], sq[0], sq[1], sq[1]}; gl_mul_multi<4>(a, b, r); }
+    { const uint64_t a[2] = {r[0], r[2]}, b[2] = {r[1], r[3]}; uint64_t o[2]; gl_mul_multi<2>(a, b, o); x = o[0]; y = o[1]; }
+#else
+    x = psd_sbox(x); y = psd_sbox(y);
+#endif
 }
 
 // al + ah * 2^32 for al, ah < 2^44 (the two accumulators of an MDS row)  ->  u64 representative.
@@ -36,6 +60,42 @@ GL_DEV uint64_t psd_recombine(uint64_t al, uint64_t ah) {
     uint64_t r1 = r0 + t;
     if (r1 < t) r1 += GL_EPS;
     return r1;
+#endif
+}
+
+// N recombinations in lock-step (the two carry steps of one fill the wait states of the others: see gl_mul_multi)
+template <int N>
+GL_DEV void psd_recombine_multi(const uint64_t (&al)[N], const uint64_t (&ah)[N], uint64_t (&out)[N]) {
+#if GL_MUL_VARIANT == 1 && defined(__HIP_DEVICE_COMPILE__)
+    static_assert(N >= 3, "three or more: no wait states of their own");
+    uint32_t t1[N], top[N], m[N];
+    uint64_t c[N], r[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(t1[j]), "=s"(c[j]) : "v"((uint32_t)(al[j] >> 32)), "v"((uint32_t)ah[j]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        asm("v_addc_co_u32_e64 %0, %1, 0, %2, %1" : "=v"(top[j]), "+s"(c[j]) : "v"((uint32_t)(ah[j] >> 32)));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const uint64_t x = ((uint64_t)t1[j] << 32) | (uint32_t)al[j];
+        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r[j]), "=s"(c[j]) : "v"(top[j]), "v"(x));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m[j]) : "s"(c[j]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) out[j] = r[j] + (uint64_t)m[j];
+#else
+#pragma unroll
+    for (int j = 0; j < N; j++) out[j] = psd_recombine(al[j], ah[j]);
 #endif
 }
 
@@ -68,9 +128,23 @@ GL_DEV uint64_t psd_mds_chain(const uint32_t (&x)[12], uint64_t addend) {
 template <int R>
 GL_DEV void psd_mds_rows(uint64_t (&s)[12], const uint32_t (&lo)[12], const uint32_t (&hi)[12], const uint64_t* rc) {
     if constexpr (R < 12) {
+#if PSD_SBOX_INTERLEAVE
+        // four rows at a time: eight chains, then their recombinations in lock-step
+        const uint64_t c0 = rc[R], c1 = rc[R + 1], c2 = rc[R + 2], c3 = rc[R + 3];
+        const uint64_t al[4] = {psd_mds_chain<R>(lo, (uint32_t)c0), psd_mds_chain<R + 1>(lo, (uint32_t)c1), psd_mds_chain<R + 2>(lo, (uint32_t)c2),
+                                psd_mds_chain<R + 3>(lo, (uint32_t)c3)};
+        const uint64_t ah[4] = {psd_mds_chain<R>(hi, c0 >> 32), psd_mds_chain<R + 1>(hi, c1 >> 32), psd_mds_chain<R + 2>(hi, c2 >> 32),
+                                psd_mds_chain<R + 3>(hi, c3 >> 32)};
+        uint64_t o[4];
+        __builtin_amdgcn_sched_barrier(0);
+        psd_recombine_multi<4>(al, ah, o);
+        s[R] = o[0]; s[R + 1] = o[1]; s[R + 2] = o[2]; s[R + 3] = o[3];
+        psd_mds_rows<R + 4>(s, lo, hi, rc);
+#else
         const uint64_t c = rc[R];
         s[R] = psd_recombine(psd_mds_chain<R>(lo, (uint32_t)c), psd_mds_chain<R>(hi, c >> 32));
         psd_mds_rows<R + 1>(s, lo, hi, rc);
+#endif
     }
 }
 // rc: 12 constants at a wave-uniform address (scalar loads)
@@ -162,12 +236,11 @@ GL_DEV void psd_kload(PsdK& k, psd_ktab c, psd_ktab add) {
         for (int j = 0; j < 3; j++) k.w[i][j] = c[3 * i + j];
     if constexpr (WITH_ADD) { k.a[0] = add[0]; k.a[1] = add[1]; }
 }
-// -> al + ah 2^32 = add + sum_{t < 11} ul[t] c[t] + sum_{t < NX} xl[t] c[11 + t], folded to a u64.  k: this output's first group (requested
+// -> (lo, hi): lo + hi 2^32 = add + sum_{t < 11} ul[t] c[t] + sum_{t < NX} xl[t] c[11 + t] (the caller folds it: psd_recombine).  k: this output's first group (requested
 // earlier); on return the NEXT output's first group (table position c + 3 (11 + NX), additive constant add_next), requested, if HAS_NEXT.
 template <int NX, bool HAS_NEXT, int XCAP>
-GL_DEV uint64_t psd_dot(const uint32_t (&ul)[11][3], const uint32_t (&xl)[XCAP][3], psd_ktab c, PsdK& k, psd_ktab add_next) {
+GL_DEV void psd_dot(const uint32_t (&ul)[11][3], const uint32_t (&xl)[XCAP][3], psd_ktab c, PsdK& k, psd_ktab add_next, uint64_t& lo, uint64_t& hi) {
     constexpr int G = PSD_K_GROUP, NT = 11 + NX, NG = (NT + G - 1) / G;
-    uint64_t lo, hi;
     PsdK cur = k;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
@@ -196,13 +269,13 @@ GL_DEV uint64_t psd_dot(const uint32_t (&ul)[11][3], const uint32_t (&xl)[XCAP][
         cur = nxt;
     }
     k = cur;
-    return psd_recombine(lo, hi);
 }
 template <int J>
 GL_DEV void psd_block_lane0(const uint32_t (&ul)[11][3], uint32_t (&xl)[PSD_K_BLOCK][3], psd_ktab mac, psd_ktab add, PsdK& k) {
     if constexpr (J < PSD_K_BLOCK) {
-        const uint64_t y = psd_dot<J, true>(ul, xl, mac + 3 * (11 * (J - 1) + (J - 1) * J / 2), k, add + 2 * J);
-        psd_split(psd_sbox(y), xl[J]);
+        uint64_t lo, hi;
+        psd_dot<J, true>(ul, xl, mac + 3 * (11 * (J - 1) + (J - 1) * J / 2), k, add + 2 * J, lo, hi);
+        psd_split(psd_sbox(psd_recombine(lo, hi)), xl[J]);
         __builtin_amdgcn_sched_barrier(0);
         psd_block_lane0<J + 1>(ul, xl, mac, add, k);
     }
@@ -211,7 +284,10 @@ template <int R>
 GL_DEV void psd_block_out(uint64_t (&s)[12], const uint32_t (&ul)[11][3], const uint32_t (&xl)[PSD_K_BLOCK][3], psd_ktab mac, psd_ktab add, PsdK& k) {
     constexpr int B = PSD_K_BLOCK;
     if constexpr (R < 12) {
-        s[R] = psd_dot<B, (R < 11)>(ul, xl, mac + 3 * (11 * (B - 1) + (B - 1) * B / 2 + (11 + B) * R), k, add + 2 * (B + R));
+        // (grouping four outgoing lanes for a lock-step recombination costs 12 live VGPRs: 102 instead of 96, a wave per SIMD less)
+        uint64_t lo, hi;
+        psd_dot<B, (R < 11)>(ul, xl, mac + 3 * (11 * (B - 1) + (B - 1) * B / 2 + (11 + B) * R), k, add + 2 * (B + R), lo, hi);
+        s[R] = psd_recombine(lo, hi);
         __builtin_amdgcn_sched_barrier(0);
         psd_block_out<R + 1>(s, ul, xl, mac, add, k);
     }
@@ -256,7 +332,7 @@ GL_DEV void psd_dense_rounds(uint64_t (&s)[12], int r0, int r1) {
         for (int h = 0; h < PSD_ROUNDS_PER_ITER; h++) {
             if (FULL) {
 #pragma unroll
-                for (int i = 0; i < 12; i++) s[i] = psd_sbox(s[i]);
+                for (int i = 0; i < 12; i += 2) psd_sbox2(s[i], s[i + 1]);
             } else {
                 s[0] = psd_sbox(s[0]);
             }
