@@ -19,6 +19,9 @@ namespace gl355 {
 #ifndef PSD_SBOX_INTERLEAVE
 #define PSD_SBOX_INTERLEAVE 1
 #endif
+#ifndef PSD_SBOX_WIDTH
+#define PSD_SBOX_WIDTH 4          // S-boxes of a full round per lock-step group: 2 or 4 (4: no wait states at all; -4 % at one wave per SIMD, nothing at full occupancy)
+#endif
 GL_DEV uint64_t psd_sbox(uint64_t x) {
 #if PSD_SBOX_INTERLEAVE && defined(__HIP_DEVICE_COMPILE__) && GL_MUL_VARIANT == 1
     const uint64_t x2 = gl_sqr(x);
@@ -63,6 +66,20 @@ GL_DEV uint64_t psd_recombine(uint64_t al, uint64_t ah) {
 #endif
 }
 
+// four S-boxes at once: every phase is four products wide, no wait states at all
+GL_DEV void psd_sbox4(uint64_t& x0, uint64_t& x1, uint64_t& x2, uint64_t& x3) {
+#if PSD_SBOX_INTERLEAVE && defined(__HIP_DEVICE_COMPILE__) && GL_MUL_VARIANT == 1
+    const uint64_t a[4] = {x0, x1, x2, x3};
+    uint64_t sq[4], c3[4], c4[4], o[4];
+    gl_mul_multi<4>(a, a, sq);
+    gl_mul_multi<4>(a, sq, c3);
+    gl_mul_multi<4>(sq, sq, c4);
+    gl_mul_multi<4>(c3, c4, o);
+    x0 = o[0]; x1 = o[1]; x2 = o[2]; x3 = o[3];
+#else
+    x0 = psd_sbox(x0); x1 = psd_sbox(x1); x2 = psd_sbox(x2); x3 = psd_sbox(x3);
+#endif
+}
 // N recombinations in lock-step (the two carry steps of one fill the wait states of the others: see gl_mul_multi)
 template <int N>
 GL_DEV void psd_recombine_multi(const uint64_t (&al)[N], const uint64_t (&ah)[N], uint64_t (&out)[N]) {
@@ -332,7 +349,11 @@ GL_DEV void psd_dense_rounds(uint64_t (&s)[12], int r0, int r1) {
         for (int h = 0; h < PSD_ROUNDS_PER_ITER; h++) {
             if (FULL) {
 #pragma unroll
+#if PSD_SBOX_WIDTH == 4
+                for (int i = 0; i < 12; i += 4) psd_sbox4(s[i], s[i + 1], s[i + 2], s[i + 3]);
+#else
                 for (int i = 0; i < 12; i += 2) psd_sbox2(s[i], s[i + 1]);
+#endif
             } else {
                 s[0] = psd_sbox(s[0]);
             }
