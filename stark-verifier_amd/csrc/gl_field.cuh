@@ -227,7 +227,8 @@ GL_DEV void gl_mul_multi(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_
         else asm("v_subb_co_u32_e64 %0, %1, %0, 0, %1" : "+v"(x1[j]), "+s"(c[j]));
         GL_MM_SB();
     }
-    // + w_lo * EPS, the carry-out repaid with +EPS
+    // + w_lo * EPS, the carry-out repaid with +EPS.  The repayment is a second multiply-add (carry in {0, 1} times EPS): as a 64-bit add every product
+    // in flight needs a zero-extended register pair of its own for the addend, i.e. a register move each
 #pragma unroll
     for (int j = 0; j < N; j++) {
         const uint64_t x = ((uint64_t)x1[j] << 32) | x0[j];
@@ -236,13 +237,13 @@ GL_DEV void gl_mul_multi(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_
     }
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        if (N == 1) asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m[j]) : "s"(c[j]));
-        else if (N == 2 && j == 0) asm("s_nop 0\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m[j]) : "s"(c[j]));
-        else asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m[j]) : "s"(c[j]));
+        if (N == 1) asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(m[j]) : "s"(c[j]));
+        else if (N == 2 && j == 0) asm("s_nop 0\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(m[j]) : "s"(c[j]));
+        else asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(m[j]) : "s"(c[j]));
         GL_MM_SB();
     }
 #pragma unroll
-    for (int j = 0; j < N; j++) r[j] += (uint64_t)m[j];
+    for (int j = 0; j < N; j++) asm("v_mad_u64_u32 %0, %1, %2, -1, %0" : "+v"(r[j]), "=s"(c[j]) : "v"(m[j]));
 #undef GL_MM_NOP
 #undef GL_MM_SB
 }
