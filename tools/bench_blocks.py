@@ -174,14 +174,14 @@ def lde_pmc():
         return None, None, None
 
 
-PSD_VALU_PER_PERM, PSD_MAD_PER_PERM = 16030, 9952       # static counts of the shipped ISA (hipcc -S): 8 x 1 113 + 2 x 3 487 + 150; 8 x 540 + 2 x 2 816
+PSD_VALU_PER_PERM, PSD_MAD_PER_PERM = 15700, 10380      # static counts of the shipped ISA (hipcc -S): VALU 8 x 1 077 + 2 x 3 476 + 156; multiply-adds 8 x 588 + 2 x 2 838
 
 
 def merkle_figures(gl, device):
     """BASELINE configs[2] / SURVEY cfg-3: MerkleTree::new over 2^22 leaves -- (L = 4, cap 4) the FRI-layer shape, (L = 135, cap 4)
     the wires-like shape (4.5 GB of leaves) -- and the Semaphore group tree (2^20 leaves, L = 4, cap 0, signal.rs:40); row-major leaves
-    resident in HBM, gl355_merkle_build, HIP-event time per build.  The kernels are integer-VALU work (a permutation is 16.0 k VALU
-    instructions, 9 952 of them v_mad_u64_u32, DESIGN 4.2): `valu` prices the build's permutations at that count against the chip's issue rate;
+    resident in HBM, gl355_merkle_build, HIP-event time per build.  The kernels are integer-VALU work (a permutation is 15.7 k VALU
+    instructions, 10 380 of them v_mad_u64_u32, DESIGN 4.2): `valu` prices the build's permutations at that count against the chip's issue rate;
     `valu.multiply_adds_only` prices just the multiply-adds the formulation needs (the distance to a kernel that issued nothing else)."""
     import torch
     ctx = gl.Context(device)
@@ -189,8 +189,8 @@ def merkle_figures(gl, device):
     g = torch.Generator(device="cuda")
     g.manual_seed(0x356)
     out = {"what": "gl355_merkle_build (leaf sponge + compression levels + cap, plonky2 digest layout), leaves resident, HIP events"}
-    # the VALU roofline of these builds: PSD_VALU_PER_PERM instructions per permutation and lane (static count of the shipped ISA: 8 full rounds x 1 113 +
-    # 2 blocks x 3 487 + the first constant layer; profiles/r05_poseidon_block_vs_dense.txt) against the issue rate for hash_leaves_kernel's
+    # the VALU roofline of these builds: PSD_VALU_PER_PERM instructions per permutation and lane (static count of the shipped ISA: 8 full rounds x 1 077 +
+    # 2 blocks x 3 476 + the first constant layer; profiles/r05_poseidon_block_vs_dense.txt) against the issue rate for hash_leaves_kernel's
     # instruction mix (valu_peak) at the shader clock sampled while the builds run
     mix, _, mix_src = valu_mix("hash_leaves_kernel")
     for log_n, L, cap in ((22, 4, 4), (22, 135, 4), (20, 4, 0)):
