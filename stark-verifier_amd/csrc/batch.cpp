@@ -47,7 +47,7 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
     struct Slot {
         uint32_t j0 = 0, nb = 0;
         std::vector<uint64_t> flat, pis, inputs, rpis, outer;
-        uint64_t* rows = nullptr;      // pinned host (host replay only)
+        uint64_t* rows = nullptr;      // pinned host: the witness rows (host replay) or the mirror of d_aux (device replay)
         uint64_t* d_rows = nullptr;    // device
         void* d_aux = nullptr;         // device replay: inputs | status | public inputs
         std::vector<uint8_t> k_rec;
@@ -154,7 +154,7 @@ extern "C" int32_t gl355_semaphore_units(gl355_ctx* const* ctxs, uint32_t n_ctx,
                         // witness generation: the tape interpreter on the side stream (default), or host threads + upload
                         if (on_device)
                             return circuit_replay_units_dev(rec, device, copy_stream, sp->nb, sp->inputs.data(), sp->d_rows, sp->d_aux, sp->rpis.data(),
-                                                            &sp->failed_unit, &sp->failed_op);
+                                                            &sp->failed_unit, &sp->failed_op, sp->rows /* pinned mirror of d_aux in this mode */);
                         const int32_t rc = circuit_replay_units(rec, threads, sp->nb, sp->inputs.data(), sp->rows, sp->rpis.data(), &sp->failed_unit, &sp->failed_op);
                         if (rc != GL355_OK) return rc;
                         if (hipSetDevice(device) != hipSuccess ||

@@ -274,17 +274,29 @@ uint64_t circuit_rows_words(const gl355_circuit_handle* ch) { return (uint64_t)c
 // device scratch of one device replay: inputs | status | public inputs
 uint64_t circuit_replay_aux_bytes(const gl355_circuit_handle* ch, uint32_t n_units) { return (uint64_t)n_units * (ch->n_inputs + 1 + ch->n_pi) * 8 + 64; }
 int32_t circuit_replay_units_dev(const gl355_circuit_handle* ch, int device, hipStream_t stream, uint32_t n_units, const uint64_t* inputs, uint64_t* d_rows,
-                                 void* d_aux, uint64_t* pis_out, uint64_t* failed_unit, uint64_t* failed_op) {
+                                 void* d_aux, uint64_t* pis_out, uint64_t* failed_unit, uint64_t* failed_op, void* h_aux) {
     if (!ch->d_tape) return GL355_E_INVALID_ARG;
     if (hipSetDevice(device) != hipSuccess) return GL355_E_HIP;
     uint64_t* d_inputs = reinterpret_cast<uint64_t*>(d_aux);
     uint64_t* d_status = d_inputs + (uint64_t)n_units * ch->n_inputs;
     uint64_t* d_pis = d_status + n_units;
-    if (hipMemcpyAsync(d_inputs, inputs, (size_t)n_units * ch->n_inputs * 8, hipMemcpyHostToDevice, stream) != hipSuccess) return GL355_E_HIP;
+    // h_aux: a pinned host mirror of d_aux (circuit_replay_aux_bytes) -- the batch runtime's side stream; nullptr: the caller's pageable memory
+    const uint64_t* src = inputs;
+    std::vector<uint64_t> back_pageable;
+    uint64_t* back;
+    if (h_aux) {
+        uint64_t* h_inputs = reinterpret_cast<uint64_t*>(h_aux);
+        memcpy(h_inputs, inputs, (size_t)n_units * ch->n_inputs * 8);
+        src = h_inputs;
+        back = h_inputs + (uint64_t)n_units * ch->n_inputs;
+    } else {
+        back_pageable.resize((size_t)n_units * (1 + ch->n_pi));
+        back = back_pageable.data();
+    }
+    if (hipMemcpyAsync(d_inputs, src, (size_t)n_units * ch->n_inputs * 8, hipMemcpyHostToDevice, stream) != hipSuccess) return GL355_E_HIP;
     GL355_TRY(tape_replay_dev(stream, ch->d_tape, ch->d_seg_start, ch->n_seq, (uint32_t)ch->seg_lens.size(), n_units, d_inputs, ch->n_inputs, d_rows,
                               circuit_rows_words(ch), ch->d_pi_pos, ch->n_pi, d_status, d_pis));
-    std::vector<uint64_t> back((size_t)n_units * (1 + ch->n_pi));
-    if (hipMemcpyAsync(back.data(), d_status, back.size() * 8, hipMemcpyDeviceToHost, stream) != hipSuccess) return GL355_E_HIP;
+    if (hipMemcpyAsync(back, d_status, (size_t)n_units * (1 + ch->n_pi) * 8, hipMemcpyDeviceToHost, stream) != hipSuccess) return GL355_E_HIP;
     for (;;) {                        // wait for the side stream without holding a core
         const hipError_t q = hipStreamQuery(stream);
         if (q == hipSuccess) break;
@@ -294,7 +306,7 @@ int32_t circuit_replay_units_dev(const gl355_circuit_handle* ch, int device, hip
     }
     for (uint32_t u = 0; u < n_units; u++)
         if (back[u] != ~0ull) { *failed_unit = u; *failed_op = back[u]; return GL355_E_WITNESS; }
-    memcpy(pis_out, back.data() + n_units, (size_t)n_units * ch->n_pi * 8);
+    memcpy(pis_out, back + n_units, (size_t)n_units * ch->n_pi * 8);
     return GL355_OK;
 }
 int32_t circuit_replay_units(const gl355_circuit_handle* ch, uint32_t threads, uint32_t n_units, const uint64_t* inputs, uint64_t* rows, uint64_t* pis_out,

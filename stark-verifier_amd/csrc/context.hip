@@ -150,7 +150,10 @@ int32_t Ctx::runtime_buffers(size_t bytes, size_t aux_bytes, uint64_t* rows[2], 
     if (bytes > rt_bytes || aux_bytes > rt_aux_bytes) {
         runtime_buffers_free();
         for (int i = 0; i < 2; i++) {
-            hipError_t e = device_replay ? hipSuccess : hipHostMalloc(&rt_rows[i], bytes, hipHostMallocDefault);   // host replay only: pinned rows
+            // host replay: pinned witness rows; device replay: a pinned mirror of the replay's device scratch (inputs | status | public inputs) -- the
+            // side stream's copies must not start from pageable memory (the runtime stages and pins those per call: not asynchronous, and the
+            // process's resident set grew by ~5 KB per unit, tools/leak_probe.py)
+            hipError_t e = hipHostMalloc(&rt_rows[i], device_replay ? (aux_bytes ? aux_bytes : 256) : bytes, hipHostMallocDefault);
             if (e == hipSuccess) e = hipMalloc(&rt_drows[i], bytes);
             if (e == hipSuccess) e = hipMalloc(&rt_aux[i], aux_bytes ? aux_bytes : 256);
             if (e != hipSuccess) { (void)hipGetLastError(); runtime_buffers_free(); return fail_hip(e, "witness staging buffers", __FILE__, __LINE__); }

@@ -281,7 +281,7 @@ int32_t tape_replay_dev(hipStream_t stream, const uint64_t* d_tape, const uint64
 // circuit_replay_aux_bytes(); the call returns after the stream has finished (polling, no spinning)
 uint64_t circuit_replay_aux_bytes(const gl355_circuit_handle* ch, uint32_t n_units);
 int32_t circuit_replay_units_dev(const gl355_circuit_handle* ch, int device, hipStream_t stream, uint32_t n_units, const uint64_t* inputs, uint64_t* d_rows,
-                                 void* d_aux, uint64_t* pis_out, uint64_t* failed_unit, uint64_t* failed_op);
+                                 void* d_aux, uint64_t* pis_out, uint64_t* failed_unit, uint64_t* failed_op, void* h_aux = nullptr);
 uint64_t circuit_rows_words(const gl355_circuit_handle* ch);
 int32_t circuit_replay_units(const gl355_circuit_handle* ch, uint32_t threads, uint32_t n_units, const uint64_t* inputs, uint64_t* rows, uint64_t* pis_out,
                              uint64_t* failed_unit, uint64_t* failed_op);

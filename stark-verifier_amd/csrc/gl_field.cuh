@@ -313,9 +313,17 @@ GL_HD gl2 gl2_make(uint64_t a, uint64_t b) { gl2 r; r.c0 = a; r.c1 = b; return r
 GL_HD gl2 gl2_add(gl2 a, gl2 b) { return gl2_make(gl_add(a.c0, b.c0), gl_add(a.c1, b.c1)); }
 GL_HD gl2 gl2_sub(gl2 a, gl2 b) { return gl2_make(gl_sub(a.c0, b.c0), gl_sub(a.c1, b.c1)); }
 GL_HD gl2 gl2_mul(gl2 a, gl2 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && GL_MUL_VARIANT == 1 && !defined(GL2_MUL_SEQUENTIAL)
+    // the four base-field products in lock-step: they fill each other's carry wait states (gl_mul_multi)
+    const uint64_t x[4] = {a.c0, a.c1, a.c0, a.c1}, y[4] = {b.c0, b.c1, b.c1, b.c0};
+    uint64_t p[4];
+    gl_mul_multi<4>(x, y, p);
+    return gl2_make(gl_add(p[0], gl_mul_small(p[1], 7)), gl_add(p[2], p[3]));
+#else
     uint64_t c0 = gl_add(gl_mul(a.c0, b.c0), gl_mul_small(gl_mul(a.c1, b.c1), 7));
     uint64_t c1 = gl_add(gl_mul(a.c0, b.c1), gl_mul(a.c1, b.c0));
     return gl2_make(c0, c1);
+#endif
 }
 GL_HD gl2 gl2_mul_base(gl2 a, uint64_t b) { return gl2_make(gl_mul(a.c0, b), gl_mul(a.c1, b)); }
 GL_HD gl2 gl2_canon(gl2 a) { return gl2_make(gl_canon(a.c0), gl_canon(a.c1)); }

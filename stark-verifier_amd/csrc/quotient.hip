@@ -172,15 +172,16 @@ GL_DEV void gate_poseidon(const QuotArgs& a, const WireSrc& w, uint64_t t, GateA
     for (int i = 0; i < 12; i++) s[i] = gl_add_canonical(s[i], PSD_ALL_RC[i]);
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
+        if (r != 0) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            if (r != 0) {
+            for (int i = 0; i < 12; i++) {
                 const uint64_t sin = WIRE(29 + 12 * (r - 1) + i);
                 g.push(gl_sub(s[i], sin));
                 s[i] = sin;
             }
-            s[i] = psd_sbox(s[i]);
         }
+#pragma unroll
+        for (int i = 0; i < 12; i += 4) psd_sbox4(s[i], s[i + 1], s[i + 2], s[i + 3]);       // four S-boxes in lock-step (poseidon.cuh)
         psd_mds(s, &PSD_ALL_RC[12 * (r + 1)]);
     }
     // partial rounds in the dense form: the S-box input of round r is s[0] + RC[4+r][0] in either form, so the
@@ -199,8 +200,10 @@ GL_DEV void gate_poseidon(const QuotArgs& a, const WireSrc& w, uint64_t t, GateA
         for (int i = 0; i < 12; i++) {
             const uint64_t sin = WIRE(87 + 12 * r + i);
             g.push(gl_sub(s[i], sin));
-            s[i] = psd_sbox(sin);
+            s[i] = sin;
         }
+#pragma unroll
+        for (int i = 0; i < 12; i += 4) psd_sbox4(s[i], s[i + 1], s[i + 2], s[i + 3]);
         psd_mds(s, &PSD_ALL_RC[12 * (27 + r)]);
     }
 #pragma unroll
