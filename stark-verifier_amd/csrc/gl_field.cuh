@@ -247,6 +247,12 @@ GL_DEV void gl_mul_multi(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_
 #undef GL_MM_NOP
 #undef GL_MM_SB
 }
+#else
+// host pass / compiler-scheduled product: one after the other
+template <int N>
+GL_HD void gl_mul_multi(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
+    for (int j = 0; j < N; j++) r[j] = gl_mul(a[j], b[j]);
+}
 #endif
 
 

@@ -383,11 +383,23 @@ __global__ void __launch_bounds__(STAGE ? 64 : 128) __attribute__((amdgpu_waves_
             for (int c = 0; c < NCH; c++) { num[c] = 1; den[c] = 1; }
             for (uint32_t j = ch * chunk; j < (ch + 1) * chunk && j < routed; j++) {
                 const uint64_t wj = WIRE(j), sj = CONST(n_sel + n_cst + j), kj = a.k_is[j];
+                if constexpr (NCH == 2) {
+                    // the eight products of a wire in two lock-step groups of four (gl_mul_multi: partners fill the carry wait states)
+                    const uint64_t a1[4] = {bx[0], bx[1], a.betas[unit * 4], a.betas[unit * 4 + 1]}, b1[4] = {kj, kj, sj, sj};
+                    uint64_t p1[4], p2[4];
+                    gl_mul_multi<4>(a1, b1, p1);
+                    const uint64_t wg0 = gl_add(wj, a.gammas[unit * 4]), wg1 = gl_add(wj, a.gammas[unit * 4 + 1]);
+                    const uint64_t a2[4] = {num[0], num[1], den[0], den[1]};
+                    const uint64_t b2[4] = {gl_add(wg0, p1[0]), gl_add(wg1, p1[1]), gl_add(wg0, p1[2]), gl_add(wg1, p1[3])};
+                    gl_mul_multi<4>(a2, b2, p2);
+                    num[0] = p2[0]; num[1] = p2[1]; den[0] = p2[2]; den[1] = p2[3];
+                } else {
 #pragma unroll
-                for (int c = 0; c < NCH; c++) {
-                    const uint64_t wg = gl_add(wj, a.gammas[unit * 4 + c]);
-                    num[c] = gl_mul(num[c], gl_add(wg, gl_mul(bx[c], kj)));
-                    den[c] = gl_mul(den[c], gl_add(wg, gl_mul(a.betas[unit * 4 + c], sj)));
+                    for (int c = 0; c < NCH; c++) {
+                        const uint64_t wg = gl_add(wj, a.gammas[unit * 4 + c]);
+                        num[c] = gl_mul(num[c], gl_add(wg, gl_mul(bx[c], kj)));
+                        den[c] = gl_mul(den[c], gl_add(wg, gl_mul(a.betas[unit * 4 + c], sj)));
+                    }
                 }
             }
 #pragma unroll
