@@ -95,6 +95,20 @@ enum { GL355_VALU_FULL32 = 0 /* v_add_u32: add / sub / logic / right shift / mov
        v_mul_lo, three-operand forms */, GL355_VALU_MAD64 = 2 /* v_mad_u64_u32 and the 64-bit shifts */, GL355_VALU_CLASSES = 3 };
 int32_t gl355_valu_probe(gl355_ctx* ctx, double rates_ginst_per_s[GL355_VALU_CLASSES], double shader_mhz[GL355_VALU_CLASSES]);
 int32_t gl355_clock_probe(gl355_ctx* ctx, uint32_t micros, double* shader_mhz);
+/* Round 6: the ceiling priced per OPCODE FORM (the three classes above proved too coarse: the job issued faster than their harmonic combination).
+ *   gl355_valu_probe_ops        one kernel per opcode form the library ships (gl355_valu_probe_op_name(i), i < GL355_VALU_PROBE_OPS; NULL beyond), each
+ *                               with `ilp` = 1, 4 or 8 independent dependency chains per lane at 8 waves per SIMD on every SIMD: rates[i] in 1e9 wave
+ *                               instructions per second, shader_mhz[i] read inside that kernel.  cost_i = 1024 SIMDs x MHz / rate, in shader cycles
+ *                               per wave instruction per SIMD; a kernel whose instructions split as f_i cannot issue faster than
+ *                               1024 x clock / sum_i f_i cost_i (tools/isa_mix.py has the f_i of every shipped kernel).
+ *   gl355_valu_probe_composite  the shipped code on register operands, no memory: 0 = the field product (four in lock-step, gl_mul_multi<4>), items =
+ *                               products; 1 = the Poseidon permutation at the hash kernels' occupancy, items = permutations; 2 = v_mad_u64_u32 and
+ *                               v_add_u32 alternating in one wave, items = pairs; 3 = the same two on different waves of a SIMD, items = instructions.
+ *                               items_g_per_s in 1e9 lane-level items per second; waves_per_simd = the resident waves the probe ran with */
+enum { GL355_VALU_PROBE_OPS = 25, GL355_VALU_PROBE_COMPOSITES = 4 };
+const char* gl355_valu_probe_op_name(uint32_t i);
+int32_t gl355_valu_probe_ops(gl355_ctx* ctx, uint32_t ilp, double rates_ginst_per_s[GL355_VALU_PROBE_OPS], double shader_mhz[GL355_VALU_PROBE_OPS]);
+int32_t gl355_valu_probe_composite(gl355_ctx* ctx, uint32_t which, double* items_g_per_s, double* shader_mhz, uint32_t* waves_per_simd);
 
 /* device memory helpers so a non-torch host (the Rust shim) can keep operands resident */
 int32_t gl355_malloc(gl355_ctx* ctx, size_t bytes, void** dptr);

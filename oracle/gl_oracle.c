@@ -279,6 +279,7 @@ static void merkle_layered(leaf_hash_fn leaf_hash, pair_hash_fn pair_hash, const
     size_t sub_dig = 2 * (sub_leaves - 1);
     uint32_t sub_bits = log2_exact(sub_leaves);
     if (sub_bits == 0) {
+#pragma omp parallel for schedule(static)
         for (size_t t = 0; t < n_cap; t++) leaf_hash(leaves + t * leaf_len, leaf_len, cap + t * 4);
         return;
     }

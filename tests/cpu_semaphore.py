@@ -10,6 +10,8 @@ import numpy as np
 from oracle_lib import CpuProver, rand_field
 
 GOLDEN_CASE = dict(log_members=2, seed=0x7E57, member=3, proof_seed=99)
+# the largest group of the reference's own sweep (access_set.rs:193-215: groups 2^20 .. 2^25, signer index 12)
+GROUP25_CASE = dict(log_members=25, seed=0x25D, member=12, proof_seed=0x25E)
 
 
 def build_case(orc, log_members, seed, config=None, gate_order="own"):

@@ -11,6 +11,8 @@
                       minted by the CPU restatement of prove() AFTER the restated reference verifier accepted it; the
                       CPU suite re-derives it, the GPU suite requires the product's proof to hash to the same value.
   unit_depth20.json   SHA-256 of the two proofs of one depth-20 unit (tests/cpu_unit.py UNIT_CASE), same rule.
+  semaphore_depth25.json  the 2^25-member group of the reference's sweep (tests/cpu_semaphore.py GROUP25_CASE): root, public inputs, proof
+                      SHA-256; `python tests/golden/make_golden.py depth25` (minutes: 67 M CPU permutations), not part of the default run.
 Run: python tests/golden/make_golden.py
 """
 import json
@@ -73,6 +75,29 @@ def mint_unit_depth20():
                "public_inputs": ["%016x" % int(x) for x in opis]}, open(os.path.join(HERE, "unit_depth20.json"), "w"), indent=1)
 
 
+def mint_group_depth25():
+    """semaphore_depth25.json: the LARGEST group of the reference's own size sweep (access_set.rs:193-215, `for pow in 20..26`): 2^25 members,
+    signer 12 -- the group root, the signal's public inputs and the SHA-256 of the make_signal proof from the CPU restatement of prove(), minted
+    only after the restated reference verifier accepted it.  ~5 minutes on 8 cores (67 M permutations for keys + tree); run with
+    `python tests/golden/make_golden.py depth25`."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import cpu_semaphore as cs
+    import plonk_verifier as pv
+    from oracle_lib import Oracle, rand_field
+    orc = Oracle()
+    g = cs.GROUP25_CASE
+    case = cs.build_case(orc, g["log_members"], g["seed"])
+    topic = rand_field(case["rng"], 4)
+    idx, vals, pi = cs.witness(orc, case, g["member"], topic)
+    flat = case["cpu"].prove_sparse(idx, vals, pi, g["proof_seed"])
+    proof = case["plonk"].parse_proof(case["data"], flat)
+    proof["public_inputs"] = pi
+    pv.verify(orc, case["data"].common(), proof)
+    json.dump({"case": g, "words": int(flat.size), "sha256": cs.digest_of(flat), "root": ["%016x" % int(x) for x in case["root"]],
+               "degree_bits": int(case["data"].degree_bits), "public_inputs": ["%016x" % int(x) for x in pi]},
+              open(os.path.join(HERE, "semaphore_depth25.json"), "w"), indent=1)
+
+
 def mint_bn254_kat():
     """poseidon_bn254_kat.json: (1) the published circomlib known answer poseidon([1,2,3,4]) for t = 5 -- the script refuses to
     write unless the big-integer model with the reference's parameters reproduces it; (2) permutation / hash vectors of the
@@ -96,6 +121,8 @@ def mint_bn254_kat():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "depth25":
+        return mint_group_depth25()
     mint_semaphore_proof()
     mint_unit_depth20()
     mint_bn254_kat()

@@ -66,6 +66,49 @@ def valu_probe(ctx):
             for i, c in enumerate(VALU_CLASSES)}
 
 
+VALU_OP_ILPS = (1, 4, 8)
+VALU_COMPOSITES = ("product_x4_lockstep", "poseidon_permutation", "mad64_add32_alternating_one_wave", "mad64_add32_on_different_waves")
+
+
+def valu_probe_ops(ctx, ilps=VALU_OP_ILPS):
+    """gl355_valu_probe_ops: per opcode FORM the issue cost in shader cycles per wave instruction per SIMD, at 1 / 4 / 8 independent chains per lane
+    (8 waves per SIMD on every SIMD); `clk` = the best of the three = what the ceiling is priced with.  -> {form: {"clk": c, "ilp1": .., "ilp4": .., "ilp8": .., "mhz": ..}}"""
+    lib = ctx.lib
+    names = []
+    i = 0
+    while True:
+        n = lib.gl355_valu_probe_op_name(i)
+        if not n:
+            break
+        names.append(n.decode())
+        i += 1
+    out = {n: {} for n in names}
+    for ilp in ilps:
+        rates = (C.c_double * len(names))()
+        mhz = (C.c_double * len(names))()
+        ctx.check(lib.gl355_valu_probe_ops(ctx.h, ilp, rates, mhz))
+        for k, n in enumerate(names):
+            clk = mhz[k] * 1e6 * N_SIMD / (rates[k] * 1e9) if rates[k] > 0 else None
+            out[n]["ilp%d" % ilp] = round(clk, 3) if clk else None
+            if clk and (out[n].get("clk") is None or clk < out[n]["clk"]):
+                out[n]["clk"] = round(clk, 3)
+                out[n]["mhz"] = round(mhz[k])
+    return out
+
+
+def valu_probe_composites(ctx):
+    """gl355_valu_probe_composite: the shipped product / permutation on register operands, and the two mixed-class experiments.
+    -> {name: {"items_g_per_s", "mhz", "waves_per_simd", "simd_clk_per_wave_item"}}"""
+    out = {}
+    for w, name in enumerate(VALU_COMPOSITES):
+        r, m, wv = C.c_double(0), C.c_double(0), C.c_uint32(0)
+        ctx.check(ctx.lib.gl355_valu_probe_composite(ctx.h, w, C.byref(r), C.byref(m), C.byref(wv)))
+        wave_items = r.value * 1e9 / 64                      # wave-level items per second, whole chip
+        out[name] = {"items_g_per_s": round(r.value, 3), "mhz": round(m.value), "waves_per_simd": wv.value,
+                     "simd_clk_per_wave_item": round(N_SIMD * m.value * 1e6 / wave_items, 2) if wave_items > 0 else None}
+    return out
+
+
 class ClockSampler:
     """shader clock during the timed region: gl355_clock_probe (one sleeping wave for 2 ms) on a context of its own every ~100 ms"""
 
