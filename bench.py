@@ -490,6 +490,16 @@ def self_launch(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True))
     rc = 0
+    grace = float(os.environ.get("GL355_BENCH_KILL_GRACE_S", "10"))
+    term_at = None                          # when the surviving ranks were asked to end (SIGTERM)
+
+    def signal_all(which, sig):             # the process groups started above, nothing else
+        for q in which:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, sig)
+                except OSError:
+                    pass
     try:
         live = list(procs)
         while live:
@@ -502,19 +512,24 @@ def self_launch(n):
                 if code != 0 and rc == 0:
                     rc = code if code > 0 else 1
                     sys.stderr.write("[bench] rank %d exited with code %d: ending the other ranks\n" % (procs.index(p), code))
-                    for q in live:          # the process groups started above, nothing else
-                        try:
-                            os.killpg(q.pid, signal.SIGTERM)
-                        except OSError:
-                            pass
+                    signal_all(live, signal.SIGTERM)
+                    term_at = time.monotonic()
+            # a rank stuck inside a native RCCL / HIP call (or one with a SIGTERM handler installed) never honours SIGTERM: after the grace
+            # period the groups are killed outright, so the launcher always returns -- non-zero -- instead of hanging
+            if term_at is not None and live and time.monotonic() - term_at > grace:
+                sys.stderr.write("[bench] %d rank(s) still alive %.0f s after SIGTERM: SIGKILL\n" % (len(live), grace))
+                signal_all(live, signal.SIGKILL)
+                term_at = float("inf")
+                deadline = time.monotonic() + 10
+                while live and time.monotonic() < deadline:
+                    live = [q for q in live if q.poll() is None]
+                    time.sleep(0.1)
+                break
     except KeyboardInterrupt:
         rc = 130
-        for q in procs:
-            if q.poll() is None:
-                try:
-                    os.killpg(q.pid, signal.SIGTERM)
-                except OSError:
-                    pass
+        signal_all(procs, signal.SIGTERM)
+        time.sleep(min(grace, 2.0))
+        signal_all(procs, signal.SIGKILL)
     raise SystemExit(rc)
 
 

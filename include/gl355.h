@@ -103,10 +103,12 @@ int32_t gl355_clock_probe(gl355_ctx* ctx, uint32_t micros, double* shader_mhz);
  *                               1024 x clock / sum_i f_i cost_i (tools/isa_mix.py has the f_i of every shipped kernel).
  *   gl355_valu_probe_composite  the shipped code on register operands, no memory: 0 = the field product (four in lock-step, gl_mul_multi<4>), items =
  *                               products; 1 = the Poseidon permutation at the hash kernels' occupancy, items = permutations; 2 = v_mad_u64_u32 and
- *                               v_add_u32 alternating in one wave, items = pairs; 3 = the same two on different waves of a SIMD, items = instructions.
+ *                               v_add_u32 alternating in one wave, items = pairs; 3 = the same two on different waves of a SIMD, items = instructions;
+ *                               4 .. 12 = runs of two opcode forms alternating in one wave (gl355_valu_probe_composite_name(i)), items = instructions.
  *                               items_g_per_s in 1e9 lane-level items per second; waves_per_simd = the resident waves the probe ran with */
-enum { GL355_VALU_PROBE_OPS = 25, GL355_VALU_PROBE_COMPOSITES = 4 };
+enum { GL355_VALU_PROBE_OPS = 25, GL355_VALU_PROBE_COMPOSITES = 13 };
 const char* gl355_valu_probe_op_name(uint32_t i);
+const char* gl355_valu_probe_composite_name(uint32_t i);
 int32_t gl355_valu_probe_ops(gl355_ctx* ctx, uint32_t ilp, double rates_ginst_per_s[GL355_VALU_PROBE_OPS], double shader_mhz[GL355_VALU_PROBE_OPS]);
 int32_t gl355_valu_probe_composite(gl355_ctx* ctx, uint32_t which, double* items_g_per_s, double* shader_mhz, uint32_t* waves_per_simd);
 

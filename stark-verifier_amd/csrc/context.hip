@@ -117,7 +117,7 @@ int32_t Ctx::alloc(size_t bytes, void** out) {
         e = hipMalloc(&p, bytes);
         if (e != hipSuccess) { (void)hipGetLastError(); return fail_hip(e, "hipMalloc(scratch)", __FILE__, __LINE__); }
     }
-    blocks.push_back({p, bytes, true});
+    blocks.push_back({p, bytes, true, block_serial++});
     *out = p;
     return GL355_OK;
 }
@@ -164,10 +164,10 @@ int32_t Ctx::runtime_buffers(size_t bytes, size_t aux_bytes, uint64_t* rows[2], 
     *copy_stream = rt_copy_stream;
     return GL355_OK;
 }
-void Ctx::trim() {
+void Ctx::trim_since(uint64_t mark) {
     (void)wait_impl();
     for (auto it = blocks.begin(); it != blocks.end();) {
-        if (!it->used) { (void)hipFree(it->p); it = blocks.erase(it); } else ++it;
+        if (!it->used && it->serial >= mark) { (void)hipFree(it->p); it = blocks.erase(it); } else ++it;
     }
 }
 void Ctx::release_all() {

@@ -67,8 +67,9 @@ struct Ctx {
     int32_t l24_mid_table(const uint64_t** out);
 
     // trivial caching device allocator (per context => per stream, so reuse is stream-ordered)
-    struct Block { void* p; size_t size; bool used; };
+    struct Block { void* p; size_t size; bool used; uint64_t serial; };
     std::vector<Block> blocks;
+    uint64_t block_serial = 0;        // blocks are numbered in creation order: trim_since(mark) only touches what a phase created itself
 
     // optional per-kernel timing (gl355_profile_enable): HIP events around every launch group
     struct ProfRec { const char* name; hipEvent_t e0, e1; uint64_t bytes; };
@@ -115,7 +116,8 @@ struct Ctx {
     int32_t runtime_buffers(size_t bytes, size_t aux_bytes, uint64_t* rows[2], uint64_t* drows[2], void* aux[2], hipStream_t* copy_stream);
     void runtime_buffers_free();
     void release_all();
-    void trim();                // hipFree every cached block that is not in use (after a one-off phase with large temporaries, e.g. a keygen)
+    void trim_since(uint64_t mark);   // hipFree every cached block CREATED at or after `mark` (= block_serial at the start of a one-off phase with large
+                                      // temporaries, e.g. a keygen) that is not in use; older blocks -- the warmed cache of proofs this context serves -- stay
     // lo[c*4096 + j] = bases[c]^j, hi[c*4096 + j] = bases[c]^(4096 j)
     int32_t pow_tables_multi(const std::vector<uint64_t>& bases, const uint64_t** lo, const uint64_t** hi);
     int32_t pow_tables(uint64_t base, const uint64_t** lo, const uint64_t** hi) {

@@ -452,6 +452,10 @@ int32_t gl355_plonk_keygen(gl355_ctx* h, const uint64_t* desc, uint64_t words, c
     if (!desc || !g || !g_lagrange || !out || words < PLK_HDR) return ctx->fail(GL355_E_INVALID_ARG, "plonk_keygen: null or truncated argument");
     *out = nullptr;
     if (desc[0] != PLK_MAGIC || desc[1] != 1) return ctx->fail(GL355_E_INVALID_ARG, "plonk_keygen: not a version-1 gl355 PLONK descriptor");
+    // keygen's temporaries (staged fixed values and mapping, the MSM scratch of 25 commitments, transform scratch: 66 GB at k = 23) are of no use to a
+    // proof: back to the device, not into the context's cache -- on every return path (declared first, so it runs after the key's own destructor on
+    // a failure), and only the blocks this call created: a context that already serves proofs keeps its warmed cache
+    struct TrimGuard { Ctx* c; uint64_t mark; ~TrimGuard() { c->trim_since(mark); } } trim_guard{ctx, ctx->block_serial};
     std::unique_ptr<gl355_plonk_pk, int32_t (*)(gl355_plonk_pk*)> pk(new (std::nothrow) gl355_plonk_pk(), gl355_plonk_pk_destroy);
     if (!pk) return GL355_E_OOM;
     pk->ctx = ctx; pk->handle = h;
@@ -650,11 +654,8 @@ int32_t gl355_plonk_keygen(gl355_ctx* h, const uint64_t* desc, uint64_t words, c
             GL355_HIP(ctx, ctx->wait());
         }
     }
-    // keygen's temporaries (staged fixed values and mapping, the MSM scratch of 25 commitments, transform scratch: 66 GB at k = 23) are of no use
-    // to a proof: back to the device, not into the context's cache
     work.reset();
-    ctx->trim();
-    *out = pk.release();
+    *out = pk.release();                 // (trim_guard frees the temporaries this call created as the function returns)
     return GL355_OK;
 }
 
@@ -702,6 +703,10 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
     if (!pk || pk->ctx != ctx || !seed || !proof || !proof_len || (pk->n_advice && !advice) || (pk->n_instance && !instance_lens))
         return ctx->fail(GL355_E_INVALID_ARG, "plonk_prove: null argument or a key of another context");
+    // the inspection hook (gl355_plonk_pk_export_quotient) arms exactly ONE call: taken and cleared here, so a proof that fails before the quotient
+    // stage disarms it too and no later proof writes through a pointer its caller may have freed
+    uint64_t* const export_quotient = pk->export_quotient;
+    pk->export_quotient = nullptr;
     const uint64_t n = pk->n, u = pk->usable;
     const uint32_t n_cosets = pk->n_pieces;
     const int32_t last_rot = -(int32_t)(pk->bf + 1);
@@ -1043,14 +1048,13 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
             for (uint32_t c = 0; c < P; c++) cs[c] = M[q][P + c];          // (V^-1)[q][c]
             GL355_TRY(lincomb(pk, rs, cs, {}, nullptr, h_coeffs + 4ull * q * n));
         }
-        if (pk->export_quotient) {             // gl355_plonk_pk_export_quotient: the pieces as canonical integers, for a comparison with the extended-domain quotient
+        if (export_quotient) {             // gl355_plonk_pk_export_quotient: the pieces as canonical integers, for a comparison with the extended-domain quotient
             uint64_t* plain = nullptr;
             GL355_TRY(D((size_t)P * n * 32, &plain));
             hipLaunchKernelGGL(plk_from_mont_kernel, dim3(blocks((uint64_t)P * n)), dim3(256), 0, ctx->stream, (const uint64_t*)h_coeffs, plain, (uint64_t)P * n);
             GL355_HIP(ctx, hipGetLastError());
-            GL355_HIP(ctx, ctx->d2h(pk->export_quotient, plain, (size_t)P * n * 32));
+            GL355_HIP(ctx, ctx->d2h(export_quotient, plain, (size_t)P * n * 32));
             GL355_HIP(ctx, ctx->wait());
-            pk->export_quotient = nullptr;
         }
         std::vector<uint64_t> pts(8ull * pk->n_pieces);
         GL355_TRY(commit_columns(pk, pk->g, h_coeffs, pk->n_pieces, pts.data()));

@@ -46,7 +46,9 @@ GL_DEV void psd_sbox2(uint64_t& x, uint64_t& y) {
 #endif
 }
 
-// al + ah * 2^32 for al, ah < 2^44 (the two accumulators of an MDS row)  ->  u64 representative.
+// al + ah * 2^32  ->  u64 representative, for accumulators whose top word ah1 = ah >> 32 satisfies ah1 + 1 < 2^32: the two chains of an MDS row
+// (al, ah < 2^44) and the block form's dot products (66 products < 2^54 plus a 32-bit constant: al, ah < 2^61, ah1 < 2^29; the bound is asserted on
+// the generated tables by tools/gen_poseidon_tables.py and tests/test_tables.py).
 // = al0 + (al1 + ah0) 2^32 + ah1 2^64: one 32-bit add with carry into the top word, then top * EPS with the carry-out repaid.
 GL_DEV uint64_t psd_recombine(uint64_t al, uint64_t ah) {
 #if GL_MUL_VARIANT == 1 && defined(__HIP_DEVICE_COMPILE__)
@@ -59,7 +61,7 @@ GL_DEV uint64_t psd_recombine(uint64_t al, uint64_t ah) {
     const uint32_t top = (uint32_t)(ah >> 32);
     const uint64_t r0 = al + mid;
     const uint64_t carry = r0 < mid ? 1u : 0u;
-    const uint64_t t = (uint64_t)(top + carry) * GL_EPS;  // (top + carry) * (2^32 - 1) < 2^44
+    const uint64_t t = (uint64_t)(top + carry) * GL_EPS;  // top + carry < 2^32 (see above): the product fits 64 bits
     uint64_t r1 = r0 + t;
     if (r1 < t) r1 += GL_EPS;
     return r1;
@@ -283,9 +285,9 @@ GL_DEV void psd_dot(const uint32_t (&ul)[11][3], const uint32_t (&xl)[XCAP][3], 
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
+        if (g + 1 < NG || HAS_NEXT) cur = nxt;          // (the last group of the last output requested nothing: nxt is not initialised then)
     }
-    k = cur;
+    if constexpr (HAS_NEXT) k = cur;
 }
 template <int J>
 GL_DEV void psd_block_lane0(const uint32_t (&ul)[11][3], uint32_t (&xl)[PSD_K_BLOCK][3], psd_ktab mac, psd_ktab add, PsdK& k) {

@@ -303,6 +303,75 @@ __global__ void __launch_bounds__(256) vpc_split_kernel(uint32_t* out, uint32_t 
     GL355_VP_CLOCK_END
 }
 
+
+// ---- pattern probes: runs of two opcode forms alternating inside one wave (8 waves per SIMD).  What they decide: whether an instruction that issues at
+// the full rate in a loop of its own keeps that rate next to multiply-adds (it does when it comes in runs of >= 2, a lone one costs a whole multiply-add
+// slot), and whether v_cndmask on constants behaves like a full-rate instruction in such runs (the lock-step product issues 10 % faster than the sum of
+// its instructions' stand-alone costs).  Operands: %0..%7 64-bit chains, %8..%15 32-bit chains, %16 = b, %17 = c; scalar pairs s[40:55].
+#define VPP_MAD(J, P) "v_mad_u64_u32 %" #J ", " P ", %16, %17, %" #J "\n\t"
+#define VPP_ADD(J, P) "v_add_u32 %" #J ", %" #J ", %16\n\t"
+#define VPP_MOV(J, P) "v_mov_b32 %" #J ", %16\n\t"
+#define VPP_CND(J, P) "v_cndmask_b32_e64 %" #J ", 0, -1, " P "\n\t"
+#define VPP_SUBCO(J, P) "v_sub_co_u32_e64 %" #J ", " P ", %" #J ", %16\n\t"
+#define VPP_RUN4A(A) A(8, "s[40:41]") A(9, "s[42:43]") A(10, "s[44:45]") A(11, "s[46:47]")
+#define VPP_RUN4B(A) A(12, "s[48:49]") A(13, "s[50:51]") A(14, "s[52:53]") A(15, "s[54:55]")
+#define VPP_MAD4A VPP_MAD(0, "s[40:41]") VPP_MAD(1, "s[42:43]") VPP_MAD(2, "s[44:45]") VPP_MAD(3, "s[46:47]")
+#define VPP_MAD4B VPP_MAD(4, "s[48:49]") VPP_MAD(5, "s[50:51]") VPP_MAD(6, "s[52:53]") VPP_MAD(7, "s[54:55]")
+// 64 instructions per iteration in every pattern
+#define VPP_44(A) VP_X4(VPP_RUN4A(A) VPP_MAD4A VPP_RUN4B(A) VPP_MAD4B)
+#define VPP_22(A) VP_X4(A(8, "s[40:41]") A(9, "s[42:43]") VPP_MAD(0, "s[40:41]") VPP_MAD(1, "s[42:43]") A(10, "s[44:45]") A(11, "s[46:47]") VPP_MAD(2, "s[44:45]") VPP_MAD(3, "s[46:47]") \
+                        A(12, "s[48:49]") A(13, "s[50:51]") VPP_MAD(4, "s[48:49]") VPP_MAD(5, "s[50:51]") A(14, "s[52:53]") A(15, "s[54:55]") VPP_MAD(6, "s[52:53]") VPP_MAD(7, "s[54:55]"))
+#define VPP_11(A) VP_X4(A(8, "s[40:41]") VPP_MAD(0, "s[40:41]") A(9, "s[42:43]") VPP_MAD(1, "s[42:43]") A(10, "s[44:45]") VPP_MAD(2, "s[44:45]") A(11, "s[46:47]") VPP_MAD(3, "s[46:47]") \
+                        A(12, "s[48:49]") VPP_MAD(4, "s[48:49]") A(13, "s[50:51]") VPP_MAD(5, "s[50:51]") A(14, "s[52:53]") VPP_MAD(6, "s[52:53]") A(15, "s[54:55]") VPP_MAD(7, "s[54:55]"))
+#define VPP_CND_SUB VP_X4(VPP_RUN4A(VPP_CND) VPP_SUBCO(12, "s[48:49]") VPP_SUBCO(13, "s[50:51]") VPP_SUBCO(14, "s[52:53]") VPP_SUBCO(15, "s[54:55]") \
+                          VPP_RUN4A(VPP_CND) VPP_SUBCO(12, "s[48:49]") VPP_SUBCO(13, "s[50:51]") VPP_SUBCO(14, "s[52:53]") VPP_SUBCO(15, "s[54:55]"))
+#define GL355_VP_PATTERN_KERNEL(NAME, BODY)                                                                                     \
+    __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t seed, VpClock* clk) {                                   \
+        GL355_VP_CLOCK_BEGIN                                                                                                    \
+        uint64_t acc[8];                                                                                                        \
+        uint32_t a32[8];                                                                                                        \
+        const uint32_t b = (blockIdx.x * 40503u + 12345u) | 1u, c = (seed & 15u) | 3u;                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; j++) { acc[j] = threadIdx.x * 2654435761ull + seed + j; a32[j] = threadIdx.x + j; } \
+        asm volatile("s_mov_b64 s[40:41], 0x55\n\ts_mov_b64 s[42:43], 0x33\n\ts_mov_b64 s[44:45], 0x0f\n\ts_mov_b64 s[46:47], 0x17\n\t" \
+                     "s_mov_b64 s[48:49], 0x71\n\ts_mov_b64 s[50:51], 0x2b\n\ts_mov_b64 s[52:53], 0x4d\n\ts_mov_b64 s[54:55], 0x63" ::: VP_SCLOB); \
+        _Pragma("unroll 1") for (int i = 0; i < VP_ITERS; i++)                                                                  \
+            asm volatile(BODY : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),         \
+                                "+v"(a32[0]), "+v"(a32[1]), "+v"(a32[2]), "+v"(a32[3]), "+v"(a32[4]), "+v"(a32[5]), "+v"(a32[6]), "+v"(a32[7])          \
+                         : "v"(b), "v"(c) : VP_SCLOB);                                                                          \
+        uint64_t s = 0;                                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; j++) s ^= acc[j] + a32[j];                                                     \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(s ^ (s >> 32));                                                 \
+        GL355_VP_CLOCK_END                                                                                                      \
+    }
+GL355_VP_PATTERN_KERNEL(vpp_add4_mad4, VPP_44(VPP_ADD))
+GL355_VP_PATTERN_KERNEL(vpp_add2_mad2, VPP_22(VPP_ADD))
+GL355_VP_PATTERN_KERNEL(vpp_add1_mad1, VPP_11(VPP_ADD))
+GL355_VP_PATTERN_KERNEL(vpp_mov4_mad4, VPP_44(VPP_MOV))
+GL355_VP_PATTERN_KERNEL(vpp_mov1_mad1, VPP_11(VPP_MOV))
+GL355_VP_PATTERN_KERNEL(vpp_cnd4_mad4, VPP_44(VPP_CND))
+GL355_VP_PATTERN_KERNEL(vpp_cnd1_mad1, VPP_11(VPP_CND))
+GL355_VP_PATTERN_KERNEL(vpp_subco4_mad4, VPP_44(VPP_SUBCO))
+GL355_VP_PATTERN_KERNEL(vpp_cnd4_subco4, VPP_CND_SUB)
+
+struct VpComposite { const char* name; VpKernel k; double items_per_lane; };
+static const VpComposite VP_COMPOSITES[] = {
+    {"product_x4_lockstep", vpc_product_kernel, 8.0 * VP_PROD_ITERS},
+    {"poseidon_permutation", vpc_permute_kernel, (double)VP_PERM_ITERS},
+    {"mad64_add32_alternating_one_wave", vpc_alt_kernel, 32.0 * VP_ITERS},
+    {"mad64_add32_on_different_waves", vpc_split_kernel, 64.0 * VP_ITERS},
+    {"pattern 4 add_u32 + 4 mad", vpp_add4_mad4, 64.0 * VP_ITERS},
+    {"pattern 2 add_u32 + 2 mad", vpp_add2_mad2, 64.0 * VP_ITERS},
+    {"pattern 1 add_u32 + 1 mad", vpp_add1_mad1, 64.0 * VP_ITERS},
+    {"pattern 4 mov_b32 + 4 mad", vpp_mov4_mad4, 64.0 * VP_ITERS},
+    {"pattern 1 mov_b32 + 1 mad", vpp_mov1_mad1, 64.0 * VP_ITERS},
+    {"pattern 4 cndmask(0,-1,sgpr) + 4 mad", vpp_cnd4_mad4, 64.0 * VP_ITERS},
+    {"pattern 1 cndmask(0,-1,sgpr) + 1 mad", vpp_cnd1_mad1, 64.0 * VP_ITERS},
+    {"pattern 4 sub_co + 4 mad", vpp_subco4_mad4, 64.0 * VP_ITERS},
+    {"pattern 4 cndmask(0,-1,sgpr) + 4 sub_co", vpp_cnd4_subco4, 64.0 * VP_ITERS},
+};
+constexpr uint32_t VP_N_COMPOSITES = sizeof(VP_COMPOSITES) / sizeof(VP_COMPOSITES[0]);
+static_assert(VP_N_COMPOSITES == GL355_VALU_PROBE_COMPOSITES, "include/gl355.h: GL355_VALU_PROBE_COMPOSITES");
+
 }  // namespace gl355
 
 using namespace gl355;
@@ -369,6 +438,7 @@ static int32_t vp_time(Ctx* ctx, VpKernel k, uint32_t blocks, uint32_t* d_out, V
 }
 
 const char* gl355_valu_probe_op_name(uint32_t i) { return i < VP_N_OPS ? VP_OPS[i].name : nullptr; }
+const char* gl355_valu_probe_composite_name(uint32_t i) { return i < VP_N_COMPOSITES ? VP_COMPOSITES[i].name : nullptr; }
 
 int32_t gl355_valu_probe_ops(gl355_ctx* h, uint32_t ilp, double rates_ginst_per_s[GL355_VALU_PROBE_OPS], double shader_mhz[GL355_VALU_PROBE_OPS]) {
     Ctx* ctx = ctx_of(h);
@@ -395,7 +465,7 @@ int32_t gl355_valu_probe_composite(gl355_ctx* h, uint32_t which, double* items_g
     if (!ctx) return GL355_E_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
     if (!items_g_per_s || !shader_mhz || which >= GL355_VALU_PROBE_COMPOSITES) return ctx->fail(GL355_E_INVALID_ARG, "valu_probe_composite: bad argument");
-    VpKernel k = which == 0 ? vpc_product_kernel : (which == 1 ? vpc_permute_kernel : (which == 2 ? vpc_alt_kernel : vpc_split_kernel));
+    VpKernel k = VP_COMPOSITES[which].k;
     int per_cu = 0, n_cu = 0;
     GL355_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0));
     GL355_HIP(ctx, hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
@@ -408,8 +478,7 @@ int32_t gl355_valu_probe_composite(gl355_ctx* h, uint32_t which, double* items_g
     VpClock* d_clk = reinterpret_cast<VpClock*>(d_out + (size_t)blocks * 256);
     double ms, mhz;
     GL355_TRY(vp_time(ctx, k, blocks, d_out, d_clk, &ms, &mhz));
-    // items: lane-level products / permutations / instruction pairs
-    const double per_lane = which == 0 ? 8.0 * VP_PROD_ITERS : (which == 1 ? (double)VP_PERM_ITERS : (which == 2 ? 32.0 * VP_ITERS : 64.0 * VP_ITERS));
+    const double per_lane = VP_COMPOSITES[which].items_per_lane;      // lane-level products / permutations / instruction pairs / instructions
     *items_g_per_s = ms > 0 ? per_lane * blocks * 256.0 / (ms * 1e-3) / 1e9 : 0;
     *shader_mhz = mhz;
     if (waves_per_simd) *waves_per_simd = (uint32_t)per_cu;        // 4 waves per block, 4 SIMDs per CU

@@ -67,7 +67,6 @@ def valu_probe(ctx):
 
 
 VALU_OP_ILPS = (1, 4, 8)
-VALU_COMPOSITES = ("product_x4_lockstep", "poseidon_permutation", "mad64_add32_alternating_one_wave", "mad64_add32_on_different_waves")
 
 
 def valu_probe_ops(ctx, ilps=VALU_OP_ILPS):
@@ -100,7 +99,13 @@ def valu_probe_composites(ctx):
     """gl355_valu_probe_composite: the shipped product / permutation on register operands, and the two mixed-class experiments.
     -> {name: {"items_g_per_s", "mhz", "waves_per_simd", "simd_clk_per_wave_item"}}"""
     out = {}
-    for w, name in enumerate(VALU_COMPOSITES):
+    w = -1
+    while True:
+        w += 1
+        name = ctx.lib.gl355_valu_probe_composite_name(w)
+        if not name:
+            break
+        name = name.decode()
         r, m, wv = C.c_double(0), C.c_double(0), C.c_uint32(0)
         ctx.check(ctx.lib.gl355_valu_probe_composite(ctx.h, w, C.byref(r), C.byref(m), C.byref(wv)))
         wave_items = r.value * 1e9 / 64                      # wave-level items per second, whole chip

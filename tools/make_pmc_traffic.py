@@ -27,14 +27,20 @@ def short(kern):
     return re.sub(r"\(.*$", "", k)
 
 
-fetch, write, sq = read("pmc_FETCH_SIZE"), read("pmc_WRITE_SIZE"), read("pmc_sq")
+import os
+fetch, write = read("pmc_FETCH_SIZE"), read("pmc_WRITE_SIZE")
+# round 6: two SQ passes of the same one-context job, 1 step and 3 steps; their difference is two steps' kernels WITHOUT the set-up (key hashes, group
+# tree, preprocessed commitments of the two circuits), VERDICT r5 #1 (c).  Older layouts have the single pass pmc_sq.
+steady = os.path.exists("%s/pmc_sq3_summary.txt" % src) and os.path.exists("%s/pmc_sq1_summary.txt" % src)
+sq = read("pmc_sq3") if steady else read("pmc_sq")
+sq1 = read("pmc_sq1") if steady else {}
 kernels = {}
 for kern, v in fetch.items():
     f, n = v["FETCH_SIZE"]
     w = write.get(kern, {}).get("WRITE_SIZE", (0.0, 0))[0]
     e = {"fetch_kb_reported": f, "write_kb_reported": w, "launches": n, "bytes_per_launch_corrected": int((2 * f + w) * 1024)}
     s = sq.get(kern)
-    if s and "SQ_INSTS_VALU" in s and s["SQ_BUSY_CYCLES"][0] > 0:
+    if s and "SQ_INSTS_VALU" in s and s.get("SQ_BUSY_CYCLES", (0, 0))[0] > 0:
         e["valu_insts_per_launch"] = s["SQ_INSTS_VALU"][0]
         e["busy_cycles_per_se"] = s["SQ_BUSY_CYCLES"][0] / 32
         e["clk_per_valu_inst_per_simd"] = round((s["SQ_BUSY_CYCLES"][0] / 32) / (s["SQ_INSTS_VALU"][0] / 1024), 2) if s["SQ_INSTS_VALU"][0] else None
@@ -46,13 +52,49 @@ for kern, v in fetch.items():
         if "SQ_INSTS_VALU_INT32" in s:
             e["valu_int32_per_launch"] = s["SQ_INSTS_VALU_INT32"][0]
     kernels[short(kern)] = e
+if steady:
+    for kern, v3 in sq.items():
+        v1 = sq1.get(kern, {})
+        e = kernels.setdefault(short(kern), {})
+        for ctr, key in (("SQ_INSTS_VALU", "steady_valu_insts"), ("SQ_INSTS_VALU_INT64", "steady_valu_int64"), ("SQ_INSTS_VALU_INT32", "steady_valu_int32")):
+            if ctr in v3:
+                t3 = v3[ctr][0] * v3[ctr][1]
+                t1 = v1[ctr][0] * v1[ctr][1] if ctr in v1 else 0.0
+                e[key] = t3 - t1
+        if "SQ_INSTS_VALU" in v3:
+            e["steady_launches"] = v3["SQ_INSTS_VALU"][1] - (v1["SQ_INSTS_VALU"][1] if "SQ_INSTS_VALU" in v1 else 0)
 doc = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over `python bench.py --steps 1 --warmup 0 --proofs-per-step 16 "
                   "--threads 1 --no-cpu-baseline` (one context, lock-step batches of 8 units; tools/prof_round5.sh, tools/make_pmc_traffic.py), per-dispatch averages in KB; FETCH_SIZE doubled "
                   "per the gfx950 note of MI355X_MICROARCH.md (HBM section); WRITE_SIZE taken as reported",
        "_valu_note": "SQ_INSTS_VALU (wave instructions, whole chip) / 1024 SIMDs vs SQ_BUSY_CYCLES / 32 shader engines, same rocprofv3 --pmc run: "
                      "cycles per VALU instruction per SIMD; the issue floor measured by tools/ubench is ~4.2-4.4",
        "kernels": kernels}
-if len(sys.argv) > 3:
+if steady and len(sys.argv) > 4:
+    # argv[3] / argv[4]: the bench lines of the 1-step and the 3-step SQ pass
+    l1 = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+    l3 = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+    u1, u3 = int(l1["config"]["units_proven_in_process"]), int(l3["config"]["units_proven_in_process"])
+    tot = {"valu": 0.0, "int64": 0.0, "int32": 0.0}
+    incl = 0.0
+    for k, e in kernels.items():
+        if k.startswith("vp") or "steady_valu_insts" not in e:
+            continue
+        tot["valu"] += e["steady_valu_insts"]
+        tot["int64"] += e.get("steady_valu_int64", 0.0)
+        tot["int32"] += e.get("steady_valu_int32", 0.0)
+    for kern, v in sq.items():
+        if "SQ_INSTS_VALU" in v and not short(kern).startswith("vp"):
+            incl += v["SQ_INSTS_VALU"][0] * v["SQ_INSTS_VALU"][1]
+    n = u3 - u1
+    for k, e in kernels.items():
+        if "steady_valu_insts" in e:
+            e["steady_valu_insts_per_unit"] = round(e["steady_valu_insts"] / n)
+    doc["job"] = {"how": "SQ_INSTS_VALU of every kernel: (3-step pass) - (1-step pass) of the same one-context job, over the units proven in between; the "
+                         "set-up kernels (2^20 key hashes, the group tree, two circuits' preprocessed commitments) cancel",
+                  "units_steady": n, "units_in_3_step_pass": u3, "valu_insts_steady_total": tot["valu"],
+                  "valu_insts_per_unit": round(tot["valu"] / n), "valu_int64_per_unit": round(tot["int64"] / n), "valu_int32_per_unit": round(tot["int32"] / n),
+                  "valu_insts_per_unit_including_setup": round(incl / u3)}
+elif len(sys.argv) > 3:
     try:
         line = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
         n_units = int(line["config"]["units_proven_in_process"])
