@@ -175,6 +175,17 @@ def cpu_baseline_recursive(pr, units=3):
                       "on 16 vCPU" % (units, pr.rc.data.degree_bits, threads, t_build, dt)}
 
 
+def expected_rate(wait_mode, device_replay, contexts):
+    """units/s one MI355X reaches with the host side in this mode (measured on 1-GPU boxes of the pool with 16 usable cores, round 6:
+    profiles/r06_hostside_8rank.txt; poll + host replay is the N = 1 headline).  The chosen mode follows from the rank's usable cores:
+    >= 12: 10 contexts, polling waits, tape on 2 host threads per context; 8..11: 8 contexts, tape on the device; < 4: sleeping waits as well."""
+    table = {("poll", False): 319.0, ("poll", True): 307.0, ("spin", False): 319.0, ("spin", True): 307.0, ("sleep", True): 282.0, ("sleep", False): 270.0}
+    r = table.get((wait_mode, bool(device_replay)))
+    if r is not None and contexts < 10:
+        r = round(r * 0.985, 1)       # 8 contexts instead of 10: -1.5 % (profiles/r03b_contexts_sweep.txt)
+    return r
+
+
 def main_recursive(args):
     """units sharded over ranks (recursion.rs:300-308: one block of members per GPU), no collective on the data path; one RCCL
     all_gather of the (nullifier | topic) leaves per step and the aggregation root on rank 0."""
@@ -251,12 +262,13 @@ def main_recursive(args):
         torch.cuda.synchronize()
     # the VALU roofline's peak: class issue rates measured on this device now (idle apart from the probe), the clock during the timed
     # region sampled by a one-wave probe on a context of its own (rank 0)
-    classes = None
+    model = None
     if rank == 0:
         try:
-            classes = valu_probe(pr.sets[0])
+            import bench_common
+            model = bench_common.VALU_MODEL = ValuModel(pr.sets[0])
         except Exception as exc:
-            sys.stderr.write("[bench] valu probe failed: %r\n" % (exc,))
+            sys.stderr.write("[bench] valu probes failed: %r\n" % (exc,))
     sampler = ClockSampler(gl, local_rank) if rank == 0 and os.environ.get("GL355_BENCH_NO_CLOCK_SAMPLER") != "1" else None
     pr.profile(True)
     barrier()
@@ -351,41 +363,62 @@ def main_recursive(args):
                         "alg_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else None} for k, v in items}
         traffic, traffic_src = pmc_traffic(dname)
         # ---- the roofline block.  Bound: the integer VALU issue rate (Poseidon / Merkle / the constraint kernel are not HBM- or
-        # MFMA-bound).  achieved = wave-level VALU instructions of ALL kernels per unit (SQ_INSTS_VALU of the committed --pmc pass, a property of the
-        # shipped kernels) x the units/s of THIS timed region; peak = 1 / sum_c f_c / rate_c: class rates measured by gl355_valu_probe in this run,
-        # moved from the clock each probe ran at to the clock sampled during the timed region; f_c = the job's dynamic instruction mix
-        # (SQ_INSTS_VALU_INT64 share + the shipped ISA's split of the rest).  The dominant kernel's own launch figures and the HBM-side
-        # figure SURVEY 8(d) also asks for follow as sub-blocks.
+        # MFMA-bound).  achieved = wave-level VALU instructions of ALL kernels per unit in steady state (SQ_INSTS_VALU of the committed --pmc passes:
+        # 3 steps minus 1 step, so the set-up kernels cancel) x the units/s of THIS timed region.  peak = 1024 SIMDs x the clock sampled during the
+        # timed region / the pair-aware floor of the job's instruction multiset: every opcode form priced at the issue cost gl355_valu_probe_ops
+        # measured in THIS run, every pair of forms that overlaps (gl355_valu_probe_pairs) allowed to -- the cheapest pairing, a linear program
+        # (tools/bench_common.py valu_costs).  Next to it: the additive model (no overlaps: what round 5 priced, which real code beats by up to 10 %),
+        # the hardware's absolute issue limit (2 clk per wave64 instruction whatever it is), and SURVEY 8(d)'s algorithmic line (multiply-adds only).
         # (the one-device rehearsal time-slices ONE GPU between the ranks: the whole job's rate is that device's rate)
         units_per_s_gpu = units / elapsed / (1 if rehearsal else max(1, world))
-        job_mix, insts_per_unit, mix_src = valu_mix(None)
-        k_mix, k_insts, _ = valu_mix(dname)
         clock_mhz = job_clock["mean_mhz"] if job_clock else None
         roofline = {"bound": "valu", "unit": "G wave-instructions/s", "kernel": "all kernels of a unit (dominant: %s)" % dname}
-        if job_mix and insts_per_unit and clock_mhz:
-            peak = valu_peak(job_mix, clock_mhz)
+        job_forms, insts_per_unit = model.job_forms_per_unit() if model else (None, None)
+        if job_forms and insts_per_unit and clock_mhz:
+            pk = model.peak(job_forms, clock_mhz)
             ach_v = insts_per_unit * units_per_s_gpu / 1e9
-            roofline.update({"achieved": round(ach_v, 1), "peak": round(peak, 1), "frac": round(ach_v / peak, 4),
-                             "valu_insts_per_unit": insts_per_unit, "units_per_s_per_gpu": round(units_per_s_gpu, 2), "mix": job_mix, "mix_source": mix_src,
-                             "nominal_clk_per_wave_inst_per_simd": NOMINAL_CLK, "clock_during_timed_region": job_clock,
-                             "clk_per_valu_inst_per_simd_achieved": round(N_SIMD * clock_mhz * 1e6 / (ach_v * 1e9), 3),
-                             "formula": "achieved = valu_insts_per_unit x units_per_s_per_gpu; peak = 1024 SIMDs x clock_during_timed_region.mean_mhz / "
-                                        "sum_c mix[c] x nominal_clk[c] (full-rate classes 2 clk, multiply / carry / 64-bit classes 4 clk per wave64 "
-                                        "instruction); valu_insts_per_unit and mix.mad64 from the committed rocprofv3 --pmc pass (SQ_INSTS_VALU, "
-                                        "SQ_INSTS_VALU_INT64), the full32 / half32 split of the rest from the shipped ISA (tools/isa_mix.py)",
-                             "probe": {"classes": classes, "peak_at_probe_rates": round(valu_peak_probe(job_mix, classes, clock_mhz), 1) if classes else None,
-                                       "note": "gl355_valu_probe in this run: what kernels that ONLY issue one class reach (G wave-instructions/s, and the clock "
-                                               "read inside each).  The job issues faster than these single-class loops, so they are not the ceiling"}})
+            job = model.pmc.get("job", {})
+            # SURVEY 8(d) cfg-3's algorithmic line: permutations x 1 077 modular multiplications x 4 v_mad_u64_u32 per 64 lanes against the measured multiply-add rate
+            mad_clk = min(model.ops[f]["clk"] for f in model.ops if f.startswith("v_mad_u64_u32"))
+            hash_share = sum(e.get("steady_valu_insts", 0.0) for k, e in model.pmc["kernels"].items()
+                             if k.split("<")[0] in ("hash_leaves_kernel", "merkle_level_kernel", "pow_grind_units_kernel", "two_to_one_kernel")) / max(1.0, job.get("valu_insts_steady_total", 1.0))
+            perm_insts = model.pmc.get("probes", {}).get("vpc_permute_kernel", {}).get("valu_insts_per_item")
+            roofline.update({
+                "achieved": round(ach_v, 1), "peak": pk["peak"], "frac": round(ach_v / pk["peak"], 4),
+                "valu_insts_per_unit": insts_per_unit, "valu_insts_per_unit_including_setup": job.get("valu_insts_per_unit_including_setup"),
+                "units_per_s_per_gpu": round(units_per_s_gpu, 2), "clock_during_timed_region": job_clock,
+                "clk_per_valu_inst_per_simd": {"achieved": round(N_SIMD * clock_mhz * 1e6 / (ach_v * 1e9), 3), "pair_aware_floor": pk.get("clk_per_inst_floor"),
+                                               "additive_model": pk["clk_per_inst_additive"], "hardware_issue_limit": 2.0},
+                "other_lines": {
+                    "additive_model": {"peak": pk["peak_additive"], "frac": round(ach_v / pk["peak_additive"], 4),
+                                       "note": "sum of stand-alone opcode costs, no overlaps: NOT a ceiling -- the lock-step product issues up to 10 % faster (composite_checks)"},
+                    "hardware_issue_limit_2clk": {"peak": round(N_SIMD * clock_mhz * 1e6 / 2.0 / 1e9, 1), "frac": round(ach_v * 1e9 * 2.0 / (N_SIMD * clock_mhz * 1e6), 4),
+                                                  "note": "MI355X_MICROARCH.md, Wave scheduling: a wave64 VALU instruction occupies its SIMD-32 for at least 2 clk"},
+                    "algorithmic_multiply_adds": None if not perm_insts else {
+                        "what": "SURVEY 8(d) cfg-3: the job's permutations x 1 077 modular multiplications x 4 v_mad_u64_u32, per 64 lanes, against 1024 SIMDs x clock / the measured multiply-add cost",
+                        "permutations_per_unit": round(hash_share * insts_per_unit * 64 / perm_insts),
+                        "frac": round(hash_share * insts_per_unit / perm_insts * 1077 * 4 * units_per_s_gpu * mad_clk / (N_SIMD * clock_mhz * 1e6), 4),
+                        "mad_clk": mad_clk}},
+                "unprobed_share_of_instructions": pk["unprobed_share"],
+                "formula": "achieved = valu_insts_per_unit x units_per_s_per_gpu; peak = achieved-independent: 1024 SIMDs x clock_during_timed_region.mean_mhz / "
+                           "clk_per_valu_inst_per_simd.pair_aware_floor, the floor = min over pairings of sum(pair costs + stand-alone costs) / instructions, costs "
+                           "measured in this run (probe), instruction multiset = sum over kernels of SQ_INSTS_VALU (steady state) split into opcode forms by the "
+                           "shipped ISA inside each of the counters' classes (INT64 / INT32 / rest)",
+                "probe": model.report()})
         else:
             roofline.update({"achieved": None, "peak": None, "frac": None, "note": "no --pmc pass / ISA histogram under profiles/ or no clock samples"})
+        k_e = model.pmc.get("kernels", {}).get(dname) if model else None
+        k_insts = k_e.get("valu_insts_per_launch") if k_e else None
+        k_forms = model.dynamic_forms(dname, k_insts, k_e.get("valu_int64_per_launch"), k_e.get("valu_int32_per_launch")) if k_insts else None
         dom = {"kernel": dname, "launches_per_unit": round(dcnt / max(1, iso_units), 1), "avg_launch_ms": round(dms / max(1, dcnt), 4),
                "how": "HIP events on the launching stream, ONE prover context (a lock-step batch of 8 units), %d units, straight after the timed region; "
                       "kernel = the scope group with the largest summed duration.  One context's launch is ~1 800 waves -- under two per SIMD -- so it "
                       "cannot fill the chip by itself (`fill`); the other contexts' kernels run in those slots, which the job-level figure above measures" % iso_units}
-        if k_mix and k_insts and dms > 0 and clock_mhz:
-            k_peak = valu_peak(k_mix, clock_mhz)
+        if k_forms and dms > 0 and clock_mhz:
+            k_pk = model.peak(k_forms, clock_mhz)
             k_ach = k_insts / (dms / max(1, dcnt) * 1e-3) / 1e9
-            dom.update({"valu_insts_per_launch": k_insts, "mix": k_mix, "achieved": round(k_ach, 1), "peak": round(k_peak, 1), "fill": round(k_ach / k_peak, 4)})
+            dom.update({"valu_insts_per_launch": k_insts, "clk_per_inst_floor": k_pk.get("clk_per_inst_floor"), "clk_per_inst_additive": k_pk["clk_per_inst_additive"],
+                        "achieved": round(k_ach, 1), "peak": k_pk["peak"], "fill": round(k_ach / k_pk["peak"], 4)})
         roofline["dominant_kernel"] = dom
         roofline["hbm"] = {"bound": "hbm", "kernel": dname, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(dbytes / max(1, dcnt)),
@@ -410,6 +443,12 @@ def main_recursive(args):
                            cores_per_rank, {"sleep": "sleeping (hipDeviceScheduleBlockingSync)", "poll": "polling (hipStreamQuery + 30-us sleeps)", "spin": "spinning"}[wait_mode], replay_threads) +
                                ("; witness tape replayed on the device" if os.environ.get("GL355_BENCH_DEVICE_REPLAY") == "1" else "; witness tape replayed on host threads") +
                                ("; rank pinned to CPUs %s (ranks take contiguous slices)" % pinned if pinned else ("; no CPU pinning (one rank)" if world == 1 else "; CPU pinning off / unavailable")),
+                       # what this rank's host side was set to, and the rate measured for that setting on one MI355X (the 8-GPU job's rate
+                       # depends on the node's cores per rank through this choice, so the line says which one it made)
+                       "host_mode": {"cores_per_rank": cores_per_rank, "contexts": n_threads, "device_waits": wait_mode,
+                                     "witness_tape": "device" if os.environ.get("GL355_BENCH_DEVICE_REPLAY") == "1" else "host threads",
+                                     "tape_replay_threads": replay_threads, "pinned_cpus": pinned},
+                       "expected_units_per_s_per_gpu": expected_rate(wait_mode, os.environ.get("GL355_BENCH_DEVICE_REPLAY") == "1", n_threads),
                        "host_cpu_ms_per_unit": round(1e3 * host_cpu_s / max(1, (hi - lo) * args.steps), 2),
                        "units_proven_in_process": int(sum(pr.units_done)),
                        "host_split": host_split},

@@ -111,6 +111,14 @@ const char* gl355_valu_probe_op_name(uint32_t i);
 const char* gl355_valu_probe_composite_name(uint32_t i);
 int32_t gl355_valu_probe_ops(gl355_ctx* ctx, uint32_t ilp, double rates_ginst_per_s[GL355_VALU_PROBE_OPS], double shader_mhz[GL355_VALU_PROBE_OPS]);
 int32_t gl355_valu_probe_composite(gl355_ctx* ctx, uint32_t which, double* items_g_per_s, double* shader_mhz, uint32_t* waves_per_simd);
+/*   gl355_valu_probe_pairs      one kernel per unordered pair (X, Y) of the twelve opcode forms that carry the job's instruction count
+ *                               (gl355_valu_probe_pair_names(i, &x, &y), i < GL355_VALU_PROBE_PAIRS): runs of four X and four Y alternating in one wave,
+ *                               8 waves per SIMD; rates[i] in 1e9 wave instructions per second (X and Y together).  2 x 1024 x MHz / rate = the cycles
+ *                               one X and one Y take TOGETHER; where that is less than the sum of their stand-alone costs the two overlap, and a
+ *                               ceiling has to price them so (bench.py: the cheapest pairing of a kernel's instructions, a small linear program) */
+enum { GL355_VALU_PROBE_PAIRS = 66 };
+int32_t gl355_valu_probe_pair_names(uint32_t i, const char** form_a, const char** form_b);
+int32_t gl355_valu_probe_pairs(gl355_ctx* ctx, double rates_ginst_per_s[GL355_VALU_PROBE_PAIRS], double shader_mhz[GL355_VALU_PROBE_PAIRS]);
 
 /* device memory helpers so a non-torch host (the Rust shim) can keep operands resident */
 int32_t gl355_malloc(gl355_ctx* ctx, size_t bytes, void** dptr);

@@ -81,6 +81,8 @@ SIGNATURES = {
     "gl355_clock_probe": (C.c_int32, [vp, C.c_uint32, C.POINTER(C.c_double)]),
     "gl355_valu_probe_op_name": (C.c_char_p, [C.c_uint32]),
     "gl355_valu_probe_composite_name": (C.c_char_p, [C.c_uint32]),
+    "gl355_valu_probe_pair_names": (C.c_int32, [C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]),
+    "gl355_valu_probe_pairs": (C.c_int32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gl355_valu_probe_ops": (C.c_int32, [vp, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gl355_valu_probe_composite": (C.c_int32, [vp, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "gl355_malloc": (C.c_int32, [vp, C.c_size_t, C.POINTER(vp)]),

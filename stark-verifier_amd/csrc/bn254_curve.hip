@@ -1317,7 +1317,6 @@ static int32_t fr_ntt_run(Ctx* ctx, const uint64_t* in, uint32_t log_in, uint64_
     uint64_t* pw_hi = pw_lo + 4 * 1024;
     uint64_t* pw = pw_hi + 4 * n_hi;
     const uint32_t hblk = (uint32_t)((n / 2 + 255) / 256);
-    static const bool staged = getenv("GL355_EXP_FR_NTT_STAGES") != nullptr;      // A/B: one global pass per stage (the first slice)
     {
         ProfScope ps(ctx, "bn254_fr_ntt", (n_in + n_out) * 32);
         hipLaunchKernelGGL(fr_twiddle_seed_kernel, dim3((uint32_t)((1024 + n_hi + 255) / 256)), dim3(256), 0, ctx->stream, tw_lo, tw_hi, n_hi, w_mont);
@@ -1327,15 +1326,7 @@ static int32_t fr_ntt_run(Ctx* ctx, const uint64_t* in, uint32_t log_in, uint64_
             if (inverse) hipLaunchKernelGGL(fr_power_plain_kernel, dim3((uint32_t)((n_pow + 255) / 256)), dim3(256), 0, ctx->stream, pw, n_pow, pw_lo, pw_hi, scale);
             else hipLaunchKernelGGL(fr_twiddle_kernel, dim3((uint32_t)((n_pow + 255) / 256)), dim3(256), 0, ctx->stream, pw, n_pow, pw_lo, pw_hi);
         }
-        if (staged && !shift && in == out && n_in == n && n_out == n) {
-            uint64_t* d = out;
-            const uint32_t blk = (uint32_t)((n + 255) / 256);
-            hipLaunchKernelGGL(fr_to_mont_kernel, dim3(blk), dim3(256), 0, ctx->stream, d, n);
-            hipLaunchKernelGGL(fr_bitrev_kernel, dim3(blk), dim3(256), 0, ctx->stream, d, log_n);
-            for (uint32_t s = 1; s <= log_n; s++)
-                hipLaunchKernelGGL(fr_stage_kernel, dim3(hblk ? hblk : 1), dim3(256), 0, ctx->stream, d, twp, log_n, s);
-            hipLaunchKernelGGL(fr_from_mont_kernel, dim3(blk), dim3(256), 0, ctx->stream, d, n, scale, inverse ? 1 : 0);
-        } else {
+        {
             // stages per pass: ten in the first (contiguous blocks), the rest in passes of at most six
             std::vector<uint32_t> ns;
             ns.push_back(std::min(10u, log_n));
@@ -1435,11 +1426,8 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
     // TOP window should not be nearly empty: scalars are < r < 2^254, so a top window of only a few bits puts everything into a handful
     // of buckets (workgroup path below, contended counters).  254 = 14 * 17 + 16 = 12 * 20 + 14.  Measured (uniform scalars, ms):
     //   2^18: c = 15 / 16 / 17 -> 3.7 / 3.9 / 4.1;   2^20: 16 / 17 / 18 -> 7.3 / 7.1 / 8.3;   2^22: 16 / 17 / 18 / 19 -> 23.6 / 19.1 / 20.7 / 32.9
-    static const uint32_t c_force = getenv("GL355_EXP_MSM_C") ? (uint32_t)atoi(getenv("GL355_EXP_MSM_C")) : 0;     // experiments
+    //   2^23-point calls, k = 23 proof: c = 18 / 19 / 20 / 21 -> 1.155 / 1.115 / 1.118 / 1.235 s
     a.c = lg <= 6 ? 4 : (lg <= 18 ? lg - 2 : (lg <= 22 ? 17 : 20));
-    if (c_force >= 4 && c_force <= 24) a.c = c_force;
-    static const uint32_t c_big = getenv("GL355_EXP_MSM_C_BIG") ? (uint32_t)atoi(getenv("GL355_EXP_MSM_C_BIG")) : 0;   // ... of the 2^23-point calls only: k = 23 proof 1.155 / 1.115 / 1.118 / 1.235 s for c = 18 / 19 / 20 / 21
-    if (c_big >= 4 && c_big <= 24 && lg >= 23) a.c = c_big;
     a.cb = a.c - 1;
     a.wps = 256 / a.c + 1;                                       // signed digits: the carry out of bit 255 needs a window of its own
     if (max_bits < 256) a.wps = std::min(a.wps, (std::max(1u, max_bits) + a.c - 1) / a.c + 1);
@@ -1462,21 +1450,19 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
         lvl_words += 2ull * W * t * 24;
     }
     // the two-level sort: from 2^11 buckets per window on (below that the histograms are small and the point count with them)
-    static const bool old_sort = getenv("GL355_EXP_MSM_OLD_SORT") != nullptr;    // A/B: device-scope atomics per point and window
-    const bool two_level = !old_sort && a.cb > MSM_FINE_BITS;
+    const bool two_level = a.cb > MSM_FINE_BITS;      // (below: one-level sort with device-scope atomics per point and window)
     a.cbits = two_level ? a.cb - MSM_FINE_BITS : 0;
     const uint64_t nbin = 1ull << a.cbits;
     a.chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, 32 * nbin), 1ull << 20);
-    // WINDOW CHUNKS ON TWO STREAMS (measured, off by default).  The windows are independent until the host combines them, and an MSM's
+    // WINDOW CHUNKS ON TWO STREAMS (measured and not used: K stays 1; the chunk machinery below is kept general).  The windows are independent until the host combines them, and an MSM's
     // phases are bound by different things: the sort by memory (scattered 4- and 8-byte writes), bucket accumulation by the VALU (0.81 of its
     // issue rate), the bucket reduction by latency -- at k = 23 the sort and the reduction are 11.5 % and 10.3 % of a proof's kernel time
-    // next to 21.5 % of accumulation.  With GL355_EXP_MSM_CHUNKS = K > 1 the windows are cut into K chunks that alternate between the
+    // next to 21.5 % of accumulation.  With K > 1 chunks the windows are cut into K chunks that alternate between the
     // context's stream and a second one, chunk i + 1 starting its sort when chunk i has finished its own, so that sort (i + 1) could run
     // under accumulate (i) and reduce (i) under accumulate (i + 1).  The k = 23 proof: K = 1 / 2 / 4 / 6 -> 1.143 / 1.142 / 1.151 / 1.207 s:
     // the accumulation kernel's waves hold the CUs' registers, the other stream's kernels get in only as it drains, and the smaller
     // launches lose what the overlap gains.  One chunk on one stream stays the default.
-    static const uint32_t chunks_env = getenv("GL355_EXP_MSM_CHUNKS") ? (uint32_t)atoi(getenv("GL355_EXP_MSM_CHUNKS")) : 1;
-    const uint32_t K = (two_level && n >= (1ull << 18)) ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)chunks_env, W, 8})) : 1;
+    const uint32_t K = 1;
     std::vector<uint32_t> w_lo(K + 1);
     for (uint32_t i = 0; i <= K; i++) w_lo[i] = (uint32_t)(W * i / K);
     // big-bucket work list: a bucket of sz > MSM_BIG points makes ceil(sz / slice) items with slice >= MSM_BIG_WG_POINTS, so over all
@@ -1587,8 +1573,8 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
                 l.out_s = lv_p; lv_p += Wc * groups * 24;
                 l.out_w = lv_p; lv_p += Wc * groups * 24;
                 // eight lanes per group where a level is latency-bound (few groups); the large first levels are throughput-bound and the scan
-                // costs them twice the wave-level additions.  GL355_EXP_MSM_COOP_MAX: largest W x groups that runs the cooperative form (0 = never)
-                static const uint64_t coop_max = getenv("GL355_EXP_MSM_COOP_MAX") ? strtoull(getenv("GL355_EXP_MSM_COOP_MAX"), nullptr, 10) : 16384;
+                // costs them twice the wave-level additions.  coop_max: the largest W x groups that runs the cooperative form
+                constexpr uint64_t coop_max = 16384;
                 if (lv.kbits == 3 && Wc * groups <= coop_max) hipLaunchKernelGGL(msm_level_coop_kernel, dim3((uint32_t)((Wc * groups + 7) / 8)), dim3(64), 0, s_, l);
                 else hipLaunchKernelGGL(msm_level_kernel, dim3((uint32_t)((Wc * groups + 63) / 64)), dim3(64), 0, s_, l);
                 cs = l.out_s; cw = l.out_w;

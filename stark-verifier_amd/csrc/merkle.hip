@@ -333,13 +333,12 @@ int32_t merkle_build_args(Ctx* ctx, LeafArgs a, uint32_t sub_bits, uint64_t* dig
     { ProfScope ps(ctx, "hash_leaves_kernel", n_leaves * ((uint64_t)a.leaf_len * 8 + 32)); GL355_TRY(launch_leaves(ctx, a)); }
     const uint64_t lanes_max = 1ull << ctx->merkle_lanes_log;
     // the last MERKLE_TOP_LEVELS levels of every cap subtree go to merkle_top_kernel (when they are lane-parallel levels anyway: at most
-    // lanes_max nodes enter it over the whole forest); GL355_EXP_MERKLE_TOP6=1: six levels as in round 2 (A/B)
+    // lanes_max nodes enter it over the whole forest)
     // Eight levels per block cost three dependent permutations more than six levels behind two forest-wide lane-parallel launches: with
     // few subtrees (one proof: 16) the separate launches spread over the whole chip and the tree is done sooner (single-unit latency 17.0 vs
     // 17.6 ms); with a lock-step batch (>= 64 subtrees) the chip is full either way and four launches fewer per unit win
     // (profiles/r03_merkle_top_ab.txt).
-    static const bool top6 = getenv("GL355_EXP_MERKLE_TOP6") != nullptr;
-    const uint32_t top_levels_max = (top6 || (n_leaves >> sub_bits) < 64) ? 6 : MERKLE_TOP_LEVELS;
+    const uint32_t top_levels_max = (n_leaves >> sub_bits) < 64 ? 6 : MERKLE_TOP_LEVELS;
     uint32_t top_levels = std::min<uint32_t>(top_levels_max, sub_bits);
     while (top_levels > 1 && ((n_leaves >> (sub_bits - top_levels + 1)) > lanes_max)) top_levels--;      // a forest of many subtrees: fewer levels each
     uint32_t top_from = sub_bits + 1;

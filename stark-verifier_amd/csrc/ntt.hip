@@ -38,18 +38,6 @@ namespace gl355 {
 hipError_t launch_rows_l24(const PassArgs& a, hipStream_t s);
 hipError_t launch_cols_l24_cosets(const PassArgs& a, hipStream_t s);
 hipError_t launch_cols_small_cosets(const PassArgs& a, uint32_t log_t, hipStream_t s);
-// GL355_EXP_NTT_NO_L24=1 keeps both passes of the two-pass LDE / forward transform on the radix-8 kernels of round 2 (A/B);
-// GL355_EXP_NTT_L24_ROWS=0 only the 4096-point rows (1 = the first, limb-quad version of the limb row kernel, 2 = default: the
-// split-exchange version; ntt_l24.hip reads the same variable)
-static bool ntt_l24_on() {
-    static const bool v = getenv("GL355_EXP_NTT_NO_L24") == nullptr;
-    return v;
-}
-static bool ntt_l24_rows_on() {
-    static const bool v = [] { const char* e = getenv("GL355_EXP_NTT_L24_ROWS"); return !(e && e[0] == '0'); }();
-    return v;
-}
-
 // out[c][i] = in[c][bitrev(i)] over 2^log_n entries of `width` u64 each (a5:
 // reverse_index_bits_in_place; out-of-place, or in place via swap when in == out).
 __global__ void bitrev_permute_kernel(const uint64_t* in, uint64_t* out, uint32_t log_n, uint32_t width,
@@ -174,21 +162,8 @@ template <int LT, int LOG_T>
 static hipError_t launch_rows_lt(const PassArgs& a, bool inv, uint64_t blocks, hipStream_t s) {
     const size_t shmem = ((1u << LT) + (1u << (LT - 4))) * sizeof(uint64_t);
     constexpr int NT = 1 << (LT - 4);
-    // the rows pass gains nothing from the FAST instantiation (measured 1.32 -> 1.45 ms: fewer registers, less overlap): off unless asked
-    static const bool rows_fast = getenv("GL355_EXP_NTT_ROWS_FAST") != nullptr;
-    const bool fast = rows_fast && !inv && !a.pre_full && !a.pre_lo && !a.post_lo && a.scale == 1 && a.canon && !a.in_bitrev && !a.out_natural;
-    static const int exp_wpe = getenv("GL355_EXP_NTT_WPE") ? atoi(getenv("GL355_EXP_NTT_WPE")) : 0;      // experiments only
-    if (fast && LT == 12 && exp_wpe == 4) {
-        auto k = ntt_rows_kernel<LT, LOG_T, false, true, 4>;
-        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
-    } else if (fast) {
-        auto k = ntt_rows_kernel<LT, LOG_T, false, true>;
-        if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
-    } else if (!inv && LT == 12 && exp_wpe == 4) {
-        auto k = ntt_rows_kernel<LT, LOG_T, false, false, 4>;
-        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
-    } else if (inv) {
+    // (the FAST instantiation and 4 waves per SIMD measured no better for rows: HISTORY rounds 2-3)
+    if (inv) {
         auto k = ntt_rows_kernel<LT, LOG_T, true>;
         if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(NT), shmem, s, a);
@@ -200,27 +175,21 @@ static hipError_t launch_rows_lt(const PassArgs& a, bool inv, uint64_t blocks, h
     return hipGetLastError();
 }
 
-// GL355_EXP_NTT_R16=1 keeps every shape on the radix-16 kernels (A/B of the radix-8 commit-path kernels, ntt_r8.hip)
-static bool ntt_r16_only() {
-    static const bool v = getenv("GL355_EXP_NTT_R16") != nullptr;
-    return v;
-}
-
 static hipError_t launch_rows(const PassArgs& a, uint32_t log_t, bool inv, hipStream_t s) {
     // 4096-point rows of the two-pass LDE / forward transform on 24-bit limbs (a.mid is set by ntt_run for exactly that shape)
     if (a.mid && !inv && log_t == 12 && a.n_cosets == 1 && !a.pre_full && !a.pre_lo && !a.post_lo && a.scale == 1 && a.canon && !a.in_bitrev &&
-        !a.out_natural && !ntt_r16_only())
+        !a.out_natural)
         return launch_rows_l24(a, s);
     // the commit-path shape (forward, whole rows of 2^12..2^14 points in natural order, at most a full pre table) runs the
     // radix-8 kernel
-    if (!ntt_r16_only() && !inv && log_t >= 12 && log_t <= 14 && !a.post_lo && a.scale == 1 && a.canon && !a.in_bitrev && !a.out_natural &&
+    if (!inv && log_t >= 12 && log_t <= 14 && !a.post_lo && a.scale == 1 && a.canon && !a.in_bitrev && !a.out_natural &&
         (a.pre_full || !a.pre_lo || !a.pre_hi)) {
         PassArgs b = a;
         if (!b.pre_full && b.pre_lo) { b.pre_full = b.pre_lo; b.pre_full_stride = 4096; }   // n <= 2^12: the one-level table is the full one
         return launch_rows_r8(b, log_t, false, s);
     }
     // ... and so do the inverse forms without multiplier tables (values -> coefficients: natural order within the row and the 1/n at the store)
-    if (!ntt_r16_only() && inv && log_t >= 12 && log_t <= 14 && !a.post_lo && !a.pre_lo && !a.pre_full && a.canon && !a.in_bitrev)
+    if (inv && log_t >= 12 && log_t <= 14 && !a.post_lo && !a.pre_lo && !a.pre_full && a.canon && !a.in_bitrev)
         return launch_rows_r8(a, log_t, true, s);
     const uint64_t total_rows = ((uint64_t)a.batch) << a.log_rows;
     const int lt = log_t <= 12 ? 12 : (int)log_t;
@@ -244,14 +213,12 @@ static hipError_t launch_cols_t(const PassArgs& a, bool inv, uint64_t blocks, hi
     const bool fast = !inv && a.pre_full && a.step_full && !a.in_bitrev && !a.out_natural && !a.post_lo && a.scale == 1 && !a.canon;
     const bool r8 = a.step_full && (inv ? !a.pre_lo && !a.pre_full : (a.pre_full || !a.pre_lo)) && !a.in_bitrev && !a.out_natural && !a.post_lo &&
                     a.scale == 1 && !a.canon;
-    static const bool per_coset = getenv("GL355_EXP_NTT_PER_COSET") != nullptr;     // A/B: one block per (tile, coset) as before
-    if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset && LOG_T == 5 && a.log_rows == 12 && ntt_l24_on()) return launch_cols_l24_cosets(a, s);
-    static const bool no_small = getenv("GL355_EXP_NTT_NO_SMALL_COLS") != nullptr;  // A/B: the tiled radix-8 kernel for 2- / 4-row column passes
-    static const bool small3 = getenv("GL355_EXP_NTT_NO_SMALL_COLS8") == nullptr;   // A/B: ... and for 8-row column passes (n = 2^15)
-    if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset && LOG_T <= (small3 ? 3 : 2) && a.log_rows == 12 && a.batch <= 65535 && ntt_l24_on() && !no_small)
+    if (r8 && !inv && a.ratio_full && a.pre_full && LOG_T == 5 && a.log_rows == 12) return launch_cols_l24_cosets(a, s);
+    // column dimension 2, 4 or 8 (n = 2^13 .. 2^15 with 4096-point rows): the streaming kernel, no tile (profiles/r03b_single_pass_ab.txt)
+    if (r8 && !inv && a.ratio_full && a.pre_full && LOG_T <= 3 && a.log_rows == 12 && a.batch <= 65535)
         return launch_cols_small_cosets(a, LOG_T, s);
-    if (r8 && !inv && !ntt_r16_only() && a.ratio_full && a.pre_full && !per_coset) return launch_cols_r8_cosets(a, LOG_T, s);
-    if (r8 && !ntt_r16_only()) return launch_cols_r8(a, LOG_T, inv, s);
+    if (r8 && !inv && a.ratio_full && a.pre_full) return launch_cols_r8_cosets(a, LOG_T, s);
+    if (r8) return launch_cols_r8(a, LOG_T, inv, s);
     if (fast) hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, false, true>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
     else if (inv) hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, true>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
     else hipLaunchKernelGGL((ntt_cols_kernel<LOG_T, false>), dim3((uint32_t)blocks), dim3(256), shmem, s, a);
@@ -333,9 +300,8 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
     if (rc) return rc;
     uint32_t l1, l2;
     // natural order in AND out, plain forward transform of 2^12 < n <= 2^20 points: two column-type passes with the transposition in LDS
-    // (ntt_cols_r8_nat_kernel) instead of two passes + the bit-reversal pass.  GL355_EXP_NTT_NO_NAT2=1: the three-pass form (A/B)
-    static const bool no_nat2 = getenv("GL355_EXP_NTT_NO_NAT2") != nullptr;
-    if (!no_nat2 && !ntt_r16_only() && !inv && !p.in_bitrev && !p.out_bitrev && p.n_cosets == 1 && !p.pre_lo && !p.post_lo && p.scale == 1 &&
+    // (ntt_cols_r8_nat_kernel) instead of two passes + the bit-reversal pass (A/B: profiles/r03_ntt_natural_two_pass.txt)
+    if (!inv && !p.in_bitrev && !p.out_bitrev && p.n_cosets == 1 && !p.pre_lo && !p.post_lo && p.scale == 1 &&
         p.log_n <= 20 && p.coset_slot[0] == 0) {
         l2 = p.log_n / 2; l1 = p.log_n - l2;               // l1 >= l2; both <= 10
         Scratch mid(ctx);
@@ -360,28 +326,16 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         // From 2^22 points on, THREE passes over 4096-element tiles beat two with 16384-point rows (one block per CU, 4 waves per SIMD):
         // after the column pass over N1 = N / 2^17 the rows are independent 2^17-point transforms, each the usual column + row pair.
         // Forward, single coset, contiguous output columns, no pre-multiplier (plain forward NTT: cfg-2 (C)); 2^22 x 16: 1.44 -> see DESIGN 4.1
-        static const bool no3 = getenv("GL355_EXP_NTT_NO_3PASS") != nullptr;
-        const bool three = !no3 && !ntt_r16_only() && !inv && p.log_n >= 22 && p.n_cosets == 1 && !p.pre_lo && !p.post_lo && p.scale == 1 &&
+        const bool three = !inv && p.log_n >= 22 && p.n_cosets == 1 && !p.pre_lo && !p.post_lo && p.scale == 1 &&
                            p.out_col_stride == (1ull << p.log_n) && p.coset_slot[0] == 0;
         // Round 5: from 2^21 points on the same shape runs in TWO passes with 4096-point limb rows: the column pass over 2^(log_n - 12) = 2^9 .. 2^11
         // points on 8192- / 16384-element tiles (16 columns per tile at 2^21 / 2^22, 8 at 2^23: launch_cols_r8_big) -- 32 bytes of HBM traffic per
         // element instead of the 48 of three passes.  2^23 (2^11-point columns, 16384-element tiles with the CU to themselves) measured slower than
-        // three passes and stays there.  GL355_EXP_NTT_BIG_COLS=0: the forms above (A/B); =13 / 14: force the tile size (and allow 2^23).
-        static const int big_env = getenv("GL355_EXP_NTT_BIG_COLS") ? atoi(getenv("GL355_EXP_NTT_BIG_COLS")) : -1;
-        const bool big_shape = !ntt_r16_only() && !inv && p.log_n >= 21 && p.log_n <= (big_env > 0 ? 23u : 22u) && p.n_cosets == 1 && !p.pre_lo && !p.post_lo && p.scale == 1 &&
-                               p.out_col_stride == (1ull << p.log_n) && p.coset_slot[0] == 0 && ntt_l24_on() && ntt_l24_rows_on();
-        uint32_t big_lt = 0;
-        if (big_shape && big_env != 0) {
-            big_lt = p.log_n <= 22 ? 13 : 14;          // measured (profiles/r05_ntt_big_ab.txt): 2^22 on 8-column 8192-element tiles beats 16-column 16384-element ones
-            if ((big_env == 13 && p.log_n <= 22) || (big_env == 14 && p.log_n >= 22)) big_lt = (uint32_t)big_env;
-        }
-        static const int big_row_env = getenv("GL355_EXP_NTT_BIG_ROW") ? atoi(getenv("GL355_EXP_NTT_BIG_ROW")) : 0;       // experiments: row size 12 / 13 / 14
-        uint32_t big_row = 12;
-        if (big_lt && big_row_env >= 12 && big_row_env <= 14 && p.log_n - big_row_env >= 9) {
-            big_row = (uint32_t)big_row_env;
-            const uint32_t c = p.log_n - big_row;           // column points: 9 -> tile 13, 10 -> 13 or 14 as asked, 11 -> 14
-            big_lt = c == 9 ? 13 : (c == 11 ? 14 : big_lt);
-        }
+        // three passes and stays there (every split measured: profiles/r05_ntt_big_ab.txt).
+        const bool big_shape = !inv && p.log_n >= 21 && p.log_n <= 22 && p.n_cosets == 1 && !p.pre_lo && !p.post_lo && p.scale == 1 &&
+                               p.out_col_stride == (1ull << p.log_n) && p.coset_slot[0] == 0;
+        const uint32_t big_lt = big_shape ? 13 : 0;        // 8192-element column tiles: 16 columns per tile at 2^21, 8 at 2^22
+        const uint32_t big_row = 12;
         const bool three_now = three && !big_lt;
         if (big_lt) { l2 = big_row; l1 = p.log_n - big_row; }
         else if (three) { l2 = 17; l1 = p.log_n - l2; }
@@ -424,7 +378,7 @@ int32_t ntt_run(Ctx* ctx, const NttPlan& p) {
         b.in = p.out; b.in_col_stride = p.out_col_stride;
         // each coset's intermediate lives in its own output block: rows pass runs per coset slot
         b.pre_lo = b.pre_hi = nullptr; b.step_lo = b.step_hi = nullptr; b.pre_full = nullptr; b.step_full = nullptr; b.ratio_full = nullptr;
-        if (ntt_l24_on() && ntt_l24_rows_on() && !inv && l2 == 12 && p.scale == 1) GL355_TRY(ctx->l24_mid_table(&b.mid));
+        if (!inv && l2 == 12 && p.scale == 1) GL355_TRY(ctx->l24_mid_table(&b.mid));
         b.log_rows = l1;  // rows per column = N1
         b.scale = p.scale; b.canon = 1;
         if (p.n_cosets == 1) {

@@ -30,43 +30,21 @@ int32_t Ctx::l24_mid_table(const uint64_t** out) {
     return GL355_OK;
 }
 
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; }
-
 // rows of 4096 points: a.batch << a.log_rows of them (forward, natural order in, bit-reversed canonical out, no multiplier tables).
-// Default: the split-exchange kernel, one row per block, 80 VGPRs / 33 KB of LDS = 3 tiles per CU.  GL355_EXP_NTT_L24_ROWS=1 keeps the
-// persistent limb-quad kernel of the first version for the A/B (0 = the radix-8 rows, decided in ntt.hip).
+// The split-exchange kernel, one row per block, 33 KB of LDS.  (The persistent limb-quad kernel of the first version, ntt_rows_l24_kernel, and the
+// prefetching variants stay in ntt_l24.cuh for tools/ubench/ubench_ntt_l24.hip: profiles/r03_ubench_ntt_l24s.txt, r05_ubench_ntt_l24s.txt.)
 hipError_t launch_rows_l24(const PassArgs& a, hipStream_t s) {
-    static const int mode = env_int("GL355_EXP_NTT_L24_ROWS", 2);
     const uint64_t total = ((uint64_t)a.batch) << a.log_rows;
-    if (mode == 1) {
-        // persistent blocks: two per CU (the 65-KB tile allows no more), each walks rows blockIdx, blockIdx + grid, ...
-        static const int n_cu = [] { int dev = 0, cu = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); return cu; }();
-        const uint64_t blocks = std::min<uint64_t>(total, 2ull * (uint64_t)n_cu);
-        auto k = ntt_rows_l24_kernel<4>;
-        static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L24_ROWS_LDS_BYTES);
-        if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(512), L24_ROWS_LDS_BYTES, s, a);
-        return hipGetLastError();
-    }
     auto k = ntt_rows_l24s_kernel<5, false>;
     hipLaunchKernelGGL(k, dim3((uint32_t)total), dim3(512), L24S_ROWS_LDS_BYTES, s, a);
     return hipGetLastError();
 }
-// 32-point column pass over all cosets: blocks over (column, 64-column tile); GL355_EXP_NTT_L24_COLS=1: the limb-quad kernel on 128-column tiles
+// 32-point column pass over all cosets: blocks over (column, 64-column tile)
 hipError_t launch_cols_l24_cosets(const PassArgs& a, hipStream_t s) {
-    static const int mode = env_int("GL355_EXP_NTT_L24_COLS", 2);
-    if (mode == 1) {
-        const uint64_t blocks = ((1ull << a.log_rows) >> 7) * a.batch;
-        auto k = ntt_cols_l24_cosets_kernel<4>;
-        static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L24_COLS_LDS_BYTES);
-        if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(512), L24_COLS_LDS_BYTES, s, a);
-        return hipGetLastError();
-    }
     const uint64_t blocks = ((1ull << a.log_rows) >> 6) * a.batch;
-    // ratio table held in registers (116 VGPRs, 4 tiles per CU): no load follows a store inside the coset loop; mode 2 = re-read per coset (84 VGPRs, 5 tiles)
-    if (mode == 2) hipLaunchKernelGGL((ntt_cols_l24s_cosets_kernel<6, 4, 1>), dim3((uint32_t)blocks), dim3(256), 32 * 64 * 8, s, a);
-    else hipLaunchKernelGGL((ntt_cols_l24s_cosets_kernel<6, 5, 0>), dim3((uint32_t)blocks), dim3(256), 32 * 64 * 8, s, a);
+    // ratio table held in registers (116 VGPRs, 4 tiles per CU): no load follows a store inside the coset loop (MODE 1 of the kernel; the variants
+    // that re-read it per coset or take one coset per block measured slower: profiles/r03_ubench_ntt_l24s.txt (4))
+    hipLaunchKernelGGL((ntt_cols_l24s_cosets_kernel<6, 4, 1>), dim3((uint32_t)blocks), dim3(256), 32 * 64 * 8, s, a);
     return hipGetLastError();
 }
 

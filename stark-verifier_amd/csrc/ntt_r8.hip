@@ -55,15 +55,7 @@ hipError_t launch_rows_r8(const PassArgs& a, uint32_t log_t, bool inv, hipStream
         case 14: {
             // a 16384-point tile at 4 waves per SIMD needs an EMPTY CU (all its VGPRs and 136 KB of LDS): alone it is the fastest form,
             // under a many-context load the blocks wait for CUs to drain (rocprof: 6 ms resident for 0.4 ms of work).
-            // GL355_EXP_NTT_LT14_WPE=8 trades registers for the chance to share a CU
-            static const bool wpe8 = getenv("GL355_EXP_NTT_LT14_WPE") && atoi(getenv("GL355_EXP_NTT_LT14_WPE")) == 8;
-            if (wpe8 && a.pre_full) {
-                const size_t shmem = ((1u << 14) + (1u << 10)) * sizeof(uint64_t);
-                auto k = ntt_rows_r8_kernel<14, true, 8>;
-                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-                hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(1024), shmem, s, a);
-                return hipGetLastError();
-            }
+            // (8 waves per SIMD, trading registers for the chance to share a CU, measured no better: HISTORY round 3)
             return launch_rows8_lt<14>(a, blocks, s);
         }
         default: return hipErrorInvalidValue;

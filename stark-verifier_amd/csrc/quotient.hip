@@ -328,7 +328,7 @@ GL_DEV void gate_reducing(const QuotArgs& a, const WireSrc& w, uint64_t t, GateA
     }
 }
 
-// STAGE (experiment, GL355_EXP_QUOT_STAGE=1): the wave first copies its 64 points' wire rows (num_wires x 64 x 8 B = 69 KB) into LDS and
+// STAGE (experiment of round 2, not instantiated any more: profiles/r02_quotient_ab.txt): the wave first copies its 64 points' wire rows (num_wires x 64 x 8 B = 69 KB) into LDS and
 // every evaluator reads them from there -- each wire column crosses the fabric once instead of ~4 times, at 2 waves per CU.
 template <int NCH, bool STAGE = false>
 __global__ void __launch_bounds__(STAGE ? 64 : 128) __attribute__((amdgpu_waves_per_eu(STAGE ? 1 : 3, 3))) quotient_kernel(QuotArgs a) {
@@ -525,15 +525,7 @@ int32_t quotient_units_dev(Ctx* ctx, const gl355_circuit* c, uint32_t B, const u
     // every column of the three oracles once per point of the quotient coset + the result
     ProfScope ps(ctx, "quotient_kernel", (uint64_t)B * nq * 8 * ((uint64_t)c->num_selectors + c->num_constants + c->num_routed_wires + c->num_wires +
                                                    (uint64_t)c->num_challenges * (2 + c->num_partial_products)));
-    static const bool stage = getenv("GL355_EXP_QUOT_STAGE") != nullptr;       // experiment only
-    if (stage && c->num_challenges == 2) {
-        const size_t shmem = (size_t)c->num_wires * 64 * 8;
-        auto k = quotient_kernel<2, true>;
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(k, dim3((uint32_t)((nq + 63) / 64), B), dim3(64), shmem, ctx->stream, a);
-        GL355_HIP(ctx, hipGetLastError());
-        return GL355_OK;
-    }
+    // (the LDS-staged variant quotient_kernel<NCH, true> measured slower -- profiles/r02_quotient_ab.txt -- and is no longer instantiated)
     const dim3 grid((uint32_t)((nq + 127) / 128), B);
     switch (c->num_challenges) {
         case 1: hipLaunchKernelGGL(quotient_kernel<1>, grid, dim3(128), 0, ctx->stream, a); break;

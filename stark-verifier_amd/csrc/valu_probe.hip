@@ -372,6 +372,32 @@ static const VpComposite VP_COMPOSITES[] = {
 constexpr uint32_t VP_N_COMPOSITES = sizeof(VP_COMPOSITES) / sizeof(VP_COMPOSITES[0]);
 static_assert(VP_N_COMPOSITES == GL355_VALU_PROBE_COMPOSITES, "include/gl355.h: GL355_VALU_PROBE_COMPOSITES");
 
+
+// ---- pair probes: every unordered pair of the opcode forms that carry the job's instruction count (generated: tools/gen_valu_pairs.py) ------------
+#define GL355_VP_PAIR_KERNEL(NAME, BODY)                                                                                        \
+    __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t seed, VpClock* clk) {                                   \
+        GL355_VP_CLOCK_BEGIN                                                                                                    \
+        uint64_t acc[8];                                                                                                        \
+        uint32_t a32[8];                                                                                                        \
+        const uint32_t b = (blockIdx.x * 40503u + 12345u) | 1u, c = (seed & 15u) | 3u;                                         \
+        const uint64_t bw = ((uint64_t)b << 7) | c;                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 8; j++) { acc[j] = threadIdx.x * 2654435761ull + seed + j; a32[j] = threadIdx.x + j; } \
+        asm volatile("s_mov_b64 s[40:41], 0x55\n\ts_mov_b64 s[42:43], 0x33\n\ts_mov_b64 s[44:45], 0x0f\n\ts_mov_b64 s[46:47], 0x17\n\t" \
+                     "s_mov_b64 s[48:49], 0x71\n\ts_mov_b64 s[50:51], 0x2b\n\ts_mov_b64 s[52:53], 0x4d\n\ts_mov_b64 s[54:55], 0x63" ::: VP_SCLOB); \
+        _Pragma("unroll 1") for (int i = 0; i < VP_ITERS; i++)                                                                  \
+            asm volatile(BODY : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),         \
+                                "+v"(a32[0]), "+v"(a32[1]), "+v"(a32[2]), "+v"(a32[3]), "+v"(a32[4]), "+v"(a32[5]), "+v"(a32[6]), "+v"(a32[7])          \
+                         : "v"(b), "v"(c), "v"(bw) : VP_SCLOB);                                                                 \
+        uint64_t s = 0;                                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; j++) s ^= acc[j] + a32[j];                                                     \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(s ^ (s >> 32));                                                 \
+        GL355_VP_CLOCK_END                                                                                                      \
+    }
+struct VpPair { const char* a; const char* b; VpKernel k; };
+#include "valu_probe_pairs.inc"
+constexpr uint32_t VP_N_PAIRS = sizeof(VP_PAIRS) / sizeof(VP_PAIRS[0]);
+static_assert(VP_N_PAIRS == GL355_VALU_PROBE_PAIRS, "include/gl355.h: GL355_VALU_PROBE_PAIRS");
+
 }  // namespace gl355
 
 using namespace gl355;
@@ -454,6 +480,30 @@ int32_t gl355_valu_probe_ops(gl355_ctx* h, uint32_t ilp, double rates_ginst_per_
     for (uint32_t i = 0; i < VP_N_OPS; i++) {
         double ms, mhz;
         GL355_TRY(vp_time(ctx, VP_OPS[i].k[slot], VP_BLOCKS, d_out, d_clk, &ms, &mhz));
+        rates_ginst_per_s[i] = ms > 0 ? insts / (ms * 1e-3) / 1e9 : 0;
+        shader_mhz[i] = mhz;
+    }
+    return GL355_OK;
+}
+
+int32_t gl355_valu_probe_pair_names(uint32_t i, const char** form_a, const char** form_b) {
+    if (i >= VP_N_PAIRS || !form_a || !form_b) return GL355_E_INVALID_ARG;
+    *form_a = VP_PAIRS[i].a; *form_b = VP_PAIRS[i].b;
+    return GL355_OK;
+}
+int32_t gl355_valu_probe_pairs(gl355_ctx* h, double rates_ginst_per_s[GL355_VALU_PROBE_PAIRS], double shader_mhz[GL355_VALU_PROBE_PAIRS]) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+    if (!rates_ginst_per_s || !shader_mhz) return ctx->fail(GL355_E_INVALID_ARG, "valu_probe_pairs: null argument");
+    Scratch sc(ctx);
+    GL355_TRY(sc.get((size_t)VP_BLOCKS * 256 * 4 + 64));
+    uint32_t* d_out = sc.as<uint32_t>();
+    VpClock* d_clk = reinterpret_cast<VpClock*>(d_out + (size_t)VP_BLOCKS * 256);
+    const double insts = (double)VP_BLOCKS * 4 /* waves */ * VP_ITERS * 64;
+    for (uint32_t i = 0; i < VP_N_PAIRS; i++) {
+        double ms, mhz;
+        GL355_TRY(vp_time(ctx, VP_PAIRS[i].k, VP_BLOCKS, d_out, d_clk, &ms, &mhz));
         rates_ginst_per_s[i] = ms > 0 ? insts / (ms * 1e-3) / 1e9 : 0;
         shader_mhz[i] = mhz;
     }

@@ -131,8 +131,8 @@ def lde_figure(gl, device, steps=40, warm=12):
 
 def lde_floors(alg_bytes, clk):
     """What bounds the two-pass LDE from below, per pass: its HBM-side traffic at the copy rate the chip reaches (6.29 TB/s, MI355X_MICROARCH.md) and
-    its VALU instructions (rocprofv3 --pmc SQ_INSTS_VALU) at the issue cost of the pass's instruction mix (tools/isa_mix.py classes at 2 / 4 clk)
-    and the clock sampled during this run.  A pass cannot beat the larger of its two floors even with perfect overlap; the sum over the passes is the
+    its VALU instructions (rocprofv3 --pmc SQ_INSTS_VALU) at the pair-aware issue floor of the pass's opcode forms (tools/isa_mix.py forms at the
+    costs gl355_valu_probe_ops / _pairs measured in this run: bench_common.ValuModel) and the clock sampled during this run.  A pass cannot beat the larger of its two floors even with perfect overlap; the sum over the passes is the
     ceiling of THIS arithmetic (64-bit modular butterflies as 24-bit-limb integer work on a 32-bit VALU) in this two-pass structure, and
     `ceiling_frac_of_hbm_peak` is where the north star's ">= 50 % of HBM" target lands for it."""
     try:
@@ -146,13 +146,17 @@ def lde_floors(alg_bytes, clk):
     out = {"clock_mhz": clk["mean_mhz"], "copy_peak_TBps": 6.29, "passes": {}}
     total = 0.0
     for name, e in d["kernels"].items():
-        f = isa.get(name, {}).get("f")
-        if not f:
+        import bench_common
+        model = bench_common.VALU_MODEL
+        forms = model.dynamic_forms(name) if model else None
+        if not forms:
             continue
-        cost = sum(f[c] * NOMINAL_CLK[c] for c in VALU_CLASSES)
+        add, fl, _ = model.cycles(forms)                   # per instruction (the forms are fractions)
+        cost = fl or add
         valu_ms = e["SQ_INSTS_VALU"] * cost / (N_SIMD * clk["mean_mhz"] * 1e6) * 1e3
         mem_ms = e["hbm_bytes_per_launch"] / copy_peak * 1e3
-        out["passes"][name] = {"valu_floor_ms": round(valu_ms, 3), "mem_floor_ms": round(mem_ms, 3), "mix": f, "clk_per_inst": round(cost, 2)}
+        out["passes"][name] = {"valu_floor_ms": round(valu_ms, 3), "mem_floor_ms": round(mem_ms, 3), "clk_per_inst_floor": round(cost, 3),
+                               "clk_per_inst_additive": round(add, 3)}
         total += max(valu_ms, mem_ms)
     if total <= 0:
         return None
@@ -192,7 +196,12 @@ def merkle_figures(gl, device):
     # the VALU roofline of these builds: PSD_VALU_PER_PERM instructions per permutation and lane (static count of the shipped ISA: 8 full rounds x 1 077 +
     # 2 blocks x 3 476 + the first constant layer; profiles/r05_poseidon_block_vs_dense.txt) against the issue rate for hash_leaves_kernel's
     # instruction mix (valu_peak) at the shader clock sampled while the builds run
-    mix, _, mix_src = valu_mix("hash_leaves_kernel")
+    import bench_common
+    model = bench_common.VALU_MODEL
+    pe = model.pmc.get("probes", {}).get("vpc_permute_kernel") if model else None        # dynamic instructions per permutation (rocprofv3 --pmc over the probe)
+    perm_forms = model.dynamic_forms("vpc_permute_kernel", pe["valu_insts_per_item"], pe["valu_int64_per_item"], pe["valu_int32_per_item"]) if pe else None
+    perm_insts = pe["valu_insts_per_item"] if pe else PSD_VALU_PER_PERM
+    mad_clk = min(v["clk"] for f, v in model.ops.items() if f.startswith("v_mad_u64_u32")) if model else 4.0
     for log_n, L, cap in ((22, 4, 4), (22, 135, 4), (20, 4, 0)):
         n = 1 << log_n
         leaves = torch.randint(0, (1 << 63) - 1, (n, L), dtype=torch.int64, device="cuda", generator=g)
@@ -218,16 +227,20 @@ def merkle_figures(gl, device):
             "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
                          "algorithmic_bytes": int(alg)},
             "valu": None}
-        if mix and clk:
-            ach_v = perms * PSD_VALU_PER_PERM / 64.0 / (ms * 1e-3) / 1e9
-            ach_m = perms * PSD_MAD_PER_PERM / 64.0 / (ms * 1e-3) / 1e9
-            peak_m = N_SIMD * clk["mean_mhz"] * 1e6 / NOMINAL_CLK["mad64"] / 1e9
-            peak_v = valu_peak(mix, clk["mean_mhz"])
+        if perm_forms and clk:
+            pk = model.peak(perm_forms, clk["mean_mhz"])
+            ach_v = perms * perm_insts / 64.0 / (ms * 1e-3) / 1e9
+            ach_m = perms * 1077 * 4 / 64.0 / (ms * 1e-3) / 1e9
+            peak_m = N_SIMD * clk["mean_mhz"] * 1e6 / mad_clk / 1e9
             out["N=2^%d L=%d cap=%d" % (log_n, L, cap)]["valu"] = {
-                "bound": "valu", "achieved": round(ach_v, 1), "peak": round(peak_v, 1), "unit": "G wave-instructions/s", "frac": round(ach_v / peak_v, 4),
-                "clock_mhz": clk["mean_mhz"], "mix": mix, "formula": "permutations x %d / 64 / time against 1024 SIMDs x clock / sum_c mix[c] x nominal_clk[c]" % PSD_VALU_PER_PERM,
-                "multiply_adds_only": {"achieved": round(ach_m, 1), "peak": round(peak_m, 1), "unit": "G v_mad_u64_u32/s (wave level)", "frac": round(ach_m / peak_m, 4),
-                                       "formula": "permutations x %d / 64 / time against 1024 SIMDs x clock / 4 clk" % PSD_MAD_PER_PERM}}
+                "bound": "valu", "achieved": round(ach_v, 1), "peak": pk["peak"], "unit": "G wave-instructions/s", "frac": round(ach_v / pk["peak"], 4),
+                "clock_mhz": clk["mean_mhz"], "valu_insts_per_permutation": perm_insts, "clk_per_inst_floor": pk.get("clk_per_inst_floor"),
+                "additive_model": {"peak": pk["peak_additive"], "frac": round(ach_v / pk["peak_additive"], 4)},
+                "formula": "permutations x valu_insts_per_permutation (rocprofv3 --pmc over the permutation probe) / 64 / time against 1024 SIMDs x clock / "
+                           "the pair-aware floor of the permutation's opcode forms (costs measured in this run)",
+                "algorithmic_multiply_adds": {"achieved": round(ach_m, 1), "peak": round(peak_m, 1), "unit": "G v_mad_u64_u32/s (wave level)", "frac": round(ach_m / peak_m, 4),
+                                              "formula": "SURVEY 8(d) cfg-3: permutations x 1 077 modular multiplications x 4 multiply-adds / 64 / time against "
+                                                         "1024 SIMDs x clock / %.3f clk (the measured v_mad_u64_u32 cost)" % mad_clk}}
         del leaves, dig, capb
         torch.cuda.empty_cache()
     ctx.close()
@@ -469,7 +482,7 @@ def halo2_valu(clock_mhz):
     isa = json.load(open(isa))["kernels"]
     dur = {re.sub(r"^(void )?gl355::", "", r["Name"]).split("(")[0]: float(r["AverageNs"]) for r in csv.DictReader(open(st))}
     out = {"clock_mhz": clock_mhz, "source": "profiles/%s + %s + %s" % tuple(os.path.basename(x) for x in (pmc, st, latest_profile("_isa_mix.json"))),
-           "formula": "insts_per_launch / avg_launch_s against 1024 SIMDs x clock / sum_c mix[c] x nominal_clk[c]", "kernels": {}}
+           "formula": "insts_per_launch / avg_launch_s against 1024 SIMDs x clock / the pair-aware floor of the kernel's opcode forms (bench_common.ValuModel)", "kernels": {}}
     for line in open(pmc):
         name = re.sub(r"^gl355::", "", line.split("(")[0])
         if name not in ("fr_fft_pass_kernel", "msm_bucket_kernel") or name not in dur or name not in isa:
@@ -485,10 +498,21 @@ def halo2_valu(clock_mhz):
         mix = {k2: al * m[k2] + (1 - al) * b[k2] for k2 in VALU_CLASSES}
         rest = mix["full32"] + mix["half32"]
         mix = {"mad64": round(f64, 4), "full32": round((1 - f64) * mix["full32"] / rest, 4), "half32": round((1 - f64) * mix["half32"] / rest, 4)}
-        peak = valu_peak(mix, clock_mhz)
+        import bench_common
+        model = bench_common.VALU_MODEL
+        fb, fm = (model.static_forms(name), model.static_forms(callee)) if model else (None, None)
+        if not (fb and fm):
+            continue
+        tb, tm = float(sum(fb.values())), float(sum(fm.values()))
+        forms = {}
+        for src_f, w, t in ((fb, 1 - al, tb), (fm, al, tm)):
+            for f, c in src_f.items():
+                forms[f] = forms.get(f, 0.0) + w * c / t
+        pk = model.peak(forms, clock_mhz)
         ach = n / (dur[name] * 1e-9) / 1e9
-        out["kernels"][name] = {"insts_per_launch": n, "avg_launch_ms": round(dur[name] * 1e-6, 4), "mix": mix, "product_share_of_instructions": round(al, 3),
-                                "achieved_ginst_s": round(ach, 1), "peak_ginst_s": round(peak, 1), "frac": round(ach / peak, 4)}
+        out["kernels"][name] = {"insts_per_launch": n, "avg_launch_ms": round(dur[name] * 1e-6, 4), "int64_share": round(f64, 4), "product_share_of_instructions": round(al, 3),
+                                "achieved_ginst_s": round(ach, 1), "peak_ginst_s": pk["peak"], "frac": round(ach / pk["peak"], 4),
+                                "clk_per_inst_floor": pk.get("clk_per_inst_floor"), "clk_per_inst_additive": pk["clk_per_inst_additive"]}
     return out
 
 

@@ -114,6 +114,212 @@ def valu_probe_composites(ctx):
     return out
 
 
+def valu_probe_pairs(ctx):
+    """gl355_valu_probe_pairs: {(form_x, form_y): shader cycles one X and one Y take together} over the twelve forms of tools/gen_valu_pairs.py"""
+    lib = ctx.lib
+    n = 0
+    names = []
+    a, b = C.c_char_p(), C.c_char_p()
+    while lib.gl355_valu_probe_pair_names(n, C.byref(a), C.byref(b)) == 0:
+        names.append((a.value.decode(), b.value.decode()))
+        n += 1
+    rates = (C.c_double * n)()
+    mhz = (C.c_double * n)()
+    ctx.check(lib.gl355_valu_probe_pairs(ctx.h, rates, mhz))
+    return {"%s+%s" % names[i]: round(2 * mhz[i] * 1e6 * N_SIMD / (rates[i] * 1e9), 3) for i in range(n) if rates[i] > 0}
+
+
+# opcode form (gl355_valu_probe_op_name / tools/isa_mix.py `forms`) -> the pair class it overlaps like (tools/gen_valu_pairs.py FORMS)
+PAIR_CLASS = {"v_add_u32": "add_u32", "v_sub_u32": "add_u32", "v_and_b32": "and_b32", "v_lshrrev_b32": "ashrrev_i32", "v_ashrrev_i32": "ashrrev_i32",
+              "v_mov_b32": "mov_b32", "v_lshlrev_b32": "lshlrev_b32", "v_alignbit_b32": "lshlrev_b32", "v_add3_u32": "lshlrev_b32",
+              "v_mul_lo_u32": "lshlrev_b32", "v_add_co_u32 sgpr": "add_co", "v_sub_co_u32 sgpr": "sub_co", "v_addc_co_u32 sgpr": "addc",
+              "v_subb_co_u32 sgpr": "subb", "v_cndmask_b32 sgpr": "cndmask_const", "v_cndmask_b32 0,-1,sgpr": "cndmask_const",
+              "v_mad_u64_u32 vvv": "mad", "v_mad_u64_u32 svv": "mad", "v_mad_u64_u32 vcv": "mad", "v_mad_u64_u32 v,-1,v": "mad",
+              "v_lshl_add_u64": "lshl_add_u64", "v_lshlrev_b64": "lshl_add_u64", "v_lshrrev_b64": "lshl_add_u64", "v_mov_b64": "lshl_add_u64",
+              "v_cmp_lt_u64 sgpr": "lshl_add_u64"}
+PAIR_FORM_OF_CLASS = {"add_u32": "v_add_u32", "and_b32": "v_and_b32", "ashrrev_i32": "v_ashrrev_i32", "mov_b32": "v_mov_b32", "lshlrev_b32": "v_lshlrev_b32",
+                      "add_co": "v_add_co_u32 sgpr", "sub_co": "v_sub_co_u32 sgpr", "addc": "v_addc_co_u32 sgpr", "subb": "v_subb_co_u32 sgpr",
+                      "cndmask_const": "v_cndmask_b32 0,-1,sgpr", "mad": "v_mad_u64_u32 svv", "lshl_add_u64": "v_lshl_add_u64"}
+
+
+def valu_costs(form_counts, ops, pairs=None):
+    """SIMD cycles a multiset of VALU instructions needs, two ways.  form_counts: {opcode form: count} (any positive weights).
+    additive   sum_f n_f x the form's stand-alone cost (gl355_valu_probe_ops, best of ILP 1 / 4 / 8); forms without a probe at the cheapest measured cost
+    floor      the pair-aware lower bound: instructions are matched up (a linear program over the twelve pair classes) so that every matched pair
+               (X, Y) costs what the pair probe measured for one X and one Y together, unmatched ones their stand-alone cost; no schedule of this
+               multiset can issue faster if overlaps are pairwise -- this prices the ceiling
+    -> (additive cycles, floor cycles or None without the pair table, weight of forms without a probe)"""
+    iso = {f: v["clk"] for f, v in ops.items() if v.get("clk")}
+    cheapest = min(iso.values())
+    cls_iso = {c: iso[f] for c, f in PAIR_FORM_OF_CLASS.items() if f in iso}
+    n_cls, add, unprobed = {}, 0.0, 0.0
+    for f, n in form_counts.items():
+        if n <= 0:
+            continue
+        c = iso.get(f)
+        cls = PAIR_CLASS.get(f)
+        if c is None or cls is None:
+            unprobed += n
+            c, cls = cheapest, "mov_b32"
+        add += n * c
+        n_cls[cls] = n_cls.get(cls, 0.0) + n
+    if not pairs:
+        return add, None, unprobed
+    try:
+        from scipy.optimize import linprog
+    except Exception:
+        return add, None, unprobed
+    classes = sorted(n_cls)
+    idx = {c: i for i, c in enumerate(classes)}
+    var, cost = [], []
+    for i, a in enumerate(classes):
+        for b in classes[i + 1:]:
+            t = pairs.get("%s+%s" % (a, b), pairs.get("%s+%s" % (b, a)))
+            if t is not None and a in cls_iso and b in cls_iso and t < cls_iso[a] + cls_iso[b]:
+                var.append((a, b)); cost.append(t)
+    for a in classes:
+        var.append((a, None)); cost.append(min(cls_iso.get(a, cheapest), cheapest if a not in cls_iso else cls_iso[a]))
+    A = [[0.0] * len(var) for _ in classes]
+    for k, (a, b) in enumerate(var):
+        A[idx[a]][k] = 1.0
+        if b is not None:
+            A[idx[b]][k] = 1.0
+    res = linprog(cost, A_eq=A, b_eq=[n_cls[c] for c in classes], bounds=[(0, None)] * len(var), method="highs")
+    return add, (float(res.fun) if res.success else None), unprobed
+
+
+# how the SQ counters classify the opcode forms (rocprofv3 --pmc over the probe kernels themselves: profiles/r06_valu_probe_pmc.txt)
+COUNTER_CLASS = {"int64": ("v_mad_u64_u32 vvv", "v_mad_u64_u32 svv", "v_mad_u64_u32 vcv", "v_mad_u64_u32 v,-1,v", "v_lshl_add_u64", "v_cmp_lt_u64 sgpr"),
+                 "int32": ("v_add_u32", "v_sub_u32", "v_ashrrev_i32", "v_add3_u32", "v_mul_lo_u32", "v_add_co_u32 sgpr", "v_sub_co_u32 sgpr",
+                           "v_addc_co_u32 sgpr", "v_subb_co_u32 sgpr")}
+_CLASS_OF_FORM = {f: c for c, fs in COUNTER_CLASS.items() for f in fs}
+
+
+class ValuModel:
+    """The VALU ceiling of round 6: issue costs per opcode form and per pair of forms MEASURED in this run (gl355_valu_probe_ops /
+    _pairs), instruction counts per kernel from the committed steady-state --pmc pass, the split into forms from the shipped ISA (tools/isa_mix.py),
+    moved to each kernel's dynamic SQ_INSTS_VALU_INT64 / _INT32 shares.  cycles(forms) -> (additive, pair-aware floor); the floor prices the peak."""
+
+    def __init__(self, ctx, run_pairs=True):
+        self.ops = valu_probe_ops(ctx)
+        self.pairs = valu_probe_pairs(ctx) if run_pairs else None
+        self.composites = valu_probe_composites(ctx)
+        self.classes = valu_probe(ctx)
+        try:
+            self.isa_path, self.pmc_path = latest_profile("_isa_mix.json"), latest_profile("_pmc_traffic.json")
+            self.isa = json.load(open(self.isa_path))["kernels"]
+            self.pmc = json.load(open(self.pmc_path))
+        except Exception:
+            self.isa, self.pmc = {}, {}
+
+    def static_forms(self, name):
+        k = self.isa.get(name)
+        if k is None:                       # template instances of one name: summed
+            acc = {}
+            for n, v in self.isa.items():
+                if n.split("<")[0] == name.split("<")[0]:
+                    for f, c in v.get("forms", {}).items():
+                        acc[f] = acc.get(f, 0) + c
+            return acc or None
+        return dict(k.get("forms", {})) or None
+
+    def dynamic_forms(self, name, n=None, n64=None, n32=None):
+        """the kernel's static form histogram scaled to `n` dynamic instructions, the INT64- / INT32-counted forms to the counters' dynamic totals"""
+        st = self.static_forms(name)
+        if not st:
+            return None
+        tot = float(sum(st.values()))
+        if n is None:
+            return {f: c / tot for f, c in st.items()}
+        if n64 is None or n32 is None:
+            return {f: n * c / tot for f, c in st.items()}
+        grp = {"int64": {}, "int32": {}, "other": {}}
+        for f, c in st.items():
+            grp[_CLASS_OF_FORM.get(f, "other")][f] = c
+        want = {"int64": n64, "int32": n32, "other": max(0.0, n - n64 - n32)}
+        out = {}
+        for g, forms in grp.items():
+            t = float(sum(forms.values()))
+            if t <= 0:
+                if want[g] > 0:             # the counter saw instructions of a class the static body does not have: the class's commonest form
+                    f = {"int64": "v_mad_u64_u32 vvv", "int32": "v_add_u32", "other": "v_mov_b32"}[g]
+                    out[f] = out.get(f, 0.0) + want[g]
+                continue
+            for f, c in forms.items():
+                out[f] = out.get(f, 0.0) + want[g] * c / t
+        return out
+
+    def job_forms_per_unit(self):
+        """{form: dynamic instructions per unit} over every kernel of the steady-state pass, and the instruction total"""
+        job = self.pmc.get("job", {})
+        n_units = job.get("units_steady")
+        if not n_units:
+            return None, None
+        acc, total = {}, 0.0
+        for name, e in self.pmc["kernels"].items():
+            n = e.get("steady_valu_insts")
+            if not n or n <= 0 or name.startswith("vp"):
+                continue
+            d = self.dynamic_forms(name, n / n_units, e.get("steady_valu_int64", 0.0) / n_units, e.get("steady_valu_int32", 0.0) / n_units)
+            if d is None:
+                d = {"unprobed:%s" % name: n / n_units}
+            for f, c in d.items():
+                acc[f] = acc.get(f, 0.0) + c
+            total += n / n_units
+        return acc, total
+
+    def cycles(self, forms):
+        return valu_costs(forms, self.ops, self.pairs)
+
+    def peak(self, forms, clock_mhz):
+        """-> {additive / floor: G wave-instructions per second the chip could issue for this multiset at `clock_mhz`, clk per instruction}"""
+        n = float(sum(forms.values()))
+        add, fl, unp = self.cycles(forms)
+        r = {"clk_per_inst_additive": round(add / n, 3), "peak_additive": round(N_SIMD * clock_mhz * 1e6 / (add / n) / 1e9, 1), "unprobed_share": round(unp / n, 4)}
+        if fl:
+            r.update({"clk_per_inst_floor": round(fl / n, 3), "peak": round(N_SIMD * clock_mhz * 1e6 / (fl / n) / 1e9, 1)})
+        else:
+            r["peak"] = r["peak_additive"]
+        return r
+
+    def composite_checks(self):
+        """the shipped product and permutation on registers against their own floors: achieved <= ceiling must hold (it is how the model is audited in
+        the run that uses it); instruction counts per item from the committed --pmc pass over the probe kernels"""
+        per_item = self.pmc.get("probes", {})
+        out = {}
+        for comp, kern in (("product_x4_lockstep", "vpc_product_kernel"), ("poseidon_permutation", "vpc_permute_kernel")):
+            c = self.composites.get(comp)
+            st = self.static_forms(kern)
+            n = per_item.get(kern, {}).get("valu_insts_per_item")
+            if not (c and st and n):
+                continue
+            e = per_item[kern]
+            forms = self.dynamic_forms(kern, n, e.get("valu_int64_per_item"), e.get("valu_int32_per_item"))
+            add, fl, _ = self.cycles(forms)
+            meas = c["simd_clk_per_wave_item"]
+            out[comp] = {"measured_simd_clk_per_wave_item": meas, "valu_insts_per_item": n, "additive_model_clk": round(add, 1),
+                         "floor_clk": round(fl, 1) if fl else None, "waves_per_simd": c["waves_per_simd"],
+                         "measured_over_floor": round(meas / fl, 4) if fl else None, "ceiling_holds": bool(fl is None or meas >= fl)}
+        return out
+
+    def report(self):
+        iso = {f: v["clk"] for f, v in self.ops.items()}
+        over = {}
+        if self.pairs:
+            ci = {c: iso.get(f) for c, f in PAIR_FORM_OF_CLASS.items()}
+            for k, t in self.pairs.items():
+                a, b = k.split("+")
+                if ci.get(a) and ci.get(b) and t < 0.97 * (ci[a] + ci[b]):
+                    over[k] = {"together": t, "alone": round(ci[a] + ci[b], 3)}
+        return {"clk_per_wave_inst_per_simd_by_opcode_form": self.ops, "pairs_that_overlap": over,
+                "pairs_measured": len(self.pairs) if self.pairs else 0, "composites": self.composites, "composite_checks": self.composite_checks(),
+                "classes_round5": self.classes,
+                "sources": [os.path.basename(x) for x in (self.isa_path, self.pmc_path) if x]}
+
+
+VALU_MODEL = None
+
+
 class ClockSampler:
     """shader clock during the timed region: gl355_clock_probe (one sleeping wave for 2 ms) on a context of its own every ~100 ms"""
 

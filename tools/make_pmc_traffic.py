@@ -103,5 +103,17 @@ elif len(sys.argv) > 3:
         doc["job"] = {"units_proven_in_process": n_units, "valu_insts_total": total, "valu_insts_per_unit": round(total / n_units)}
     except Exception as exc:
         print("no job figure:", exc)
+# the composite probes of csrc/valu_probe.hip under the same counters (pmc_probe_summary.txt): dynamic instructions per product / per permutation
+if os.path.exists("%s/pmc_probe_summary.txt" % src):
+    pr = read("pmc_probe")
+    per_lane = {"vpc_product_kernel": 8 * 2048, "vpc_permute_kernel": 48}       # VP_PROD_ITERS x 8 products, VP_PERM_ITERS (csrc/valu_probe.hip)
+    doc["probes"] = {}
+    for kern, v in pr.items():
+        k = short(kern)
+        if k in per_lane and "SQ_INSTS_VALU" in v and "SQ_WAVES" in v:
+            items = v["SQ_WAVES"][0] * per_lane[k]                               # wave-level items per launch
+            doc["probes"][k] = {"valu_insts_per_item": round(v["SQ_INSTS_VALU"][0] / items, 2),
+                                "valu_int64_per_item": round(v.get("SQ_INSTS_VALU_INT64", (0, 0))[0] / items, 2),
+                                "valu_int32_per_item": round(v.get("SQ_INSTS_VALU_INT32", (0, 0))[0] / items, 2)}
 json.dump(doc, open(dst, "w"), indent=1)
 print("wrote", dst, len(kernels), "kernels")

@@ -18,6 +18,7 @@ ctx = gl.Context(0)
 out = {"classes": bc.valu_probe(ctx)}
 out["ops"] = bc.valu_probe_ops(ctx)
 out["composites"] = bc.valu_probe_composites(ctx)
+out["pairs"] = bc.valu_probe_pairs(ctx)
 v = C.c_double(0)
 ctx.check(ctx.lib.gl355_clock_probe(ctx.h, 2000, C.byref(v)))
 out["idle_clock_mhz"] = round(v.value)
