@@ -175,15 +175,14 @@ def cpu_baseline_recursive(pr, units=3):
                       "on 16 vCPU" % (units, pr.rc.data.degree_bits, threads, t_build, dt)}
 
 
-def expected_rate(wait_mode, device_replay, contexts):
-    """units/s one MI355X reaches with the host side in this mode (measured on 1-GPU boxes of the pool with 16 usable cores, round 6:
-    profiles/r06_hostside_8rank.txt; poll + host replay is the N = 1 headline).  The chosen mode follows from the rank's usable cores:
-    >= 12: 10 contexts, polling waits, tape on 2 host threads per context; 8..11: 8 contexts, tape on the device; < 4: sleeping waits as well."""
-    table = {("poll", False): 319.0, ("poll", True): 307.0, ("spin", False): 319.0, ("spin", True): 307.0, ("sleep", True): 282.0, ("sleep", False): 270.0}
-    r = table.get((wait_mode, bool(device_replay)))
-    if r is not None and contexts < 10:
-        r = round(r * 0.985, 1)       # 8 contexts instead of 10: -1.5 % (profiles/r03b_contexts_sweep.txt)
-    return r
+def expected_rate(cores_per_rank):
+    """units/s ONE MI355X reaches when its rank has this many usable host cores (bench.py picks the wait / replay mode from that number; measured with
+    one rank confined by taskset on a 1-GPU box, tools/hostside_one_rank.sh -> profiles/r06_hostside_8rank.txt).  An 8-GPU node with 8 x k cores should
+    see 8 x this figure: the ranks share nothing on the host side."""
+    for k, r in ((16, 317.0), (12, 314.0), (8, 307.0), (3, 306.0), (2, 303.0), (1, 285.0)):
+        if cores_per_rank >= k:
+            return r
+    return None
 
 
 def main_recursive(args):
@@ -242,10 +241,12 @@ def main_recursive(args):
     blocking = sleeping_waits
     # the witness tape of the recursive proof is host work inside each context's thread (7 ms, the context's stream idles
     # meanwhile); its FRI-query segments replay on 2 threads when the waits sleep and cores are to spare (191 -> 195 proofs/s)
-    replay_threads = int(os.environ.get("GL355_BENCH_REPLAY_THREADS", 2 if cores_per_rank >= 8 else 1))
+    replay_threads = int(os.environ.get("GL355_BENCH_REPLAY_THREADS", 2 if cores_per_rank >= 12 else 1))
     # witness generation of the recursive circuit: on the device (tape interpreter on the context's side stream: 2 host cores per
     # rank are enough, 255 units/s) or on host threads (4 % more throughput when the rank has cores to spare: 270 vs 259 units/s)
-    os.environ.setdefault("GL355_BENCH_DEVICE_REPLAY", "0" if cores_per_rank >= 8 else "1")
+    # (round 6, profiles/r06_hostside_8rank.txt: one rank at 8 cores reaches 307 units/s with the tape on host threads at 12.4 ms of host CPU per unit and
+    # 306 with the tape on the device at 4.8 ms -- the host tape only pays from 12 cores on, where ten contexts fit as well: 314-317)
+    os.environ.setdefault("GL355_BENCH_DEVICE_REPLAY", "0" if cores_per_rank >= 12 else "1")
     pr = RecursiveProvers(gl, local_rank, n_threads, args.log_members, replay_threads=replay_threads, blocking_sync=2 if wait_mode == "poll" else 0)
     comm = open_comm(lib, par, pr.sets[0], rank, world, rehearsal, dev)
     per = args.proofs_per_step
@@ -321,7 +322,7 @@ def main_recursive(args):
         # gl355_semaphore_prove (witness + proof, n = 2^13) then gl355_circuit_prove_tape (tape replay + proof), host-visible wall time
         # (a lone unit has the rank's host cores to itself: its witness tape replays on up to 8 threads instead of the throughput setting)
         # and polls its stream without sleeping: GL355_OPT_BLOCKING_SYNC 3)
-        lat_rt = max(1, min(8, cores_per_rank // 2))
+        lat_rt = int(os.environ.get("GL355_BENCH_LAT_REPLAY_THREADS", max(1, min(8, cores_per_rank // 2))))
         all_sets[0].set_option(3, lat_rt)
         all_sets[0].set_option(2, 3)
         lat = []
@@ -448,7 +449,7 @@ def main_recursive(args):
                        "host_mode": {"cores_per_rank": cores_per_rank, "contexts": n_threads, "device_waits": wait_mode,
                                      "witness_tape": "device" if os.environ.get("GL355_BENCH_DEVICE_REPLAY") == "1" else "host threads",
                                      "tape_replay_threads": replay_threads, "pinned_cpus": pinned},
-                       "expected_units_per_s_per_gpu": expected_rate(wait_mode, os.environ.get("GL355_BENCH_DEVICE_REPLAY") == "1", n_threads),
+                       "expected_units_per_s_per_gpu": expected_rate(cores_per_rank),
                        "host_cpu_ms_per_unit": round(1e3 * host_cpu_s / max(1, (hi - lo) * args.steps), 2),
                        "units_proven_in_process": int(sum(pr.units_done)),
                        "host_split": host_split},

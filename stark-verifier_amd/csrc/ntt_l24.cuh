@@ -388,6 +388,121 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Round 6 experiment: the split-exchange row pass with the NEXT row fetched by LDS-DMA (global_load_lds_dwordx4: global -> LDS without passing
+// through registers) while this row is transformed.  The register-staged prefetch of round 3 / 5 cost 16 VGPRs and with them the kernel's occupancy
+// (profiles/r05_ubench_ntt_l24s.txt: 0.66-0.70 ms against 0.56); a DMA costs none, only 32 KB of LDS for the raw row next to the 33-KB tile
+// (2 blocks per CU either way).  Persistent blocks walk rows blockIdx, blockIdx + grid, ...  Every barrier is a raw s_barrier behind lgkmcnt(0):
+// __syncthreads() would drain the DMA in flight (its fence waits vmcnt(0)).  One vector-memory counter orders everything: at the top of an
+// iteration the row's four DMA pieces per wave are older than the previous row's eight stores, so vmcnt(8) retires exactly them; the barrier that
+// follows makes the other waves' pieces visible.  The DMA of row r + 1 is issued behind the first barrier of row r, when every thread has read
+// its elements of row r out of the raw buffer.  Same cells, same arithmetic, same output as ntt_rows_l24s_kernel.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr size_t L24D_ROWS_LDS_BYTES = 0;      // static LDS: (4096 + 64) * 8 + 4096 * 8 = 66 048 B
+#define GL355_L24D_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <int WPE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_rows_l24d_kernel(PassArgs a) {
+    // two DISTINCT LDS objects: the compiler orders a ds access behind an LDS-DMA in flight unless it can prove they do not alias, and inside one
+    // dynamic array it cannot (it then waits vmcnt(0) in front of every tile access, i.e. right behind the DMA's issue)
+    __shared__ __attribute__((aligned(16))) uint64_t lds_raw[4096 + 64];
+    __shared__ __attribute__((aligned(16))) uint64_t raw[4096];
+    int2* lp = reinterpret_cast<int2*>(lds_raw);
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const uint64_t total_rows = ((uint64_t)a.batch) << a.log_rows;
+    const uint32_t cA1 = 65 * w + lane, cA2 = 520 * w + lane, cB1 = 65 * lane + w, cB2 = 65 * lane + 8 * w, cST = tid + w;
+    auto row_ptr = [&](uint64_t row, const uint64_t* base, uint64_t stride) {
+        const uint64_t col = row >> a.log_rows, rin = row & ((1ull << a.log_rows) - 1);
+        return base + col * stride + (rin << 12);
+    };
+    typedef __attribute__((address_space(3))) void* lds_vptr;
+    typedef const __attribute__((address_space(1))) void* glb_vptr;
+    // wave w fetches elements [512 w, 512 w + 512) of the row as four 1-KB pieces: lane l of piece j brings elements 512 w + 128 j + 2 l, + 1
+    auto dma_row = [&](const uint64_t* rowp) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t e0 = 512 * w + 128 * j;
+            __builtin_amdgcn_global_load_lds((glb_vptr)(rowp + e0 + 2 * lane), (lds_vptr)(raw + e0), 16, 0, 0);
+        }
+    };
+    uint64_t row = blockIdx.x;
+    const uint32_t tid8 = tid * 8;
+    const uint32_t raw_addr = (uint32_t)(uintptr_t)(lds_vptr)raw + tid8;      // LDS byte address of this thread's first element
+    // the eight mid twiddles of a thread are the same for every row: held in registers by the persistent block (the LDS limit of two blocks per CU
+    // leaves 128 VGPRs per lane; a load inside the loop would be waited for with vmcnt(0) and drain the DMA in flight)
+    uint64_t tw[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) tw[s] = a.mid[64 * (8 * w + s) + lane];
+    if (row < total_rows) dma_row(row_ptr(row, a.in, a.in_col_stride));
+    bool first = true;
+    while (row < total_rows) {
+        const uint64_t next = row + gridDim.x;
+        // this row's DMA pieces have landed (they are older than the previous row's 8 stores), then everybody's
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        first = false;
+        GL355_L24D_BARRIER();
+        L24 y[8], z[8];
+        {
+            // the raw row through ds_read_b64 written out: as C loads the compiler orders them behind "the DMA that may still be in flight" with a
+            // vmcnt(0) of its own, which would also wait for the previous row's stores
+            uint64_t x[8];
+            asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:4096\n\tds_read_b64 %2, %8 offset:8192\n\tds_read_b64 %3, %8 offset:12288\n\t"
+                         "ds_read_b64 %4, %8 offset:16384\n\tds_read_b64 %5, %8 offset:20480\n\tds_read_b64 %6, %8 offset:24576\n\tds_read_b64 %7, %8 offset:28672\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]) : "v"(raw_addr) : "memory");
+#pragma unroll
+            for (int q = 0; q < 8; q++) y[q] = l24_split(x[q]);
+        }
+        dif8_l24<false>(y);
+        l24_twiddles_r<6, false>(y, w);
+#pragma unroll
+        for (int q = 0; q < 8; q++) lp[cA1 + 520 * q] = make_int2(y[q].l[0], y[q].l[1]);
+        GL355_L24D_BARRIER();                                  // the raw row has been consumed by every thread
+        if (next < total_rows) dma_row(row_ptr(next, a.in, a.in_col_stride));
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const int2 t = lp[cA2 + 65 * r]; z[r].l[0] = t.x; z[r].l[1] = t.y; }
+        GL355_L24D_BARRIER();
+#pragma unroll
+        for (int q = 0; q < 8; q++) lp[cA1 + 520 * q] = make_int2(y[q].l[2], y[q].l[3]);
+        GL355_L24D_BARRIER();
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const int2 t = lp[cA2 + 65 * r]; z[r].l[2] = t.x; z[r].l[3] = t.y; }
+        dif8_l24<false>(z);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            lds_raw[cA2 + 65 * s] = gl_mul(l24_value(z[s]), tw[s]);
+            if (s & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        GL355_L24D_BARRIER();
+#pragma unroll
+        for (int q = 0; q < 8; q++) y[q] = l24_split(lds_raw[cB1 + 8 * q]);
+        dif8_l24<false>(y);
+        l24_twiddles_r<6, false>(y, w);
+#pragma unroll
+        for (int q = 0; q < 8; q++) lp[cB1 + 8 * q] = make_int2(y[q].l[0], y[q].l[1]);
+        GL355_L24D_BARRIER();
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const int2 t = lp[cB2 + r]; z[r].l[0] = t.x; z[r].l[1] = t.y; }
+        GL355_L24D_BARRIER();
+#pragma unroll
+        for (int q = 0; q < 8; q++) lp[cB1 + 8 * q] = make_int2(y[q].l[2], y[q].l[3]);
+        GL355_L24D_BARRIER();
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const int2 t = lp[cB2 + r]; z[r].l[2] = t.x; z[r].l[3] = t.y; }
+        dif8_l24<false>(z);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            lds_raw[cB2 + s] = gl_canon(l24_value(z[s]));
+            if (s & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        GL355_L24D_BARRIER();
+        const __amdgpu_buffer_rsrc_t rout = l24_row_rsrc(row_ptr(row, a.out, a.out_col_stride));
+#pragma unroll
+        for (int q = 0; q < 8; q++) l24_row_store(rout, tid8, q, lds_raw[cST + 520 * q]);
+        row = next;
+        // (the next iteration's first barrier also frees the tile: every thread has read its store-order cells before it gets there)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Column pass of the LDE over all cosets (the shape of ntt_cols_r8_cosets_kernel<5>): 32 rows x 128 columns per tile, 32 = 8 x 4 with
 // omega_32 = 2^78 shift twiddles between the radix-8 and the radix-4 round, the 4-step twiddle (a.step_full) at the store.  Threads
 // tid >> 7 = r are wave-uniform.  A thread stores to the same eight places with the same step twiddles for every coset: they are loaded
