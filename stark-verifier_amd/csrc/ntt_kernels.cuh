@@ -253,6 +253,18 @@ struct PassArgs {
     uint32_t canon;            // canonicalise at store (last pass)
 };
 
+// coset_slot[c] inside a coset loop WITHOUT a memory access (round 6).  Indexed by the loop counter the byte array is read from the kernel-argument
+// segment by a vector load, and the s_waitcnt vmcnt(0) in front of its use also waits for every store of the previous coset: the all-cosets column
+// kernels drained their store queue eight times per tile (the "missing overlap" of DESIGN 4.1).  The sixteen bytes are taken once, as two scalars.
+struct CosetSlots { uint64_t lo, hi; };
+GL_DEV CosetSlots coset_slots_of(const PassArgs& a) {
+    CosetSlots s;
+    __builtin_memcpy(&s.lo, a.coset_slot, 8);
+    __builtin_memcpy(&s.hi, a.coset_slot + 8, 8);
+    return s;
+}
+GL_DEV uint32_t coset_slot_at(const CosetSlots& s, uint32_t c) { return (uint32_t)(((c < 8 ? s.lo : s.hi) >> (8 * (c & 7))) & 0xffu); }
+
 // radix-8 commit-path kernels, compiled in ntt_r8.hip
 hipError_t launch_rows_r8(const PassArgs& a, uint32_t log_t, bool inv, hipStream_t s);
 hipError_t launch_cols_r8(const PassArgs& a, uint32_t log_t, bool inv, hipStream_t s);
@@ -660,6 +672,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
         const uint64_t gi = ((uint64_t)(g >> LOG_TC) << log_n2) + c0 + (g & (TC - 1));
         v[i] = gl_mul(in[gi], a.pre_full[gi]);
     }
+    const CosetSlots slots = coset_slots_of(a);
     for (uint32_t c = 0; c < a.n_cosets; c++) {
         if (c) {        // the ratio table is re-read per coset (L2-resident, coalesced) rather than held: 16 VGPRs less, no spills
 #pragma unroll
@@ -668,7 +681,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
                 v[i] = gl_mul(v[i], a.ratio_full[((uint64_t)(g >> LOG_TC) << log_n2) + c0 + (g & (TC - 1))]);
             }
         }
-        uint64_t* out = a.out + (uint64_t)a.coset_slot[c] * a.coset_out_stride + col * a.out_col_stride;
+        uint64_t* out = a.out + (uint64_t)coset_slot_at(slots, c) * a.coset_out_stride + col * a.out_col_stride;
         auto store = [&](uint32_t g, uint64_t val) {
             const uint64_t go = ((uint64_t)(g >> LOG_TC) << log_n2) + c0 + (g & (TC - 1));
             out[go] = gl_mul(val, a.step_full[go]);

@@ -533,12 +533,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
     for (int t2 = 0; t2 < 2; t2++)
 #pragma unroll
         for (int k = 0; k < 4; k++) step[4 * t2 + k] = a.step_full[((uint64_t)(4 * (r + 4 * t2) + k) << log_n2) + c0 + cc];
+    const CosetSlots slots = coset_slots_of(a);
     for (uint32_t c = 0; c < a.n_cosets; c++) {
         if (c) {        // the ratio table is re-read per coset (L2-resident, coalesced) rather than held: 16 VGPRs less, no spills
 #pragma unroll
             for (int q = 0; q < 8; q++) v[q] = gl_mul(v[q], a.ratio_full[((uint64_t)(r + 4 * q) << log_n2) + c0 + cc]);
         }
-        uint64_t* out = a.out + (uint64_t)a.coset_slot[c] * a.coset_out_stride + col * a.out_col_stride;
+        uint64_t* out = a.out + (uint64_t)coset_slot_at(slots, c) * a.coset_out_stride + col * a.out_col_stride;
         L24 y[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) y[q] = l24_split(v[q]);
@@ -615,13 +616,14 @@ __global__ void __launch_bounds__(4 << LOG_TC) __attribute__((amdgpu_waves_per_e
 #pragma unroll
         for (int k = 0; k < 4; k++) step[4 * t2 + k] = l24_buf_load(rs_step, vst, (16 * t2 + k) * row_bytes);
     const uint32_t c_begin = MODE == 2 ? blockIdx.y : 0, c_end = MODE == 2 ? blockIdx.y + 1 : a.n_cosets;
+    const CosetSlots slots = coset_slots_of(a);
     for (uint32_t c = c_begin; c < c_end; c++) {
         if (c != c_begin) {
 #pragma unroll
             for (int q = 0; q < 8; q++) v[q] = gl_mul(v[q], MODE == 1 ? ratio[q] : l24_buf_load(rs_ratio, vld, 4 * q * row_bytes));
             __syncthreads();                                // the previous coset's hi pairs have been read
         }
-        const __amdgpu_buffer_rsrc_t rs_out = l24_buf_rsrc(a.out + (uint64_t)a.coset_slot[c] * a.coset_out_stride + col * a.out_col_stride, n_bytes);
+        const __amdgpu_buffer_rsrc_t rs_out = l24_buf_rsrc(a.out + (uint64_t)coset_slot_at(slots, c) * a.coset_out_stride + col * a.out_col_stride, n_bytes);
         L24 y[8], z[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) y[q] = l24_split(v[q]);
@@ -678,12 +680,13 @@ __global__ void __launch_bounds__(256) ntt_cols_small_cosets_kernel(PassArgs a) 
         ratio[k] = a.ratio_full[gi];
         step[k] = a.step_full[gi];
     }
+    const CosetSlots slots = coset_slots_of(a);
     for (uint32_t c = 0; c < a.n_cosets; c++) {
         if (c) {
 #pragma unroll
             for (int k = 0; k < T; k++) v[k] = gl_mul(v[k], ratio[k]);
         }
-        uint64_t* out = a.out + (uint64_t)a.coset_slot[c] * a.coset_out_stride + col * a.out_col_stride + i2;
+        uint64_t* out = a.out + (uint64_t)coset_slot_at(slots, c) * a.coset_out_stride + col * a.out_col_stride + i2;
         uint64_t y[T];
         if constexpr (LOG_T == 1) {
             y[0] = gl_add(v[0], v[1]); y[1] = gl_sub(v[0], v[1]);
