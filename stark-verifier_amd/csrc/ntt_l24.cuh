@@ -388,6 +388,66 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE)))
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Round 6 experiment: the limb-QUAD row pass (16-byte cells, 65-KB tile, 5 barriers per row) as ONE ROW PER BLOCK -- the quad kernel above is
+// persistent with a register-staged prefetch (128 VGPRs); this is its arithmetic and exchange pattern with the launch shape of the shipped
+// split-exchange kernel (fresh blocks, no prefetch): two blocks per CU either way (LDS here, registers there), 3 barriers fewer per row.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int WPE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE))) ntt_rows_l24q_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_raw[];
+    int4* lq = reinterpret_cast<int4*>(lds_raw);
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    auto put = [&](uint32_t cell, const L24& v) { lq[cell] = make_int4(v.l[0], v.l[1], v.l[2], v.l[3]); };
+    auto get = [&](uint32_t cell) { const int4 q = lq[cell]; L24 v; v.l[0] = q.x; v.l[1] = q.y; v.l[2] = q.z; v.l[3] = q.w; return v; };
+    auto put8 = [&](uint32_t cell, uint64_t v) { lds_raw[2 * cell] = v; };
+    auto get8 = [&](uint32_t cell) { return lds_raw[2 * cell]; };
+    const uint32_t cA1 = 65 * w + lane, cA2 = 520 * w + lane, cB1 = 65 * lane + w, cB2 = 65 * lane + 8 * w, cST = tid + w;
+    const uint64_t row = blockIdx.x;
+    const uint64_t col = row >> a.log_rows, rin = row & ((1ull << a.log_rows) - 1);
+    const uint32_t tid8 = tid * 8;
+    const __amdgpu_buffer_rsrc_t rs_in = l24_row_rsrc(a.in + col * a.in_col_stride + (rin << 12));
+    L24 y[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) y[q] = l24_split(l24_row_load(rs_in, tid8, q));
+    dif8_l24<false>(y);
+    l24_twiddles_r<6, false>(y, w);
+#pragma unroll
+    for (int q = 0; q < 8; q++) put(cA1 + 520 * q, y[q]);
+    uint64_t tw[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) tw[s] = a.mid[64 * (8 * w + s) + lane];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; r++) y[r] = get(cA2 + 65 * r);
+    dif8_l24<false>(y);
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        put8(cA2 + 65 * s, gl_mul(l24_value(y[s]), tw[s]));
+        if (s & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; q++) y[q] = l24_split(get8(cB1 + 8 * q));
+    dif8_l24<false>(y);
+    l24_twiddles_r<6, false>(y, w);
+#pragma unroll
+    for (int q = 0; q < 8; q++) put(cB1 + 8 * q, y[q]);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; r++) y[r] = get(cB2 + r);
+    dif8_l24<false>(y);
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        put8(cB2 + s, gl_canon(l24_value(y[s])));
+        if (s & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs_out = l24_row_rsrc(a.out + col * a.out_col_stride + (rin << 12));
+#pragma unroll
+    for (int q = 0; q < 8; q++) l24_row_store(rs_out, tid8, q, get8(cST + 520 * q));
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Round 6 experiment: the split-exchange row pass with the NEXT row fetched by LDS-DMA (global_load_lds_dwordx4: global -> LDS without passing
 // through registers) while this row is transformed.  The register-staged prefetch of round 3 / 5 cost 16 VGPRs and with them the kernel's occupancy
 // (profiles/r05_ubench_ntt_l24s.txt: 0.66-0.70 ms against 0.56); a DMA costs none, only 32 KB of LDS for the raw row next to the 33-KB tile

@@ -85,6 +85,22 @@ int main(int argc, char** argv) {
             printf("rows l24d (LDS-DMA) g=%-5u %.3f ms  %.0f GB/s moved\n", g, td, gb / td * 1e3);
         }
     }
+    {   // the limb-quad exchange, one row per block (65-KB tile, 5 barriers)
+        PassArgs qa = a; qa.out = o2;
+        CK(hipMemset(o2, 0, batch * N * 8)); CK(hipMemset(bad, 0, 8));
+        auto run_q = [&](auto kq, const char* name) {
+            CK(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L24_ROWS_LDS_BYTES));
+            hipLaunchKernelGGL(kq, dim3(rows), dim3(512), L24_ROWS_LDS_BYTES, 0, qa);
+            CK(hipMemset(bad, 0, 8));
+            hipLaunchKernelGGL(diff_kernel, dim3(2048), dim3(256), 0, 0, o1, o2, batch * N, bad);
+            CK(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
+            float tq = timeit([&] { hipLaunchKernelGGL(kq, dim3(rows), dim3(512), L24_ROWS_LDS_BYTES, 0, qa); }, 200);
+            printf("rows %s (quad cells, one row per block)  %.3f ms  %.0f GB/s moved   vs l24s: %llu words differ\n", name, tq, gb / tq * 1e3, hb);
+        };
+        run_q(ntt_rows_l24q_kernel<4>, "l24q wpe4");
+        run_q(ntt_rows_l24q_kernel<5>, "l24q wpe5");
+        run_q(ntt_rows_l24q_kernel<3>, "l24q wpe3");
+    }
     // in the LDE: column pass then row pass, per pair
     PassArgs c; memset(&c, 0, sizeof c);
     c.in = cin; c.out = in; c.in_col_stride = n; c.out_col_stride = N; c.batch = batch; c.n_cosets = 8; c.coset_out_stride = n;
