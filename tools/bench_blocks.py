@@ -148,10 +148,12 @@ def lde_floors(alg_bytes, clk):
     for name, e in d["kernels"].items():
         import bench_common
         model = bench_common.VALU_MODEL
-        forms = model.dynamic_forms(name) if model else None
+        n64, n32 = e.get("SQ_INSTS_VALU_INT64"), e.get("SQ_INSTS_VALU_INT32")
+        forms = (model.dynamic_forms(name, 1.0, n64 / e["SQ_INSTS_VALU"], n32 / e["SQ_INSTS_VALU"]) if n64 is not None and n32 is not None
+                 else model.dynamic_forms(name)) if model else None
         if not forms:
             continue
-        add, fl, _ = model.cycles(forms)                   # per instruction (the forms are fractions)
+        add, fl, _ = model.cycles(forms)                   # per instruction (the forms are fractions; moved to the counters' dynamic class shares)
         cost = fl or add
         valu_ms = e["SQ_INSTS_VALU"] * cost / (N_SIMD * clk["mean_mhz"] * 1e6) * 1e3
         mem_ms = e["hbm_bytes_per_launch"] / copy_peak * 1e3

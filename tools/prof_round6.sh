@@ -28,7 +28,7 @@ if [ $WHAT = lde ] || [ $WHAT = all ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d $O/ldepmc_$c -- python tools/prof_lde.py > /dev/null 2> $O/ldepmc_$c.err
   done
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/ldepmc_sq -- python tools/prof_lde.py > /dev/null 2> $O/ldepmc_sq.err
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/ldepmc_sq -- python tools/prof_lde.py > /dev/null 2> $O/ldepmc_sq.err
 fi
 python - <<'PY'
 import csv, glob, os, collections, shutil
