@@ -384,6 +384,9 @@ GL_DEV void dif_last_round_sink(const uint64_t* lds, int LO, int tid, int nthrea
     constexpr int R = 1 << RHO;
     const int tasks = (1 << LT) >> RHO;
     const int fbit = LO;
+    // unrolled (the trip count is a compile-time constant at every call site: a radix-2 / radix-4 last round is 4 / 2 trips): rolled, every trip's
+    // table loads in the sink were issued and waited for behind the previous trip's stores -- one exposed load latency per trip (round 6)
+#pragma unroll
     for (int t = tid; t < tasks; t += nthreads) {
         const uint32_t low = t & ((1u << fbit) - 1), high = t >> fbit;
         const uint32_t idx0 = (high << (fbit + RHO)) | low;
@@ -396,6 +399,47 @@ GL_DEV void dif_last_round_sink(const uint64_t* lds, int LO, int tid, int nthrea
         }
 #pragma unroll
         for (int q = 0; q < R; q++) sink(idx0 + ((uint32_t)q << fbit), x[q]);
+    }
+}
+// The same with a TABLE WORD per output (the 4-step twiddle applied at the store): fetch(tile index) for all of a thread's outputs first, then the
+// network and the stores.  Written as `out[go] = v * table[go]` inside the sink, every table load sat behind the previous output's store (the
+// compiler cannot prove that `out` and the table do not alias) and was waited for with vmcnt(0), which also drains that store: eight exposed load
+// latencies per thread and tile (round 6; the all-cosets column kernels always held their eight step words in registers).
+template <int LT, int RHO, bool INV, int PAD, class Fetch, class Sink>
+GL_DEV void dif_last_round_sink_tab(const uint64_t* lds, int LO, int tid, int nthreads, Fetch fetch, Sink sink) {
+    constexpr int R = 1 << RHO;
+    const int tasks = (1 << LT) >> RHO;
+    const int fbit = LO;
+    constexpr int MAXW = 16;                                 // table words a thread holds at once
+    uint64_t w[MAXW];
+    const int trips = (tasks + nthreads - 1) / nthreads;     // compile-time at every call site
+    const bool all_first = trips * R <= MAXW;
+    if (all_first) {
+#pragma unroll
+        for (int k = 0; k < MAXW / R; k++) {
+            const int t = tid + k * nthreads;
+            if (k < trips && t < tasks) {
+                const uint32_t idx0 = ((uint32_t)(t >> fbit) << (fbit + RHO)) | (t & ((1u << fbit) - 1));
+#pragma unroll
+                for (int q = 0; q < R; q++) w[k * R + q] = fetch(idx0 + ((uint32_t)q << fbit));
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < (all_first ? MAXW / R : 64); k++) {
+        const int t = tid + k * nthreads;
+        if (k >= trips || t >= tasks) break;
+        const uint32_t low = t & ((1u << fbit) - 1), high = t >> fbit;
+        const uint32_t idx0 = (high << (fbit + RHO)) | low;
+        uint64_t x[16], wk[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) wk[q] = all_first ? w[(k * R + q) % MAXW] : fetch(idx0 + ((uint32_t)q << fbit));
+#pragma unroll
+        for (int q = 0; q < R; q++) x[q] = lds[lds_phys_t<PAD>(idx0 + ((uint32_t)q << fbit))];
+        if constexpr (GL355_NTT_R8_LAZY != 0 && RHO == 3) dif8_lazy<INV>(x);
+        else dif_regs<RHO, INV>(x);
+#pragma unroll
+        for (int q = 0; q < R; q++) sink(idx0 + ((uint32_t)q << fbit), x[q], wk[q]);
     }
 }
 // rounds between a register-fed first round and (KEEP_LAST) a sunk last round; x holds the thread's 8 loaded elements
@@ -574,7 +618,12 @@ __global__ void __launch_bounds__(LT == 12 ? 512 : 1024) __attribute__((amdgpu_w
             if constexpr (PRE && !(GL355_NTT_KO & 32)) x[i] = gl_mul(x[i], (GL355_NTT_KO & 16) ? gi + 3 : pre[gi]);
         }
         dif_tile_r8_regs<LT, LOG_T, INV, true>(x, lds, a.tw_r8, LOG_TC, tid, NT);
-        dif_last_round_sink<LT, R8Last<LOG_T>::RHO, INV>(lds, LOG_TC, tid, NT, store);
+        if constexpr (GL355_NTT_KO & (16 | 32 | 64)) dif_last_round_sink<LT, R8Last<LOG_T>::RHO, INV>(lds, LOG_TC, tid, NT, store);
+        else {
+            auto addr = [&](uint32_t g) { return ((uint64_t)(g >> LOG_TC) << log_n2) + c0 + (g & (TC - 1)); };
+            dif_last_round_sink_tab<LT, R8Last<LOG_T>::RHO, INV, 0>(lds, LOG_TC, tid, NT, [&](uint32_t g) { return a.step_full[addr(g)]; },
+                                                                   [&](uint32_t g, uint64_t v, uint64_t w) { out[addr(g)] = gl_mul(v, w); });
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < EPT; i++) {
@@ -631,12 +680,18 @@ __global__ void __launch_bounds__(1 << (LT - 3)) __attribute__((amdgpu_waves_per
     if constexpr (PASS == 0) {
         dif_tile_r8_regs<LT, LOG_T, false, false, 1>(x, lds, a.tw_r8, LOG_TC, tid, NT);
         // out[(c0 + cc) * N1 + k1] = tile[bitrev(k1)][cc] * omega^(k1 (c0 + cc)): lanes run over k1
+        uint64_t sw[8];                      // the eight step words first: a load behind a store waits for that store (see dif_last_round_sink_tab)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t g = tid + i * NT;
+            sw[i] = a.step_full[((c0 + (g >> LOG_T)) << LOG_T) + (g & ((1u << LOG_T) - 1))];
+        }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const uint32_t g = tid + i * NT;
             const uint32_t k1 = g & ((1u << LOG_T) - 1), cc = g >> LOG_T;
             const uint64_t go = ((c0 + cc) << LOG_T) + k1;
-            out[go] = gl_mul(lds[lds_phys_t<1>((brev(k1, LOG_T) << LOG_TC) | cc)], a.step_full[go]);
+            out[go] = gl_mul(lds[lds_phys_t<1>((brev(k1, LOG_T) << LOG_TC) | cc)], sw[i]);
         }
     } else {
         auto store = [&](uint32_t g, uint64_t v) {

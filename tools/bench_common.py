@@ -152,7 +152,7 @@ def valu_costs(form_counts, ops, pairs=None):
     iso = {f: v["clk"] for f, v in ops.items() if v.get("clk")}
     cheapest = min(iso.values())
     cls_iso = {c: iso[f] for c, f in PAIR_FORM_OF_CLASS.items() if f in iso}
-    n_cls, add, unprobed = {}, 0.0, 0.0
+    n_cls, c_cls, add, unprobed = {}, {}, 0.0, 0.0
     for f, n in form_counts.items():
         if n <= 0:
             continue
@@ -163,6 +163,7 @@ def valu_costs(form_counts, ops, pairs=None):
             c, cls = cheapest, "mov_b32"
         add += n * c
         n_cls[cls] = n_cls.get(cls, 0.0) + n
+        c_cls[cls] = c_cls.get(cls, 0.0) + n * c          # an unmatched instruction costs what its OWN form costs alone
     if not pairs:
         return add, None, unprobed
     try:
@@ -175,10 +176,10 @@ def valu_costs(form_counts, ops, pairs=None):
     for i, a in enumerate(classes):
         for b in classes[i + 1:]:
             t = pairs.get("%s+%s" % (a, b), pairs.get("%s+%s" % (b, a)))
-            if t is not None and a in cls_iso and b in cls_iso and t < cls_iso[a] + cls_iso[b]:
+            if t is not None and a in cls_iso and b in cls_iso and t < c_cls[a] / n_cls[a] + c_cls[b] / n_cls[b]:
                 var.append((a, b)); cost.append(t)
     for a in classes:
-        var.append((a, None)); cost.append(min(cls_iso.get(a, cheapest), cheapest if a not in cls_iso else cls_iso[a]))
+        var.append((a, None)); cost.append(c_cls[a] / n_cls[a])
     A = [[0.0] * len(var) for _ in classes]
     for k, (a, b) in enumerate(var):
         A[idx[a]][k] = 1.0
