@@ -1,10 +1,10 @@
 """The reference's own group-size sweep (src/plonky2_semaphore/access_set.rs:193-215: `for pow in 20..26` -- private keys, public keys =
-hash_no_pad(sk | 0^4), AccessSet(MerkleTree::new(public_keys, 0)), then test_membership_proof(private_keys[12], 12)) at its LARGEST size and one
-intermediate size (2^20 is tests/test_gpu_large.py):
-  * 2^23 and 2^25 members: every public key, every digest of the plonky2-layout `digests` buffer and the root against the oracle
+hash_no_pad(sk | 0^4), AccessSet(MerkleTree::new(public_keys, 0)), then test_membership_proof(private_keys[12], 12)) at its LARGEST size and at
+every intermediate size (2^20 is tests/test_gpu_large.py):
+  * 2^21 ... 2^25 members: every public key, every digest of the plonky2-layout `digests` buffer and the root against the oracle
     (33.5 M + 33.5 M permutations at 2^25), Merkle paths through gl355_merkle_prove against the oracle's MerkleTree::prove and its verifier;
-  * the depth-25 make_signal proof (access_set.rs:61-104) byte-identical to the CPU restatement of prove() (oracle/gl_prover.c), accepted by the
-    restated reference verifier (tests/plonk_verifier.py) and equal to the committed digest tests/golden/semaphore_depth25.json.
+  * the make_signal proof of every depth 21 ... 25 (access_set.rs:61-104) byte-identical to the CPU restatement of prove() (oracle/gl_prover.c), accepted by the
+    restated reference verifier (tests/plonk_verifier.py) and equal to the committed digest tests/golden/semaphore_depth25.json (depth 25).
 All through the C ABI, tolerance zero."""
 import importlib
 import json
@@ -56,13 +56,29 @@ def check_group(gl, ctx, orc, sks, keys_want, dig_want, root_want):
     return keys, t
 
 
-def test_group_2p23_keys_tree_paths(gl, ctx, orc):
+@pytest.mark.parametrize("log_members", [21, 22, 23, 24])
+def test_group_sweep_keys_tree_paths_and_signal(gl, ctx, orc, log_members):
+    """every intermediate size of the reference's loop `for pow in 20..26` (2^20 is tests/test_gpu_large.py, 2^25 below): the group in full against the
+    oracle, then test_membership_proof(private_keys[12], 12) -- the make_signal proof of that depth byte-identical to the CPU restatement of prove() and
+    accepted by the restated reference verifier"""
     orc.L.orc_set_num_threads(host_threads())
-    rng = np.random.default_rng(0x23D)
-    sks = rand_field(rng, (1 << 23, 4))
-    keys_want = orc.merkle_build(np.concatenate([sks, np.zeros_like(sks)], axis=1), 23)[1]
-    dig_want, cap_want = orc.merkle_build(keys_want, 0)
-    check_group(gl, ctx, orc, sks, keys_want, dig_want, cap_want[0])
+    case = cs.build_case(orc, log_members, 0x23D + log_members)
+    keys, tree = check_group(gl, ctx, orc, case["sks"], case["keys"], case["digests"], case["root"])
+    sem = importlib.import_module("stark-verifier_amd.semaphore")
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    aset = sem.AccessSet(ctx, keys)
+    assert aset.tree_height() == log_members
+    data, rows = aset.build(None)
+    topic = rand_field(case["rng"], 4)
+    idx, vals, pi = aset.witness_rows(rows, case["sks"][12], topic, 12)
+    cidx, cvals, cpi = cs.witness(orc, case, 12, topic)
+    eq(vals, cvals); eq(pi, cpi)
+    flat = plonk.prove_sparse(ctx, data, idx, vals, pi, 0x5EED + log_members, flat_only=True)
+    eq(flat, case["cpu"].prove_sparse(cidx, cvals, cpi, 0x5EED + log_members))
+    proof = plonk.parse_proof(data, flat)
+    proof["public_inputs"] = pi
+    pv.verify(orc, data.common(), proof)
+    eq(pi[:4], case["root"])
 
 
 @pytest.fixture(scope="module")
