@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 import cpu_semaphore as cs
+import cpu_unit as cu
 import plonk_verifier as pv
 from oracle_lib import rand_field
 
@@ -139,3 +140,31 @@ def test_signal_depth25_byte_identical_and_golden(gl, ctx, orc, group25):
     pv.verify(orc, data.common(), proof2)
     eq(pi2[:4], pi[:4])
     assert not np.array_equal(pi2[4:8], pi[4:8])
+
+
+def test_recursive_proof_over_the_depth25_signal(gl, ctx, orc, group25):
+    """the second half of a unit at the top of the sweep: the recursive proof (wrapper.rs:35-56 over the Poseidon-Goldilocks config) that verifies the
+    depth-25 signal in-circuit -- GPU proof == CPU restatement of prove() byte for byte, accepted by the restated reference verifier, and it re-exposes
+    the signal's root | nullifier | topic"""
+    case = group25
+    g = cs.GROUP25_CASE
+    sem = importlib.import_module("stark-verifier_amd.semaphore")
+    plonk = importlib.import_module("stark-verifier_amd.plonk")
+    rec = importlib.import_module("stark-verifier_amd.recursion")
+    topic = case.get("topic")
+    if topic is None:
+        topic = case["topic"] = rand_field(case["rng"], 4)
+    cidx, cvals, cpi = cs.witness(orc, case, g["member"], topic)
+    flat = case["cpu"].prove_sparse(cidx, cvals, cpi, g["proof_seed"])            # == the GPU proof (previous test)
+    rc = rec.RecursiveCircuit(ctx, case["data"].common(), k=1).build([(flat, cpi)], np.random.default_rng(5))
+    got, gpis = rc.prove_flat([(flat, cpi)], 0x25F)
+    crc = cu.recursive_cpu_circuit(orc, case["data"].common(), flat, cpi)
+    eq(crc["data"].circuit_digest, rc.data.circuit_digest)
+    rows, cpis = cu.replay(crc, np.concatenate([flat, cpi]))
+    eq(gpis, cpis)
+    eq(got, crc["cpu"].prove_sparse(crc["row_idx"], rows, cpis, 0x25F))
+    proof = plonk.parse_proof(rc.data, got)
+    proof["public_inputs"] = gpis
+    pv.verify(orc, rc.data.common(), proof)
+    eq(gpis[:4], case["root"])
+    eq(gpis[4:12], cpi[4:12])
