@@ -424,6 +424,7 @@ def main_recursive(args):
         roofline["hbm"] = {"bound": "hbm", "kernel": dname, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(dbytes / max(1, dcnt)),
                            "note": "secondary figure (SURVEY 8(d) asks for it): the dominant kernel is not HBM-bound"}
+        roofline["traffic"] = traffic          # HBM-side bytes per launch of the dominant kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per the guide); details in `hbm`
         roofline["gpu_ms_per_unit_all_kernels"] = round(sum(v[1] for v in iso.values()) / max(1, iso_units), 3)
         roofline["kernel_groups"] = groups(iso, iso_units, 10)
         roofline["timed_region_events"] = {"what": "the same scopes on 1 of the %d concurrent streams during the timed region "
