@@ -247,6 +247,82 @@ GL_DEV void gl_mul_multi(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_
 #undef GL_MM_NOP
 #undef GL_MM_SB
 }
+// ONE product (and a lock-step PAIR) whose carry wait states are filled by the CALLER's instructions (round 6): fill(k), k = 0 .. 4, is invoked between the
+// VALU instruction that writes a carry pair and the one that reads it and has to issue at least two (pair form: one) VALU instructions of its own.  For a lone
+// dependent chain with free issue slots -- the 16-lane permutation's partial rounds, whose S-box is on the critical path while the MDS row's multiply-adds
+// are independent of it -- this hides the fillers behind the chain instead of queueing them in front of it.  Same arithmetic as gl_mul_multi<1> / <2>;
+// tools/check_hazards.py checks the distances on the emitted ISA.
+template <class F>
+GL_DEV uint64_t gl_mul_fill(uint64_t a, uint64_t b, F&& fill) {
+#define GL_MF_SB() __builtin_amdgcn_sched_barrier(0)
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t t = (uint64_t)a0 * b0;
+    const uint64_t u = (uint64_t)a0 * b1 + (t >> 32);
+    uint64_t v, c, r;
+    uint32_t ch, x0, x1, m;
+    GL_MF_SB();
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(v), "=s"(c) : "v"(a1), "v"(b0), "v"(u)); GL_MF_SB();
+    fill(0); GL_MF_SB();
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(ch) : "s"(c)); GL_MF_SB();
+    const uint64_t w = (uint64_t)a1 * b1 + (((uint64_t)ch << 32) | (v >> 32)); GL_MF_SB();
+    asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(x0), "=s"(c) : "v"((uint32_t)t), "v"((uint32_t)(w >> 32))); GL_MF_SB();
+    fill(1); GL_MF_SB();
+    asm("v_subb_co_u32_e64 %0, %1, %2, 0, %1" : "=v"(x1), "+s"(c) : "v"((uint32_t)v)); GL_MF_SB();
+    fill(2); GL_MF_SB();
+    asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m) : "s"(c)); GL_MF_SB();
+    asm("v_sub_co_u32_e64 %0, %1, %0, %2" : "+v"(x0), "=s"(c) : "v"(m)); GL_MF_SB();
+    fill(3); GL_MF_SB();
+    asm("v_subb_co_u32_e64 %0, %1, %0, 0, %1" : "+v"(x1), "+s"(c)); GL_MF_SB();
+    const uint64_t x = ((uint64_t)x1 << 32) | x0;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(c) : "v"((uint32_t)w), "v"(x)); GL_MF_SB();
+    fill(4); GL_MF_SB();
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(m) : "s"(c)); GL_MF_SB();
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %0" : "+v"(r), "=s"(c) : "v"(m));
+    return r;
+}
+template <class F>
+GL_DEV void gl_mul2_fill(const uint64_t (&a)[2], const uint64_t (&b)[2], uint64_t (&r)[2], F&& fill) {
+    uint32_t a0[2], a1[2], b0[2], b1[2], ch[2], x0[2], x1[2], m[2];
+    uint64_t t[2], u[2], v[2], w[2], c[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) { a0[j] = (uint32_t)a[j]; a1[j] = (uint32_t)(a[j] >> 32); b0[j] = (uint32_t)b[j]; b1[j] = (uint32_t)(b[j] >> 32); }
+#pragma unroll
+    for (int j = 0; j < 2; j++) { t[j] = (uint64_t)a0[j] * b0[j]; u[j] = (uint64_t)a0[j] * b1[j] + (t[j] >> 32); }
+    GL_MF_SB();
+#pragma unroll
+    for (int j = 0; j < 2; j++) { asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(v[j]), "=s"(c[j]) : "v"(a1[j]), "v"(b0[j]), "v"(u[j])); GL_MF_SB(); }
+    fill(0); GL_MF_SB();
+#pragma unroll
+    for (int j = 0; j < 2; j++) { asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(ch[j]) : "s"(c[j])); GL_MF_SB(); }
+#pragma unroll
+    for (int j = 0; j < 2; j++) w[j] = (uint64_t)a1[j] * b1[j] + (((uint64_t)ch[j] << 32) | (v[j] >> 32));
+    GL_MF_SB();
+#pragma unroll
+    for (int j = 0; j < 2; j++) { asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(x0[j]), "=s"(c[j]) : "v"((uint32_t)t[j]), "v"((uint32_t)(w[j] >> 32))); GL_MF_SB(); }
+    fill(1); GL_MF_SB();
+#pragma unroll
+    for (int j = 0; j < 2; j++) { asm("v_subb_co_u32_e64 %0, %1, %2, 0, %1" : "=v"(x1[j]), "+s"(c[j]) : "v"((uint32_t)v[j])); GL_MF_SB(); }
+    fill(2); GL_MF_SB();
+#pragma unroll
+    for (int j = 0; j < 2; j++) { asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m[j]) : "s"(c[j])); GL_MF_SB(); }
+#pragma unroll
+    for (int j = 0; j < 2; j++) { asm("v_sub_co_u32_e64 %0, %1, %0, %2" : "+v"(x0[j]), "=s"(c[j]) : "v"(m[j])); GL_MF_SB(); }
+    fill(3); GL_MF_SB();
+#pragma unroll
+    for (int j = 0; j < 2; j++) { asm("v_subb_co_u32_e64 %0, %1, %0, 0, %1" : "+v"(x1[j]), "+s"(c[j])); GL_MF_SB(); }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const uint64_t x = ((uint64_t)x1[j] << 32) | x0[j];
+        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r[j]), "=s"(c[j]) : "v"((uint32_t)w[j]), "v"(x));
+        GL_MF_SB();
+    }
+    fill(4); GL_MF_SB();
+#pragma unroll
+    for (int j = 0; j < 2; j++) { asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(m[j]) : "s"(c[j])); GL_MF_SB(); }
+#pragma unroll
+    for (int j = 0; j < 2; j++) asm("v_mad_u64_u32 %0, %1, %2, -1, %0" : "+v"(r[j]), "=s"(c[j]) : "v"(m[j]));
+#undef GL_MF_SB
+}
 #else
 // host pass / compiler-scheduled product: one after the other
 template <int N>

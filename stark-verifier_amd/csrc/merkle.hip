@@ -117,16 +117,29 @@ __device__ __constant__ const uint32_t PSD_CIRC_DEV[12] = {17, 15, 41, 16, 2, 28
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  \
         __builtin_amdgcn_wave_barrier();                        \
     } while (0)
+// PSD_LANES_FORM (round 6): the 22 PARTIAL rounds of the 16-lane permutation.
+//   0  as the full rounds: S-box (only lane 0's matters), the state through the ring, the whole MDS row: S-box + LDS round trip + 24 multiply-adds +
+//      recombination, one after the other on the critical path;
+//   3  only element 0 changes in a partial round's S-box, so the other eleven elements go through the ring BEFORE it (lane 0 publishes a zero), and each
+//      lane's row over them is accumulated INSIDE lane 0's x^7: the row's twelve terms (two multiply-adds each) are the fillers of the products' carry
+//      wait states (gl_mul_fill / gl_mul2_fill) -- written any other way the compiler queues the row's multiply-adds as a block in front of the S-box
+//      chain (forms 1 and 2 of profiles/r06_lanes_partial_rounds_ab.txt: no gain).  x^7 then arrives by a DPP row broadcast (row_newbcast:0: one 16-lane
+//      row = one state) for the last two multiply-adds.
+// Form 3 is 16 % faster per permutation (tree tops 0.080 -> 0.067 ms, a lone unit 11.7 -> 11.0 ms) and costs 16 more VGPRs: under a lock-step load, where
+// these kernels share the CUs with the hash kernels of nine other contexts, the job measured 0.8 % SLOWER with it (320.8 vs 323.3 units/s) -- so the
+// launch code takes form 3 for a lone proof's forest (fewer than 64 cap subtrees) and form 0 for lock-step batches.  PSD_LANES_FORM = 0 / 3 forces one (A/B).
+#ifndef PSD_LANES_FORM
+#define PSD_LANES_FORM -1
+#endif
+template <int FORM>
 GL_DEV uint64_t psd_permute_lanes(uint64_t s, int li, uint64_t* ring /* 24 u64 of this 16-lane group */) {
     const bool active = li < 12;
     const int me = active ? li : 0;
     // the constant index depends on the lane, so this is a vector load: fetch round r+1's constant while round r
     // computes (a load issued and awaited inside the round costs an L2 round trip per round, ~40 % of the latency)
     s = gl_add_canonical(s, PSD_ALL_RC[me]);
-#pragma unroll 1
-    for (int r = 0; r < 30; r++) {
+    auto dense_round = [&](int r, bool full) {
         const uint64_t rc_next = PSD_ALL_RC[12 * (r + 1) + me];     // row 30 is zero; consumed by this round's MDS accumulators
-        const bool full = r < 4 || r >= 26;
         if (full || li == 0) s = psd_sbox(s);
         if (active) { ring[me] = s; ring[me + 12] = s; }
         GL_WAVE_LDS_SYNC();
@@ -140,11 +153,53 @@ GL_DEV uint64_t psd_permute_lanes(uint64_t s, int li, uint64_t* ring /* 24 u64 o
         }
         GL_WAVE_LDS_SYNC();
         s = psd_recombine(al, ah);
+    };
+#if !defined(__HIP_DEVICE_COMPILE__) || GL_MUL_VARIANT != 1
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) dense_round(r, r < 4 || r >= 26);
+#else
+    if constexpr (FORM == 0) {
+#pragma unroll 1
+        for (int r = 0; r < 30; r++) dense_round(r, r < 4 || r >= 26);
+        return s;
     }
+    // row `me`'s coefficient of element 0: M[me][0] = CIRC[(12 - me) % 12], + 8 on the diagonal
+    const uint32_t c_elem0 = PSD_CIRC_DEV[(12 - me) % 12] + (me == 0 ? 8u : 0u);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) dense_round(r, true);
+#pragma unroll 1
+    for (int r = 4; r < 26; r++) {
+        const uint64_t rc_next = PSD_ALL_RC[12 * (r + 1) + me];
+        if (active) { const uint64_t pub = li == 0 ? 0 : s; ring[me] = pub; ring[me + 12] = pub; }     // element 0 is added below, after its S-box
+        GL_WAVE_LDS_SYNC();
+        uint64_t xr[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) xr[j] = ring[me + j];
+        uint64_t al = (uint32_t)rc_next, ah = rc_next >> 32;
+        auto term = [&](int j) {                                   // one element of the row: two multiply-adds (the + 8 of row 0 belongs to element 0)
+            al += (uint64_t)(uint32_t)xr[j] * PSD_CIRC_DEV[j];
+            ah += (uint64_t)(uint32_t)(xr[j] >> 32) * PSD_CIRC_DEV[j];
+        };
+        // x^7 = (x x^2)(x^2 x^2), every lane computes it (lane 0's is the one used); terms 0 .. 11 ride in the carry wait states of its four products
+        const uint64_t x2 = gl_mul_fill(s, s, [&](int k) { term(k); });
+        uint64_t p34[2];
+        { const uint64_t pa[2] = {s, x2}, pb[2] = {x2, x2}; gl_mul2_fill(pa, pb, p34, [&](int k) { term(5 + k); }); }
+        const uint64_t x7 = gl_mul_fill(p34[0], p34[1], [&](int k) { if (k < 2) term(10 + k); else asm volatile("s_nop 1"); });
+        const uint32_t x0l = __builtin_amdgcn_update_dpp(0u, (uint32_t)x7, 0x150, 0xf, 0xf, false);           // row_newbcast:0
+        const uint32_t x0h = __builtin_amdgcn_update_dpp(0u, (uint32_t)(x7 >> 32), 0x150, 0xf, 0xf, false);
+        al += (uint64_t)x0l * c_elem0;
+        ah += (uint64_t)x0h * c_elem0;
+        GL_WAVE_LDS_SYNC();
+        s = psd_recombine(al, ah);
+    }
+#pragma unroll 1
+    for (int r = 26; r < 30; r++) dense_round(r, true);
+#endif
     return s;
 }
 
 // one 16-lane group = one parent node of layer `layer`; block = 64 threads = 4 nodes
+template <int FORM>
 __global__ void __launch_bounds__(64) merkle_level_lanes_kernel(uint64_t* digests, uint64_t* cap, uint32_t sub_bits,
                                                                uint32_t layer, uint64_t n_nodes) {
     __shared__ uint64_t rings[4][24];
@@ -158,7 +213,7 @@ __global__ void __launch_bounds__(64) merkle_level_lanes_kernel(uint64_t* digest
     uint64_t* tree = digests + t * 2 * (sub_leaves - 1) * 4;
     const uint64_t child = digest_slot(layer - 1, 2 * k);  // left child; the right one follows it
     uint64_t s = (li < 8) ? tree[child * 4 + li] : 0;
-    s = psd_permute_lanes(s, li, rings[grp]);
+    s = psd_permute_lanes<FORM>(s, li, rings[grp]);
     if (valid && li < 4) {
         uint64_t* dst = (layer == sub_bits) ? cap + t * 4 : tree + digest_slot(layer, k) * 4;
         dst[li] = gl_canon(s);
@@ -172,6 +227,7 @@ __global__ void __launch_bounds__(64) merkle_level_lanes_kernel(uint64_t* digest
 // lane-parallel launches (12.7 % of the kernel time of the 8-context profile between them); with eight levels a tree is leaf hashing,
 // its wide levels, and this.  Trees of at most 2^8 leaves per cap entry are built whole.  Waves whose groups have no node on a level skip it.
 #define MERKLE_TOP_LEVELS 8
+template <int FORM>
 __global__ void __launch_bounds__(1024) merkle_top_kernel(uint64_t* digests, uint64_t* cap, uint32_t sub_bits, uint32_t layer0, uint32_t n_levels) {
     __shared__ uint64_t rings[64][24];
     __shared__ uint64_t lvl[2][(1 << (MERKLE_TOP_LEVELS - 1)) * 4];
@@ -190,7 +246,7 @@ __global__ void __launch_bounds__(1024) merkle_top_kernel(uint64_t* digests, uin
                 const int j = valid ? base + grp : 0;
                 uint64_t s = 0;
                 if (li < 8) s = (l == 0) ? tree[digest_slot(layer - 1, 2 * (uint64_t)j) * 4 + li] : lvl[cur][(2 * j) * 4 + li];
-                s = psd_permute_lanes(s, li, rings[grp]);
+                s = psd_permute_lanes<FORM>(s, li, rings[grp]);
                 if (valid && li < 4) {
                     const uint64_t v = gl_canon(s);
                     lvl[cur ^ 1][j * 4 + li] = v;
@@ -339,6 +395,9 @@ int32_t merkle_build_args(Ctx* ctx, LeafArgs a, uint32_t sub_bits, uint64_t* dig
     // 17.6 ms); with a lock-step batch (>= 64 subtrees) the chip is full either way and four launches fewer per unit win
     // (profiles/r03_merkle_top_ab.txt).
     const uint32_t top_levels_max = (n_leaves >> sub_bits) < 64 ? 6 : MERKLE_TOP_LEVELS;
+    // a lone proof's forest (16 cap subtrees) is latency-bound: the partial rounds with the row inside the S-box (psd_permute_lanes<3>); a lock-step batch
+    // shares the chip with other contexts' hash kernels, where the 16 extra registers of that form cost more than its shorter chain gains
+    const bool fast_lanes = PSD_LANES_FORM < 0 ? (n_leaves >> sub_bits) < 64 : PSD_LANES_FORM == 3;
     uint32_t top_levels = std::min<uint32_t>(top_levels_max, sub_bits);
     while (top_levels > 1 && ((n_leaves >> (sub_bits - top_levels + 1)) > lanes_max)) top_levels--;      // a forest of many subtrees: fewer levels each
     uint32_t top_from = sub_bits + 1;
@@ -347,7 +406,8 @@ int32_t merkle_build_args(Ctx* ctx, LeafArgs a, uint32_t sub_bits, uint64_t* dig
         const uint64_t n_nodes = n_leaves >> layer;
         if (layer == top_from) {
             ProfScope ps(ctx, "merkle_top_kernel", (2 * n_nodes - (n_leaves >> sub_bits)) * 96);
-            hipLaunchKernelGGL(merkle_top_kernel, dim3((uint32_t)(n_leaves >> sub_bits)), dim3(1024), 0, ctx->stream, digests, cap, sub_bits, layer, top_levels);
+            if (fast_lanes) hipLaunchKernelGGL(merkle_top_kernel<3>, dim3((uint32_t)(n_leaves >> sub_bits)), dim3(1024), 0, ctx->stream, digests, cap, sub_bits, layer, top_levels);
+            else hipLaunchKernelGGL(merkle_top_kernel<0>, dim3((uint32_t)(n_leaves >> sub_bits)), dim3(1024), 0, ctx->stream, digests, cap, sub_bits, layer, top_levels);
             GL355_HIP(ctx, hipGetLastError());
             break;
         }
@@ -355,8 +415,10 @@ int32_t merkle_build_args(Ctx* ctx, LeafArgs a, uint32_t sub_bits, uint64_t* dig
         ProfScope ps(ctx, n_nodes <= lanes_max ? "merkle_level_lanes_kernel" : "merkle_level_kernel", n_nodes * 96);
         if (n_nodes <= lanes_max) {
             // small level: 16 lanes per node (latency ~10x lower than one lane per node)
-            hipLaunchKernelGGL(merkle_level_lanes_kernel, dim3((uint32_t)((n_nodes + 3) / 4)), dim3(64), 0, ctx->stream,
-                               digests, cap, sub_bits, layer, n_nodes);
+            if (fast_lanes) hipLaunchKernelGGL(merkle_level_lanes_kernel<3>, dim3((uint32_t)((n_nodes + 3) / 4)), dim3(64), 0, ctx->stream,
+                                               digests, cap, sub_bits, layer, n_nodes);
+            else hipLaunchKernelGGL(merkle_level_lanes_kernel<0>, dim3((uint32_t)((n_nodes + 3) / 4)), dim3(64), 0, ctx->stream,
+                                    digests, cap, sub_bits, layer, n_nodes);
         } else {
             hipLaunchKernelGGL(merkle_level_kernel, dim3((uint32_t)((n_nodes + 255) / 256)), dim3(256), 0, ctx->stream,
                                digests, cap, sub_bits, layer, n_nodes);
