@@ -581,7 +581,13 @@ int32_t gl355_aggregation_root(gl355_ctx* ctx, const uint64_t* leaves, uint64_t 
  *                        advice / fixed / permutation polynomial): the sets' windows run as more windows of one MSM, so the point conversion is
  *                        shared and the latency-bound reduction levels are paid once (<= 64 sets, <= 2^27 scalars in all)
  *   gl355_bn254_g1_fixed_base_mul   out[i] = scalars[i] * base: the powers-of-tau loop of ParamsKZG::setup (verifier_api.rs:77),
- *                        8-bit windows over a per-call table, one inversion per output; out is n x 8 affine points */
+ *                        8-bit windows over a per-call table, one inversion per output; out is n x 8 affine points
+ *   gl355_bn254_g1_msm_prepare / _msm_prepared / _msm_bases_free   a base set that serves many MSMs (ParamsKZG's `g` / `g_lagrange`, verifier_api.rs:77:
+ *                        every commitment of create_proof is an MSM over one of the two).  prepare builds once, on the device, the affine multiples
+ *                        2^(c w) P_i of every base for every window w (64 B x n x windows, 6.4 GB at n = 2^23); with them the digits of ALL windows of a
+ *                        scalar set fall into one set of buckets, so the bucket reduction and the per-bucket bookkeeping are paid once per set instead of
+ *                        once per window, and no window sums are combined on the host.  _msm_prepared: results as gl355_bn254_g1_msm_batch over the
+ *                        prepared points (scalars n_sets x n x 4).  The handle belongs to the context it was made on; free it before the context. */
 int32_t gl355_bn254_fr_ntt(gl355_ctx* ctx, uint64_t* data /* n x 4 */, uint32_t log_n, int32_t inverse);
 int32_t gl355_bn254_fr_coset_ntt(gl355_ctx* ctx, const uint64_t* in, uint32_t log_small, uint32_t log_n, const uint64_t shift[4], int32_t inverse,
                                  uint64_t* out);
@@ -589,6 +595,11 @@ int32_t gl355_bn254_g1_msm(gl355_ctx* ctx, const uint64_t* points /* n x 8 */, c
 int32_t gl355_bn254_g1_msm_batch(gl355_ctx* ctx, const uint64_t* points /* n x 8 */, const uint64_t* scalars /* n_sets x n x 4 */, uint64_t n,
                                  uint32_t n_sets, uint64_t* results /* n_sets x 8 */);
 int32_t gl355_bn254_g1_fixed_base_mul(gl355_ctx* ctx, const uint64_t base[8], const uint64_t* scalars /* n x 4 */, uint64_t n, uint64_t* out /* n x 8 */);
+typedef struct gl355_msm_bases gl355_msm_bases;
+int32_t gl355_bn254_g1_msm_prepare(gl355_ctx* ctx, const uint64_t* points /* n x 8 */, uint64_t n, gl355_msm_bases** out);
+int32_t gl355_bn254_g1_msm_prepared(gl355_ctx* ctx, const gl355_msm_bases* bases, const uint64_t* scalars /* n_sets x n x 4 */, uint32_t n_sets,
+                                    uint64_t* results /* n_sets x 8 */);
+int32_t gl355_bn254_g1_msm_bases_free(gl355_ctx* ctx, gl355_msm_bases* bases);
 
 /* ---- KZG composites over those kernels: what halo2_proofs' ParamsKZG / create_proof do with them at the reference's
  * k = 23 (verifier_api.rs:77-92 `ParamsKZG::<Bn256>::setup`, `create_proof_checked`; chip/native_chip/test_utils.rs:57-95; README.md:171-177).

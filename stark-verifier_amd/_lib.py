@@ -187,6 +187,9 @@ SIGNATURES = {
     "gl355_bn254_fr_coset_ntt": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_int32, vp]),
     "gl355_bn254_g1_msm": (C.c_int32, [vp, vp, vp, C.c_uint64, vp]),
     "gl355_bn254_g1_msm_batch": (C.c_int32, [vp, vp, vp, C.c_uint64, C.c_uint32, vp]),
+    "gl355_bn254_g1_msm_prepare": (C.c_int32, [vp, vp, C.c_uint64, C.POINTER(vp)]),
+    "gl355_bn254_g1_msm_prepared": (C.c_int32, [vp, vp, vp, C.c_uint32, vp]),
+    "gl355_bn254_g1_msm_bases_free": (C.c_int32, [vp, vp]),
     "gl355_bn254_g1_fixed_base_mul": (C.c_int32, [vp, vp, vp, C.c_uint64, vp]),
     "gl355_kzg_setup": (C.c_int32, [vp, vp, C.c_uint32, vp, vp]),
     "gl355_kzg_commit": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_int32, vp]),

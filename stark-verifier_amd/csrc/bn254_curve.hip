@@ -17,8 +17,16 @@
 // affine additions, FFT stages one global pass each.
 #include "bn254_field.cuh"
 #include "bn254_f29.cuh"
+#include <memory>
 #include <vector>
 
+// gl355_bn254_g1_msm_prepare's handle: the window multiples of a base set (device), see msm_table_build_kernel
+struct gl355_msm_bases {
+    gl355::Ctx* ctx;
+    uint32_t* tab;              // [wps][n][16]
+    uint64_t n;
+    uint32_t c, wps;
+};
 namespace gl355 {
 
 // host_bn254_curve.cpp: sum_w 2^(c w) (S_w + Wt_w) as an affine point (canonical integers; zeros = the identity)
@@ -316,8 +324,17 @@ struct MsmArgs {
     uint32_t* coarse_start;     // [W][2^cbits] exclusive scan of the counts
     uint32_t* coarse_fill;      // [W][2^cbits] reservation cursors of the scatter
     uint32_t cbits, chunk;      // coarse bits (cb - MSM_FINE_BITS), points per block of the coarse kernels
+    uint32_t have_table;        // pm is a prepared table (gl355_bn254_g1_msm_prepare): msm_digits_kernel converts nothing
+    // regions of the fine sort with more than MSM_FINE_BIG pairs (skewed scalars: runs of equal values put a window's points into one coarse bin) are
+    // cut into slices of MSM_FINE_SLICE pairs, one workgroup each (msm_fine_big_* kernels)
+    uint32_t* fb_counters;      // [2]            big regions, slices
+    uint32_t* fb_regions;       // [max_reg][2]   region (w << cbits | bin), slices
+    uint32_t* fb_items;         // [max_items][2] region, slice
+    uint32_t fb_max_reg, fb_max_items;
 };
 #define MSM_FINE_BITS 10u
+#define MSM_FINE_BIG (1u << 17)   // pairs in a (window, coarse bin) region above which it is sorted by several workgroups
+#define MSM_FINE_SLICE (1u << 15)
 #define MSM_UNROLL 8
 #define MSM_SIZE_BINS 128
 #define MSM_BIG 256u            // a lane sums at most this many points; a normal bucket holds 8-64
@@ -444,6 +461,70 @@ __global__ void msm_scatter_kernel(MsmArgs a) {
         }
     }
 }
+// ---- prepared bases (round 6): tab[w][i] = 2^(c w) P_i in the bucket loops' table form, w < wps.  One lane per base walks its windows by c doublings
+// each (Jacobian, 8 x 32-bit form), keeps X | Y in the table slot and Z and the running product of the Zs in scratch, inverts the product once
+// and walks back (Montgomery's trick along the lane's own chain: 3 products per window instead of an inversion).  A multiple of a point of this
+// prime-order group is never the identity and never has y = 0, so no Z is zero.
+struct MsmTabArgs {
+    const uint64_t* points;     // [n][8] affine, canonical
+    uint32_t* tab;              // [wps][n][16]
+    uint32_t* zs;               // [wps - 1][chunk][8]  Z of window w + 1 (Montgomery)
+    uint32_t* pre;              // [wps - 1][chunk][8]  Z_1 ... Z_(w + 1)
+    uint64_t n, i0, chunk;      // this launch covers bases [i0, min(n, i0 + chunk))
+    uint32_t c, wps;
+};
+__global__ void __launch_bounds__(256) msm_table_build_kernel(MsmTabArgs a) {
+    const uint64_t li = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, i = a.i0 + li;
+    if (li >= a.chunk || i >= a.n) return;
+    const u256 x = load256(a.points + 8 * i), y = load256(a.points + 8 * i + 4);
+    if (u_is_zero(x) && u_is_zero(y)) {
+        for (uint32_t w = 0; w < a.wps; w++) {
+            uint32_t* t = a.tab + 16ull * ((uint64_t)w * a.n + i);
+#pragma unroll
+            for (int j = 0; j < 16; j++) t[j] = 0;
+        }
+        return;
+    }
+    jac q;
+    q.x = m_from_int<F_Q>(x); q.y = m_from_int<F_Q>(y); q.z = u_const(BN254C_FQ_ONE);
+    {
+        const u256 xt = msm_table_form(q.x), yt = msm_table_form(q.y);
+        uint32_t* t = a.tab + 16ull * i;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { t[j] = xt.l[j]; t[8 + j] = yt.l[j]; }
+    }
+    u256 prefix = q.z;
+    for (uint32_t w = 1; w < a.wps; w++) {
+        for (uint32_t d = 0; d < a.c; d++) q = j_double(q);
+        uint32_t* t = a.tab + 16ull * ((uint64_t)w * a.n + i);
+        uint32_t* z = a.zs + 8ull * ((uint64_t)(w - 1) * a.chunk + li);
+        uint32_t* pr = a.pre + 8ull * ((uint64_t)(w - 1) * a.chunk + li);
+        prefix = w == 1 ? q.z : m_mul<F_Q>(prefix, q.z);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { t[j] = q.x.l[j]; t[8 + j] = q.y.l[j]; z[j] = q.z.l[j]; pr[j] = prefix.l[j]; }
+    }
+    if (a.wps < 2) return;
+    u256 inv = m_inv<F_Q>(prefix);                            // 1 / (Z_1 ... Z_(wps - 1))
+    for (uint32_t w = a.wps - 1; w >= 1; w--) {
+        uint32_t* t = a.tab + 16ull * ((uint64_t)w * a.n + i);
+        const uint32_t* z = a.zs + 8ull * ((uint64_t)(w - 1) * a.chunk + li);
+        u256 zi = inv, zw, X, Y;
+        if (w > 1) {
+            const uint32_t* pr = a.pre + 8ull * ((uint64_t)(w - 2) * a.chunk + li);
+            u256 pw;
+#pragma unroll
+            for (int j = 0; j < 8; j++) pw.l[j] = pr[j];
+            zi = m_mul<F_Q>(inv, pw);                         // 1 / Z_w
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { zw.l[j] = z[j]; X.l[j] = t[j]; Y.l[j] = t[8 + j]; }
+        inv = m_mul<F_Q>(inv, zw);
+        const u256 zi2 = m_mul<F_Q>(zi, zi);
+        const u256 xt = msm_table_form(m_mul<F_Q>(X, zi2)), yt = msm_table_form(m_mul<F_Q>(Y, m_mul<F_Q>(zi2, zi)));
+#pragma unroll
+        for (int j = 0; j < 8; j++) { t[j] = xt.l[j]; t[8 + j] = yt.l[j]; }
+    }
+}
 // ---- the sort in two levels (round 3).  The histogram and the scatter above pay one DEVICE-scope atomic per point and window each
 // (2 x 109 M at 2^23 points: 4.0 + 6.0 of 36.6 ms -- the L2s of the eight XCDs are not coherent, so those atomics execute at the memory
 // side).  Here the digits are written once (msm_digits_kernel), blocks of `chunk` points count and scatter them by part of the digit's bits
@@ -456,12 +537,19 @@ __global__ void msm_scatter_kernel(MsmArgs a) {
 __global__ void msm_digits_kernel(MsmArgs a) {            // points to Montgomery form + the signed digits of every window
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const u256 x = load256(a.points + 8 * i), y = load256(a.points + 8 * i + 4);
-    const bool ident = u_is_zero(x) && u_is_zero(y);
-    const u256 xm = ident ? u_zero() : msm_table_form(m_from_int<F_Q>(x)), ym = ident ? u_zero() : msm_table_form(m_from_int<F_Q>(y));
-    uint32_t* d = a.pm + 16 * i;
+    bool ident;
+    if (a.have_table) {                                       // the table's first slice IS pm; the identity is all zeros there too
+        const uint4* t = reinterpret_cast<const uint4*>(a.pm + 16 * i);
+        const uint4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+        ident = (t0.x | t0.y | t0.z | t0.w | t1.x | t1.y | t1.z | t1.w | t2.x | t2.y | t2.z | t2.w | t3.x | t3.y | t3.z | t3.w) == 0;
+    } else {
+        const u256 x = load256(a.points + 8 * i), y = load256(a.points + 8 * i + 4);
+        ident = u_is_zero(x) && u_is_zero(y);
+        const u256 xm = ident ? u_zero() : msm_table_form(m_from_int<F_Q>(x)), ym = ident ? u_zero() : msm_table_form(m_from_int<F_Q>(y));
+        uint32_t* d = a.pm + 16 * i;
 #pragma unroll
-    for (int j = 0; j < 8; j++) { d[j] = xm.l[j]; d[8 + j] = ym.l[j]; }
+        for (int j = 0; j < 8; j++) { d[j] = xm.l[j]; d[8 + j] = ym.l[j]; }
+    }
     for (uint32_t set = 0; set < a.n_sets; set++) {
         const uint64_t* k = a.scalars + 4 * ((uint64_t)set * a.n + i);
         uint32_t carry = 0;
@@ -558,6 +646,7 @@ __global__ void __launch_bounds__(256) msm_fine_sort_kernel(MsmArgs a) {
     const uint32_t bin = blockIdx.x, w = blockIdx.y, nbin = 1u << a.cbits, tid = threadIdx.x;
     const uint32_t start = a.coarse_start[(uint64_t)w * nbin + bin], cnt = a.coarse_cnt[(uint64_t)w * nbin + bin];
     constexpr uint32_t NF = 1u << MSM_FINE_BITS, PER = NF / 256;
+    if (cnt > MSM_FINE_BIG) return;                                   // msm_fine_big_* (one workgroup would walk the whole region alone)
     for (uint32_t f = tid; f < NF; f += 256) fh[f] = 0;
     __syncthreads();
     const uint32_t* pr = a.pairs + 2ull * ((uint64_t)w * a.n + start);
@@ -597,6 +686,107 @@ __global__ void __launch_bounds__(256) msm_fine_sort_kernel(MsmArgs a) {
         for (int j = 0; j < MSM_UNROLL; j++) { const uint32_t k = k0 + 256u * j; pp[j] = k < cnt ? *reinterpret_cast<const uint2*>(pr + 2ull * k) : make_uint2(0u, 0xFFFFFFFFu); }
 #pragma unroll
         for (int j = 0; j < MSM_UNROLL; j++) if (pp[j].y != 0xFFFFFFFFu) out[fbase[pp[j].y] + atomicAdd(&fh[pp[j].y], 1u)] = pp[j].x;
+    }
+}
+// ---- big regions of the fine sort.  A column whose values come in long runs (a grand product that stands still where its constraint is switched off, a
+// constant, 0 / 1 flags) puts millions of pairs into ONE (window, coarse bin) region, and the single workgroup of msm_fine_sort_kernel walked it alone:
+// 15 - 28 ms per call in a k = 23 proof against 1 - 7 for uniform columns.  Such regions are listed and cut into slices; a slice's workgroup counts its fine
+// bins in LDS and adds them to the bucket counts (a.hist, zeroed by the caller), one workgroup per region turns counts into offsets, and the slices reserve
+// their ranges per fine bin with one atomic each and scatter.  Same outputs as msm_fine_sort_kernel (hist = start, cursor = end of every bucket, idx).
+__global__ void __launch_bounds__(256) msm_fine_big_list_kernel(MsmArgs a) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (a.n_windows << a.cbits)) return;
+    const uint32_t cnt = a.coarse_cnt[r];
+    if (cnt <= MSM_FINE_BIG) return;
+    const uint32_t slices = (cnt + MSM_FINE_SLICE - 1) / MSM_FINE_SLICE;
+    const uint32_t slot = atomicAdd(a.fb_counters, 1u), first = atomicAdd(a.fb_counters + 1, slices);
+    if (slot >= a.fb_max_reg || first + slices > a.fb_max_items) return;      // cannot happen: the bounds are sums over all pairs (host side)
+    a.fb_regions[2 * slot] = r; a.fb_regions[2 * slot + 1] = slices;
+    for (uint32_t k = 0; k < slices; k++) { a.fb_items[2 * (first + k)] = r; a.fb_items[2 * (first + k) + 1] = k; }
+}
+// the fine-bin histogram of pairs [lo, hi) of a region in LDS (fh zeroed by the caller)
+GL_DEV void msm_fine_slice_hist(const uint32_t* pr, uint32_t lo, uint32_t hi, uint32_t* fh) {
+    for (uint32_t k0 = lo + threadIdx.x; k0 < hi; k0 += 256 * MSM_UNROLL) {
+        uint32_t f[MSM_UNROLL];
+#pragma unroll
+        for (int j = 0; j < MSM_UNROLL; j++) { const uint32_t k = k0 + 256u * j; f[j] = k < hi ? pr[2ull * k + 1] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int j = 0; j < MSM_UNROLL; j++) if (f[j] != 0xFFFFFFFFu) atomicAdd(&fh[f[j]], 1u);
+    }
+}
+__global__ void __launch_bounds__(256) msm_fine_big_count_kernel(MsmArgs a) {
+    __shared__ uint32_t fh[1u << MSM_FINE_BITS];
+    constexpr uint32_t NF = 1u << MSM_FINE_BITS;
+    const uint32_t n_items = min(a.fb_counters[1], a.fb_max_items), nbin = 1u << a.cbits;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const uint32_t r = a.fb_items[2 * it], sl = a.fb_items[2 * it + 1], w = r >> a.cbits, bin = r & (nbin - 1);
+        const uint32_t start = a.coarse_start[r], cnt = a.coarse_cnt[r];
+        const uint32_t lo = sl * MSM_FINE_SLICE, hi = min(cnt, lo + MSM_FINE_SLICE);
+        for (uint32_t f = threadIdx.x; f < NF; f += 256) fh[f] = 0;
+        __syncthreads();
+        msm_fine_slice_hist(a.pairs + 2ull * ((uint64_t)w * a.n + start), lo, hi, fh);
+        __syncthreads();
+        const uint64_t bucket0 = ((uint64_t)w << a.cb) + bin;
+        for (uint32_t f = threadIdx.x; f < NF; f += 256) if (fh[f]) atomicAdd(a.hist + bucket0 + ((uint64_t)f << a.cbits), fh[f]);
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) msm_fine_big_scan_kernel(MsmArgs a) {      // counts -> offsets, one workgroup per big region
+    __shared__ uint32_t part[256];
+    constexpr uint32_t NF = 1u << MSM_FINE_BITS, PER = NF / 256;
+    const uint32_t n_reg = min(a.fb_counters[0], a.fb_max_reg), nbin = 1u << a.cbits, tid = threadIdx.x;
+    for (uint32_t q = blockIdx.x; q < n_reg; q += gridDim.x) {
+        const uint32_t r = a.fb_regions[2 * q], w = r >> a.cbits, bin = r & (nbin - 1);
+        const uint64_t bucket0 = ((uint64_t)w << a.cb) + bin;
+        uint32_t c[PER], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; j++) { c[j] = a.hist[bucket0 + ((uint64_t)(tid * PER + j) << a.cbits)]; sum += c[j]; }
+        part[tid] = sum;
+        __syncthreads();
+        for (int stp = 1; stp < 256; stp <<= 1) {
+            const uint32_t o = tid >= (uint32_t)stp ? part[tid - stp] : 0;
+            __syncthreads();
+            part[tid] += o;
+            __syncthreads();
+        }
+        uint32_t run = a.coarse_start[r] + (tid ? part[tid - 1] : 0);
+#pragma unroll
+        for (uint32_t j = 0; j < PER; j++) {
+            const uint64_t b = bucket0 + ((uint64_t)(tid * PER + j) << a.cbits);
+            a.hist[b] = run; a.cursor[b] = run;                       // the scatter's reservations move the cursor to the bucket's end
+            run += c[j];
+        }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) msm_fine_big_scatter_kernel(MsmArgs a) {
+    __shared__ uint32_t fh[1u << MSM_FINE_BITS], fbase[1u << MSM_FINE_BITS];
+    constexpr uint32_t NF = 1u << MSM_FINE_BITS;
+    const uint32_t n_items = min(a.fb_counters[1], a.fb_max_items), nbin = 1u << a.cbits;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const uint32_t r = a.fb_items[2 * it], sl = a.fb_items[2 * it + 1], w = r >> a.cbits, bin = r & (nbin - 1);
+        const uint32_t start = a.coarse_start[r], cnt = a.coarse_cnt[r];
+        const uint32_t lo = sl * MSM_FINE_SLICE, hi = min(cnt, lo + MSM_FINE_SLICE);
+        const uint32_t* pr = a.pairs + 2ull * ((uint64_t)w * a.n + start);
+        for (uint32_t f = threadIdx.x; f < NF; f += 256) fh[f] = 0;
+        __syncthreads();
+        msm_fine_slice_hist(pr, lo, hi, fh);
+        __syncthreads();
+        const uint64_t bucket0 = ((uint64_t)w << a.cb) + bin;
+        for (uint32_t f = threadIdx.x; f < NF; f += 256) {
+            fbase[f] = fh[f] ? atomicAdd(a.cursor + bucket0 + ((uint64_t)f << a.cbits), fh[f]) : 0;
+            fh[f] = 0;
+        }
+        __syncthreads();
+        uint32_t* out = a.idx + (uint64_t)w * a.n;
+        for (uint32_t k0 = lo + threadIdx.x; k0 < hi; k0 += 256 * MSM_UNROLL) {
+            uint2 pp[MSM_UNROLL];
+#pragma unroll
+            for (int j = 0; j < MSM_UNROLL; j++) { const uint32_t k = k0 + 256u * j; pp[j] = k < hi ? *reinterpret_cast<const uint2*>(pr + 2ull * k) : make_uint2(0u, 0xFFFFFFFFu); }
+#pragma unroll
+            for (int j = 0; j < MSM_UNROLL; j++) if (pp[j].y != 0xFFFFFFFFu) out[fbase[pp[j].y] + atomicAdd(&fh[pp[j].y], 1u)] = pp[j].x;
+        }
+        __syncthreads();
     }
 }
 // Buckets by decreasing size.  A lane sums one bucket, so a wave takes as long as its largest bucket: with 2^20 points in 2^16
@@ -764,10 +954,12 @@ __global__ void __launch_bounds__(256) msm_bucket_kernel(MsmArgs a) {
 // Buckets of MSM_BIG < sz <= MSM_MID points (the top window of a uniform 2^23-point MSM: 2^13 buckets of ~1024) are cut into items of
 // MSM_MID_SLICE points summed by ONE LANE each, like ordinary buckets, and their <= 32 partial sums are added by one lane per bucket: a
 // workgroup per 1024-point bucket spent its time in the 8-level tree over 256 lane sums of 4 points each (4.0 of 38.5 ms at 2^23).
-#define MSM_MID 2048u
+#define MSM_MID 8192u
 #define MSM_MID_SLICE 64u
 GL_DEV uint32_t msm_big_slice(uint32_t sz) {                       // points per item: at most 256 items per bucket
-    if (sz <= MSM_MID) return MSM_MID_SLICE;
+    // (mid-size buckets: at most 32 lane items of 64 .. 256 points -- with prepared bases and 22-bit windows the 12 significant bits of the top window make
+    // 2^11 buckets of 2^12 points each, which took the workgroup path at 2.4 times the lane path's cost per addition while MSM_MID was 2048)
+    if (sz <= MSM_MID) return max(MSM_MID_SLICE, (sz + 31) / 32);
     const uint32_t need = (sz + 255) / 256;
     return need > MSM_BIG_WG_POINTS ? ((need + 255) & ~255u) : MSM_BIG_WG_POINTS;
 }
@@ -800,7 +992,7 @@ __global__ void __launch_bounds__(256) msm_mid_partial_kernel(MsmArgs a) {
         const uint32_t id = a.big_items[2 * it], off = a.big_items[2 * it + 1], w = id >> a.cb;
         const uint32_t base = a.hist[id], end = a.cursor[id];
         if (end - base > MSM_MID) continue;                        // a workgroup item (below)
-        const uint32_t lo = base + off, hi = min(end, lo + MSM_MID_SLICE);
+        const uint32_t lo = base + off, hi = min(end, lo + msm_big_slice(end - base));
         MSM_ACC_INIT(acc);
         for (uint32_t k = lo; k < hi; k++) MSM_ACC_ADD(a, acc, a.idx[(uint64_t)w * a.n + k]);
         j_store(a.big_partial + 24ull * it, MSM_ACC_JAC(acc));
@@ -1396,18 +1588,19 @@ int32_t gl355_bn254_fr_coset_ntt(gl355_ctx* h, const uint64_t* in, uint32_t log_
 namespace gl355 {
 // max_bits: every scalar of the call is below 2^max_bits (256: no promise).  Windows above that hold only zero digits: they are not built,
 // sorted or reduced (range-check columns are 16-bit values, the arithmetic chip's operands 64-bit: 2 and 5 windows of 20 bits instead of 13)
-int32_t bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t m, uint32_t max_bits, uint64_t* result);
 }
 extern "C" {
 static int32_t msm_run(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t m, uint64_t* result) {
     return bn254_msm_bits(h, points, scalars, n, m, 256, result);
 }
 }  // extern "C"
-int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t m, uint32_t max_bits, uint64_t* result) {
+int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t m, uint32_t max_bits, uint64_t* result,
+                              const gl355_msm_bases* bases) {
     Ctx* ctx = ctx_of(h);
     if (!ctx) return GL355_E_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
-    if (!result || ((!points || !scalars) && n)) return ctx->fail(GL355_E_INVALID_ARG, "bn254_g1_msm: null argument");
+    if (bases && (bases->ctx != ctx || bases->n != n)) return ctx->fail(GL355_E_INVALID_ARG, "bn254_g1_msm: prepared bases of another context or size");
+    if (!result || ((!(points || bases) || !scalars) && n)) return ctx->fail(GL355_E_INVALID_ARG, "bn254_g1_msm: null argument");
     if (n > (1ull << 26)) return ctx->fail(GL355_E_UNSUPPORTED, "bn254_g1_msm: more than 2^26 points");
     if (m == 0) return GL355_OK;
     if (m > 64 || (uint64_t)m * n > (1ull << 27)) return ctx->fail(GL355_E_UNSUPPORTED, "bn254_g1_msm_batch: more than 64 scalar sets or 2^27 scalars in all");
@@ -1427,17 +1620,32 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
     // of buckets (workgroup path below, contended counters).  254 = 14 * 17 + 16 = 12 * 20 + 14.  Measured (uniform scalars, ms):
     //   2^18: c = 15 / 16 / 17 -> 3.7 / 3.9 / 4.1;   2^20: 16 / 17 / 18 -> 7.3 / 7.1 / 8.3;   2^22: 16 / 17 / 18 / 19 -> 23.6 / 19.1 / 20.7 / 32.9
     //   2^23-point calls, k = 23 proof: c = 18 / 19 / 20 / 21 -> 1.155 / 1.115 / 1.118 / 1.235 s
-    a.c = lg <= 6 ? 4 : (lg <= 18 ? lg - 2 : (lg <= 22 ? 17 : 20));
+    a.c = bases ? bases->c : (lg <= 6 ? 4 : (lg <= 18 ? lg - 2 : (lg <= 22 ? 17 : 20)));
     a.cb = a.c - 1;
     a.wps = 256 / a.c + 1;                                       // signed digits: the carry out of bit 255 needs a window of its own
     if (max_bits < 256) a.wps = std::min(a.wps, (std::max(1u, max_bits) + a.c - 1) / a.c + 1);
+    if (bases && a.wps > bases->wps) return ctx->fail(GL355_E_INVALID_ARG, "bn254_g1_msm: prepared bases hold too few windows");
     a.n_sets = m;
     a.n_windows = a.wps * m;
-    const uint64_t nb = 1ull << a.cb, W = a.n_windows;
+    // SHARED BUCKETS (prepared bases): point i of window w is the table entry w n + i, whose own digit is the scalar's w-th -- an MSM of wps n
+    // points with ONE window per scalar set.  The digit array [set][w][i] is already that MSM's [set][w n + i], so past msm_digits_kernel every
+    // kernel runs unchanged on the virtual sizes: 2^cb buckets per SET to size-sort, accumulate and reduce instead of per window, and the set's
+    // sum comes out of the last level (no doublings between windows on the host).
+    const uint32_t real_wps = a.wps;
+    const uint64_t real_n = n;
+    if (bases) {
+        if (n * real_wps >= (1ull << 31)) return ctx->fail(GL355_E_UNSUPPORTED, "bn254_g1_msm: prepared bases x windows beyond 2^31 entries");
+        a.have_table = 1;
+    }
+    const uint64_t nb = 1ull << a.cb;
+    uint64_t W = a.n_windows;
     Staged sp(ctx), ss(ctx);
-    GL355_TRY(sp.open(points, n * 64, 1));
+    if (!bases) GL355_TRY(sp.open(points, n * 64, 1));
     GL355_TRY(ss.open(scalars, (uint64_t)m * n * 32, 1));
-    a.points = sp.as<uint64_t>(); a.scalars = ss.as<uint64_t>();
+    a.points = bases ? nullptr : sp.as<uint64_t>(); a.scalars = ss.as<uint64_t>();
+    // from here on the sizes are the virtual ones when the bases are prepared (one window of wps n points per set)
+    const uint64_t rn = real_n;                                  // msm_digits_kernel alone runs on the real sizes
+    if (bases) { n = real_n * real_wps; W = m; }
     // reduction levels: groups of 8 items, the last level takes what is left
     struct Lv { uint32_t t_in, kbits, shift; };
     std::vector<Lv> levels;
@@ -1478,13 +1686,14 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
         c_lvl_words[i] = lvl_words / W * Wc;
         lvl_words_all += c_lvl_words[i];
     }
-    const uint64_t sort_words = two_level ? 3 * W * n + 3 * W * nbin + 2 : 0;
+    const uint64_t fb_max_reg = W * n / MSM_FINE_BIG + 1, fb_max_items = W * n / MSM_FINE_SLICE + fb_max_reg + 1;      // (sums over all pairs)
+    const uint64_t sort_words = two_level ? 3 * W * n + 3 * W * nbin + 2 + 2 + 2 * fb_max_reg + 2 * fb_max_items : 0;
     Scratch buf(ctx);
-    const uint64_t words32 = n * 16 + 3 * W * nb + W * n + W * nb * 24 + (uint64_t)K * (MSM_SIZE_BINS + 4) + lvl_words_all + 64 +
+    const uint64_t words32 = (bases ? 0 : n * 16) + 3 * W * nb + W * n + W * nb * 24 + (uint64_t)K * (MSM_SIZE_BINS + 4) + lvl_words_all + 64 +
                              2ull * tot_items + 3ull * tot_big + 24ull * tot_items + sort_words;
     GL355_TRY(buf.get(words32 * 4 + 64));
     uint32_t* p = buf.as<uint32_t>();
-    a.pm = p; p += n * 16;
+    if (bases) a.pm = bases->tab; else { a.pm = p; p += n * 16; }
     a.hist = p; p += W * nb;
     uint32_t* small = p; p += (uint64_t)K * (MSM_SIZE_BINS + 4);  // per chunk: size histogram + the two work-list counters, cleared with the histograms
     a.cursor = p; p += W * nb;
@@ -1502,10 +1711,15 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
         a.coarse_cnt = p; p += W * nbin;
         a.coarse_fill = p; p += W * nbin;
         a.coarse_start = p; p += W * nbin;
+        a.fb_counters = p; p += 2;
+        a.fb_regions = p; p += 2 * fb_max_reg;
+        a.fb_items = p; p += 2 * fb_max_items;
+        a.fb_max_reg = (uint32_t)fb_max_reg; a.fb_max_items = (uint32_t)fb_max_items;
         GL355_HIP(ctx, hipMemsetAsync(a.coarse_cnt, 0, 2 * W * nbin * 4, ctx->stream));
+        GL355_HIP(ctx, hipMemsetAsync(a.fb_counters, 0, 8, ctx->stream));
     }
     GL355_HIP(ctx, hipMemsetAsync(a.hist, 0, (W * nb + (uint64_t)K * (MSM_SIZE_BINS + 4)) * 4, ctx->stream));
-    const uint32_t blk = (uint32_t)((n + 255) / 256);
+    const uint32_t blk = (uint32_t)((rn + 255) / 256);
     std::vector<const uint32_t*> fin_s(K), fin_w(K, nullptr);
     std::vector<const uint32_t*> counters(K);
     {
@@ -1513,6 +1727,7 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
         hipStream_t st[2] = {ctx->stream, ctx->stream};
         hipEvent_t ev_ready = nullptr;
         if (two_level) hipLaunchKernelGGL(msm_digits_kernel, dim3(blk), dim3(256), 0, ctx->stream, a);
+        if (bases) { a.n = n; a.n_windows = (uint32_t)W; a.wps = 1; }      // the virtual MSM: every kernel below sees one window per set
         if (K > 1) {
             GL355_TRY(ctx->aux_stream_get(&st[1]));
             GL355_TRY(ctx->order_event(0, &ev_ready));
@@ -1544,6 +1759,11 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
                 hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3((uint32_t)Wc), dim3(1024), 0, s_, c);
                 hipLaunchKernelGGL(msm_coarse_scatter_kernel, cgrid, dim3(256), nbin * 8, s_, c);
                 hipLaunchKernelGGL(msm_fine_sort_kernel, dim3((uint32_t)nbin, (uint32_t)Wc), dim3(256), 0, s_, c);
+                // regions too large for one workgroup (usually none: the three kernels behind the list then find empty work lists)
+                hipLaunchKernelGGL(msm_fine_big_list_kernel, dim3((uint32_t)((Wc * nbin + 255) / 256)), dim3(256), 0, s_, c);
+                hipLaunchKernelGGL(msm_fine_big_count_kernel, dim3(2048), dim3(256), 0, s_, c);
+                hipLaunchKernelGGL(msm_fine_big_scan_kernel, dim3(256), dim3(256), 0, s_, c);
+                hipLaunchKernelGGL(msm_fine_big_scatter_kernel, dim3(2048), dim3(256), 0, s_, c);
             } else {
                 hipLaunchKernelGGL(msm_prepare_kernel, dim3(blk), dim3(256), 0, s_, c);
                 hipLaunchKernelGGL(msm_scan_kernel, dim3((uint32_t)Wc), dim3(1024), 0, s_, c);
@@ -1618,6 +1838,64 @@ int32_t gl355_bn254_g1_msm_batch(gl355_ctx* h, const uint64_t* points, const uin
 }
 
 
+// Window width of a prepared base set.  With the buckets shared by all windows the reduction is paid once per scalar set, so wider windows than the
+// per-window form's 17 - 20 bits pay: fewer windows = fewer additions in the bucket loops (n per window), until the buckets outnumber them.
+static uint32_t msm_prepared_window_bits(uint32_t lg) {
+    // ... and the top window should not be nearly empty (r < 2^254: a top window of two bits is four buckets of millions of points): the widest c from
+    // lg - 1 down whose top window keeps at least c / 3 bits.  2^23: 22 (11 windows of 22 bits + 12 bits), 2^22, 2^21: 20, 2^20: 19, 2^18: 17
+    // (k = 23 proof, ms of MSM kernels: c = 20 / 21 / 22 / 23 -> 409 / 440 / 408 / 480 before the mid-size bucket items grew; 417 without tables)
+    for (uint32_t c = std::min(22u, std::max(13u, lg) - 1); c > 12; c--)
+        if (254 - c * (253 / c) >= (c + 2) / 3) return c;
+    return 12;
+}
+int32_t gl355_bn254_g1_msm_prepare(gl355_ctx* h, const uint64_t* points, uint64_t n, gl355_msm_bases** out) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GL355_E_HIP, "hipSetDevice failed");
+    if (!points || !out || !n) return ctx->fail(GL355_E_INVALID_ARG, "bn254_g1_msm_prepare: null argument or no points");
+    uint32_t lg = 0;
+    while ((1ull << lg) < n) lg++;
+    const uint32_t c = msm_prepared_window_bits(lg), wps = 256 / c + 1;
+    if (n > (1ull << 26) || n * wps >= (1ull << 31)) return ctx->fail(GL355_E_UNSUPPORTED, "bn254_g1_msm_prepare: too many points");
+    std::unique_ptr<gl355_msm_bases> b(new gl355_msm_bases{ctx, nullptr, n, c, wps});
+    void* tab = nullptr;
+    GL355_TRY(ctx->alloc((size_t)wps * n * 64, &tab));
+    b->tab = static_cast<uint32_t*>(tab);
+    Staged sp(ctx);
+    int32_t rc = sp.open(points, n * 64, 1);
+    Scratch tmp(ctx);
+    MsmTabArgs a;
+    memset(&a, 0, sizeof a);
+    a.points = sp.as<uint64_t>(); a.tab = b->tab; a.n = n; a.c = c; a.wps = wps;
+    a.chunk = std::min<uint64_t>(n, 1ull << 20);
+    if (rc == GL355_OK) rc = tmp.get((size_t)(wps - 1) * a.chunk * 64 + 64);
+    if (rc != GL355_OK) { ctx->release(tab); return rc; }
+    a.zs = tmp.as<uint32_t>(); a.pre = a.zs + 8ull * (wps - 1) * a.chunk;
+    {
+        ProfScope ps(ctx, "bn254_g1_msm_prepare", n * 64ull * (1 + wps));
+        for (a.i0 = 0; a.i0 < n; a.i0 += a.chunk)
+            hipLaunchKernelGGL(msm_table_build_kernel, dim3((uint32_t)((a.chunk + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    }
+    if (hipGetLastError() != hipSuccess || ctx->wait() != hipSuccess) { ctx->release(tab); return ctx->fail(GL355_E_HIP, "bn254_g1_msm_prepare: kernel failed"); }
+    *out = b.release();
+    return GL355_OK;
+}
+int32_t gl355_bn254_g1_msm_prepared(gl355_ctx* h, const gl355_msm_bases* bases, const uint64_t* scalars, uint32_t n_sets, uint64_t* results) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (!bases) return ctx->fail(GL355_E_INVALID_ARG, "bn254_g1_msm_prepared: null bases");
+    return bn254_msm_bits(h, nullptr, scalars, bases->n, n_sets, 256, results, bases);
+}
+int32_t gl355_bn254_g1_msm_bases_free(gl355_ctx* h, gl355_msm_bases* bases) {
+    Ctx* ctx = ctx_of(h);
+    if (!ctx) return GL355_E_INVALID_ARG;
+    if (!bases) return GL355_OK;
+    if (bases->ctx != ctx) return ctx->fail(GL355_E_INVALID_ARG, "bn254_g1_msm_bases_free: bases of another context");
+    (void)ctx->wait();
+    ctx->release(bases->tab);
+    delete bases;
+    return GL355_OK;
+}
 int32_t gl355_bn254_g1_fixed_base_mul(gl355_ctx* h, const uint64_t base[8], const uint64_t* scalars, uint64_t n, uint64_t* out) {
     Ctx* ctx = ctx_of(h);
     if (!ctx) return GL355_E_INVALID_ARG;

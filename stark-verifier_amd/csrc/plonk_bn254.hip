@@ -71,6 +71,9 @@ struct gl355_plonk_pk {
     uint32_t n_fix_cos = 0;
     uint64_t* export_quotient = nullptr;                                  // host buffer the next proof's quotient pieces are copied to (inspection hook)
     const uint64_t *g = nullptr, *g_lagrange = nullptr;                   // the caller's resident SRS (device) or owned copies
+    // the SRS's window multiples (gl355_bn254_g1_msm_prepare): every commitment of a proof is an MSM over one of the two base sets, and with the
+    // tables its windows share one bucket set.  2 x 6.4 GB at k = 23; null below k = 22, when the device is short of memory or with GL355_PLONK_MSM_TABLES=0
+    gl355_msm_bases *tab_g = nullptr, *tab_gl = nullptr;
     uint32_t* d_gate_code = nullptr;
     std::vector<uint32_t*> d_lk_code;                                     // per lookup: input program, table program
     int32_t* d_q[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
@@ -135,6 +138,7 @@ int32_t commit_columns(gl355_plonk_pk* pk, const uint64_t* bases, const uint64_t
     if (!sets) return GL355_OK;
     tail = std::min(tail, n);
     const uint64_t nt = n - tail;
+    const gl355_msm_bases* tab = bases == pk->g ? pk->tab_g : (bases == pk->g_lagrange ? pk->tab_gl : nullptr);
     // <= 2^27 scalars and <= 64 sets per batched MSM (bn254_curve.hip)
     const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, (1ull << 27) / n));
     Scratch plain(ctx);
@@ -162,7 +166,8 @@ int32_t commit_columns(gl355_plonk_pk* pk, const uint64_t* bases, const uint64_t
         const uint32_t max_m = std::max(1u, 72u / (cls[s0] + 1));
         uint32_t m = 1;
         while (s0 + m < sets && m < per && m < max_m && cls[s0 + m] == cls[s0]) m++;
-        GL355_TRY(bn254_msm_bits(pk->handle, bases, d_plain + 4ull * s0 * n, n, m, std::min(256u, 20 * cls[s0]), out_host + 8ull * s0));
+        // (columns of at most 20 bits are one window either way: the per-window form's 2^19 buckets are cheaper to size-sort and reduce than the tables' 2^21)
+        GL355_TRY(bn254_msm_bits(pk->handle, bases, d_plain + 4ull * s0 * n, n, m, std::min(256u, 20 * cls[s0]), out_host + 8ull * s0, cls[s0] >= 2 ? tab : nullptr));
         s0 += m;
     }
     if (nt) {
@@ -439,6 +444,8 @@ int32_t gl355_plonk_pk_destroy(gl355_plonk_pk* pk) {
     if (pk->ctx && hipSetDevice(pk->ctx->device) == hipSuccess) {
         (void)pk->ctx->wait();
         for (void* p : pk->owned) pk->ctx->release(p);
+        (void)gl355_bn254_g1_msm_bases_free(pk->handle, pk->tab_g);
+        (void)gl355_bn254_g1_msm_bases_free(pk->handle, pk->tab_gl);
     }
     delete pk;
     return GL355_OK;
@@ -544,6 +551,18 @@ int32_t gl355_plonk_keygen(gl355_ctx* h, const uint64_t* desc, uint64_t words, c
     auto D = [&](size_t bytes, auto** ptr) { return k_->dalloc(bytes, reinterpret_cast<void**>(ptr)); };
     if (ptr_is_device(g)) pk->g = g; else { uint64_t* d; GL355_TRY(D(n * 64, &d)); GL355_TRY(upload(ctx, d, g, n * 64)); pk->g = d; }
     if (ptr_is_device(g_lagrange)) pk->g_lagrange = g_lagrange; else { uint64_t* d; GL355_TRY(D(n * 64, &d)); GL355_TRY(upload(ctx, d, g_lagrange, n * 64)); pk->g_lagrange = d; }
+    {
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        // worth their memory from k = 22 on: below that a column's shared bucket set (2^18 buckets at k = 20) is too few lanes for the bucket kernel --
+        // k = 20 proof 0.176 s without, 0.184 s with; k = 23: 1.010 / 0.962 s.  GL355_PLONK_MSM_TABLES=0 / 1: never / from k = 12 (A/B, small-memory runs, tests)
+        const char* e = getenv("GL355_PLONK_MSM_TABLES");
+        const bool want = e ? (atoi(e) != 0 && pk->k >= 12) : pk->k >= 22;
+        if (want && (size_t)n * 64 * 13 * 2 < free_b / 4) {
+            GL355_TRY(gl355_bn254_g1_msm_prepare(h, pk->g, n, &pk->tab_g));
+            GL355_TRY(gl355_bn254_g1_msm_prepare(h, pk->g_lagrange, n, &pk->tab_gl));
+        }
+    }
     GL355_TRY(D((n / 2 + 1) * 32, &pk->tw_fwd));
     GL355_TRY(D((n / 2 + 1) * 32, &pk->tw_inv));
     GL355_TRY(bn254_fr_twiddles(ctx, pk->k, false, pk->tw_fwd));

@@ -221,6 +221,93 @@ def test_g1_msm_batch_equals_single_msms(ctx, orc):
     assert ctx.lib.gl355_bn254_g1_msm_batch(ctx.h, pts.ctypes.data, sc.ctypes.data, 4, 65, out.ctypes.data) == -5       # GL355_E_UNSUPPORTED
 
 
+class PreparedBases:
+    """gl355_bn254_g1_msm_prepare / _msm_prepared / _msm_bases_free around one base set"""
+    def __init__(self, ctx, pts):
+        import ctypes
+        self.ctx, self.n = ctx, pts.shape[0]
+        self.h = ctypes.c_void_p()
+        pts = np.ascontiguousarray(pts, dtype=np.uint64)
+        ctx.check(ctx.lib.gl355_bn254_g1_msm_prepare(ctx.h, pts.ctypes.data, self.n, ctypes.byref(self.h)))
+
+    def msm(self, sc):
+        sc = np.ascontiguousarray(sc, dtype=np.uint64)
+        m = 1 if sc.ndim == 2 else sc.shape[0]
+        out = np.zeros((m, 8), dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.gl355_bn254_g1_msm_prepared(self.ctx.h, self.h, sc.ctypes.data, m, out.ctypes.data))
+        return out[0] if sc.ndim == 2 else out
+
+    def close(self):
+        self.ctx.check(self.ctx.lib.gl355_bn254_g1_msm_bases_free(self.ctx.h, self.h))
+
+
+@pytest.mark.parametrize("n", [1, 3, 64, 300, 4096])
+def test_g1_msm_prepared_vs_oracle(ctx, orc, n):
+    """prepared bases (window multiples tabulated once, all windows into one bucket set) == the oracle's MSM, with an identity, a zero scalar,
+    a repeated base, full-width scalars (>= r included) and several scalar sets per call"""
+    cv = Bn254Curve(orc)
+    rng = np.random.default_rng(0x4F2 + n)
+    pts = cv.multiples_array(int(rng.integers(1, 1 << 40)), int(rng.integers(1, 1 << 40)), n)
+    sc = np.stack([rand_scalars(rng, n, below_r=False) for _ in range(3)])
+    if n > 3:
+        pts[2] = 0
+        sc[0, 1] = 0
+        pts[3] = pts[0]
+        sc[1, :, :] = 0                                    # an all-zero set
+        sc[2, :, 1:] = 0; sc[2, :, 0] &= np.uint64(0xFFFF)     # 16-bit values (a range-check column)
+    pb = PreparedBases(ctx, pts)
+    try:
+        assert np.array_equal(pb.msm(sc[0]), cv.msm_arrays(pts, sc[0]))
+        out = pb.msm(sc)
+        for j in range(3):
+            assert np.array_equal(out[j], cv.msm_arrays(pts, sc[j])), j
+    finally:
+        pb.close()
+
+
+@pytest.mark.parametrize("n", [16385, 100003, 1 << 18])
+def test_g1_msm_prepared_equals_plain(ctx, orc, n):
+    """at sizes past the oracle's reach: prepared == the per-window MSM on the same inputs (uniform, skewed and short scalars; the identity,
+    equal and opposite bases under one scalar), and bases (i + 1) * 11 G so that one of them is also checked as a single scalar multiplication"""
+    cv = Bn254Curve(orc)
+    rng = np.random.default_rng(0x4F3 + n)
+    pts = cv.multiples_array(11, 11, n)
+    mult = [11 * (i + 1) for i in range(n)]
+    pts[2] = 0; mult[2] = 0
+    pts[7] = pts[0]; mult[7] = mult[0]
+    pts[13, 4:] = cv.scalars([pm.Q - cv.ints(pts[12:13, 4:])[0]])[0]; pts[13, :4] = pts[12, :4]; mult[13] = -mult[12]
+    uni = rand_scalars(rng, n)
+    uni[13] = uni[12]; uni[7] = uni[0]
+    vals = np.zeros(n, dtype=object)
+    for limb in range(4):
+        vals += uni[:, limb].astype(object) << (64 * limb)
+    skew = cv.scalars([pm.R - 1 if v else 7 for v in rng.integers(0, 2, size=n)])
+    short = np.zeros((n, 4), dtype=np.uint64); short[:, 0] = rng.integers(0, 1 << 16, size=n, dtype=np.uint64)
+    const = cv.scalars([0x1234567890ABCDEF1122334455667788990011223344556677] * n)
+    sets = np.stack([uni, skew, short, const])
+    pb = PreparedBases(ctx, pts)
+    try:
+        out = pb.msm(sets)
+        for j in range(sets.shape[0]):
+            assert np.array_equal(out[j], gpu_msm(ctx, pts, sets[j])), j
+        k = int(sum(int(v) * m for v, m in zip(vals, mult)) % pm.R)
+        assert cv._unpt(out[0]) == cv.mul(pm.G, k)
+    finally:
+        pb.close()
+
+
+def test_g1_msm_prepared_errors(ctx, orc):
+    import ctypes
+    cv = Bn254Curve(orc)
+    pts = cv.multiples_array(3, 3, 8)
+    h = ctypes.c_void_p()
+    assert ctx.lib.gl355_bn254_g1_msm_prepare(ctx.h, None, 8, ctypes.byref(h)) == -1
+    assert ctx.lib.gl355_bn254_g1_msm_prepare(ctx.h, pts.ctypes.data, 0, ctypes.byref(h)) == -1
+    out = np.zeros(8, dtype=np.uint64)
+    assert ctx.lib.gl355_bn254_g1_msm_prepared(ctx.h, None, pts.ctypes.data, 1, out.ctypes.data) == -1
+    assert ctx.lib.gl355_bn254_g1_msm_bases_free(ctx.h, None) == 0
+
+
 @pytest.mark.parametrize("log_small,log_n", [(3, 3), (6, 9), (9, 11), (10, 13), (12, 14)])
 def test_fr_coset_ntt_vs_oracle(ctx, orc, log_small, log_n):
     """coeff_to_extended / extended_to_coeff of halo2's EvaluationDomain: c_i shift^i zero-padded, transformed -- against the oracle's FFT of

@@ -42,8 +42,10 @@ def test_keccak256_entry(ctx):
         assert out.raw == hm.keccak256(m)
 
 
-@pytest.mark.parametrize("k,tb", [(7, 5), (8, 6), (9, 7), (10, 7), (12, 9), (13, 10)])
-def test_proof_bytes_equal_the_oracle(ctx, k, tb):
+@pytest.mark.parametrize("k,tb,tables", [(7, 5, 0), (8, 6, 0), (9, 7, 0), (10, 7, 0), (12, 9, 0), (13, 10, 0), (12, 9, 1), (13, 10, 1)])
+def test_proof_bytes_equal_the_oracle(ctx, k, tb, tables, monkeypatch):
+    # tables = 1: the key holds the SRS's window multiples and every commitment of more than 20 bits runs on shared buckets (the default from k = 22 on)
+    monkeypatch.setenv("GL355_PLONK_MSM_TABLES", str(tables))
     cs, cfg, w, prover = build(ctx, k, tb)
     params = hm.Params(k, TAU)
     pk = hm.keygen(params, cs, w.fixed_ints(), w.assembly)
@@ -132,9 +134,12 @@ def test_k12_proof_passes_the_verifier(ctx):
     prover.close()
 
 
-def test_k17_reference_table_size(ctx):
+@pytest.mark.parametrize("tables", [0, 1])
+def test_k17_reference_table_size(ctx, tables, monkeypatch):
     """k = 17: the smallest circuit that holds the reference's real 16-bit range table and the Goldilocks modulus (arithmetic_chip.rs:19,140-151);
-    64 chained Poseidon permutations, every usable row an arithmetic row; the proof passes the verifier restatement"""
+    64 chained Poseidon permutations, every usable row an arithmetic row; the proof passes the verifier restatement -- with and without the
+    SRS's window tables in the key"""
+    monkeypatch.setenv("GL355_PLONK_MSM_TABLES", str(tables))
     k = 17
     cs, cfg, w, prover = build(ctx, k, 16, n_perm=64)
     assert cfg.arithmetic_config.modulus == ch.GOLDILOCKS_MODULUS and cs.degree() == 6 and len(cs.lookups) == 9 and cs.num_advice == 19
