@@ -104,6 +104,16 @@ __global__ void __launch_bounds__(256) fr_stage_kernel(uint64_t* data, const uin
     store256(pv, m_sub<F_R>(u, v));
 }
 
+// the block constants of the coset form (FrPass::btw): out[2^(t-1) + b] = gpow[t] * w_(2^t)^rev(b), 1 <= t <= log_n, b < 2^(t-1); gpow[t] = g^(n / 2^t)
+// (Montgomery, from the host), w_(2^t)^r = tw[r 2^(log_n - t)].  Entry 0 is unused.
+__global__ void fr_coset_twiddle_kernel(const uint64_t* tw, const uint64_t* gpow, uint32_t log_n, uint64_t* out) {
+    const uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (e == 0 || e >= (1ull << log_n)) return;
+    const uint32_t t = 64 - __clzll((unsigned long long)e);                   // 2^(t-1) <= e < 2^t
+    const uint64_t b = e - (1ull << (t - 1));
+    const uint64_t r = t > 1 ? __brevll(b) >> (64 - (t - 1)) : 0;
+    store256(out + 4 * e, m_mul<F_R>(load256(tw + 4 * (r << (log_n - t))), load256(gpow + 4 * t)));
+}
 // Several decimation-in-time stages per pass over HBM: a workgroup takes a tile of 2^ns "rows" at stride 2^s0 times C adjacent
 // columns (1024 elements, 32 KB of LDS as 8 limb planes so that lanes hit consecutive banks) through stages s0+1 .. s0+ns.  The first
 // pass (s0 = 0: contiguous 1024-element blocks, ten stages) also does the bit reversal and the conversion to Montgomery form on its
@@ -130,6 +140,12 @@ struct FrPass {
     // (u + v, (u - v) w), bit-reversed output.  The passes of a dif transform run from the highest s0 down; `first` then marks the pass that
     // reads the input (conversion, pre-multipliers, zero padding), `last` the s0 = 0 pass.
     uint32_t no_gather, dif;
+    // COSET form (bn254_fr_ntt_mont_coset_dif): out[bitrev(k)] = sum_i in[i] g^i w^(ik) with NO multiplication by g^i up front and no per-position
+    // twiddles.  Write a block of 2^s values as the coset transform of its own shift g': its halves u, v combine as (u + G v, u - G v) with the ONE
+    // constant G = g'^(2^(s-1)) per block, and the halves are coset transforms again, with shifts g' and g' w_(2^s).  btw[2^(t-1) + b] holds the constant of
+    // block b of the t-th stage from the top (fr_coset_twiddle_kernel): g^(n / 2^t) w_(2^t)^rev(b).  Stages run from the top down as for `dif`; in a pass over
+    // the high stages a tile sees a handful of blocks, so its twiddle loads are broadcasts instead of 32-byte pieces of as many cache lines.
+    const uint64_t* btw;
 };
 __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
     __shared__ uint32_t lds[8][1024];
@@ -161,6 +177,7 @@ __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
     // 451 ms -- the pass is neither call- nor twiddle-latency-bound; it runs at 0.72 of the VALU rate of its mix.  The butterflies on nine
     // 29-bit limbs (bn254_f29.cuh: inlined product against twiddles in the 2^261 form, sums reduced on the top limb, 36 KB of LDS) were built
     // too: evaluate_h 442 against 435 ms -- the product it saves is paid back in limb planes, normalisations and a block less per CU.)
+    const bool block_tw = a.btw != nullptr, dif_fly = a.dif && !block_tw;
     for (uint32_t it = 1; it <= a.ns; it++) {
         const uint32_t st = a.dif ? a.ns + 1 - it : it;
         const uint32_t s = a.s0 + st, lh = st - 1, half = 1u << lh;
@@ -170,12 +187,14 @@ __global__ void __launch_bounds__(256) fr_fft_pass_kernel(FrPass a) {
             const uint32_t r_lo = ((q >> lh) << (lh + 1)) | pos;
             const uint32_t e0 = (r_lo << log_c) | c, e1 = e0 + (half << log_c);
             const uint64_t j = ((uint64_t)pos << a.s0) + c0 + c;
-            const u256 w = load256(a.tw + 4 * (j << (a.log_n - s)));
+            // block form: the pair's block of 2^s values is number (global index >> s) = hi 2^(ns - st) + (q >> lh)
+            const u256 w = block_tw ? load256(a.btw + 4 * ((1ull << (a.log_n - s)) + (hi << (a.ns - st)) + (q >> lh)))
+                                    : load256(a.tw + 4 * (j << (a.log_n - s)));
             u256 u, v;
 #pragma unroll
             for (int l = 0; l < 8; l++) { u.l[l] = lds[l][e0]; v.l[l] = lds[l][e1]; }
             u256 p, m;
-            if (a.dif) { p = m_add<F_R>(u, v); m = m_mul<F_R>(m_sub<F_R>(u, v), w); }
+            if (dif_fly) { p = m_add<F_R>(u, v); m = m_mul<F_R>(m_sub<F_R>(u, v), w); }
             else { v = m_mul<F_R>(v, w); p = m_add<F_R>(u, v); m = m_sub<F_R>(u, v); }
 #pragma unroll
             for (int l = 0; l < 8; l++) { lds[l][e0] = p.l[l]; lds[l][e1] = m.l[l]; }
@@ -1397,6 +1416,53 @@ int32_t bn254_fr_ntt_mont_dif(Ctx* ctx, const uint64_t* in, uint64_t n_in, uint6
         pa.in_mont = 1; pa.out_mont = 1; pa.no_gather = 1; pa.dif = 1;
         pa.n_in = n_in; pa.n_out = n;
         pa.pre = pre;
+        hipLaunchKernelGGL(fr_fft_pass_kernel, dim3(tiles), dim3(256), 0, ctx->stream, pa);
+    }
+    GL355_HIP(ctx, hipGetLastError());
+    return GL355_OK;
+}
+// The coset transform in block form: out[bitrev(k)] = sum_i in[i] shift^i w^(ik) for i < n_in (zero beyond), the same values bn254_fr_ntt_mont_dif gives with
+// pre[i] = shift^i -- without the power table, its product per element and the scattered twiddle loads of the high stages (FrPass::btw).  `btw`: n elements,
+// filled here for this shift (one product per entry: 0.1 ms at 2^23) -- callers transform many columns per shift and pass fill = false after the first.
+int32_t bn254_fr_ntt_mont_coset_dif(Ctx* ctx, const uint64_t* in, uint64_t n_in, uint64_t* out, uint32_t log_n, const uint64_t* tw, const uint64_t shift_plain[4],
+                                    uint64_t* btw, bool fill) {
+    const uint64_t n = 1ull << log_n;
+    if (log_n == 0) {
+        GL355_HIP(ctx, hipMemcpyAsync(out, in, 32, hipMemcpyDeviceToDevice, ctx->stream));
+        return GL355_OK;
+    }
+    if (fill) {
+        // gpow[t] = shift^(n / 2^t), t = 1 .. log_n (Montgomery): repeated squaring from the bottom
+        std::vector<u256> gp(log_n + 1);
+        memset(gp.data(), 0, gp.size() * sizeof(u256));
+        H256 g = h_from_words(shift_plain);
+        for (uint32_t t = log_n; t >= 1; t--) {
+            gp[t] = h_to_mont(g);
+            g = h_mulmod(g, g);
+        }
+        Scratch d(ctx);
+        GL355_TRY(d.get(gp.size() * 32));
+        GL355_HIP(ctx, hipMemcpyAsync(d.p, gp.data(), gp.size() * 32, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(fr_coset_twiddle_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, tw, d.as<uint64_t>(), log_n, btw);
+        GL355_HIP(ctx, hipGetLastError());
+        GL355_HIP(ctx, ctx->wait());                                     // gp is pageable host memory
+    }
+    std::vector<uint32_t> ns;
+    ns.push_back(std::min(10u, log_n));
+    const uint32_t rem = log_n - ns[0], more = (rem + 6) / 7;
+    for (uint32_t k = 0; k < more; k++) ns.push_back(rem / more + (k < rem % more ? 1 : 0));
+    std::vector<uint32_t> s0s(ns.size());
+    for (size_t k = 0, s0 = 0; k < ns.size(); k++) { s0s[k] = (uint32_t)s0; s0 += ns[k]; }
+    const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, n / 1024);
+    for (size_t k = ns.size(); k-- > 0;) {
+        FrPass pa;
+        memset(&pa, 0, sizeof pa);
+        pa.first = k + 1 == ns.size(); pa.last = k == 0;
+        pa.in = pa.first ? in : out;
+        pa.out = out;
+        pa.tw = tw; pa.btw = btw; pa.log_n = log_n; pa.s0 = s0s[k]; pa.ns = ns[k];
+        pa.in_mont = 1; pa.out_mont = 1; pa.no_gather = 1; pa.dif = 1;
+        pa.n_in = n_in; pa.n_out = n;
         hipLaunchKernelGGL(fr_fft_pass_kernel, dim3(tiles), dim3(256), 0, ctx->stream, pa);
     }
     GL355_HIP(ctx, hipGetLastError());

@@ -286,6 +286,8 @@ int32_t bn254_fr_ntt_mont(Ctx* ctx, const uint64_t* in, uint64_t n_in, uint64_t*
 int32_t bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t m, uint32_t max_bits, uint64_t* result,
                        const gl355_msm_bases* bases = nullptr);
 int32_t bn254_fr_ntt_mont_dif(Ctx* ctx, const uint64_t* in, uint64_t n_in, uint64_t* out, uint32_t log_n, const uint64_t* tw, const uint64_t* pre);
+int32_t bn254_fr_ntt_mont_coset_dif(Ctx* ctx, const uint64_t* in, uint64_t n_in, uint64_t* out, uint32_t log_n, const uint64_t* tw, const uint64_t shift_plain[4],
+                                    uint64_t* btw /* n elements */, bool fill);
 int32_t bn254_fr_ntt_mont_from_bitrev(Ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t n_out, uint32_t log_n, const uint64_t* tw, const uint64_t* post,
                                       const uint64_t scale_plain[4]);
 // Q[i] = sum_{j > i} A[j] z^(j - i - 1), E = sum_j A[j] z^j on device arrays (see the division kernels)

@@ -372,17 +372,16 @@ Fr plonk_zeta() {
 int32_t plonk_fixed_cosets(gl355_plonk_pk* pk, uint32_t c0, uint32_t c1, uint64_t* out, uint64_t* pre, uint64_t* work) {
     const uint64_t n = pk->n;
     const Fr ext_omega = Fr::root_of_unity(pk->ext_k);
-    const uint64_t one_w[4] = {1, 0, 0, 0};
+
     Fr base = plonk_zeta() * ext_omega.pow_u64(c0);
     for (uint32_t c = c0; c < c1; c++) {
         uint64_t bw[4];
         base.to_words(bw);
-        GL355_TRY(bn254_fr_power_table(pk->ctx, bw, one_w, n, pre));
         uint64_t* dst = out + 4ull * (uint64_t)(c - c0) * pk->n_fix_cos * n;
         for (uint32_t i = 0; i < pk->n_fix_cos; i++) {
             const uint64_t* src = i < pk->n_fixed ? pk->fixed_polys + 4ull * i * n
                                   : (i < pk->n_fixed + pk->n_perm ? pk->sigma_polys + 4ull * (i - pk->n_fixed) * n : pk->l_polys + 4ull * (i - pk->n_fixed - pk->n_perm) * n);
-            GL355_TRY(bn254_fr_ntt_mont_dif(pk->ctx, src, n, dst + 4ull * i * n, pk->k, pk->tw_fwd, pre));
+            GL355_TRY(bn254_fr_ntt_mont_coset_dif(pk->ctx, src, n, dst + 4ull * i * n, pk->k, pk->tw_fwd, bw, pre, i == 0));     // `pre`: the coset's block constants
         }
         base = base * ext_omega;
     }
@@ -958,7 +957,7 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
         const uint64_t** d_csig = d_cperm + pk->n_perm;
         const uint64_t** d_cz = d_csig + pk->n_perm;
         const Fr ext_omega = Fr::root_of_unity(pk->ext_k);
-        const uint64_t one_w[4] = {1, 0, 0, 0};
+
         Fr base = plonk_zeta();                                    // zeta * ext_omega^c
         for (uint32_t c = 0; c < n_cosets; c++) {
             // the key's polynomials on this coset: precomputed, or recomputed into fix_tmp
@@ -983,8 +982,8 @@ int32_t gl355_plonk_prove(gl355_ctx* h, gl355_plonk_pk* pk, const uint64_t* advi
             const uint64_t *c_l0 = fixc(pk->n_fixed + pk->n_perm), *c_ll = c_l0 + 4 * n, *c_la = c_l0 + 8 * n;
             uint64_t bw[4];
             base.to_words(bw);
-            GL355_TRY(bn254_fr_power_table(ctx, bw, one_w, n, pre));
-            for (uint32_t i = 0; i < n_dyn; i++) GL355_TRY(bn254_fr_ntt_mont_dif(ctx, src[i], n, cos + 4ull * i * n, pk->k, pk->tw_fwd, pre));
+            // (round 6: the coset transform in block form -- no power table, no product per coefficient, broadcast twiddles in the high stages)
+            for (uint32_t i = 0; i < n_dyn; i++) GL355_TRY(bn254_fr_ntt_mont_coset_dif(ctx, src[i], n, cos + 4ull * i * n, pk->k, pk->tw_fwd, bw, pre, i == 0));
             // custom gates
             GL355_TRY(run_program(pk, pk->d_gate_code, (uint32_t)(pk->gate_code.size() / 4), d_cos_kind, y, nullptr, acc, true));
             if (pk->n_sets) {
