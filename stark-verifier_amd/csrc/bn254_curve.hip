@@ -1687,9 +1687,14 @@ int32_t gl355::bn254_msm_bits(gl355_ctx* h, const uint64_t* points, const uint64
     //   2^18: c = 15 / 16 / 17 -> 3.7 / 3.9 / 4.1;   2^20: 16 / 17 / 18 -> 7.3 / 7.1 / 8.3;   2^22: 16 / 17 / 18 / 19 -> 23.6 / 19.1 / 20.7 / 32.9
     //   2^23-point calls, k = 23 proof: c = 18 / 19 / 20 / 21 -> 1.155 / 1.115 / 1.118 / 1.235 s
     a.c = bases ? bases->c : (lg <= 6 ? 4 : (lg <= 18 ? lg - 2 : (lg <= 22 ? 17 : 20)));
+    // scalars shorter than a window (range-check limbs): ONE window just wide enough that no digit reaches 2^(c-1), so nothing is negative, nothing carries
+    // and the carry window does not exist -- 2^16 buckets for a 16-bit column instead of two windows of 2^19 (two-level sort from 12 bits on)
+    const bool one_window = !bases && max_bits + 1 < a.c && max_bits + 1 >= 12;
+    if (one_window) a.c = max_bits + 1;
     a.cb = a.c - 1;
     a.wps = 256 / a.c + 1;                                       // signed digits: the carry out of bit 255 needs a window of its own
     if (max_bits < 256) a.wps = std::min(a.wps, (std::max(1u, max_bits) + a.c - 1) / a.c + 1);
+    if (one_window) a.wps = 1;
     if (bases && a.wps > bases->wps) return ctx->fail(GL355_E_INVALID_ARG, "bn254_g1_msm: prepared bases hold too few windows");
     a.n_sets = m;
     a.n_windows = a.wps * m;

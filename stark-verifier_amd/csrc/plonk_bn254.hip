@@ -154,11 +154,12 @@ int32_t commit_columns(gl355_plonk_pk* pk, const uint64_t* bases, const uint64_t
     std::vector<unsigned long long> ors(4ull * sets);
     GL355_HIP(ctx, ctx->d2h(ors.data(), d_or, (size_t)sets * 32));
     GL355_HIP(ctx, ctx->wait());
-    std::vector<uint32_t> cls(sets);
+    std::vector<uint32_t> cls(sets), nbits(sets);
     for (uint32_t s = 0; s < sets; s++) {
         uint32_t bits = 0;
         for (int l = 3; l >= 0 && !bits; l--) if (ors[4 * s + l]) bits = 64 * l + 64 - (uint32_t)__builtin_clzll(ors[4 * s + l]);
-        cls[s] = (std::max(1u, bits) + 19) / 20;                 // classes of 20 bits (the MSM's windows are 17 .. 20 bits wide)
+        nbits[s] = std::max(1u, bits);
+        cls[s] = (nbits[s] + 19) / 20;                           // classes of 20 bits (the MSM's windows are 17 .. 20 bits wide)
     }
     for (uint32_t s0 = 0; s0 < sets;) {
         // ... and <= 72 windows per call: the sort's scratch is ~230 MB per window at k = 23 (nine full-size columns in one call held 29 GB of the
@@ -166,8 +167,12 @@ int32_t commit_columns(gl355_plonk_pk* pk, const uint64_t* bases, const uint64_t
         const uint32_t max_m = std::max(1u, 72u / (cls[s0] + 1));
         uint32_t m = 1;
         while (s0 + m < sets && m < per && m < max_m && cls[s0 + m] == cls[s0]) m++;
-        // (columns of at most 20 bits are one window either way: the per-window form's 2^19 buckets are cheaper to size-sort and reduce than the tables' 2^21)
-        GL355_TRY(bn254_msm_bits(pk->handle, bases, d_plain + 4ull * s0 * n, n, m, std::min(256u, 20 * cls[s0]), out_host + 8ull * s0, cls[s0] >= 2 ? tab : nullptr));
+        // (columns of at most 20 bits are one window either way: the per-window form's buckets are cheaper to size-sort and reduce than the tables' 2^21 --
+        // and it gets the run's exact bit length: a 16-bit column is ONE window of 17 bits, 2^16 buckets, and no carry window)
+        uint32_t run_bits = 0;
+        for (uint32_t j = 0; j < m; j++) run_bits = std::max(run_bits, nbits[s0 + j]);
+        GL355_TRY(bn254_msm_bits(pk->handle, bases, d_plain + 4ull * s0 * n, n, m, cls[s0] >= 2 ? std::min(256u, 20 * cls[s0]) : run_bits, out_host + 8ull * s0,
+                                 cls[s0] >= 2 ? tab : nullptr));
         s0 += m;
     }
     if (nt) {
