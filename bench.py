@@ -322,7 +322,7 @@ def main_recursive(args):
         # gl355_semaphore_prove (witness + proof, n = 2^13) then gl355_circuit_prove_tape (tape replay + proof), host-visible wall time
         # (a lone unit has the rank's host cores to itself: its witness tape replays on up to 8 threads instead of the throughput setting)
         # and polls its stream without sleeping: GL355_OPT_BLOCKING_SYNC 3)
-        lat_rt = int(os.environ.get("GL355_BENCH_LAT_REPLAY_THREADS", max(1, min(14, cores_per_rank - 2))))      # 28 FRI-query segments: 14 threads = two rounds (11.9 vs 12.1 ms with 8)
+        lat_rt = int(os.environ.get("GL355_BENCH_LAT_REPLAY_THREADS", 28 if cores_per_rank >= 16 else max(1, min(14, cores_per_rank - 2))))      # 28 FRI-query segments: one thread each from 16 cores on (0.3 ms bursts; 11.06 vs 11.18 ms with 14 = two rounds, profiles/r06_latency_replay_threads.txt), 14 below
         all_sets[0].set_option(3, lat_rt)
         all_sets[0].set_option(2, 3)
         lat = []
