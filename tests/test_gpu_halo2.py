@@ -149,6 +149,18 @@ def test_k17_reference_table_size(ctx, tables, monkeypatch):
     prover.close()
 
 
+def test_k16_short_columns_commit_through_one_window(ctx):
+    """k = 16 with a 12-bit range table: the range-limb and permuted-lookup columns are 12-bit values, shorter than the MSM's 14-bit window at 2^16 points, so
+    their commitments take the one-window form (a window of 13 bits, no carry window, bn254_msm_bits) -- otherwise reached only at k = 23, where 16-bit columns
+    meet 20-bit windows.  The proof passes the verifier restatement, which recomputes nothing from the prover: a wrong commitment fails the opening check."""
+    k = 16
+    cs, cfg, w, prover = build(ctx, k, 12, n_perm=8)
+    vk = dict(digest=prover.digest, fixed_commitments=[pt(c) for c in prover.fixed_commitments], sigma_commitments=[pt(c) for c in prover.sigma_commitments])
+    proof = prover.prove(w.advice, w.instance, bytes(range(32)))
+    assert hv.verify(k, cs, vk, w.instance, proof, TAU)
+    prover.close()
+
+
 def test_a_lookup_input_outside_the_table_is_an_error(gl, ctx):
     k, tb = 8, 6
     cs, cfg, w, prover = build(ctx, k, tb)
