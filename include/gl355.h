@@ -636,7 +636,9 @@ int32_t gl355_kzg_open(gl355_ctx* ctx, const uint64_t* g, const uint64_t* coeffs
  *   gl355_plonk_keygen       keygen_vk / keygen_pk (verifier_api.rs:78-79) as far as proving needs them: fixed_values [fixed columns][2^k]
  *                            scalars, mapping [permutation columns][2^k][2] u32 = the (column position, row) each cell's sigma points to
  *                            (permutation::keygen::Assembly); g / g_lagrange = ParamsKZG's two bases (device pointers are used in place and must
- *                            outlive the key, host arrays are copied).  The key lives on the context's device.
+ *                            outlive the key, host arrays are copied).  The key lives on the context's device.  From k = 22 on it also holds the two
+ *                            bases' window tables (gl355_bn254_g1_msm_prepare: 2 x 6.4 GB at k = 23) when a quarter of the free device memory covers
+ *                            them; GL355_PLONK_MSM_TABLES=0 / 1 in the environment: never / from k = 12 on.  Proof bytes do not depend on it.
  *   gl355_plonk_pk_info      [k, extended k, permutation sets, quotient pieces, usable rows, proof bytes, fixed columns, permutation columns]
  *   gl355_plonk_pk_commitments   the verifying key's fixed and permutation commitments
  *   gl355_plonk_pk_digest / _set_digest   the transcript's initial scalar (halo2: vk.transcript_repr).  A descriptor whose digest field
