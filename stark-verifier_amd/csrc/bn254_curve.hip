@@ -946,10 +946,61 @@ GL_DEV jac29 jac29_lift(const jac& p) {                              // the 8 x 
     if (!r.ident) { r.x = f29_lift_inl(p.x); r.y = f29_lift_inl(p.y); r.z = f29_lift_inl(p.z); }
     return r;
 }
+// ---- the bucket loops' accumulator in XYZZ coordinates (x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2): the mixed addition is 10 products where the Jacobian one is
+// 11 -- ZZ and ZZZ are kept instead of being rebuilt from Z (z^2, y2 z) at every step.  madd-2008-s: U2 = x2 ZZ, S2 = y2 ZZZ, P = U2 - X, R = S2 - Y,
+// PP = P^2, PPP = P PP, Q = X PP, X3 = R^2 - PPP - 2 Q, Y3 = R (Q - X3) - Y PPP, ZZ3 = ZZ PP, ZZZ3 = ZZZ PPP; the sums and differences carry the bounds of the
+// Jacobian form above (P < 9.3, R < 5.3, X3 < 5.3, Y3 < 3.3; ZZ, ZZZ are products: < 1.3).  A finished sum leaves as the Jacobian point (X ZZ, Y ZZZ, ZZ).
+struct xyzz29 { f29 x, y, zz, zzz; bool ident; };
+GL_DEV jac msm_xyzz_lower(const xyzz29& p) {
+    if (p.ident) return j_identity();
+    jac r;
+    r.x = f29_lower(f29_mul(p.x, p.zz)); r.y = f29_lower(f29_mul(p.y, p.zzz)); r.z = f29_lower(p.zz);
+    return r;
+}
+GL_DEV void msm_add_point_xyzz(const MsmArgs& a, xyzz29& acc, uint32_t e) {
+    const uint32_t* p = a.pm + 16ull * (e & 0x7fffffffu);
+    u256 x8, y8;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { x8.l[j] = p[j]; y8.l[j] = p[8 + j]; }
+    const f29 x2 = f29_from_u256(x8);
+    f29 y2 = f29_from_u256(y8);                                      // < q, n
+    if (e >> 31) y2 = f29_norm(f29_neg(y2, FQ29_C2));                 // 2 q - y < 2 q, n
+    if (acc.ident) { acc.x = x2; acc.y = y2; acc.zz = f29_const(FQ29_ONE); acc.zzz = acc.zz; acc.ident = false; return; }
+    const f29 u2 = f29_mul(x2, acc.zz), s2 = f29_mul(y2, acc.zzz);
+    const f29 h = f29_norm(f29_sub(u2, acc.x, FQ29_C8));            // P < 9.3, n
+    const f29 h2 = f29_mul(h, h);
+    const f29 r = f29_norm(f29_sub(s2, acc.y, FQ29_C4));            // R < 5.3, n
+    if (f29_is_zero_mod(h2)) {                                       // the same x: twice the affine point, or the identity (rare)
+        jac29 t;
+        t.ident = false;
+        jac29_same_x(t, x2, y2, f29_is_zero_mod(f29_mul(r, r)));
+        if (t.ident) { acc.ident = true; return; }
+        acc.x = t.x; acc.y = t.y; acc.zz = f29_mul(t.z, t.z); acc.zzz = f29_mul(acc.zz, t.z);
+        return;
+    }
+    const f29 h3 = f29_mul(h2, h), v = f29_mul(acc.x, h2);
+    const f29 w = f29_norm(f29_add(h3, f29_add(v, v)));              // PPP + 2 Q < 3.9, n
+    const f29 x3 = f29_norm(f29_sub(f29_mul(r, r), w, FQ29_C4));     // < 5.3, n
+    const f29 m1 = f29_mul(f29_sub(v, x3, FQ29_C8), r);              // (Q + 8 q - X3 < 9.3) R
+    const f29 y3 = f29_norm(f29_sub(m1, f29_mul(acc.y, h3), FQ29_C2));   // < 3.3, n
+    acc.zz = f29_mul(acc.zz, h2);
+    acc.zzz = f29_mul(acc.zzz, h3);
+    acc.x = x3; acc.y = y3;
+}
+#ifndef GL355_MSM_XYZZ
+#define GL355_MSM_XYZZ 1
+#endif
+#if GL355_MSM_XYZZ
+#define MSM_ACC_T xyzz29
+#define MSM_ACC_INIT(A) xyzz29 A; A.ident = true
+#define MSM_ACC_ADD(ARGS, A, E) msm_add_point_xyzz(ARGS, A, E)
+#define MSM_ACC_JAC(A) msm_xyzz_lower(A)
+#else
 #define MSM_ACC_T jac29
 #define MSM_ACC_INIT(A) jac29 A; A.ident = true
 #define MSM_ACC_ADD(ARGS, A, E) msm_add_point29(ARGS, A, E)
 #define MSM_ACC_JAC(A) jac29_lower(A)
+#endif
 #else
 #define MSM_ACC_T jac
 #define MSM_ACC_INIT(A) jac A = j_identity()
